@@ -1,0 +1,206 @@
+/* include/kgwas.h — C ABI of libkgwas: the MI355X-native k-mer association-scan engine.
+ *
+ * Drop-in boundary for ONE hot path of voichek/kmersGWAS: the associate_kmers /
+ * emma_kinship_kmers scan. The reference has no plugin or FFI interface — its boundary is
+ * the process (argv + files) and, inside the binary, the method surface of
+ * MultipleKmersDataBases and BestAssociationsHeap. Each entry point below names the
+ * reference interface it replaces (paths relative to the reference tree).
+ *
+ * Conventions: plain C, no exceptions cross the boundary. Every function returns
+ * KGWAS_OK (0) or a negative KGWAS_ERR_*; kgwas_last_error() gives the thread-local
+ * message. Handles are created and freed by the library. Caller-owned input buffers are
+ * only read during the call. Result pointers stay valid until the owning handle is
+ * destroyed. All compute runs on the GPU through hand-written gfx950 kernels: there is
+ * NO CPU fallback — without a usable HIP device the compute entry points fail with
+ * KGWAS_ERR_DEVICE.
+ */
+#ifndef KGWAS_H
+#define KGWAS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KGWAS_OK 0
+#define KGWAS_ERR_ARG (-1)    /* bad argument */
+#define KGWAS_ERR_IO (-2)     /* file cannot be opened / read / written */
+#define KGWAS_ERR_FORMAT (-3) /* a reference std::logic_error: bad magic, k, size, unknown accession ... */
+#define KGWAS_ERR_DEVICE (-4) /* no HIP device or a HIP call failed */
+#define KGWAS_ERR_STATE (-5)  /* call out of order */
+#define KGWAS_ERR_NOMEM (-6)
+
+const char* kgwas_last_error(void);
+int kgwas_version(void);
+int kgwas_device_count(int* n_devices);
+
+/* ------------------------------------------------------------------------------------
+ * .table / .names reader.
+ * Replaces MultipleKmersDataBases::MultipleKmersDataBases header guards
+ * (src/kmers_multiple_databases.cpp:39-94), load_kmers_talbe_column_names
+ * (src/kmer_general.cpp:45-53) and create_map_from_all_DBs (:297-311).
+ * kmer_len == 0 skips the k check (for tools that do not know k).
+ * ---------------------------------------------------------------------------------- */
+typedef struct kgwas_table kgwas_table;
+int kgwas_table_open(const char* base, uint32_t kmer_len, kgwas_table** out);
+int kgwas_table_info(const kgwas_table* t, uint64_t* n_acc_file, uint64_t* n_rows, uint64_t* words_per_row,
+                     uint32_t* kmer_len);
+int kgwas_table_name(const kgwas_table* t, uint64_t i, const char** name);
+/* col_out[i] = file column of accession acc[i]; unknown or duplicated name -> KGWAS_ERR_FORMAT
+ * (intersect_phenotypes_to_present_DBs with must_be_present, src/kmer_general.cpp:239-253;
+ *  get_index_DB :227-237). */
+int kgwas_table_column_map(const kgwas_table* t, const char* const* acc, uint64_t n, uint64_t* col_out);
+/* Raw rows [u64 kmer][W_f u64] of file rows [row0, row0+n) into dst (host). */
+int kgwas_table_read_rows(kgwas_table* t, uint64_t row0, uint64_t n, uint64_t* dst);
+void kgwas_table_close(kgwas_table* t);
+
+/* ------------------------------------------------------------------------------------
+ * Phenotype TSV. Replaces load_phenotypes_file (src/kmer_general.cpp:175-205).
+ * ---------------------------------------------------------------------------------- */
+typedef struct kgwas_pheno kgwas_pheno;
+int kgwas_pheno_load(const char* path, kgwas_pheno** out);
+int kgwas_pheno_info(const kgwas_pheno* p, uint64_t* n_pheno, uint64_t* n_acc);
+int kgwas_pheno_name(const kgwas_pheno* p, uint64_t j, const char** name);
+int kgwas_pheno_accession(const kgwas_pheno* p, uint64_t i, const char** acc);
+/* Y: n_pheno x n_acc float32, row-major, accession (file) order of the TSV. */
+int kgwas_pheno_values(const kgwas_pheno* p, const float** Y);
+void kgwas_pheno_free(kgwas_pheno* p);
+
+/* min_count = max(ceil(n_acc*maf), mac) (src/associate_kmers.cpp:99-103). */
+uint64_t kgwas_min_count(uint64_t n_acc, double maf, uint64_t mac);
+
+/* ------------------------------------------------------------------------------------
+ * BestAssociationsHeap (src/best_associations_heap.h:32-54, .cpp:26-127): bounded min-heap
+ * with the reference's strict-'>' replacement, backed by the same std::priority_queue type
+ * so that ties resolve identically. Used by the scan for its host-side replay and exposed
+ * for cross-shard merges.
+ * ---------------------------------------------------------------------------------- */
+typedef struct kgwas_heap kgwas_heap;
+int kgwas_heap_new(uint64_t max_results, kgwas_heap** out);
+/* add_association for n entries in the given order. */
+int kgwas_heap_add_many(kgwas_heap* h, const uint64_t* kmer, const double* score, const uint64_t* row, uint64_t n);
+int kgwas_heap_size(const kgwas_heap* h, uint64_t* size, uint64_t* insertions, double* lowest);
+/* output_to_file_with_scores order: ascending pops from a copy; arrays hold `size` entries. */
+int kgwas_heap_pop_all(const kgwas_heap* h, uint64_t* kmer, double* score, uint64_t* row);
+/* get_kmers_for_output: (kmer, rank, row) sorted by row; rank = queue size at pop (best = 1). */
+int kgwas_heap_output_list(const kgwas_heap* h, uint64_t* kmer, uint64_t* rank, uint64_t* row);
+void kgwas_heap_free(kgwas_heap* h);
+
+/* ------------------------------------------------------------------------------------
+ * Association scan session = pass 1 of associate_kmers (src/associate_kmers.cpp:99-148):
+ * MultipleKmersDataBases::load_kmers (MAC filter + squeeze, :103-146),
+ * add_kmers_to_heap / calculate_kmer_score (:275-284, :327-363) for every phenotype column,
+ * feeding one BestAssociationsHeap per column. Rows are fed in file order, in any number of
+ * feed calls; results do not depend on how the rows are split.
+ * ---------------------------------------------------------------------------------- */
+typedef struct kgwas_scan kgwas_scan;
+
+#define KGWAS_KERNEL_AUTO 0
+#define KGWAS_KERNEL_VALU 1 /* exact-order select+add on the vector ALU */
+#define KGWAS_KERNEL_MFMA 2 /* exact-order f32 MFMA (v_mfma_f32_16x16x4_f32) */
+
+typedef struct kgwas_scan_params {
+    uint32_t struct_size;    /* sizeof(kgwas_scan_params) */
+    int32_t device;          /* HIP device ordinal */
+    uint64_t n_acc_file;     /* S_f: accessions (bit columns) in the table */
+    uint64_t n_acc;          /* S: phenotyped accessions */
+    const uint64_t* col;     /* [S] file column of phenotyped accession i (phenotype order) */
+    uint64_t n_pheno;        /* phenotype columns (1 + permutations) */
+    const float* Y;          /* n_pheno x S float32 row-major, phenotype order */
+    const uint64_t* topn;    /* [n_pheno] heap sizes (-n / --first_phenotype_best) */
+    uint64_t min_count;      /* effective minor allele count */
+    uint64_t chunk_rows;     /* max rows per device chunk; 0 = default */
+    uint32_t host_threads;   /* replay threads; 0 = hardware concurrency */
+    uint32_t kernel;         /* KGWAS_KERNEL_* */
+    uint32_t record_history; /* keep every effective heap push (for cross-shard merges) */
+    uint32_t reserved;
+} kgwas_scan_params;
+
+typedef struct kgwas_scan_stats {
+    uint64_t rows_fed;          /* file rows seen */
+    uint64_t rows_tested;       /* rows passing the MAC filter (= .tested_kmers) */
+    uint64_t candidates;        /* (row, phenotype) records shipped device -> host */
+    uint64_t heap_pushes;       /* effective pushes over all heaps */
+    uint64_t chunks;            /* device chunks launched */
+    uint64_t score_launches;    /* launches of the scoring kernel */
+    double score_kernel_ms;     /* sum of hipEvent durations of the scoring kernel */
+    double squeeze_kernel_ms;   /* sum of hipEvent durations of the squeeze kernel (0 in direct mode) */
+    double replay_ms;           /* host wall time spent replaying candidates (summed over threads) */
+    uint32_t kernel_used;       /* KGWAS_KERNEL_VALU or KGWAS_KERNEL_MFMA */
+    uint32_t direct_mode;       /* 1 = scorer read the file layout in place (no squeeze pass) */
+} kgwas_scan_stats;
+
+int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out);
+/* Rows already resident in HBM (file layout, 8-byte aligned). hip_stream may be NULL. */
+int kgwas_scan_feed_device(kgwas_scan* s, const void* d_rows, uint64_t n_rows, uint64_t first_row, void* hip_stream);
+/* Rows in host memory; copied to the device through pinned double buffers. */
+int kgwas_scan_feed_host(kgwas_scan* s, const uint64_t* rows, uint64_t n_rows, uint64_t first_row);
+int kgwas_scan_finish(kgwas_scan* s);
+/* Heap of phenotype j in heap-pop (ascending score) order: rank of entry i is n - i.
+ * row = file row index. Valid after kgwas_scan_finish. */
+int kgwas_scan_result(kgwas_scan* s, uint64_t j, uint64_t* n, const uint64_t** kmer, const double** score,
+                      const uint64_t** row);
+/* Effective pushes of phenotype j in row order (needs record_history). */
+int kgwas_scan_history(kgwas_scan* s, uint64_t j, uint64_t* n, const uint64_t** kmer, const double** score,
+                       const uint64_t** row);
+int kgwas_scan_get_stats(const kgwas_scan* s, kgwas_scan_stats* st);
+void kgwas_scan_destroy(kgwas_scan* s);
+
+/* calculate_kmer_score for every row and phenotype column (src/kmers_multiple_databases.cpp:327-363):
+ * scores[j*n_rows + r] (0 for rows the MAC filter drops), popcnt[r] = masked popcount N1,
+ * outputs in host memory. rows_on_device selects how `rows` is interpreted. */
+int kgwas_scan_scores_dense(kgwas_scan* s, const void* rows, int rows_on_device, uint64_t n_rows, double* scores,
+                            uint32_t* popcnt);
+
+/* Cross-shard merge: replay shard histories (shards in row order) through fresh heaps.
+ * counts[g*n_pheno + j] entries of shard g / phenotype j, concatenated by phenotype inside
+ * kmer[g] / score[g] / row[g]. Returns one heap per phenotype in out_heaps[j]. */
+int kgwas_merge_shards(uint64_t n_pheno, const uint64_t* topn, uint64_t n_shards, const uint64_t* counts,
+                       const uint64_t* const* kmer, const double* const* score, const uint64_t* const* row,
+                       uint32_t threads, kgwas_heap** out_heaps);
+
+/* ------------------------------------------------------------------------------------
+ * Kinship = emma_kinship_kmers (src/emma_kinship_kmers.cpp:77-111) with
+ * update_emma_kinshhip_calculation (src/kmers_multiple_databases.cpp:418-438):
+ * over rows with min_count <= popcount(all S_f columns) <= S_f - min_count,
+ * K[i][j] += 1 ^ g_i ^ g_j for j < i.
+ * ---------------------------------------------------------------------------------- */
+typedef struct kgwas_kinship kgwas_kinship;
+int kgwas_kinship_create(int32_t device, uint64_t n_acc_file, uint64_t min_count, kgwas_kinship** out);
+int kgwas_kinship_feed_device(kgwas_kinship* k, const void* d_rows, uint64_t n_rows, void* hip_stream);
+int kgwas_kinship_feed_host(kgwas_kinship* k, const uint64_t* rows, uint64_t n_rows);
+/* Hamming-distance partials (S_f x S_f u64, full symmetric) and rows used so far: integer, so
+ * partials of different shards simply add (all-reduce) before kgwas_kinship_from_partials. */
+int kgwas_kinship_partials(kgwas_kinship* k, uint64_t* hamming, uint64_t* n_used);
+/* K (S_f x S_f, lower triangle j < i filled like the reference, rest 0) from summed partials. */
+int kgwas_kinship_from_partials(uint64_t n_acc_file, const uint64_t* hamming, uint64_t n_used, uint64_t* K);
+int kgwas_kinship_get_stats(const kgwas_kinship* k, double* kernel_ms, uint64_t* launches, uint64_t* rows_fed);
+void kgwas_kinship_destroy(kgwas_kinship* k);
+/* The matrix text emma_kinship_kmers prints to stdout (:95-111). Returns needed bytes. */
+uint64_t kgwas_kinship_format(uint64_t n_acc_file, const uint64_t* K, uint64_t n_used, char* out, uint64_t cap);
+
+/* ------------------------------------------------------------------------------------
+ * Pass 2 of associate_kmers (src/associate_kmers.cpp:150-205): <base>.bed/.bim/.fam for one
+ * phenotype column from its heap (pop order) — write_PA (src/kmers_multiple_databases.cpp:218-252),
+ * BedBimFilesHandle (src/kmer_general.h:133-147), write_fam_file (src/kmer_general.cpp:207-225).
+ * The winners' rows are fetched by file row index instead of re-scanning the table.
+ * ---------------------------------------------------------------------------------- */
+int kgwas_write_plink(const char* out_base, kgwas_table* t, const uint64_t* col, uint64_t n_acc,
+                      const char* const* acc_names, const float* y, uint64_t n, const uint64_t* kmer_pop,
+                      const uint64_t* row_pop);
+
+/* ------------------------------------------------------------------------------------
+ * Seeded synthetic table rows: kmer = row + 1, per-row frequency q/256 with
+ * q in [5, 250], bits from a counter-based generator, so any shard can be produced on its GPU.
+ * The host variant is the bit-identical twin used to write small .table files for the CLIs.
+ * ---------------------------------------------------------------------------------- */
+int kgwas_synth_rows_device(void* d_rows, uint64_t first_row, uint64_t n_rows, uint64_t n_acc_file, uint64_t seed,
+                            void* hip_stream);
+int kgwas_synth_rows_host(uint64_t* rows, uint64_t first_row, uint64_t n_rows, uint64_t n_acc_file, uint64_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KGWAS_H */

@@ -1,0 +1,148 @@
+"""ctypes binding of libkgwas.so (the C ABI declared in include/kgwas.h).
+
+The shared library is built in-tree by ``make -C kmersgwas_amd/csrc`` (see __graft_entry__.build()).
+There is no Python or CPU fallback for the compute path: if the library is missing, importing this
+module raises, and if no HIP device is usable the compute entry points return KGWAS_ERR_DEVICE,
+which surfaces here as KgwasError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libkgwas.so")
+
+KGWAS_OK = 0
+KGWAS_ERR_ARG, KGWAS_ERR_IO, KGWAS_ERR_FORMAT, KGWAS_ERR_DEVICE, KGWAS_ERR_STATE, KGWAS_ERR_NOMEM = -1, -2, -3, -4, -5, -6
+KERNEL_AUTO, KERNEL_VALU, KERNEL_MFMA = 0, 1, 2
+
+# Every symbol include/kgwas.h declares (tests check the library exports each one).
+SYMBOLS = [
+    "kgwas_last_error", "kgwas_version", "kgwas_device_count",
+    "kgwas_table_open", "kgwas_table_info", "kgwas_table_name", "kgwas_table_column_map", "kgwas_table_read_rows",
+    "kgwas_table_close",
+    "kgwas_pheno_load", "kgwas_pheno_info", "kgwas_pheno_name", "kgwas_pheno_accession", "kgwas_pheno_values",
+    "kgwas_pheno_free", "kgwas_min_count",
+    "kgwas_heap_new", "kgwas_heap_add_many", "kgwas_heap_size", "kgwas_heap_pop_all", "kgwas_heap_output_list",
+    "kgwas_heap_free",
+    "kgwas_scan_create", "kgwas_scan_feed_device", "kgwas_scan_feed_host", "kgwas_scan_finish", "kgwas_scan_result",
+    "kgwas_scan_history", "kgwas_scan_get_stats", "kgwas_scan_destroy", "kgwas_scan_scores_dense",
+    "kgwas_merge_shards",
+    "kgwas_kinship_create", "kgwas_kinship_feed_device", "kgwas_kinship_feed_host", "kgwas_kinship_partials",
+    "kgwas_kinship_from_partials", "kgwas_kinship_get_stats", "kgwas_kinship_destroy", "kgwas_kinship_format",
+    "kgwas_write_plink",
+    "kgwas_synth_rows_device", "kgwas_synth_rows_host",
+]
+
+
+class KgwasError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("libkgwas error %d: %s" % (code, msg))
+        self.code = code
+        self.msg = msg
+
+
+class ScanParams(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("device", C.c_int32),
+        ("n_acc_file", C.c_uint64), ("n_acc", C.c_uint64), ("col", C.POINTER(C.c_uint64)),
+        ("n_pheno", C.c_uint64), ("Y", C.POINTER(C.c_float)), ("topn", C.POINTER(C.c_uint64)),
+        ("min_count", C.c_uint64), ("chunk_rows", C.c_uint64),
+        ("host_threads", C.c_uint32), ("kernel", C.c_uint32), ("record_history", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+
+class ScanStats(C.Structure):
+    _fields_ = [
+        ("rows_fed", C.c_uint64), ("rows_tested", C.c_uint64), ("candidates", C.c_uint64),
+        ("heap_pushes", C.c_uint64), ("chunks", C.c_uint64), ("score_launches", C.c_uint64),
+        ("score_kernel_ms", C.c_double), ("squeeze_kernel_ms", C.c_double), ("replay_ms", C.c_double),
+        ("kernel_used", C.c_uint32), ("direct_mode", C.c_uint32),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "libkgwas.so not found at %s — build it with `make -C kmersgwas_amd/csrc` "
+        "(or __graft_entry__.build()). There is no fallback implementation." % LIB_PATH)
+
+lib = C.CDLL(LIB_PATH)
+
+_vp, _u64, _u32, _i32, _dbl = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32, C.c_double
+_pp = C.POINTER(C.c_void_p)
+_pu64 = C.POINTER(C.c_uint64)
+_pdbl = C.POINTER(C.c_double)
+_pstr = C.POINTER(C.c_char_p)
+
+lib.kgwas_last_error.restype = C.c_char_p
+lib.kgwas_version.restype = C.c_int
+lib.kgwas_device_count.argtypes = [C.POINTER(C.c_int)]
+lib.kgwas_table_open.argtypes = [C.c_char_p, _u32, _pp]
+lib.kgwas_table_info.argtypes = [_vp, _pu64, _pu64, _pu64, C.POINTER(_u32)]
+lib.kgwas_table_name.argtypes = [_vp, _u64, _pstr]
+lib.kgwas_table_column_map.argtypes = [_vp, _pstr, _u64, _pu64]
+lib.kgwas_table_read_rows.argtypes = [_vp, _u64, _u64, _vp]
+lib.kgwas_table_close.argtypes = [_vp]
+lib.kgwas_table_close.restype = None
+lib.kgwas_pheno_load.argtypes = [C.c_char_p, _pp]
+lib.kgwas_pheno_info.argtypes = [_vp, _pu64, _pu64]
+lib.kgwas_pheno_name.argtypes = [_vp, _u64, _pstr]
+lib.kgwas_pheno_accession.argtypes = [_vp, _u64, _pstr]
+lib.kgwas_pheno_values.argtypes = [_vp, C.POINTER(C.POINTER(C.c_float))]
+lib.kgwas_pheno_free.argtypes = [_vp]
+lib.kgwas_pheno_free.restype = None
+lib.kgwas_min_count.argtypes = [_u64, _dbl, _u64]
+lib.kgwas_min_count.restype = _u64
+lib.kgwas_heap_new.argtypes = [_u64, _pp]
+lib.kgwas_heap_add_many.argtypes = [_vp, _vp, _vp, _vp, _u64]
+lib.kgwas_heap_size.argtypes = [_vp, _pu64, _pu64, _pdbl]
+lib.kgwas_heap_pop_all.argtypes = [_vp, _vp, _vp, _vp]
+lib.kgwas_heap_output_list.argtypes = [_vp, _vp, _vp, _vp]
+lib.kgwas_heap_free.argtypes = [_vp]
+lib.kgwas_heap_free.restype = None
+lib.kgwas_scan_create.argtypes = [C.POINTER(ScanParams), _pp]
+lib.kgwas_scan_feed_device.argtypes = [_vp, _vp, _u64, _u64, _vp]
+lib.kgwas_scan_feed_host.argtypes = [_vp, _vp, _u64, _u64]
+lib.kgwas_scan_finish.argtypes = [_vp]
+lib.kgwas_scan_result.argtypes = [_vp, _u64, _pu64, C.POINTER(_pu64), C.POINTER(_pdbl), C.POINTER(_pu64)]
+lib.kgwas_scan_history.argtypes = [_vp, _u64, _pu64, C.POINTER(_pu64), C.POINTER(_pdbl), C.POINTER(_pu64)]
+lib.kgwas_scan_get_stats.argtypes = [_vp, C.POINTER(ScanStats)]
+lib.kgwas_scan_destroy.argtypes = [_vp]
+lib.kgwas_scan_destroy.restype = None
+lib.kgwas_scan_scores_dense.argtypes = [_vp, _vp, C.c_int, _u64, _vp, _vp]
+lib.kgwas_merge_shards.argtypes = [_u64, _vp, _u64, _vp, _pp, _pp, _pp, _u32, _pp]
+lib.kgwas_kinship_create.argtypes = [_i32, _u64, _u64, _pp]
+lib.kgwas_kinship_feed_device.argtypes = [_vp, _vp, _u64, _vp]
+lib.kgwas_kinship_feed_host.argtypes = [_vp, _vp, _u64]
+lib.kgwas_kinship_partials.argtypes = [_vp, _vp, _pu64]
+lib.kgwas_kinship_from_partials.argtypes = [_u64, _vp, _u64, _vp]
+lib.kgwas_kinship_get_stats.argtypes = [_vp, _pdbl, _pu64, _pu64]
+lib.kgwas_kinship_destroy.argtypes = [_vp]
+lib.kgwas_kinship_destroy.restype = None
+lib.kgwas_kinship_format.argtypes = [_u64, _vp, _u64, C.c_char_p, _u64]
+lib.kgwas_kinship_format.restype = _u64
+lib.kgwas_write_plink.argtypes = [C.c_char_p, _vp, _vp, _u64, _pstr, _vp, _u64, _vp, _vp]
+lib.kgwas_synth_rows_device.argtypes = [_vp, _u64, _u64, _u64, _u64, _vp]
+lib.kgwas_synth_rows_host.argtypes = [_vp, _u64, _u64, _u64, _u64]
+
+
+def check(rc: int) -> None:
+    if rc != KGWAS_OK:
+        raise KgwasError(rc, (lib.kgwas_last_error() or b"").decode(errors="replace"))
+
+
+def ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    check(lib.kgwas_device_count(C.byref(n)))
+    return n.value

@@ -1,0 +1,45 @@
+// common.h — error plumbing shared by the host side of libkgwas.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <stdexcept>
+#include <string>
+
+#include "../../include/kgwas.h"
+
+namespace kgwas {
+
+// Thread-local last error (kgwas_last_error()).
+void set_error(const std::string& msg);
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define KGWAS_HIP(expr)                                                                                     \
+    do {                                                                                                    \
+        hipError_t _e = (expr);                                                                             \
+        if (_e != hipSuccess)                                                                               \
+            throw ::kgwas::Error(KGWAS_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));      \
+    } while (0)
+
+// Run body, translate exceptions into a status code + message. No exception crosses the C ABI.
+template <class F>
+int guarded(F&& body) {
+    try {
+        body();
+        return KGWAS_OK;
+    } catch (const Error& e) {
+        set_error(e.what());
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        set_error("out of host memory");
+        return KGWAS_ERR_NOMEM;
+    } catch (const std::exception& e) {
+        set_error(e.what());
+        return KGWAS_ERR_ARG;
+    }
+}
+
+}  // namespace kgwas

@@ -1,0 +1,72 @@
+// kernels.h — host-visible launch interface of the gfx950 kernels (kernels.hip).
+// Internal to libkgwas; the public boundary is include/kgwas.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace kgwas {
+
+// One candidate record shipped device -> host (sparse mode).
+struct Cand {
+    uint64_t kmer;
+    double score;
+    uint64_t row;  // global file row index
+};
+
+// Where the scorer reads a row's squeezed bits from.
+//   direct mode  : the .table rows in place  (stride 2*(1+W_f) dwords, bits start at dword 2)
+//   squeezed mode: the squeeze kernel's output (stride 2*W_m dwords, bits start at dword 0)
+struct RowSrc {
+    const uint32_t* base;
+    uint64_t stride_dw;
+    uint32_t off_dw;
+    uint32_t avail_dw;  // dwords of bit data present in a row
+};
+
+struct ScoreArgs {
+    RowSrc src;
+    const uint32_t* dmask;      // [2*W_m] AND mask per squeezed dword (0 where no data exists)
+    const uint64_t* file_rows;  // the .table rows (for k-mer ids)
+    uint64_t file_stride_w;     // 1 + W_f
+    uint64_t n_rows;            // rows in this launch
+    uint64_t first_row;         // global file row of row 0
+    uint32_t S;                 // phenotyped accessions
+    uint32_t W_m;               // 64-bit words per squeezed row (even)
+    uint32_t n_pheno;
+    uint32_t min_count;
+    const float* Yperm;   // VALU kernel: [n_pheno][L] permuted, padded (L = 64*W_m)
+    const float* Ymfma;   // MFMA kernel: [n_ctiles][L][16] chain-step major
+    const float* sums;    // [n_pheno] float32 sequential sums
+    const double* thr;    // [n_pheno] stale heap minima (sparse mode)
+    // dense outputs (null in sparse mode)
+    double* dense;        // [n_pheno][n_rows]
+    uint32_t* n1_out;     // [n_rows] masked popcount
+    uint64_t* kmer_out;   // [n_rows]
+    // sparse outputs (null in dense mode)
+    Cand* cand;           // [n_pheno][cap]
+    uint32_t* cand_cnt;   // [n_pheno]
+    uint32_t cap;
+    unsigned long long* tested;  // MAC-passing rows, accumulated
+};
+
+// Scoring kernels. rows_per_block only matters for the MFMA kernel (multiple of 128).
+hipError_t launch_score_valu(const ScoreArgs& a, hipStream_t st);
+hipError_t launch_score_mfma(const ScoreArgs& a, uint32_t rows_per_block, hipStream_t st);
+size_t mfma_lds_bytes(uint32_t W_m);
+
+// Squeeze: out[r][2*W_m dwords] bit i = file bit colmap[i] (colmap[i] == 0xFFFFFFFF -> 0).
+hipError_t launch_squeeze(const uint64_t* file_rows, uint64_t file_stride_w, uint64_t n_rows, const uint32_t* colmap,
+                          uint32_t W_m, uint32_t W_f, uint32_t* out, hipStream_t st);
+
+// Synthetic rows.
+hipError_t launch_synth(uint64_t* rows, uint64_t first_row, uint64_t n_rows, uint64_t n_acc, uint64_t seed,
+                        hipStream_t st);
+
+// Kinship: transpose+filter, then Hamming Gram accumulation into H (S_pad x S_pad u64).
+//  T: [S_pad][n_rw] u32, n_rw = ceil(n_rows/64)*2
+hipError_t launch_kin_transpose(const uint64_t* file_rows, uint64_t file_stride_w, uint64_t n_rows, uint32_t S_f,
+                                uint32_t S_pad, uint32_t min_count, uint32_t* T, uint64_t n_rw,
+                                unsigned long long* n_used, hipStream_t st);
+hipError_t launch_kin_gram(const uint32_t* T, uint64_t n_rw, uint32_t S_pad, unsigned long long* H, hipStream_t st);
+
+}  // namespace kgwas

@@ -1,0 +1,182 @@
+// kinship.cpp — emma_kinship_kmers' accumulation (src/emma_kinship_kmers.cpp:77-102,
+// src/kmers_multiple_databases.cpp:418-438) as two GPU kernels per chunk:
+//   kin_transpose: MAC filter over all S_f columns + bit transpose (sample-major bit planes)
+//   kin_gram     : Hamming distances H[i][j] += popcount(T_i ^ T_j)
+// and the closed form K[i][j] = sum_rows (1 ^ g_i ^ g_j) = n_used - H[i][j]. Everything is
+// integer, so partial results of different chunks / shards / GPUs simply add.
+// Also hosts the synthetic-row entry points.
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "common.h"
+#include "kernels.h"
+#include "synth.h"
+
+using namespace kgwas;
+
+struct kgwas_kinship {
+    int device = 0;
+    uint64_t S_f = 0, W_f = 0, min_count = 0;
+    uint32_t S_pad = 0;
+    uint64_t chunk_rows = 0, n_rw_cap = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_user = nullptr, ev0 = nullptr, ev1 = nullptr;
+    uint32_t* d_T = nullptr;
+    unsigned long long* d_H = nullptr;
+    unsigned long long* d_n = nullptr;
+    uint64_t* d_stage = nullptr;
+    size_t stage_words = 0;
+    double kernel_ms = 0;
+    uint64_t launches = 0, rows_fed = 0;
+    ~kgwas_kinship() {
+        (void)hipSetDevice(device);
+        if (d_T) (void)hipFree(d_T);
+        if (d_H) (void)hipFree(d_H);
+        if (d_n) (void)hipFree(d_n);
+        if (d_stage) (void)hipFree(d_stage);
+        if (ev_user) (void)hipEventDestroy(ev_user);
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+static void kin_feed(kgwas_kinship* k, const uint64_t* d_rows, uint64_t n_rows) {
+    const uint64_t stride = 1 + k->W_f;
+    for (uint64_t pos = 0; pos < n_rows; pos += k->chunk_rows) {
+        const uint64_t c = std::min<uint64_t>(k->chunk_rows, n_rows - pos);
+        const uint64_t n_rw = (c + 511) / 512 * 16;  // u32 words per sample, whole 512-row blocks
+        KGWAS_HIP(hipEventRecord(k->ev0, k->stream));
+        KGWAS_HIP(launch_kin_transpose(d_rows + pos * stride, stride, c, (uint32_t)k->S_f, k->S_pad,
+                                       (uint32_t)std::min<uint64_t>(k->min_count, 0xFFFFFFFFull), k->d_T, n_rw, k->d_n,
+                                       k->stream));
+        KGWAS_HIP(launch_kin_gram(k->d_T, n_rw, k->S_pad, k->d_H, k->stream));
+        KGWAS_HIP(hipEventRecord(k->ev1, k->stream));
+        KGWAS_HIP(hipStreamSynchronize(k->stream));
+        float ms = 0;
+        KGWAS_HIP(hipEventElapsedTime(&ms, k->ev0, k->ev1));
+        k->kernel_ms += ms;
+        k->launches++;
+    }
+    k->rows_fed += n_rows;
+}
+
+extern "C" {
+
+int kgwas_kinship_create(int32_t device, uint64_t n_acc_file, uint64_t min_count, kgwas_kinship** out) {
+    return guarded([&] {
+        if (!out || n_acc_file == 0 || n_acc_file >= (1ull << 31)) throw Error(KGWAS_ERR_ARG, "kgwas_kinship_create: bad argument");
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess || n <= 0)
+            throw Error(KGWAS_ERR_DEVICE, "no HIP device available: libkgwas has no CPU fallback");
+        if (device < 0 || device >= n) throw Error(KGWAS_ERR_ARG, "device ordinal out of range");
+        KGWAS_HIP(hipSetDevice(device));
+        std::unique_ptr<kgwas_kinship> k(new kgwas_kinship);
+        k->device = device;
+        k->S_f = n_acc_file;
+        k->W_f = (n_acc_file + 63) / 64;
+        k->min_count = min_count;
+        k->S_pad = (uint32_t)((n_acc_file + 63) / 64 * 64);
+        k->chunk_rows = 1ull << 20;  // the reference's own batch size (src/emma_kinship_kmers.cpp:89)
+        k->n_rw_cap = (k->chunk_rows + 511) / 512 * 16;
+        KGWAS_HIP(hipStreamCreateWithFlags(&k->stream, hipStreamNonBlocking));
+        KGWAS_HIP(hipEventCreate(&k->ev_user));
+        KGWAS_HIP(hipEventCreate(&k->ev0));
+        KGWAS_HIP(hipEventCreate(&k->ev1));
+        KGWAS_HIP(hipMalloc((void**)&k->d_T, (size_t)k->S_pad * k->n_rw_cap * 4));
+        KGWAS_HIP(hipMalloc((void**)&k->d_H, (size_t)k->S_pad * k->S_pad * 8));
+        KGWAS_HIP(hipMalloc((void**)&k->d_n, 8));
+        KGWAS_HIP(hipMemset(k->d_H, 0, (size_t)k->S_pad * k->S_pad * 8));
+        KGWAS_HIP(hipMemset(k->d_n, 0, 8));
+        *out = k.release();
+    });
+}
+
+int kgwas_kinship_feed_device(kgwas_kinship* k, const void* d_rows, uint64_t n_rows, void* hip_stream) {
+    return guarded([&] {
+        if (!k || (!d_rows && n_rows)) throw Error(KGWAS_ERR_ARG, "kgwas_kinship_feed_device: null argument");
+        KGWAS_HIP(hipSetDevice(k->device));
+        KGWAS_HIP(hipEventRecord(k->ev_user, (hipStream_t)hip_stream));
+        KGWAS_HIP(hipStreamWaitEvent(k->stream, k->ev_user, 0));
+        kin_feed(k, reinterpret_cast<const uint64_t*>(d_rows), n_rows);
+    });
+}
+
+int kgwas_kinship_feed_host(kgwas_kinship* k, const uint64_t* rows, uint64_t n_rows) {
+    return guarded([&] {
+        if (!k || (!rows && n_rows)) throw Error(KGWAS_ERR_ARG, "kgwas_kinship_feed_host: null argument");
+        KGWAS_HIP(hipSetDevice(k->device));
+        const uint64_t stride = 1 + k->W_f;
+        const size_t need = (size_t)k->chunk_rows * stride;
+        if (k->stage_words < need) {
+            if (k->d_stage) (void)hipFree(k->d_stage);
+            k->d_stage = nullptr;
+            KGWAS_HIP(hipMalloc((void**)&k->d_stage, need * 8));
+            k->stage_words = need;
+        }
+        for (uint64_t pos = 0; pos < n_rows; pos += k->chunk_rows) {
+            const uint64_t c = std::min<uint64_t>(k->chunk_rows, n_rows - pos);
+            KGWAS_HIP(hipMemcpy(k->d_stage, rows + pos * stride, c * stride * 8, hipMemcpyHostToDevice));
+            kin_feed(k, k->d_stage, c);
+        }
+    });
+}
+
+int kgwas_kinship_partials(kgwas_kinship* k, uint64_t* hamming, uint64_t* n_used) {
+    return guarded([&] {
+        if (!k || !hamming || !n_used) throw Error(KGWAS_ERR_ARG, "kgwas_kinship_partials: null argument");
+        KGWAS_HIP(hipSetDevice(k->device));
+        KGWAS_HIP(hipStreamSynchronize(k->stream));
+        std::vector<unsigned long long> H((size_t)k->S_pad * k->S_pad);
+        KGWAS_HIP(hipMemcpy(H.data(), k->d_H, H.size() * 8, hipMemcpyDeviceToHost));
+        unsigned long long n = 0;
+        KGWAS_HIP(hipMemcpy(&n, k->d_n, 8, hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < k->S_f; i++)
+            for (uint64_t j = 0; j < k->S_f; j++) hamming[i * k->S_f + j] = H[i * k->S_pad + j];
+        *n_used = n;
+    });
+}
+
+int kgwas_kinship_from_partials(uint64_t n_acc, const uint64_t* hamming, uint64_t n_used, uint64_t* K) {
+    return guarded([&] {
+        if (!hamming || !K) throw Error(KGWAS_ERR_ARG, "kgwas_kinship_from_partials: null argument");
+        for (uint64_t i = 0; i < n_acc; i++)
+            for (uint64_t j = 0; j < n_acc; j++)
+                K[i * n_acc + j] = (j < i) ? (n_used - hamming[i * n_acc + j]) : 0;  // lower triangle, as :430-432
+    });
+}
+
+int kgwas_kinship_get_stats(const kgwas_kinship* k, double* kernel_ms, uint64_t* launches, uint64_t* rows_fed) {
+    return guarded([&] {
+        if (!k) throw Error(KGWAS_ERR_ARG, "kgwas_kinship_get_stats: null");
+        if (kernel_ms) *kernel_ms = k->kernel_ms;
+        if (launches) *launches = k->launches;
+        if (rows_fed) *rows_fed = k->rows_fed;
+    });
+}
+
+void kgwas_kinship_destroy(kgwas_kinship* k) { delete k; }
+
+// ---- synthetic rows ---------------------------------------------------------------------------
+int kgwas_synth_rows_device(void* d_rows, uint64_t first_row, uint64_t n_rows, uint64_t n_acc, uint64_t seed,
+                            void* hip_stream) {
+    return guarded([&] {
+        if ((!d_rows && n_rows) || n_acc == 0) throw Error(KGWAS_ERR_ARG, "kgwas_synth_rows_device: bad argument");
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) throw Error(KGWAS_ERR_DEVICE, "no HIP device available");
+        KGWAS_HIP(launch_synth(reinterpret_cast<uint64_t*>(d_rows), first_row, n_rows, n_acc, seed, (hipStream_t)hip_stream));
+    });
+}
+
+int kgwas_synth_rows_host(uint64_t* rows, uint64_t first_row, uint64_t n_rows, uint64_t n_acc, uint64_t seed) {
+    return guarded([&] {
+        if ((!rows && n_rows) || n_acc == 0) throw Error(KGWAS_ERR_ARG, "kgwas_synth_rows_host: bad argument");
+        const uint64_t W = 1 + (n_acc + 63) / 64;
+        for (uint64_t r = 0; r < n_rows; r++)
+            for (uint32_t w = 0; w < W; w++) rows[r * W + w] = synth_word(seed, first_row + r, w, n_acc);
+    });
+}
+
+}  // extern "C"

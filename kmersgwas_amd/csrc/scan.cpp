@@ -1,0 +1,852 @@
+// scan.cpp — association-scan session: pass 1 of associate_kmers (src/associate_kmers.cpp:99-148)
+// re-designed around the GPU.
+//
+//   reference                                    here
+//   ---------------------------------------     -------------------------------------------------
+//   load_kmers: read, MAC filter, squeeze        rows stream from HBM in file layout; MAC predicate
+//   (serial, per-bit)                            and (only if the column map is not the identity
+//                                                prefix) a squeeze kernel, per device chunk
+//   one CTPL task per phenotype column           one kernel scores every (k-mer, column) pair of a
+//   scoring the batch (SSE) into its heap        chunk; only pairs that beat a stale heap minimum
+//                                                come back; the host replays them, in row order,
+//                                                through the same std::priority_queue
+//
+// Exactness argument (SURVEY.md §7 hard part 1): once a heap is full add_association is a
+// no-op unless score > lowest_score, and lowest_score never decreases. A row whose score is
+// <= ANY earlier value of lowest_score can therefore be dropped without changing the heap's
+// history. Until every heap is full the chunks run in dense mode (all scores come back).
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "common.h"
+#include "heap.h"
+#include "kernels.h"
+
+using namespace kgwas;
+
+namespace {
+
+// Minimal persistent worker pool: parallel_for over phenotype columns.
+class Pool {
+   public:
+    explicit Pool(unsigned n) : stop_(false), gen_(0), pending_(0), n_items_(0) {
+        if (n < 1) n = 1;
+        for (unsigned i = 1; i < n; i++) th_.emplace_back([this] { loop(); });
+    }
+    ~Pool() {
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            stop_ = true;
+            gen_++;
+        }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    void parallel_for(size_t n, const std::function<void(size_t)>& fn) {
+        if (n == 0) return;
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            fn_ = &fn;
+            n_items_ = n;
+            next_.store(0);
+            pending_ = th_.size();
+            gen_++;
+        }
+        cv_.notify_all();
+        run();
+        std::unique_lock<std::mutex> lk(mu_);
+        done_cv_.wait(lk, [this] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+
+   private:
+    void run() {
+        for (;;) {
+            size_t i = next_.fetch_add(1);
+            if (i >= n_items_) break;
+            (*fn_)(i);
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+            }
+            run();
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                if (--pending_ == 0) done_cv_.notify_all();
+            }
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_cv_;
+    bool stop_;
+    uint64_t gen_;
+    size_t pending_;
+    const std::function<void(size_t)>* fn_ = nullptr;
+    size_t n_items_;
+    std::atomic<size_t> next_{0};
+};
+
+struct History {
+    std::vector<uint64_t> kmer, row;
+    std::vector<double> score;
+};
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    void alloc(size_t count) {
+        release();
+        if (count) KGWAS_HIP(hipMalloc((void**)&p, count * sizeof(T)));
+        n = count;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    ~DevBuf() { release(); }
+};
+template <class T>
+struct PinBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    void alloc(size_t count) {
+        release();
+        if (count) KGWAS_HIP(hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocMapped));
+        n = count;
+    }
+    T* dev() const {
+        T* d = nullptr;
+        if (p) KGWAS_HIP(hipHostGetDevicePointer((void**)&d, p, 0));
+        return d;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    ~PinBuf() { release(); }
+};
+
+struct Slot {
+    PinBuf<Cand> cand;  // written by the GPU straight into mapped host memory
+    Cand* d_cand = nullptr;
+    DevBuf<uint32_t> d_cnt;
+    PinBuf<uint32_t> h_cnt;
+    DevBuf<unsigned long long> d_tested;
+    PinBuf<unsigned long long> h_tested;
+    hipEvent_t ev_sq0 = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_done = nullptr;
+    const uint64_t* rows = nullptr;
+    uint64_t first_row = 0, n_rows = 0;
+    bool squeezed = false, busy = false;
+};
+
+}  // namespace
+
+struct kgwas_scan {
+    int device = 0;
+    uint64_t S_f = 0, S = 0, W_f = 0, W_m = 0, L = 0, n_pheno = 0, min_count = 0;
+    std::vector<uint64_t> col, topn;
+    std::vector<float> Y;
+    bool direct = false;
+    uint32_t kernel_used = 0;
+    bool record_history = false;
+    uint64_t chunk_max = 0, dense_rows = 0;
+    uint32_t cap = 0;
+    uint64_t max_topn = 0;
+
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_user = nullptr, ev_ds = nullptr, ev_d0 = nullptr, ev_d1 = nullptr;  // caller sync + dense-chunk timing
+    DevBuf<uint32_t> d_dmask, d_colmap, d_sq;
+    DevBuf<float> d_Yperm, d_Ymfma, d_sums;
+    DevBuf<double> d_thr;
+    PinBuf<double> h_thr;  // two halves, alternated, so an in-flight upload is never overwritten
+    uint32_t thr_flip = 0;
+    Slot slot[2];
+    // dense mode
+    DevBuf<double> d_dense;
+    DevBuf<uint32_t> d_n1;
+    DevBuf<uint64_t> d_kmer;
+    PinBuf<double> h_dense;
+    PinBuf<uint32_t> h_n1;
+    PinBuf<uint64_t> h_kmer;
+    DevBuf<unsigned long long> d_tested_dense;
+    // host feed staging
+    DevBuf<uint64_t> d_stage;
+
+    std::vector<BestHeap> heaps;
+    std::vector<History> hist;
+    bool all_full = false;
+    uint64_t rows_done = 0;  // rows whose replay is complete
+    std::unique_ptr<Pool> pool;
+    kgwas_scan_stats st{};
+    bool finished = false;
+    std::vector<std::vector<uint64_t>> res_kmer, res_row;
+    std::vector<std::vector<double>> res_score;
+
+    ~kgwas_scan() {
+        (void)hipSetDevice(device);
+        for (auto& s : slot) {
+            if (s.ev_sq0) (void)hipEventDestroy(s.ev_sq0);
+            if (s.ev_k0) (void)hipEventDestroy(s.ev_k0);
+            if (s.ev_k1) (void)hipEventDestroy(s.ev_k1);
+            if (s.ev_done) (void)hipEventDestroy(s.ev_done);
+        }
+        if (ev_user) (void)hipEventDestroy(ev_user);
+        if (ev_ds) (void)hipEventDestroy(ev_ds);
+        if (ev_d0) (void)hipEventDestroy(ev_d0);
+        if (ev_d1) (void)hipEventDestroy(ev_d1);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+void fill_args(kgwas_scan* s, ScoreArgs& a, const uint64_t* d_rows, uint64_t n_rows, uint64_t first_row,
+               bool squeezed) {
+    memset(&a, 0, sizeof(a));
+    if (squeezed) {
+        a.src.base = s->d_sq.p;
+        a.src.stride_dw = 2 * s->W_m;
+        a.src.off_dw = 0;
+        a.src.avail_dw = (uint32_t)(2 * s->W_m);
+    } else {
+        a.src.base = reinterpret_cast<const uint32_t*>(d_rows);
+        a.src.stride_dw = 2 * (1 + s->W_f);
+        a.src.off_dw = 2;
+        a.src.avail_dw = (uint32_t)(2 * s->W_f);
+    }
+    a.dmask = s->d_dmask.p;
+    a.file_rows = d_rows;
+    a.file_stride_w = 1 + s->W_f;
+    a.n_rows = n_rows;
+    a.first_row = first_row;
+    a.S = (uint32_t)s->S;
+    a.W_m = (uint32_t)s->W_m;
+    a.n_pheno = (uint32_t)s->n_pheno;
+    a.min_count = (uint32_t)std::min<uint64_t>(s->min_count, 0xFFFFFFFFull);
+    a.Yperm = s->d_Yperm.p;
+    a.Ymfma = s->d_Ymfma.p;
+    a.sums = s->d_sums.p;
+    a.thr = s->d_thr.p;
+}
+
+uint32_t pick_rows_per_block(uint64_t n_rows, uint64_t n_ctiles) {
+    for (uint32_t rpb : {1024u, 512u, 256u}) {
+        const uint64_t blocks = ((n_rows + rpb - 1) / rpb) * n_ctiles;
+        if (blocks >= 1024) return rpb;
+    }
+    return 128u;
+}
+
+void launch_score(kgwas_scan* s, const ScoreArgs& a) {
+    if (s->kernel_used == KGWAS_KERNEL_MFMA) {
+        const uint64_t nct = (s->n_pheno + 15) / 16;
+        KGWAS_HIP(launch_score_mfma(a, pick_rows_per_block(a.n_rows, nct), s->stream));
+    } else {
+        KGWAS_HIP(launch_score_valu(a, s->stream));
+    }
+    s->st.score_launches++;
+}
+
+void maybe_squeeze(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows) {
+    if (s->direct) return;
+    KGWAS_HIP(launch_squeeze(d_rows, 1 + s->W_f, n_rows, s->d_colmap.p, (uint32_t)s->W_m, (uint32_t)s->W_f, s->d_sq.p,
+                             s->stream));
+}
+
+void upload_thresholds(kgwas_scan* s) {
+    double* h = s->h_thr.p + (s->thr_flip & 1u) * s->n_pheno;
+    s->thr_flip++;
+    for (uint64_t j = 0; j < s->n_pheno; j++) h[j] = s->heaps[j].lowest();
+    KGWAS_HIP(hipMemcpyAsync(s->d_thr.p, h, s->n_pheno * sizeof(double), hipMemcpyHostToDevice, s->stream));
+}
+
+void refresh_full(kgwas_scan* s) {
+    bool all = true;
+    for (auto& h : s->heaps) all = all && h.full();
+    s->all_full = all;
+}
+
+// Dense chunk: every score comes back; replay every kept row into every heap.
+void run_dense(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, uint64_t first_row, double* out_scores,
+               uint32_t* out_n1, bool replay) {
+    ScoreArgs a;
+    hipEvent_t e0 = s->ev_d0, e1 = s->ev_d1, es = s->ev_ds;
+    fill_args(s, a, d_rows, n_rows, first_row, !s->direct);
+    a.dense = s->d_dense.p;
+    a.n1_out = s->d_n1.p;
+    a.kmer_out = s->d_kmer.p;
+    a.tested = s->d_tested_dense.p;
+    KGWAS_HIP(hipMemsetAsync(s->d_tested_dense.p, 0, sizeof(unsigned long long), s->stream));
+    KGWAS_HIP(hipEventRecord(es, s->stream));
+    maybe_squeeze(s, d_rows, n_rows);
+    KGWAS_HIP(hipEventRecord(e0, s->stream));
+    launch_score(s, a);
+    KGWAS_HIP(hipEventRecord(e1, s->stream));
+    KGWAS_HIP(hipMemcpyAsync(s->h_dense.p, s->d_dense.p, s->n_pheno * n_rows * sizeof(double), hipMemcpyDeviceToHost,
+                             s->stream));
+    KGWAS_HIP(hipMemcpyAsync(s->h_n1.p, s->d_n1.p, n_rows * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    KGWAS_HIP(hipMemcpyAsync(s->h_kmer.p, s->d_kmer.p, n_rows * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream));
+    KGWAS_HIP(hipStreamSynchronize(s->stream));
+    float ms = 0;
+    KGWAS_HIP(hipEventElapsedTime(&ms, e0, e1));
+    s->st.score_kernel_ms += ms;
+    if (!s->direct) {
+        KGWAS_HIP(hipEventElapsedTime(&ms, es, e0));
+        s->st.squeeze_kernel_ms += ms;
+    }
+    s->st.chunks++;
+    if (out_scores) memcpy(out_scores, s->h_dense.p, s->n_pheno * n_rows * sizeof(double));
+    if (out_n1) memcpy(out_n1, s->h_n1.p, n_rows * sizeof(uint32_t));
+    if (!replay) return;
+
+    auto t0 = std::chrono::steady_clock::now();
+    const uint64_t S = s->S, mc = s->min_count;
+    uint64_t kept = 0;
+    for (uint64_t r = 0; r < n_rows; r++) {
+        const uint64_t n1 = s->h_n1.p[r];
+        if (S >= mc && n1 >= mc && n1 <= S - mc) kept++;
+    }
+    s->st.rows_tested += kept;
+    s->st.candidates += kept * s->n_pheno;
+    std::atomic<uint64_t> pushes(0);
+    s->pool->parallel_for(s->n_pheno, [&](size_t j) {
+        BestHeap& h = s->heaps[j];
+        const double* sc = s->h_dense.p + j * n_rows;
+        uint64_t local = 0;
+        for (uint64_t r = 0; r < n_rows; r++) {
+            const uint64_t n1 = s->h_n1.p[r];
+            if (!(S >= mc && n1 >= mc && n1 <= S - mc)) continue;
+            if (h.add(s->h_kmer.p[r], sc[r], (size_t)(first_row + r))) {
+                local++;
+                if (s->record_history) {
+                    s->hist[j].kmer.push_back(s->h_kmer.p[r]);
+                    s->hist[j].score.push_back(sc[r]);
+                    s->hist[j].row.push_back(first_row + r);
+                }
+            }
+        }
+        pushes += local;
+    });
+    s->st.heap_pushes += pushes.load();
+    s->st.replay_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    s->rows_done += n_rows;
+    refresh_full(s);
+    upload_thresholds(s);
+}
+
+void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_rows, uint64_t first_row) {
+    ScoreArgs a;
+    fill_args(s, a, d_rows, n_rows, first_row, !s->direct);
+    a.cand = sl.d_cand;
+    a.cand_cnt = sl.d_cnt.p;
+    a.cap = s->cap;
+    a.tested = sl.d_tested.p;
+    KGWAS_HIP(hipMemsetAsync(sl.d_cnt.p, 0, s->n_pheno * sizeof(uint32_t), s->stream));
+    KGWAS_HIP(hipMemsetAsync(sl.d_tested.p, 0, sizeof(unsigned long long), s->stream));
+    KGWAS_HIP(hipEventRecord(sl.ev_sq0, s->stream));
+    maybe_squeeze(s, d_rows, n_rows);
+    KGWAS_HIP(hipEventRecord(sl.ev_k0, s->stream));
+    launch_score(s, a);
+    KGWAS_HIP(hipEventRecord(sl.ev_k1, s->stream));
+    KGWAS_HIP(hipMemcpyAsync(sl.h_cnt.p, sl.d_cnt.p, s->n_pheno * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    KGWAS_HIP(hipMemcpyAsync(sl.h_tested.p, sl.d_tested.p, sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                             s->stream));
+    KGWAS_HIP(hipEventRecord(sl.ev_done, s->stream));
+    sl.rows = d_rows;
+    sl.first_row = first_row;
+    sl.n_rows = n_rows;
+    sl.busy = true;
+    s->st.chunks++;
+}
+
+void process_range_sync(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_rows, uint64_t first_row);
+
+// Wait for a submitted sparse chunk, replay its candidates in row order, refresh thresholds.
+// Returns false if a candidate list overflowed (nothing was replayed).
+bool reap_sparse(kgwas_scan* s, Slot& sl) {
+    KGWAS_HIP(hipEventSynchronize(sl.ev_done));  // kernel done (mapped candidate writes visible) + counts copied
+    sl.busy = false;
+    float ms = 0;
+    KGWAS_HIP(hipEventElapsedTime(&ms, sl.ev_k0, sl.ev_k1));
+    s->st.score_kernel_ms += ms;
+    if (!s->direct) {
+        KGWAS_HIP(hipEventElapsedTime(&ms, sl.ev_sq0, sl.ev_k0));
+        s->st.squeeze_kernel_ms += ms;
+    }
+    for (uint64_t j = 0; j < s->n_pheno; j++)
+        if (sl.h_cnt.p[j] > s->cap) return false;
+
+    auto t0 = std::chrono::steady_clock::now();
+    s->st.rows_tested += *sl.h_tested.p;
+    std::atomic<uint64_t> pushes(0), cands(0);
+    s->pool->parallel_for(s->n_pheno, [&](size_t j) {
+        const uint32_t n = sl.h_cnt.p[j];
+        if (!n) return;
+        Cand* c = sl.cand.p + j * (uint64_t)s->cap;
+        std::sort(c, c + n, [](const Cand& x, const Cand& y) { return x.row < y.row; });
+        BestHeap& h = s->heaps[j];
+        uint64_t local = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            if (h.add(c[i].kmer, c[i].score, (size_t)c[i].row)) {
+                local++;
+                if (s->record_history) {
+                    s->hist[j].kmer.push_back(c[i].kmer);
+                    s->hist[j].score.push_back(c[i].score);
+                    s->hist[j].row.push_back(c[i].row);
+                }
+            }
+        }
+        pushes += local;
+        cands += n;
+    });
+    s->st.heap_pushes += pushes.load();
+    s->st.candidates += cands.load();
+    s->st.replay_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    s->rows_done += sl.n_rows;
+    upload_thresholds(s);
+    return true;
+}
+
+// Synchronous processing of a row range (overflow recovery): halve until the lists fit,
+// fall back to dense chunks for very small ranges.
+void process_range_sync(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_rows, uint64_t first_row) {
+    const uint64_t stride = 1 + s->W_f;
+    if (n_rows <= s->dense_rows) {
+        run_dense(s, d_rows, n_rows, first_row, nullptr, nullptr, true);
+        return;
+    }
+    submit_sparse(s, sl, d_rows, n_rows, first_row);
+    if (reap_sparse(s, sl)) return;
+    const uint64_t half = n_rows / 2;
+    process_range_sync(s, sl, d_rows, half, first_row);
+    process_range_sync(s, sl, d_rows + half * stride, n_rows - half, first_row + half);
+}
+
+uint64_t next_sparse_chunk(const kgwas_scan* s) {
+    // Expected candidates per column for a chunk of c rows against thresholds that reflect
+    // rows_done rows: about topn * c / rows_done. Keep that under cap / 4.
+    const double m = (double)std::max<uint64_t>(s->rows_done, 1);
+    double c = m * (double)s->cap / (4.0 * (double)std::max<uint64_t>(s->max_topn, 1));
+    uint64_t ci = (uint64_t)std::min<double>(c, (double)s->chunk_max);
+    ci = std::max<uint64_t>(ci, std::min<uint64_t>(s->dense_rows, s->chunk_max));
+    ci = std::min<uint64_t>(ci, s->chunk_max);
+    return (ci + 127) / 128 * 128;
+}
+
+void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, uint64_t first_row) {
+    const uint64_t stride = 1 + s->W_f;
+    uint64_t pos = 0;
+    int pending = -1, k = 0;
+    auto drain = [&]() {
+        if (pending < 0) return;
+        Slot& sl = s->slot[pending];
+        pending = -1;
+        if (!reap_sparse(s, sl)) {
+            KGWAS_HIP(hipStreamSynchronize(s->stream));
+            process_range_sync(s, sl, sl.rows, sl.n_rows, sl.first_row);
+        }
+    };
+    while (pos < n_rows) {
+        if (!s->all_full) {
+            drain();
+            const uint64_t c = std::min<uint64_t>(s->dense_rows, n_rows - pos);
+            run_dense(s, d_rows + pos * stride, c, first_row + pos, nullptr, nullptr, true);
+            pos += c;
+            continue;
+        }
+        const uint64_t c = std::min<uint64_t>(next_sparse_chunk(s), n_rows - pos);
+        if (!s->direct && pending >= 0) drain();  // the squeeze buffer is single: no overlap in squeezed mode
+        Slot& sl = s->slot[k & 1];
+        submit_sparse(s, sl, d_rows + pos * stride, c, first_row + pos);
+        const int mine = k & 1;
+        k++;
+        pos += c;
+        if (pending >= 0) {
+            // reap the older chunk while the one just submitted runs
+            Slot& old = s->slot[pending];
+            pending = -1;
+            if (!reap_sparse(s, old)) {
+                // overflow: let the newer chunk finish, redo the older range synchronously, then
+                // the newer one is reaped in order below.
+                KGWAS_HIP(hipStreamSynchronize(s->stream));
+                Slot& spare = old;
+                process_range_sync(s, spare, old.rows, old.n_rows, old.first_row);
+            }
+        }
+        pending = mine;
+    }
+    drain();
+    s->st.rows_fed += n_rows;
+}
+
+void check_device(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        throw Error(KGWAS_ERR_DEVICE,
+                    "no HIP device available: libkgwas has no CPU fallback (hipGetDeviceCount: " +
+                        std::string(e == hipSuccess ? "0 devices" : hipGetErrorString(e)) + ")");
+    if (device < 0 || device >= n) throw Error(KGWAS_ERR_ARG, "device ordinal out of range");
+}
+
+}  // namespace
+
+extern "C" {
+
+int kgwas_device_count(int* n_devices) {
+    return guarded([&] {
+        if (!n_devices) throw Error(KGWAS_ERR_ARG, "null argument");
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        *n_devices = (e == hipSuccess) ? n : 0;
+    });
+}
+
+int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
+    return guarded([&] {
+        if (!p || !out) throw Error(KGWAS_ERR_ARG, "kgwas_scan_create: null argument");
+        if (p->struct_size != sizeof(kgwas_scan_params)) throw Error(KGWAS_ERR_ARG, "kgwas_scan_params: size mismatch");
+        if (!p->col || !p->Y || !p->topn || p->n_acc == 0 || p->n_pheno == 0 || p->n_acc_file == 0)
+            throw Error(KGWAS_ERR_ARG, "kgwas_scan_create: empty problem");
+        if (p->n_acc > p->n_acc_file) throw Error(KGWAS_ERR_ARG, "more phenotyped accessions than table columns");
+        if (p->n_acc_file >= (1ull << 31)) throw Error(KGWAS_ERR_ARG, "too many accessions");
+        check_device(p->device);
+        KGWAS_HIP(hipSetDevice(p->device));
+        std::unique_ptr<kgwas_scan> s(new kgwas_scan);
+        s->device = p->device;
+        s->S_f = p->n_acc_file;
+        s->S = p->n_acc;
+        s->W_f = (s->S_f + 63) / 64;
+        s->W_m = 2 * ((s->S + 127) / 128);  // src/kmers_multiple_databases.cpp:51
+        s->L = 64 * s->W_m;
+        s->n_pheno = p->n_pheno;
+        s->min_count = p->min_count;
+        s->col.assign(p->col, p->col + s->S);
+        s->topn.assign(p->topn, p->topn + s->n_pheno);
+        s->Y.assign(p->Y, p->Y + s->n_pheno * s->S);
+        s->record_history = p->record_history != 0;
+        std::vector<bool> seen(s->S_f, false);
+        for (uint64_t i = 0; i < s->S; i++) {
+            if (s->col[i] >= s->S_f) throw Error(KGWAS_ERR_ARG, "column index out of range");
+            if (seen[s->col[i]]) throw Error(KGWAS_ERR_ARG, "duplicate column index");
+            seen[s->col[i]] = true;
+        }
+        for (uint64_t j = 0; j < s->n_pheno; j++) {
+            if (s->topn[j] == 0) throw Error(KGWAS_ERR_ARG, "heap size must be >= 1");
+            s->max_topn = std::max(s->max_topn, s->topn[j]);
+        }
+        s->direct = true;
+        for (uint64_t i = 0; i < s->S; i++) s->direct = s->direct && (s->col[i] == i);
+
+        bool finite = true;
+        for (float v : s->Y) finite = finite && std::isfinite(v);
+        uint32_t kern = p->kernel;
+        const bool mfma_fits = mfma_lds_bytes((uint32_t)s->W_m) <= 160u * 1024u;
+        if (kern == KGWAS_KERNEL_AUTO) kern = (s->n_pheno >= 4 && finite && mfma_fits) ? KGWAS_KERNEL_MFMA : KGWAS_KERNEL_VALU;
+        if (kern == KGWAS_KERNEL_MFMA && !mfma_fits)
+            throw Error(KGWAS_ERR_ARG, "MFMA scorer: phenotype tile does not fit LDS for this many accessions");
+        if (kern == KGWAS_KERNEL_MFMA && !finite)
+            throw Error(KGWAS_ERR_ARG, "MFMA scorer needs finite phenotype values (0*inf); use the VALU scorer");
+        if (kern != KGWAS_KERNEL_MFMA && kern != KGWAS_KERNEL_VALU) throw Error(KGWAS_ERR_ARG, "unknown kernel id");
+        s->kernel_used = kern;
+
+        s->chunk_max = p->chunk_rows ? p->chunk_rows : (4ull << 20);
+        s->chunk_max = std::max<uint64_t>(128, (s->chunk_max + 127) / 128 * 128);
+        s->dense_rows = std::min<uint64_t>(16384, s->chunk_max);
+        const uint64_t budget = 4ull << 20;  // candidate records per slot
+        uint64_t cap = std::min<uint64_t>(2 * s->max_topn + 4096, std::max<uint64_t>(budget / s->n_pheno, 1024));
+        s->cap = (uint32_t)std::min<uint64_t>(cap, 0x7FFFFFFFull);
+
+        KGWAS_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+        KGWAS_HIP(hipEventCreate(&s->ev_user));
+        KGWAS_HIP(hipEventCreate(&s->ev_ds));
+        KGWAS_HIP(hipEventCreate(&s->ev_d0));
+        KGWAS_HIP(hipEventCreate(&s->ev_d1));
+
+        // ---- constant device data --------------------------------------------------------
+        const uint64_t S = s->S, L = s->L, W_m = s->W_m, P = s->n_pheno;
+        std::vector<uint32_t> dmask(2 * W_m, 0), colmap(L, 0xFFFFFFFFu);
+        for (uint64_t d = 0; d < 2 * W_m; d++) {
+            if (!s->direct)
+                dmask[d] = 0xFFFFFFFFu;
+            else if (32 * d + 32 <= S)
+                dmask[d] = 0xFFFFFFFFu;
+            else if (32 * d < S)
+                dmask[d] = (1u << (S - 32 * d)) - 1u;
+        }
+        for (uint64_t i = 0; i < S; i++) colmap[i] = (uint32_t)s->col[i];
+        const uint64_t P4 = (P + 3) / 4 * 4, nct = (P + 15) / 16;
+        std::vector<float> Yperm(P4 * L, 0.0f), Ymfma(nct * L * 16, 0.0f), sums(P, 0.0f);
+        std::vector<float> V(L);
+        for (uint64_t j = 0; j < P; j++) {
+            std::fill(V.begin(), V.end(), 0.0f);
+            for (uint64_t i = 0; i < S; i++) V[i] = s->Y[j * S + i];
+            float* R = &Yperm[j * L];
+            // permute_scores (src/kmer_general.cpp:155-167): R[128b+4s+l] = V[128b+32l+31-s]
+            for (uint64_t b = 0; b < L / 128; b++)
+                for (uint64_t sx = 0; sx < 32; sx++)
+                    for (uint64_t l = 0; l < 4; l++) R[128 * b + 4 * sx + l] = V[128 * b + 32 * l + 31 - sx];
+            // update_scores_and_sum (src/kmers_multiple_databases.cpp:288-295): sequential float32 sum
+            volatile float sum = 0.0f;
+            for (uint64_t i = 0; i < L; i++) sum = sum + R[i];
+            sums[j] = sum;
+            // MFMA layout: [ct][(b*4+l)*32+s][n] = V[128b+32l+31-s]
+            const uint64_t ct = j / 16, n = j % 16;
+            for (uint64_t b = 0; b < L / 128; b++)
+                for (uint64_t l = 0; l < 4; l++)
+                    for (uint64_t sx = 0; sx < 32; sx++)
+                        Ymfma[(ct * L + (b * 4 + l) * 32 + sx) * 16 + n] = V[128 * b + 32 * l + 31 - sx];
+        }
+        s->d_dmask.alloc(dmask.size());
+        s->d_colmap.alloc(colmap.size());
+        s->d_sums.alloc(P);
+        s->d_thr.alloc(P);
+        s->h_thr.alloc(2 * P);
+        KGWAS_HIP(hipMemcpy(s->d_dmask.p, dmask.data(), dmask.size() * 4, hipMemcpyHostToDevice));
+        KGWAS_HIP(hipMemcpy(s->d_colmap.p, colmap.data(), colmap.size() * 4, hipMemcpyHostToDevice));
+        KGWAS_HIP(hipMemcpy(s->d_sums.p, sums.data(), P * 4, hipMemcpyHostToDevice));
+        if (kern == KGWAS_KERNEL_MFMA) {
+            s->d_Ymfma.alloc(Ymfma.size());
+            KGWAS_HIP(hipMemcpy(s->d_Ymfma.p, Ymfma.data(), Ymfma.size() * 4, hipMemcpyHostToDevice));
+        } else {
+            s->d_Yperm.alloc(Yperm.size());
+            KGWAS_HIP(hipMemcpy(s->d_Yperm.p, Yperm.data(), Yperm.size() * 4, hipMemcpyHostToDevice));
+        }
+        if (!s->direct) s->d_sq.alloc(s->chunk_max * 2 * W_m);
+
+        for (auto& sl : s->slot) {
+            sl.cand.alloc((uint64_t)s->cap * P);
+            sl.d_cand = sl.cand.dev();
+            sl.d_cnt.alloc(P);
+            sl.h_cnt.alloc(P);
+            sl.d_tested.alloc(1);
+            sl.h_tested.alloc(1);
+            KGWAS_HIP(hipEventCreate(&sl.ev_sq0));
+            KGWAS_HIP(hipEventCreate(&sl.ev_k0));
+            KGWAS_HIP(hipEventCreate(&sl.ev_k1));
+            KGWAS_HIP(hipEventCreate(&sl.ev_done));
+        }
+        s->d_dense.alloc(P * s->dense_rows);
+        s->h_dense.alloc(P * s->dense_rows);
+        s->d_n1.alloc(s->dense_rows);
+        s->h_n1.alloc(s->dense_rows);
+        s->d_kmer.alloc(s->dense_rows);
+        s->h_kmer.alloc(s->dense_rows);
+        s->d_tested_dense.alloc(1);
+
+        for (uint64_t j = 0; j < P; j++) s->heaps.emplace_back((size_t)s->topn[j]);
+        s->hist.resize(P);
+        unsigned nt = p->host_threads ? p->host_threads : std::max(1u, std::thread::hardware_concurrency());
+        nt = (unsigned)std::min<uint64_t>(nt, P);
+        s->pool.reset(new Pool(nt));
+        s->st.kernel_used = kern;
+        s->st.direct_mode = s->direct ? 1 : 0;
+        *out = s.release();
+    });
+}
+
+int kgwas_scan_feed_device(kgwas_scan* s, const void* d_rows, uint64_t n_rows, uint64_t first_row, void* hip_stream) {
+    return guarded([&] {
+        if (!s || (!d_rows && n_rows)) throw Error(KGWAS_ERR_ARG, "kgwas_scan_feed_device: null argument");
+        if (s->finished) throw Error(KGWAS_ERR_STATE, "scan already finished");
+        KGWAS_HIP(hipSetDevice(s->device));
+        // order our stream after whatever the caller queued on theirs (e.g. the generator kernel)
+        KGWAS_HIP(hipEventRecord(s->ev_user, (hipStream_t)hip_stream));
+        KGWAS_HIP(hipStreamWaitEvent(s->stream, s->ev_user, 0));
+        feed_device_impl(s, reinterpret_cast<const uint64_t*>(d_rows), n_rows, first_row);
+    });
+}
+
+int kgwas_scan_feed_host(kgwas_scan* s, const uint64_t* rows, uint64_t n_rows, uint64_t first_row) {
+    return guarded([&] {
+        if (!s || (!rows && n_rows)) throw Error(KGWAS_ERR_ARG, "kgwas_scan_feed_host: null argument");
+        if (s->finished) throw Error(KGWAS_ERR_STATE, "scan already finished");
+        KGWAS_HIP(hipSetDevice(s->device));
+        const uint64_t stride = 1 + s->W_f;
+        const uint64_t piece = s->chunk_max;
+        if (s->d_stage.n < piece * stride) s->d_stage.alloc(piece * stride);
+        for (uint64_t pos = 0; pos < n_rows; pos += piece) {
+            const uint64_t c = std::min<uint64_t>(piece, n_rows - pos);
+            KGWAS_HIP(hipMemcpyAsync(s->d_stage.p, rows + pos * stride, c * stride * 8, hipMemcpyHostToDevice, s->stream));
+            KGWAS_HIP(hipStreamSynchronize(s->stream));
+            feed_device_impl(s, s->d_stage.p, c, first_row + pos);
+        }
+    });
+}
+
+int kgwas_scan_finish(kgwas_scan* s) {
+    return guarded([&] {
+        if (!s) throw Error(KGWAS_ERR_ARG, "kgwas_scan_finish: null");
+        if (s->finished) return;
+        KGWAS_HIP(hipSetDevice(s->device));
+        KGWAS_HIP(hipStreamSynchronize(s->stream));
+        s->res_kmer.resize(s->n_pheno);
+        s->res_row.resize(s->n_pheno);
+        s->res_score.resize(s->n_pheno);
+        s->pool->parallel_for(s->n_pheno,
+                              [&](size_t j) { s->heaps[j].pop_all(s->res_kmer[j], s->res_score[j], s->res_row[j]); });
+        s->finished = true;
+    });
+}
+
+int kgwas_scan_result(kgwas_scan* s, uint64_t j, uint64_t* n, const uint64_t** kmer, const double** score,
+                      const uint64_t** row) {
+    return guarded([&] {
+        if (!s || j >= s->n_pheno) throw Error(KGWAS_ERR_ARG, "kgwas_scan_result: bad argument");
+        if (!s->finished) throw Error(KGWAS_ERR_STATE, "call kgwas_scan_finish first");
+        if (n) *n = s->res_kmer[j].size();
+        if (kmer) *kmer = s->res_kmer[j].data();
+        if (score) *score = s->res_score[j].data();
+        if (row) *row = s->res_row[j].data();
+    });
+}
+
+int kgwas_scan_history(kgwas_scan* s, uint64_t j, uint64_t* n, const uint64_t** kmer, const double** score,
+                       const uint64_t** row) {
+    return guarded([&] {
+        if (!s || j >= s->n_pheno) throw Error(KGWAS_ERR_ARG, "kgwas_scan_history: bad argument");
+        if (!s->record_history) throw Error(KGWAS_ERR_STATE, "scan was created without record_history");
+        if (n) *n = s->hist[j].kmer.size();
+        if (kmer) *kmer = s->hist[j].kmer.data();
+        if (score) *score = s->hist[j].score.data();
+        if (row) *row = s->hist[j].row.data();
+    });
+}
+
+int kgwas_scan_get_stats(const kgwas_scan* s, kgwas_scan_stats* st) {
+    return guarded([&] {
+        if (!s || !st) throw Error(KGWAS_ERR_ARG, "kgwas_scan_get_stats: null");
+        *st = s->st;
+    });
+}
+
+void kgwas_scan_destroy(kgwas_scan* s) { delete s; }
+
+int kgwas_scan_scores_dense(kgwas_scan* s, const void* rows, int rows_on_device, uint64_t n_rows, double* scores,
+                            uint32_t* popcnt) {
+    return guarded([&] {
+        if (!s || (!rows && n_rows) || !scores || !popcnt) throw Error(KGWAS_ERR_ARG, "kgwas_scan_scores_dense: null argument");
+        KGWAS_HIP(hipSetDevice(s->device));
+        const uint64_t stride = 1 + s->W_f;
+        const uint64_t piece = s->dense_rows;
+        if (!rows_on_device && s->d_stage.n < piece * stride) s->d_stage.alloc(std::max<uint64_t>(piece, s->chunk_max) * stride);
+        std::vector<double> tmp(s->n_pheno * piece);
+        for (uint64_t pos = 0; pos < n_rows; pos += piece) {
+            const uint64_t c = std::min<uint64_t>(piece, n_rows - pos);
+            const uint64_t* d_rows;
+            if (rows_on_device) {
+                d_rows = reinterpret_cast<const uint64_t*>(rows) + pos * stride;
+            } else {
+                KGWAS_HIP(hipMemcpy(s->d_stage.p, reinterpret_cast<const uint64_t*>(rows) + pos * stride, c * stride * 8,
+                                    hipMemcpyHostToDevice));
+                d_rows = s->d_stage.p;
+            }
+            run_dense(s, d_rows, c, pos, tmp.data(), popcnt + pos, false);
+            for (uint64_t j = 0; j < s->n_pheno; j++)
+                memcpy(scores + j * n_rows + pos, tmp.data() + j * c, c * sizeof(double));
+        }
+    });
+}
+
+// ---- BestAssociationsHeap through the C ABI -------------------------------------------------
+struct kgwas_heap {
+    BestHeap h;
+    explicit kgwas_heap(size_t n) : h(n) {}
+};
+
+int kgwas_heap_new(uint64_t max_results, kgwas_heap** out) {
+    return guarded([&] {
+        if (!out || max_results == 0) throw Error(KGWAS_ERR_ARG, "kgwas_heap_new: bad argument");
+        *out = new kgwas_heap((size_t)max_results);
+    });
+}
+int kgwas_heap_add_many(kgwas_heap* h, const uint64_t* kmer, const double* score, const uint64_t* row, uint64_t n) {
+    return guarded([&] {
+        if (!h || (n && (!kmer || !score || !row))) throw Error(KGWAS_ERR_ARG, "kgwas_heap_add_many: null argument");
+        for (uint64_t i = 0; i < n; i++) h->h.add(kmer[i], score[i], (size_t)row[i]);
+    });
+}
+int kgwas_heap_size(const kgwas_heap* h, uint64_t* size, uint64_t* insertions, double* lowest) {
+    return guarded([&] {
+        if (!h) throw Error(KGWAS_ERR_ARG, "kgwas_heap_size: null");
+        if (size) *size = h->h.size();
+        if (insertions) *insertions = h->h.inserted();
+        if (lowest) *lowest = h->h.lowest();
+    });
+}
+int kgwas_heap_pop_all(const kgwas_heap* h, uint64_t* kmer, double* score, uint64_t* row) {
+    return guarded([&] {
+        if (!h) throw Error(KGWAS_ERR_ARG, "kgwas_heap_pop_all: null");
+        std::vector<uint64_t> k, r;
+        std::vector<double> sc;
+        h->h.pop_all(k, sc, r);
+        if (kmer) memcpy(kmer, k.data(), k.size() * 8);
+        if (score) memcpy(score, sc.data(), sc.size() * 8);
+        if (row) memcpy(row, r.data(), r.size() * 8);
+    });
+}
+int kgwas_heap_output_list(const kgwas_heap* h, uint64_t* kmer, uint64_t* rank, uint64_t* row) {
+    return guarded([&] {
+        if (!h || !kmer || !rank || !row) throw Error(KGWAS_ERR_ARG, "kgwas_heap_output_list: null");
+        std::vector<uint64_t> k, r;
+        std::vector<double> sc;
+        h->h.pop_all(k, sc, r);
+        const size_t n = k.size();
+        std::vector<size_t> idx(n);
+        for (size_t i = 0; i < n; i++) idx[i] = i;
+        std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return r[a] < r[b]; });
+        for (size_t i = 0; i < n; i++) {
+            kmer[i] = k[idx[i]];
+            rank[i] = n - idx[i];
+            row[i] = r[idx[i]];
+        }
+    });
+}
+void kgwas_heap_free(kgwas_heap* h) { delete h; }
+
+int kgwas_merge_shards(uint64_t n_pheno, const uint64_t* topn, uint64_t n_shards, const uint64_t* counts,
+                       const uint64_t* const* kmer, const double* const* score, const uint64_t* const* row,
+                       uint32_t threads, kgwas_heap** out_heaps) {
+    return guarded([&] {
+        if (!topn || !counts || !kmer || !score || !row || !out_heaps) throw Error(KGWAS_ERR_ARG, "kgwas_merge_shards: null");
+        for (uint64_t j = 0; j < n_pheno; j++) {
+            if (topn[j] == 0) throw Error(KGWAS_ERR_ARG, "heap size must be >= 1");
+            out_heaps[j] = new kgwas_heap((size_t)topn[j]);
+        }
+        std::vector<std::vector<uint64_t>> off(n_shards, std::vector<uint64_t>(n_pheno + 1, 0));
+        for (uint64_t g = 0; g < n_shards; g++)
+            for (uint64_t j = 0; j < n_pheno; j++) off[g][j + 1] = off[g][j] + counts[g * n_pheno + j];
+        unsigned nt = threads ? threads : std::max(1u, std::thread::hardware_concurrency());
+        nt = (unsigned)std::min<uint64_t>(nt, n_pheno);
+        Pool pool(nt);
+        pool.parallel_for(n_pheno, [&](size_t j) {
+            BestHeap& h = out_heaps[j]->h;
+            for (uint64_t g = 0; g < n_shards; g++) {  // shards in row order
+                const uint64_t o = off[g][j], n = counts[g * n_pheno + j];
+                for (uint64_t i = 0; i < n; i++) h.add(kmer[g][o + i], score[g][o + i], (size_t)row[g][o + i]);
+            }
+        });
+    });
+}
+
+}  // extern "C"

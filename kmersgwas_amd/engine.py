@@ -1,0 +1,311 @@
+"""Host-side mirror of the reference's interface for the association-scan path, over the C ABI.
+
+Names follow the reference's classes (src/kmers_multiple_databases.h, src/best_associations_heap.h):
+
+  KmersTable            <- MultipleKmersDataBases' ctor guards + .names            (a-1, a-2)
+  Phenotypes            <- load_phenotypes_file                                    (a-10)
+  AssociationScan       <- load_kmers + add_kmers_to_heap over all columns (pass 1) (a-3 .. a-8)
+  BestAssociationsHeap  <- BestAssociationsHeap                                    (a-7)
+  Kinship               <- update_emma_kinshhip_calculation / emma_kinship_kmers    (a-9)
+
+Everything numeric happens inside libkgwas (HIP kernels on the GPU + the std::priority_queue
+replay); this module only moves buffers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Sequence
+
+import numpy as np
+
+from . import capi
+from .capi import lib, check, ptr
+
+
+def min_count(n_acc: int, maf: float, mac: int) -> int:
+    return int(lib.kgwas_min_count(n_acc, maf, mac))
+
+
+class KmersTable:
+    def __init__(self, base: str, kmer_len: int = 0):
+        self._h = C.c_void_p()
+        check(lib.kgwas_table_open(base.encode(), kmer_len, C.byref(self._h)))
+        a, r, w, k = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint32()
+        check(lib.kgwas_table_info(self._h, C.byref(a), C.byref(r), C.byref(w), C.byref(k)))
+        self.base = base
+        self.n_acc, self.n_rows, self.words_per_row, self.kmer_len = a.value, r.value, w.value, k.value
+        self.names = []
+        for i in range(self.n_acc):
+            s = C.c_char_p()
+            check(lib.kgwas_table_name(self._h, i, C.byref(s)))
+            self.names.append(s.value.decode())
+
+    def column_map(self, accessions: Sequence[str]) -> np.ndarray:
+        arr = (C.c_char_p * len(accessions))(*[a.encode() for a in accessions])
+        out = np.zeros(len(accessions), dtype=np.uint64)
+        check(lib.kgwas_table_column_map(self._h, arr, len(accessions), out.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return out
+
+    def read_rows(self, row0: int, n: int) -> np.ndarray:
+        out = np.empty((n, 1 + self.words_per_row), dtype=np.uint64)
+        check(lib.kgwas_table_read_rows(self._h, row0, n, ptr(out)))
+        return out
+
+    def close(self):
+        if self._h:
+            lib.kgwas_table_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        self.close()
+
+
+class Phenotypes:
+    def __init__(self, path: str):
+        h = C.c_void_p()
+        check(lib.kgwas_pheno_load(path.encode(), C.byref(h)))
+        try:
+            p, a = C.c_uint64(), C.c_uint64()
+            check(lib.kgwas_pheno_info(h, C.byref(p), C.byref(a)))
+            self.names, self.accessions = [], []
+            s = C.c_char_p()
+            for j in range(p.value):
+                check(lib.kgwas_pheno_name(h, j, C.byref(s)))
+                self.names.append(s.value.decode())
+            for i in range(a.value):
+                check(lib.kgwas_pheno_accession(h, i, C.byref(s)))
+                self.accessions.append(s.value.decode())
+            y = C.POINTER(C.c_float)()
+            check(lib.kgwas_pheno_values(h, C.byref(y)))
+            n = p.value * a.value
+            self.Y = (np.ctypeslib.as_array(y, shape=(n,)).copy() if n else np.zeros(0, np.float32)).reshape(
+                p.value, a.value)
+        finally:
+            lib.kgwas_pheno_free(h)
+
+
+class BestAssociationsHeap:
+    def __init__(self, max_results: int, _handle=None):
+        self._h = C.c_void_p(_handle) if _handle else C.c_void_p()
+        if not _handle:
+            check(lib.kgwas_heap_new(max_results, C.byref(self._h)))
+
+    def add_associations(self, kmer, score, row):
+        k = np.ascontiguousarray(kmer, np.uint64)
+        s = np.ascontiguousarray(score, np.float64)
+        r = np.ascontiguousarray(row, np.uint64)
+        check(lib.kgwas_heap_add_many(self._h, ptr(k), ptr(s), ptr(r), len(k)))
+
+    def add_association(self, kmer, score, row):
+        self.add_associations([kmer], [score], [row])
+
+    def _size(self):
+        n, ins, low = C.c_uint64(), C.c_uint64(), C.c_double()
+        check(lib.kgwas_heap_size(self._h, C.byref(n), C.byref(ins), C.byref(low)))
+        return n.value, ins.value, low.value
+
+    def __len__(self):
+        return self._size()[0]
+
+    @property
+    def lowest_score(self):
+        return self._size()[2]
+
+    def pop_all(self):
+        n = len(self)
+        k, s, r = np.zeros(n, np.uint64), np.zeros(n, np.float64), np.zeros(n, np.uint64)
+        check(lib.kgwas_heap_pop_all(self._h, ptr(k), ptr(s), ptr(r)))
+        return k, s, r
+
+    def get_kmers_for_output(self):
+        n = len(self)
+        k, rk, r = np.zeros(n, np.uint64), np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+        check(lib.kgwas_heap_output_list(self._h, ptr(k), ptr(rk), ptr(r)))
+        return k, rk, r
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib.kgwas_heap_free(self._h)
+            self._h = None
+
+
+class AssociationScan:
+    """Pass 1 of associate_kmers for all phenotype columns at once."""
+
+    def __init__(self, n_acc_file: int, col, Y, topn, min_count: int, device: int = 0, kernel: int = capi.KERNEL_AUTO,
+                 chunk_rows: int = 0, host_threads: int = 0, record_history: bool = False):
+        self.col = np.ascontiguousarray(col, np.uint64)
+        self.Y = np.ascontiguousarray(Y, np.float32)
+        if self.Y.ndim == 1:
+            self.Y = self.Y[None, :]
+        self.n_pheno, self.n_acc = self.Y.shape
+        self.topn = np.ascontiguousarray(np.broadcast_to(np.asarray(topn, np.uint64), (self.n_pheno,)))
+        self.n_acc_file = n_acc_file
+        self.words_per_row = (n_acc_file + 63) // 64
+        p = capi.ScanParams()
+        p.struct_size = C.sizeof(capi.ScanParams)
+        p.device = device
+        p.n_acc_file = n_acc_file
+        p.n_acc = self.n_acc
+        p.col = self.col.ctypes.data_as(C.POINTER(C.c_uint64))
+        p.n_pheno = self.n_pheno
+        p.Y = self.Y.ctypes.data_as(C.POINTER(C.c_float))
+        p.topn = self.topn.ctypes.data_as(C.POINTER(C.c_uint64))
+        p.min_count = min_count
+        p.chunk_rows = chunk_rows
+        p.host_threads = host_threads
+        p.kernel = kernel
+        p.record_history = 1 if record_history else 0
+        self._h = C.c_void_p()
+        check(lib.kgwas_scan_create(C.byref(p), C.byref(self._h)))
+
+    # rows: uint64 array (n_rows, 1 + W_f) in host memory
+    def feed_host(self, rows: np.ndarray, first_row: int = 0):
+        rows = np.ascontiguousarray(rows, np.uint64)
+        n = rows.size // (1 + self.words_per_row)
+        check(lib.kgwas_scan_feed_host(self._h, ptr(rows), n, first_row))
+
+    # device pointer to rows already resident in HBM (e.g. torch tensor .data_ptr())
+    def feed_device(self, d_ptr: int, n_rows: int, first_row: int = 0, stream: int = 0):
+        check(lib.kgwas_scan_feed_device(self._h, C.c_void_p(d_ptr), n_rows, first_row, C.c_void_p(stream)))
+
+    def finish(self):
+        check(lib.kgwas_scan_finish(self._h))
+
+    def _lists(self, fn, j):
+        n = C.c_uint64()
+        k, s, r = C.POINTER(C.c_uint64)(), C.POINTER(C.c_double)(), C.POINTER(C.c_uint64)()
+        check(fn(self._h, j, C.byref(n), C.byref(k), C.byref(s), C.byref(r)))
+        m = n.value
+        if m == 0:
+            return np.zeros(0, np.uint64), np.zeros(0, np.float64), np.zeros(0, np.uint64)
+        return (np.ctypeslib.as_array(k, shape=(m,)).copy(), np.ctypeslib.as_array(s, shape=(m,)).copy(),
+                np.ctypeslib.as_array(r, shape=(m,)).copy())
+
+    def result(self, j: int):
+        """(kmers, scores, file rows) of column j in heap-pop order (ascending score; rank of entry i = n - i)."""
+        return self._lists(lib.kgwas_scan_result, j)
+
+    def history(self, j: int):
+        return self._lists(lib.kgwas_scan_history, j)
+
+    def stats(self) -> dict:
+        st = capi.ScanStats()
+        check(lib.kgwas_scan_get_stats(self._h, C.byref(st)))
+        return st.as_dict()
+
+    def scores_dense(self, rows=None, d_ptr: int = 0, n_rows: int = 0):
+        """calculate_kmer_score for every row x column. Returns (scores[n_pheno, n_rows], popcnt[n_rows])."""
+        if rows is not None:
+            rows = np.ascontiguousarray(rows, np.uint64)
+            n_rows = rows.size // (1 + self.words_per_row)
+            src, on_dev = ptr(rows), 0
+        else:
+            src, on_dev = C.c_void_p(d_ptr), 1
+        sc = np.zeros((self.n_pheno, n_rows), np.float64)
+        pc = np.zeros(n_rows, np.uint32)
+        check(lib.kgwas_scan_scores_dense(self._h, src, on_dev, n_rows, ptr(sc), ptr(pc)))
+        return sc, pc
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.kgwas_scan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+def merge_shards(topn, shard_histories, threads: int = 0):
+    """Cross-shard merge. shard_histories[g][j] = (kmer, score, row) arrays of shard g (row order),
+    shards listed in row order. Returns one BestAssociationsHeap per phenotype column."""
+    G = len(shard_histories)
+    P = len(shard_histories[0])
+    topn = np.ascontiguousarray(np.broadcast_to(np.asarray(topn, np.uint64), (P,)))
+    counts = np.zeros((G, P), np.uint64)
+    ks, ss, rs = [], [], []
+    for g in range(G):
+        for j in range(P):
+            counts[g, j] = len(shard_histories[g][j][0])
+        ks.append(np.ascontiguousarray(np.concatenate([np.asarray(h[0], np.uint64) for h in shard_histories[g]])))
+        ss.append(np.ascontiguousarray(np.concatenate([np.asarray(h[1], np.float64) for h in shard_histories[g]])))
+        rs.append(np.ascontiguousarray(np.concatenate([np.asarray(h[2], np.uint64) for h in shard_histories[g]])))
+    kp = (C.c_void_p * G)(*[a.ctypes.data for a in ks])
+    sp = (C.c_void_p * G)(*[a.ctypes.data for a in ss])
+    rp = (C.c_void_p * G)(*[a.ctypes.data for a in rs])
+    out = (C.c_void_p * P)()
+    check(lib.kgwas_merge_shards(P, ptr(topn), G, ptr(counts), kp, sp, rp, threads, out))
+    return [BestAssociationsHeap(0, _handle=out[j]) for j in range(P)]
+
+
+class Kinship:
+    def __init__(self, n_acc_file: int, min_count: int, device: int = 0):
+        self.n_acc = n_acc_file
+        self.words_per_row = (n_acc_file + 63) // 64
+        self._h = C.c_void_p()
+        check(lib.kgwas_kinship_create(device, n_acc_file, min_count, C.byref(self._h)))
+
+    def feed_host(self, rows: np.ndarray):
+        rows = np.ascontiguousarray(rows, np.uint64)
+        check(lib.kgwas_kinship_feed_host(self._h, ptr(rows), rows.size // (1 + self.words_per_row)))
+
+    def feed_device(self, d_ptr: int, n_rows: int, stream: int = 0):
+        check(lib.kgwas_kinship_feed_device(self._h, C.c_void_p(d_ptr), n_rows, C.c_void_p(stream)))
+
+    def partials(self):
+        H = np.zeros((self.n_acc, self.n_acc), np.uint64)
+        n = C.c_uint64()
+        check(lib.kgwas_kinship_partials(self._h, ptr(H), C.byref(n)))
+        return H, n.value
+
+    def matrix(self):
+        H, n = self.partials()
+        return kinship_from_partials(H, n), n
+
+    def stats(self):
+        ms, l, r = C.c_double(), C.c_uint64(), C.c_uint64()
+        check(lib.kgwas_kinship_get_stats(self._h, C.byref(ms), C.byref(l), C.byref(r)))
+        return dict(kernel_ms=ms.value, launches=l.value, rows_fed=r.value)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.kgwas_kinship_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+def kinship_from_partials(H: np.ndarray, n_used: int) -> np.ndarray:
+    H = np.ascontiguousarray(H, np.uint64)
+    K = np.zeros_like(H)
+    check(lib.kgwas_kinship_from_partials(H.shape[0], ptr(H), n_used, ptr(K)))
+    return K
+
+
+def kinship_format(K: np.ndarray, n_used: int) -> bytes:
+    K = np.ascontiguousarray(K, np.uint64)
+    need = lib.kgwas_kinship_format(K.shape[0], ptr(K), n_used, None, 0)
+    buf = C.create_string_buffer(int(need) + 1)
+    lib.kgwas_kinship_format(K.shape[0], ptr(K), n_used, buf, need)
+    return buf.raw[:need]
+
+
+def write_plink(out_base: str, table: KmersTable, col, acc_names, y, kmer_pop, row_pop):
+    col = np.ascontiguousarray(col, np.uint64)
+    y = np.ascontiguousarray(y, np.float32)
+    kmer_pop = np.ascontiguousarray(kmer_pop, np.uint64)
+    row_pop = np.ascontiguousarray(row_pop, np.uint64)
+    arr = (C.c_char_p * len(acc_names))(*[a.encode() for a in acc_names])
+    check(lib.kgwas_write_plink(out_base.encode(), table._h, ptr(col), len(col), arr, ptr(y), len(kmer_pop),
+                                ptr(kmer_pop), ptr(row_pop)))
+
+
+def synth_rows_host(first_row: int, n_rows: int, n_acc: int, seed: int) -> np.ndarray:
+    out = np.empty((n_rows, 1 + (n_acc + 63) // 64), np.uint64)
+    check(lib.kgwas_synth_rows_host(ptr(out), first_row, n_rows, n_acc, seed))
+    return out
+
+
+def synth_rows_device(d_ptr: int, first_row: int, n_rows: int, n_acc: int, seed: int, stream: int = 0):
+    check(lib.kgwas_synth_rows_device(C.c_void_p(d_ptr), first_row, n_rows, n_acc, seed, C.c_void_p(stream)))

@@ -1,0 +1,595 @@
+// oracle/oracle.cpp — TEST INFRASTRUCTURE ONLY. NOT PART OF THE PRODUCT.
+//
+// CPU restatement of the voichek/kmersGWAS association-scan hot path
+// (associate_kmers / emma_kinship_kmers), written from the reference's text.
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+// load this file's shared object; nothing under kmersgwas_amd/ links it.
+//
+// PARITY STATUS: *parity unpinned*. The reference has no tests, golden vectors
+// or fixtures for this path, and it cannot be built in this
+// image: src/kmer_general.h:19 includes KMC/kmc_api/kmc_file.h and
+// src/associate_kmers.cpp:29-30 include CTPL and cxxopts, all three empty git
+// submodules (.gitmodules:1-9). Building it would need stand-in headers, which
+// the build rules forbid, so there is no oracle/_ref. What anchors this file:
+//   * every function cites the reference file:line it restates;
+//   * the float32 accumulation order is stated three independent ways (scalar
+//     loop here, SSE4.1 intrinsic statement here, NumPy in oracle_np.py) and
+//     tests/test_oracle.py requires all three to agree bit-for-bit;
+//   * the heap is libstdc++'s own std::priority_queue over the same tuple and
+//     comparator types the reference declares (src/kmer_general.h:113-128),
+//     cross-checked against a pure-Python restatement of push_heap/pop_heap;
+//   * hand-derived known answers in tests/golden/known_answers.json.
+//
+// All citations are relative to /root/reference/.
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <queue>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <tuple>
+#include <vector>
+
+#include <nmmintrin.h>
+#include <smmintrin.h>
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// Heap element / comparator: same types as src/kmer_general.h:113-128
+// (k-mer, score, row id), min-heap on score through std::priority_queue.
+// ---------------------------------------------------------------------------
+typedef std::tuple<uint64_t, double, size_t> HeapEntry;
+struct HeapCmp {
+    bool operator()(const HeapEntry& a, const HeapEntry& b) const {
+        return std::get<1>(a) > std::get<1>(b);
+    }
+};
+typedef std::priority_queue<HeapEntry, std::vector<HeapEntry>, HeapCmp> HeapQueue;
+
+// BestAssociationsHeap (src/best_associations_heap.cpp:26-59)
+struct OrcHeap {
+    size_t max_results;
+    HeapQueue q;
+    size_t cnt_kmers, cnt_pops, cnt_push;
+    double lowest;
+    explicit OrcHeap(size_t n) : max_results(n), cnt_kmers(0), cnt_pops(0), cnt_push(0), lowest(0) {}
+    // add_association (src/best_associations_heap.cpp:43-59)
+    void add(uint64_t kmer, double score, size_t row) {
+        cnt_kmers++;
+        if (q.size() < max_results) {
+            q.push(HeapEntry(kmer, score, row));
+            cnt_push++;
+            lowest = std::get<1>(q.top());
+        } else if (score > lowest) {
+            HeapEntry e(kmer, score, row);
+            cnt_pops++;
+            cnt_push++;
+            q.pop();
+            q.push(e);
+            lowest = std::get<1>(q.top());
+        }
+    }
+};
+
+inline uint64_t popcnt64(uint64_t x) { return (uint64_t)__builtin_popcountll(x); }
+
+// permute_scores (src/kmer_general.cpp:155-167): R[128b + 4s + l] = V[128b + 32l + 31 - s]
+void permute_scores(const std::vector<float>& V, std::vector<float>& R) {
+    R.assign(V.size(), 0.0f);
+    size_t out = 0;
+    for (size_t base = 0; base < V.size(); base += 128)
+        for (size_t s = 0; s < 32; s++)
+            for (size_t l = 0; l < 4; l++) R[out++] = V[base + 32 * l + 31 - s];
+}
+
+// update_scores_and_sum (src/kmers_multiple_databases.cpp:288-295): pad to 64*W_m,
+// permute, then a sequential float32 sum over the permuted vector.
+float prepare_scores(const float* y, size_t S, size_t W_m, std::vector<float>& R) {
+    std::vector<float> V(64 * W_m, 0.0f);
+    for (size_t i = 0; i < S; i++) V[i] = y[i];
+    permute_scores(V, R);
+    float sum = 0;
+    for (size_t i = 0; i < R.size(); i++) sum += R[i];
+    return sum;
+}
+
+// calculate_kmer_score (src/kmers_multiple_databases.cpp:327-363), scalar statement.
+// Four float32 accumulators (the SSE lanes); lane l of 128-bit block b walks its
+// 32-bit sub-word from bit 31 down to bit 0, adding R[128b+4s+l] when the bit is set.
+double score_scalar(const uint64_t* sq, const float* R, float sum, size_t S, size_t W_m, double N1,
+                    uint64_t min_in_group) {
+    double N = (double)S;
+    double N0 = N - N1;
+    if (!(((double)min_in_group <= N0) && ((double)min_in_group <= N1))) return 0;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (size_t b = 0; b < W_m / 2; b++) {
+        uint32_t sub[4] = {(uint32_t)(sq[2 * b] & 0xFFFFFFFFu), (uint32_t)(sq[2 * b] >> 32),
+                           (uint32_t)(sq[2 * b + 1] & 0xFFFFFFFFu), (uint32_t)(sq[2 * b + 1] >> 32)};
+        const float* Rb = R + 128 * b;
+        for (size_t s = 0; s < 32; s++)
+            for (size_t l = 0; l < 4; l++) {
+                float term = ((sub[l] >> (31 - s)) & 1u) ? Rb[4 * s + l] : 0.0f;
+                acc[l] = acc[l] + term;
+            }
+    }
+    float yf = acc[0] + acc[1];  // float adds, left to right (:358)
+    yf = yf + acc[2];
+    yf = yf + acc[3];
+    double yigi = (double)yf;
+    double p1 = N * yigi;  // no FMA in the reference build (Makefile:4)
+    double p2 = N1 * (double)sum;
+    double r = p1 - p2;
+    r = r * r;
+    double d1 = N * N1;
+    double d2 = N1 * N1;
+    return r / (d1 - d2);
+}
+
+// The same function stated with the SSE4.1 operations the reference text names
+// (blendv on the sign bit, add_ps, slli_epi32 by 1; :347-356). Independent second
+// statement used to cross-check score_scalar.
+double score_sse(const uint64_t* sq, const float* R, float sum, size_t S, size_t W_m, double N1,
+                 uint64_t min_in_group) {
+    double N = (double)S;
+    double N0 = N - N1;
+    if (!(((double)min_in_group <= N0) && ((double)min_in_group <= N1))) return 0;
+    __m128 sums = _mm_setzero_ps();
+    for (size_t b = 0; b < W_m / 2; b++) {
+        __m128 mask = _mm_castsi128_ps(_mm_loadu_si128((const __m128i*)(sq + 2 * b)));
+        for (size_t i = 0; i < 128; i += 4) {
+            __m128 f = _mm_loadu_ps(R + 128 * b + i);
+            __m128 sel = _mm_blendv_ps(_mm_setzero_ps(), f, mask);
+            sums = _mm_add_ps(sums, sel);
+            mask = _mm_castsi128_ps(_mm_slli_epi32(_mm_castps_si128(mask), 1));
+        }
+    }
+    float out[4];
+    _mm_storeu_ps(out, sums);
+    double yigi = out[0] + out[1] + out[2] + out[3];
+    double r = N * yigi - N1 * sum;
+    r = r * r;
+    return r / (N * N1 - N1 * N1);
+}
+
+// One kept row after load_kmers (src/kmers_multiple_databases.cpp:103-146).
+struct Batch {
+    std::vector<uint64_t> kmers;
+    std::vector<uint64_t> sq;       // W_m words per kept row
+    std::vector<double> popcnt;     // (double)N1
+    std::vector<uint64_t> file_row; // true file row (not in the reference; for the tests)
+    size_t row_offset;              // m_row_offset: file rows read before this batch
+};
+
+struct ColMap {
+    size_t S, S_f, W_f, W_m;
+    std::vector<size_t> word_idx, bit_idx;
+    std::vector<uint64_t> mask;
+};
+
+// create_map_from_all_DBs (src/kmers_multiple_databases.cpp:297-311), with the
+// name lookup already done by the caller (col[i] = file column of accession i).
+ColMap make_map(const uint64_t* col, size_t S, size_t S_f) {
+    ColMap m;
+    m.S = S;
+    m.S_f = S_f;
+    m.W_f = (S_f + 63) / 64;              // :48
+    m.W_m = 2 * ((S + 127) / 128);        // :51
+    m.mask.assign(m.W_f, 0);
+    for (size_t i = 0; i < S; i++) {
+        m.word_idx.push_back(col[i] / 64);
+        m.bit_idx.push_back(col[i] % 64);
+        m.mask[col[i] / 64] |= (1ull << (col[i] % 64));
+    }
+    return m;
+}
+
+// load_kmers (:103-146) over an in-memory image of the .table body.
+// Reads rows [*cursor, ...) until batch_size rows are kept or n_rows is reached.
+bool load_batch(const uint64_t* rows, size_t n_rows, size_t* cursor, const ColMap& m, size_t batch_size,
+                size_t mac, Batch& out) {
+    out.row_offset = *cursor;
+    out.kmers.clear();
+    out.sq.clear();
+    out.popcnt.clear();
+    out.file_row.clear();
+    if (*cursor >= n_rows) return false;
+    const size_t stride = 1 + m.W_f;
+    while (out.kmers.size() < batch_size && *cursor < n_rows) {
+        const uint64_t* row = rows + (*cursor) * stride;
+        size_t this_row = *cursor;
+        (*cursor)++;
+        uint64_t pc = 0;  // calculate_unsqueezed_popcnt (:149-154)
+        for (size_t w = 0; w < m.W_f; w++) pc += popcnt64(row[1 + w] & m.mask[w]);
+        if (pc >= mac && pc <= (m.S - mac)) {  // size_t arithmetic as in :119
+            out.kmers.push_back(row[0]);
+            size_t off = out.sq.size();
+            out.sq.resize(off + m.W_m, 0);
+            for (size_t i = 0; i < m.S; i++) {  // per-bit squeeze (:125-132)
+                uint64_t bit = (row[1 + m.word_idx[i]] >> m.bit_idx[i]) & 1ull;
+                out.sq[off + (i >> 6)] |= bit << (i & 63);
+            }
+            out.popcnt.push_back((double)pc);
+            out.file_row.push_back(this_row);
+        }
+    }
+    return true;
+}
+
+// bits2kmer31 (src/kmer_general.cpp:77-87)
+std::string bits_to_kmer(uint64_t w, size_t k) {
+    static const char bp[4] = {'A', 'C', 'G', 'T'};
+    std::string s(k, 'X');
+    for (size_t i = 0; i < k; i++) {
+        s[k - 1 - i] = bp[w & 3];
+        w >>= 2;
+    }
+    return s;
+}
+
+// Hash64 (src/kmer_general.h:31-40) and hash_presence_absence_pattern
+// (src/kmers_multiple_databases.cpp:367-374)
+inline uint64_t hash64(uint64_t key) {
+    key ^= key >> 33;
+    key *= 0xff51afd7ed558ccdULL;
+    key ^= key >> 33;
+    key *= 0xc4ceb9fe1a85ec53ULL;
+    key ^= key >> 33;
+    return key;
+}
+uint64_t pattern_hash(const uint64_t* sq, size_t W_m) {
+    uint64_t seed = 0;
+    for (size_t w = 0; w < W_m; w++) seed ^= hash64(sq[w]) + 0x9e3779b97f4a7c15ULL + (seed << 6) + (seed >> 2);
+    return seed;
+}
+
+// write_PA's genotype bytes (src/kmers_multiple_databases.cpp:218-239): 4 samples per
+// byte, 2 bits each, present -> 11, absent -> 00; 16 bytes per 64-bit word while acc < S.
+void pa_bytes(const uint64_t* sq, size_t W_m, size_t S, std::string& out) {
+    size_t acc = 0;
+    for (size_t w = 0; w < W_m; w++) {
+        uint64_t v = sq[w];
+        for (size_t bi = 0; bi < 16 && acc < S; bi++) {
+            unsigned char b = 0;
+            for (int q = 0; q < 4; q++) {
+                if (v & 1) b |= (unsigned char)(3u << (2 * q));
+                v >>= 1;
+            }
+            out.push_back((char)b);
+            acc += 4;
+        }
+    }
+}
+
+struct AssocResult {
+    // per phenotype, heap-pop (ascending score) order
+    std::vector<std::vector<uint64_t>> kmer, ref_row, file_row;
+    std::vector<std::vector<double>> score;
+    uint64_t tested;
+    uint64_t patterns;
+};
+
+}  // namespace
+
+extern "C" {
+
+// ---- small exported pieces (for unit tests) --------------------------------
+
+// a-4. Returns the float32 sum; writes the permuted padded vector (64*W_m floats).
+float orc_prepare_scores(const float* y, uint64_t S, uint64_t W_m, float* R_out) {
+    std::vector<float> R;
+    float s = prepare_scores(y, S, W_m, R);
+    std::memcpy(R_out, R.data(), R.size() * sizeof(float));
+    return s;
+}
+
+// a-5, both statements. which = 0 scalar, 1 SSE.
+double orc_score(const uint64_t* sq, const float* R, float sum, uint64_t S, uint64_t W_m, double N1,
+                 uint64_t min_in_group, int which) {
+    return which ? score_sse(sq, R, sum, S, W_m, N1, min_in_group)
+                 : score_scalar(sq, R, sum, S, W_m, N1, min_in_group);
+}
+
+// a-3 on a whole in-memory table: kept flags, squeezed rows (n_rows*W_m, unkept rows zero),
+// masked popcounts. Returns number kept.
+uint64_t orc_squeeze(const uint64_t* rows, uint64_t n_rows, uint64_t S_f, const uint64_t* col, uint64_t S,
+                     uint64_t mac, uint64_t* sq_out, uint32_t* popcnt_out, uint8_t* kept_out) {
+    ColMap m = make_map(col, S, S_f);
+    size_t cursor = 0;
+    Batch b;
+    uint64_t kept = 0;
+    std::memset(sq_out, 0, n_rows * m.W_m * 8);
+    for (size_t r = 0; r < n_rows; r++) {
+        const uint64_t* row = rows + r * (1 + m.W_f);
+        uint64_t pc = 0;
+        for (size_t w = 0; w < m.W_f; w++) pc += popcnt64(row[1 + w] & m.mask[w]);
+        popcnt_out[r] = (uint32_t)pc;
+        kept_out[r] = 0;
+    }
+    while (load_batch(rows, n_rows, &cursor, m, 4096, mac, b)) {
+        for (size_t i = 0; i < b.kmers.size(); i++) {
+            std::memcpy(sq_out + b.file_row[i] * m.W_m, &b.sq[i * m.W_m], m.W_m * 8);
+            kept_out[b.file_row[i]] = 1;
+            kept++;
+        }
+    }
+    return kept;
+}
+
+// Dense scores: out[j*n_rows + r] for every file row r (0 for rows the MAC filter drops;
+// kept_out tells them apart). Y is n_pheno x S row-major, phenotype order.
+uint64_t orc_scores_dense(const uint64_t* rows, uint64_t n_rows, uint64_t S_f, const uint64_t* col, uint64_t S,
+                          const float* Y, uint64_t n_pheno, uint64_t mac, int which, double* out,
+                          uint8_t* kept_out) {
+    ColMap m = make_map(col, S, S_f);
+    std::vector<std::vector<float>> R(n_pheno);
+    std::vector<float> sums(n_pheno);
+    for (size_t j = 0; j < n_pheno; j++) sums[j] = prepare_scores(Y + j * S, S, m.W_m, R[j]);
+    for (size_t r = 0; r < n_rows; r++) kept_out[r] = 0;
+    for (size_t i = 0; i < n_pheno * n_rows; i++) out[i] = 0;
+    size_t cursor = 0;
+    Batch b;
+    uint64_t kept = 0;
+    while (load_batch(rows, n_rows, &cursor, m, 65536, mac, b)) {
+        for (size_t i = 0; i < b.kmers.size(); i++) {
+            kept_out[b.file_row[i]] = 1;
+            kept++;
+            for (size_t j = 0; j < n_pheno; j++)
+                out[j * n_rows + b.file_row[i]] =
+                    which ? score_sse(&b.sq[i * m.W_m], R[j].data(), sums[j], S, m.W_m, b.popcnt[i], mac)
+                          : score_scalar(&b.sq[i * m.W_m], R[j].data(), sums[j], S, m.W_m, b.popcnt[i], mac);
+        }
+    }
+    return kept;
+}
+
+// ---- heap (a-7) -------------------------------------------------------------
+void* orc_heap_new(uint64_t n) { return new OrcHeap((size_t)n); }
+void orc_heap_free(void* h) { delete (OrcHeap*)h; }
+void orc_heap_add(void* h, uint64_t kmer, double score, uint64_t row) { ((OrcHeap*)h)->add(kmer, score, row); }
+void orc_heap_add_many(void* h, const uint64_t* kmer, const double* score, const uint64_t* row, uint64_t n) {
+    for (uint64_t i = 0; i < n; i++) ((OrcHeap*)h)->add(kmer[i], score[i], row[i]);
+}
+uint64_t orc_heap_size(void* h) { return ((OrcHeap*)h)->q.size(); }
+uint64_t orc_heap_insertions(void* h) { return ((OrcHeap*)h)->cnt_kmers; }
+double orc_heap_lowest(void* h) { return ((OrcHeap*)h)->lowest; }
+void orc_heap_stats(void* h, uint64_t* pops, uint64_t* pushes) {
+    *pops = ((OrcHeap*)h)->cnt_pops;
+    *pushes = ((OrcHeap*)h)->cnt_push;
+}
+// output_to_file_with_scores order (src/best_associations_heap.cpp:82-92): pop ascending
+// from a copy. Arrays must hold orc_heap_size entries.
+void orc_heap_pop_all(void* h, uint64_t* kmer, double* score, uint64_t* row) {
+    HeapQueue tmp(((OrcHeap*)h)->q);
+    size_t i = 0;
+    while (!tmp.empty()) {
+        kmer[i] = std::get<0>(tmp.top());
+        score[i] = std::get<1>(tmp.top());
+        row[i] = std::get<2>(tmp.top());
+        tmp.pop();
+        i++;
+    }
+}
+// get_kmers_for_output (:110-127): pop ascending, rank = queue size at pop, sort by row.
+void orc_heap_output_list(void* h, uint64_t* kmer, uint64_t* rank, uint64_t* row) {
+    HeapQueue tmp(((OrcHeap*)h)->q);
+    std::vector<std::tuple<uint64_t, uint64_t, size_t>> lst;
+    while (!tmp.empty()) {
+        lst.push_back(std::make_tuple(std::get<0>(tmp.top()), (uint64_t)tmp.size(), std::get<2>(tmp.top())));
+        tmp.pop();
+    }
+    std::sort(lst.begin(), lst.end(),
+              [](const std::tuple<uint64_t, uint64_t, size_t>& a, const std::tuple<uint64_t, uint64_t, size_t>& b) {
+                  return std::get<2>(a) < std::get<2>(b);
+              });
+    for (size_t i = 0; i < lst.size(); i++) {
+        kmer[i] = std::get<0>(lst[i]);
+        rank[i] = std::get<1>(lst[i]);
+        row[i] = std::get<2>(lst[i]);
+    }
+}
+
+// ---- pass 1 of associate_kmers (src/associate_kmers.cpp:99-148) -------------
+// rows: in-memory image of the table body. topn[j] per phenotype. threads: pool size
+// (one task per phenotype column per batch, as CTPL is used in :134-141).
+// Outputs, per phenotype j, at out_*[j*cap ...]: heap-pop order; out_n[j] entries.
+// out_refrow holds the reference's own row id (m_row_offset + index in kept batch, :283),
+// out_filerow the true file row. Returns tested k-mers (heap[0].number_of_insertion()).
+// timing[0] = seconds in load_kmers, timing[1] = seconds scoring (wall).
+uint64_t orc_associate(const uint64_t* rows, uint64_t n_rows, uint64_t S_f, const uint64_t* col, uint64_t S,
+                       const float* Y, uint64_t n_pheno, const uint64_t* topn, uint64_t mac, uint64_t batch_size,
+                       uint64_t threads, uint64_t cap, uint64_t* out_n, uint64_t* out_kmer, double* out_score,
+                       uint64_t* out_refrow, uint64_t* out_filerow, int count_patterns, uint64_t* n_patterns,
+                       double* timing) {
+    ColMap m = make_map(col, S, S_f);
+    std::vector<OrcHeap> heaps;
+    for (size_t j = 0; j < n_pheno; j++) heaps.emplace_back((size_t)topn[j]);
+    // the file-row of each heap element is recovered through a side table keyed by ref row id
+    std::vector<uint64_t> patt;
+    size_t cursor = 0;
+    Batch b;
+    double t_load = 0, t_score = 0;
+    if (threads < 1) threads = 1;
+    for (;;) {
+        auto t0 = std::chrono::steady_clock::now();
+        bool more = load_batch(rows, n_rows, &cursor, m, batch_size, mac, b);
+        auto t1 = std::chrono::steady_clock::now();
+        t_load += std::chrono::duration<double>(t1 - t0).count();
+        if (!more) break;
+        if (count_patterns)
+            for (size_t i = 0; i < b.kmers.size(); i++) patt.push_back(pattern_hash(&b.sq[i * m.W_m], m.W_m));
+        std::atomic<size_t> next(0);
+        auto work = [&]() {
+            for (;;) {
+                size_t j = next.fetch_add(1);
+                if (j >= n_pheno) break;
+                std::vector<float> R;  // add_kmers_to_heap (:275-284)
+                float sum = prepare_scores(Y + j * S, S, m.W_m, R);
+                for (size_t i = 0; i < b.kmers.size(); i++)
+                    heaps[j].add(b.kmers[i],
+                                 score_sse(&b.sq[i * m.W_m], R.data(), sum, S, m.W_m, b.popcnt[i], mac),
+                                 b.row_offset + i);
+            }
+        };
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < threads && t < n_pheno; t++) pool.emplace_back(work);
+        work();
+        for (auto& th : pool) th.join();
+        auto t2 = std::chrono::steady_clock::now();
+        t_score += std::chrono::duration<double>(t2 - t1).count();
+    }
+    if (timing) {
+        timing[0] = t_load;
+        timing[1] = t_score;
+    }
+    if (count_patterns && n_patterns) {
+        std::sort(patt.begin(), patt.end());
+        *n_patterns = (uint64_t)(std::unique(patt.begin(), patt.end()) - patt.begin());
+    }
+    // Second pass (as the reference's pass 2 does, :170-195) to map ref row ids to file rows.
+    std::vector<std::vector<HeapEntry>> popped(n_pheno);
+    for (size_t j = 0; j < n_pheno; j++) {
+        HeapQueue tmp(heaps[j].q);
+        while (!tmp.empty()) {
+            popped[j].push_back(tmp.top());
+            tmp.pop();
+        }
+        out_n[j] = popped[j].size();
+        for (size_t i = 0; i < popped[j].size() && i < cap; i++) {
+            out_kmer[j * cap + i] = std::get<0>(popped[j][i]);
+            out_score[j * cap + i] = std::get<1>(popped[j][i]);
+            out_refrow[j * cap + i] = std::get<2>(popped[j][i]);
+            out_filerow[j * cap + i] = ~0ull;
+        }
+    }
+    {
+        // ref id -> file row, by replaying the loader only
+        std::vector<std::pair<uint64_t, std::pair<size_t, size_t>>> want;  // ref id -> (j, i)
+        for (size_t j = 0; j < n_pheno; j++)
+            for (size_t i = 0; i < popped[j].size() && i < cap; i++)
+                want.push_back(std::make_pair((uint64_t)std::get<2>(popped[j][i]), std::make_pair(j, i)));
+        std::sort(want.begin(), want.end());
+        size_t cur = 0, wi = 0;
+        Batch bb;
+        while (load_batch(rows, n_rows, &cur, m, batch_size, mac, bb)) {
+            for (size_t i = 0; i < bb.kmers.size() && wi < want.size(); i++) {
+                while (wi < want.size() && want[wi].first == bb.row_offset + i) {
+                    out_filerow[want[wi].second.first * cap + want[wi].second.second] = bb.file_row[i];
+                    wi++;
+                }
+            }
+        }
+    }
+    return heaps.empty() ? 0 : heaps[0].cnt_kmers;
+}
+
+// ---- pass 2 + output files of associate_kmers (:150-205) --------------------
+// Writes <base>.<j>.<name>.bed/.bim/.fam for one phenotype from its heap-pop-order list
+// (kmers, scores unused, ref rows), exactly as the reference would: entries sorted by
+// row id, bim name "<KMER>_<rank>", bed = 3 magic bytes + genotype bytes, fam through
+// ostream's default float formatting (src/kmer_general.cpp:207-225).
+int orc_write_plink(const char* base_path, const uint64_t* rows, uint64_t n_rows, uint64_t S_f,
+                    const uint64_t* col, uint64_t S, const char* const* acc_names, const float* y,
+                    uint64_t kmer_len, uint64_t n, const uint64_t* kmer_pop, const uint64_t* filerow_pop) {
+    ColMap m = make_map(col, S, S_f);
+    std::vector<std::tuple<uint64_t, uint64_t, uint64_t>> lst;  // kmer, rank, file row
+    for (uint64_t i = 0; i < n; i++) lst.push_back(std::make_tuple(kmer_pop[i], n - i, filerow_pop[i]));
+    std::sort(lst.begin(), lst.end(),
+              [](const std::tuple<uint64_t, uint64_t, uint64_t>& a, const std::tuple<uint64_t, uint64_t, uint64_t>& b) {
+                  return std::get<2>(a) < std::get<2>(b);
+              });
+    std::string base(base_path);
+    std::ofstream bed(base + ".bed", std::ios::binary), bim(base + ".bim");
+    if (!bed || !bim) return -1;
+    bed << (char)0x6C << (char)0x1B << (char)0x01;  // src/kmer_general.h:138
+    for (size_t i = 0; i < lst.size(); i++) {
+        uint64_t fr = std::get<2>(lst[i]);
+        if (fr >= n_rows) return -2;
+        const uint64_t* row = rows + fr * (1 + m.W_f);
+        std::vector<uint64_t> sq(m.W_m, 0);
+        for (size_t c = 0; c < S; c++) sq[c >> 6] |= ((row[1 + m.word_idx[c]] >> m.bit_idx[c]) & 1ull) << (c & 63);
+        bim << "0\t" << bits_to_kmer(std::get<0>(lst[i]), kmer_len) << "_" << std::to_string(std::get<1>(lst[i]))
+            << "\t0\t0\t0\t1\n";
+        std::string bytes;
+        pa_bytes(sq.data(), m.W_m, S, bytes);
+        bed.write(bytes.data(), bytes.size());
+    }
+    std::ofstream fam(base + ".fam");
+    for (size_t i = 0; i < S; i++) fam << acc_names[i] << " " << acc_names[i] << " 0 0 0 " << y[i] << std::endl;
+    return 0;
+}
+
+// ---- kinship (a-9) ----------------------------------------------------------
+// update_emma_kinshhip_calculation (src/kmers_multiple_databases.cpp:418-438) over rows
+// passing ceil(S_f*maf) <= popcount <= S_f - that, all S_f columns in file order
+// (src/emma_kinship_kmers.cpp:77-92). K is S_f x S_f, lower triangle filled (j < i).
+uint64_t orc_kinship(const uint64_t* rows, uint64_t n_rows, uint64_t S_f, uint64_t min_count, uint64_t* K) {
+    const size_t W_f = (S_f + 63) / 64;
+    std::memset(K, 0, S_f * S_f * 8);
+    uint64_t n = 0;
+    std::vector<uint64_t> g(S_f);
+    for (size_t r = 0; r < n_rows; r++) {
+        const uint64_t* row = rows + r * (1 + W_f);
+        uint64_t pc = 0;
+        for (size_t w = 0; w < W_f; w++) pc += popcnt64(row[1 + w]);
+        if (!(pc >= min_count && pc <= (S_f - min_count))) continue;
+        for (size_t i = 0; i < S_f; i++) g[i] = (row[1 + (i >> 6)] >> (i & 63)) & 1ull;
+        for (size_t i = 0; i < S_f; i++)
+            for (size_t j = 0; j < i; j++) K[i * S_f + j] += (1ull ^ g[i] ^ g[j]);
+        n++;
+    }
+    return n;
+}
+
+// Text of the matrix emma_kinship_kmers prints (src/emma_kinship_kmers.cpp:95-111):
+// K/n, diagonal 1, symmetric, tab separated, ostream default precision.
+// Returns bytes needed; writes up to cap bytes.
+uint64_t orc_kinship_text(const uint64_t* K, uint64_t S_f, uint64_t n, char* out, uint64_t cap) {
+    std::ostringstream os;
+    std::vector<std::vector<double>> Kn(S_f, std::vector<double>(S_f, 0));
+    for (size_t i = 0; i < S_f; i++) {
+        Kn[i][i] = 1;
+        for (size_t j = 0; j < i; j++) {
+            Kn[i][j] = static_cast<double>(K[i * S_f + j]) / static_cast<double>(n);
+            Kn[j][i] = Kn[i][j];
+        }
+    }
+    for (size_t i = 0; i < S_f; i++) {
+        for (size_t j = 0; j < S_f; j++) {
+            if (j > 0) os << "\t";
+            os << Kn[i][j];
+        }
+        os << "\n";
+    }
+    std::string s = os.str();
+    if (out && cap) std::memcpy(out, s.data(), std::min<uint64_t>(cap, s.size()));
+    return s.size();
+}
+
+// std::stof as load_phenotypes_file applies it (src/kmer_general.cpp:198)
+float orc_stof(const char* s) { return std::stof(std::string(s)); }
+
+// bits2kmer31 for tests
+void orc_bits2kmer(uint64_t w, uint64_t k, char* out) {
+    std::string s = bits_to_kmer(w, k);
+    std::memcpy(out, s.data(), k);
+    out[k] = 0;
+}
+
+uint64_t orc_pattern_hash(const uint64_t* sq, uint64_t W_m) { return pattern_hash(sq, W_m); }
+
+// min_count = max(ceil(S*maf), mac) (src/associate_kmers.cpp:99-103)
+uint64_t orc_min_count(uint64_t S, double maf, uint64_t mac) {
+    size_t mc = (size_t)std::ceil(static_cast<double>(S) * maf);
+    if (mc < mac) mc = mac;
+    return mc;
+}
+
+}  // extern "C"
