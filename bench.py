@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py — association-scan throughput on MI355X.
+
+Metric (BASELINE.json): k-mers x permutations scored per second. A "step" is one full pass of the
+hot path (associate_kmers pass 1: MAC filter, score every k-mer against every phenotype column,
+top-N heaps with best_associations_heap semantics) over a synthetic table that is already resident
+in HBM when the timed region starts. At N=1 the workload is BASELINE.json configs[1]: 100M k-mers x
+1024 samples, 1 phenotype + 100 permutations, top 10001 per column. With N>1 every rank scans its
+own 100M-row shard (weak scaling) and rank 0 merges the ranks' heap histories over RCCL.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+HBM_PEAK_GBPS = 8000.0
+
+
+def make_phenotypes(S, n_perm, seed):
+    rng = np.random.default_rng(seed)
+    y0 = rng.standard_normal(S).astype(np.float32)
+    cols = [y0]
+    for p in range(n_perm):
+        cols.append(np.random.default_rng(seed + 1 + p).permutation(y0))
+    return np.ascontiguousarray(np.stack(cols).astype(np.float32))
+
+
+def cpu_baseline(S, Y, mac, topn, seed, sample_rows, threads):
+    """Oracle (CPU restatement of the reference algorithm: per-bit squeeze loader + SSE-order
+    scorer + std::priority_queue, one thread per phenotype column) on a bounded sample."""
+    import kmersgwas_amd as kg
+    from oracle import binding as ob
+    rows = kg.synth_rows_host(0, sample_rows, S, seed)
+    t0 = time.perf_counter()
+    res = ob.associate(rows, S, np.arange(S, dtype=np.uint64), Y, topn, mac, batch_size=10_000_000, threads=threads)
+    dt = time.perf_counter() - t0
+    return dict(value=sample_rows * Y.shape[0] / dt, unit="kmer*phenotype/s", cores=threads, kind="port",
+                sample="%d rows x %d samples x %d columns of the same synthetic table; oracle/oracle.cpp "
+                       "(load %.2fs + score %.2fs)" % (sample_rows, S, Y.shape[0], res["t_load"], res["t_score"]),
+                seconds=dt)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--rows", type=int, default=100_000_000, help="k-mer rows per GPU")
+    ap.add_argument("--samples", type=int, default=1024)
+    ap.add_argument("--perms", type=int, default=100)
+    ap.add_argument("--topn", type=int, default=10001)
+    ap.add_argument("--kernel", type=int, default=0)
+    ap.add_argument("--chunk-rows", type=int, default=0)
+    ap.add_argument("--cpu-sample-rows", type=int, default=200_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import kmersgwas_amd as kg
+    from kmersgwas_amd import dist as kdist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.cuda.current_device()
+
+    S, P, M = args.samples, args.perms + 1, args.rows
+    W = 1 + (S + 63) // 64
+    seed_table, seed_y = 20240601, 7
+    Y = make_phenotypes(S, args.perms, seed_y)
+    mac = kg.min_count(S, 0.05, 5)
+    col = np.arange(S, dtype=np.uint64)
+
+    # Table shard resident in HBM before timing (generated on the device; never touches PCIe).
+    table = torch.empty(M * W, dtype=torch.int64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    first_row = rank * M
+    kg.synth_rows_device(table.data_ptr(), first_row, M, S, seed_table, stream)
+    torch.cuda.synchronize()
+
+    def one_step():
+        scan = kg.AssociationScan(S, col, Y, args.topn, mac, device=dev, kernel=args.kernel,
+                                  chunk_rows=args.chunk_rows, record_history=(world > 1))
+        scan.feed_device(table.data_ptr(), M, first_row, stream)
+        scan.finish()
+        st = scan.stats()
+        heaps = None
+        if world > 1:
+            heaps, tested = kdist.merge_on_root(scan, args.topn)
+        else:
+            tested = st["rows_tested"]
+        return scan, st, heaps, tested
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        scan, st, heaps, tested = one_step()
+        scan.close()
+    sync()
+    t0 = time.perf_counter()
+    stats = []
+    last = None
+    for _ in range(args.steps):
+        if last is not None:
+            last.close()
+        last, st, heaps, tested = one_step()
+        stats.append(st)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        ms_per_step = dt * 1e3 / args.steps
+        total_rows = M * world
+        value = total_rows * P / (ms_per_step / 1e3)
+        k_ms = sum(s["score_kernel_ms"] for s in stats)
+        k_launch = sum(s["score_launches"] for s in stats)
+        rows_scored = M * args.steps  # this rank
+        flop_per_row = 2.0 * S * P    # 2*S flop per (k-mer, phenotype)
+        avg_ms = k_ms / max(k_launch, 1)
+        achieved_tflops = flop_per_row * rows_scored / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        kernel_name = {1: "score_valu_kernel", 2: "score_mfma_kernel"}[stats[-1]["kernel_used"]]
+        # sanity on the final result of the last step: ascending pops, full heaps
+        k, sc, r = (heaps[0].pop_all() if world > 1 else last.result(0))
+        assert (np.diff(sc) >= 0).all() and len(k) == min(args.topn, tested)
+        out = {
+            "metric": "k-mers x permutations scored/sec", "value": value, "unit": "kmer*phenotype/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "synthetic %dM k-mers x %d samples per GPU, 1 phenotype + %d permutations, "
+                                   "top-%d per column, maf 0.05 / mac 5 (BASELINE.json configs[1])"
+                                   % (M // 1_000_000, S, args.perms, args.topn),
+                       "rows_per_gpu": M, "samples": S, "phenotype_columns": P, "topn": args.topn,
+                       "min_count": int(mac), "sharding": "rows, contiguous per rank" if world > 1 else "none"},
+            "rows_per_s": total_rows / (ms_per_step / 1e3),
+            "hbm_read_GBps_algorithmic": total_rows * 8.0 * W / (ms_per_step / 1e3) / 1e9,
+            "rows_tested": int(tested),
+            "roofline": {"bound": "mfma" if stats[-1]["kernel_used"] == 2 else "valu", "kernel": kernel_name,
+                         "achieved": achieved_tflops, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved_tflops / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "launches": k_launch, "avg_launch_ms": avg_ms,
+                         "kernel_ms_per_step": k_ms / args.steps,
+                         "hbm_frac_of_8TBps": (rows_scored * 8.0 * W / (k_ms * 1e-3) / 1e9) / HBM_PEAK_GBPS
+                         if k_ms > 0 else 0.0},
+            "host": {"replay_ms_per_step": sum(s["replay_ms"] for s in stats) / args.steps,
+                     "candidates_per_step": sum(s["candidates"] for s in stats) // args.steps,
+                     "heap_pushes_per_step": sum(s["heap_pushes"] for s in stats) // args.steps,
+                     "chunks_per_step": sum(s["chunks"] for s in stats) // args.steps,
+                     "cores": os.cpu_count()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(S, Y, mac, args.topn, seed_table, args.cpu_sample_rows,
+                                               threads=os.cpu_count() or 1)
+        print(json.dumps(out))
+    if last is not None:
+        last.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -73,6 +73,36 @@ if not os.path.exists(LIB_PATH):
         "libkgwas.so not found at %s — build it with `make -C kmersgwas_amd/csrc` "
         "(or __graft_entry__.build()). There is no fallback implementation." % LIB_PATH)
 
+
+
+def _load_hip_runtime():
+    """A process must hold exactly ONE HIP runtime. libkgwas.so has no DT_NEEDED on libamdhip64 and
+    binds to whichever copy is already global: the one bundled with the PyTorch wheel when torch is
+    installed (so that device pointers / streams of torch tensors mean the same thing on both sides and
+    a later `import torch` finds its runtime already loaded), /opt/rocm's otherwise."""
+    import importlib.util
+    cands = []
+    try:
+        spec = importlib.util.find_spec("torch")
+        if spec and spec.origin:
+            cands.append(os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so"))
+    except Exception:  # pragma: no cover
+        pass
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cands += [os.path.join(rocm, "lib", "libamdhip64.so.7"), os.path.join(rocm, "lib", "libamdhip64.so"),
+              "libamdhip64.so.7", "libamdhip64.so"]
+    errs = []
+    for c in cands:
+        if os.path.isabs(c) and not os.path.exists(c):
+            continue
+        try:
+            return C.CDLL(c, mode=C.RTLD_GLOBAL), c
+        except OSError as e:  # pragma: no cover
+            errs.append("%s: %s" % (c, e))
+    raise ImportError("no HIP runtime (libamdhip64) could be loaded: %s" % "; ".join(errs))
+
+
+_hip, HIP_RUNTIME_PATH = _load_hip_runtime()
 lib = C.CDLL(LIB_PATH)
 
 _vp, _u64, _u32, _i32, _dbl = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32, C.c_double

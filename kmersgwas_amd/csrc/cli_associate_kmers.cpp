@@ -1,0 +1,192 @@
+// associate_kmers — drop-in for the reference tool of the same name (src/associate_kmers.cpp),
+// same options, same output files, scoring done on the GPU through libkgwas' C ABI.
+//
+//   kmers_gwas.py:133-148 runs:  associate_kmers -p <pheno> -b <base> -o <dir> -n 10001 --parallel T
+//        --kmers_table <table> --kmer_len 31 --maf 0.05 --mac 5 [--pattern_counter]
+//        [--first_phenotype_best N]  2> log
+//   outputs (src/associate_kmers.cpp:150-205): <dir>/<base>.<j>.<name>.{bed,bim,fam} per column,
+//        <dir>/<base>.tested_kmers, optional <base>.<j>.best_kmers.scores.
+//
+// Differences from the reference, all invisible to the pipeline: the table is read once (the
+// winners' rows are fetched by file row index instead of a second full pass, :167-195);
+// --parallel sizes the host replay pool instead of a per-column scoring pool; extra options
+// --device and --kernel select the GPU and the scoring kernel.
+#include <sys/time.h>
+
+#include <cmath>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "../../include/kgwas.h"
+#include "cli_args.h"
+
+using namespace std;
+
+static double now_s() {
+    struct timeval tv;
+    gettimeofday(&tv, NULL);
+    return tv.tv_sec + tv.tv_usec / 1e6;
+}
+
+// Data errors are uncaught std::logic_error in the reference (terminate -> SIGABRT).
+[[noreturn]] static void die_logic(const string& what) {
+    cerr << "terminate called after throwing an instance of 'std::logic_error'\n  what():  " << what << endl;
+    abort();
+}
+static void ck(int rc) {
+    if (rc == KGWAS_OK) return;
+    if (rc == KGWAS_ERR_FORMAT || rc == KGWAS_ERR_IO) die_logic(kgwas_last_error());
+    cerr << "associate_kmers: " << kgwas_last_error() << endl;
+    exit(rc == KGWAS_ERR_DEVICE ? 3 : 1);
+}
+
+int main(int argc, char* argv[]) {
+    CliArgs vm({
+        {"phenotype_file", 'p', true, "phenotype file name", ""},
+        {"base_name", 'b', true, "base name to use for all files", ""},
+        {"output_dir", 'o', true, "where to save output files", "."},
+        {"kmers_table", 0, true, "Presence/absemce k-mer file", ""},
+        {"best", 'n', true, "Number of best k-mers to report", "1000000"},
+        {"first_phenotype_best", 0, true, "if provided will save a different number of k-mers for the first phenotype", ""},
+        {"batch_size", 0, true, "Loading only part of the presence absence info to memory", "10000000"},
+        {"parallel", 0, true, "Max number of threads to use", "4"},
+        {"kmer_len", 0, true, "Length of the k-mers", ""},
+        {"maf", 0, true, "Minor allele frequency", "0.05"},
+        {"mac", 0, true, "Minor allele count", "5"},
+        {"k_mers_scores", 0, false, "output the best k_mers scores in binary format", ""},
+        {"pattern_counter", 0, false, "Count the number of unique presence/absence patterns", ""},
+        {"device", 0, true, "GPU ordinal", "0"},
+        {"kernel", 0, true, "scoring kernel: 0 auto, 1 vector ALU, 2 f32 MFMA", "0"},
+        {"help", 0, false, "print help", ""},
+    });
+    const string desc = "Associate k-mers presence/absence pattern with a phenotype of interest";
+    try {
+        vm.parse(argc, argv);
+        if (vm.count("help")) {
+            cerr << vm.help("associate_kmers", desc) << endl;
+            exit(0);
+        }
+        const string fn_base = vm.str("output_dir", ".") + "/" + vm.str("base_name");
+        const size_t heap_size = vm.u64("best", 1000000);
+        size_t batch_size = vm.u64("batch_size", 10000000);
+        const size_t threads = vm.u64("parallel", 4);
+        const unsigned long long kmer_length = vm.u64("kmer_len");
+        if ((kmer_length > 31) || (kmer_length < 10)) {
+            cerr << "kmer length has to be between 10-31" << endl;
+            exit(1);
+        }
+        const double maf = vm.f64("maf", 0.05);
+        const size_t mac = vm.u64("mac", 5);
+        const string table_base = vm.str("kmers_table");
+        const string pheno_file = vm.str("phenotype_file");
+        if (vm.count("pattern_counter")) {
+            cerr << "associate_kmers: --pattern_counter is not implemented by this engine yet" << endl;
+            exit(1);
+        }
+
+        // Phenotypes (load_phenotypes_file) and the table they must all be present in.
+        kgwas_pheno* ph = nullptr;
+        ck(kgwas_pheno_load(pheno_file.c_str(), &ph));
+        uint64_t phenotypes_n = 0, n_accessions = 0;
+        ck(kgwas_pheno_info(ph, &phenotypes_n, &n_accessions));
+        if (phenotypes_n == 0) die_logic("phenotype file has no phenotype columns | " + pheno_file);
+        vector<const char*> acc(n_accessions), pname(phenotypes_n);
+        for (uint64_t i = 0; i < n_accessions; i++) ck(kgwas_pheno_accession(ph, i, &acc[i]));
+        for (uint64_t j = 0; j < phenotypes_n; j++) ck(kgwas_pheno_name(ph, j, &pname[j]));
+        const float* Y = nullptr;
+        ck(kgwas_pheno_values(ph, &Y));
+
+        kgwas_table* tbl = nullptr;
+        // .names is consulted first (intersect_phenotypes_to_present_DBs, :86-88), then the ctor guards
+        ck(kgwas_table_open(table_base.c_str(), (uint32_t)kmer_length, &tbl));
+        uint64_t S_f = 0, n_rows = 0, W_f = 0;
+        ck(kgwas_table_info(tbl, &S_f, &n_rows, &W_f, nullptr));
+        vector<uint64_t> col(n_accessions);
+        ck(kgwas_table_column_map(tbl, acc.data(), n_accessions, col.data()));
+
+        vector<uint64_t> topn(phenotypes_n, heap_size);
+        if (vm.count("first_phenotype_best")) topn[0] = vm.u64("first_phenotype_best");
+
+        const uint64_t min_count = kgwas_min_count(n_accessions, maf, mac);
+        cerr << "Effective minor allele count:\t" << min_count << endl;
+
+        kgwas_scan_params sp;
+        sp.struct_size = sizeof(sp);
+        sp.device = (int32_t)vm.u64("device", 0);
+        sp.n_acc_file = S_f;
+        sp.n_acc = n_accessions;
+        sp.col = col.data();
+        sp.n_pheno = phenotypes_n;
+        sp.Y = Y;
+        sp.topn = topn.data();
+        sp.min_count = min_count;
+        sp.chunk_rows = 0;
+        sp.host_threads = (uint32_t)threads;
+        sp.kernel = (uint32_t)vm.u64("kernel", 0);
+        sp.record_history = 0;
+        sp.reserved = 0;
+        kgwas_scan* scan = nullptr;
+        ck(kgwas_scan_create(&sp, &scan));
+
+        // Pass 1: stream the table through the GPU in file order.
+        const uint64_t max_batch_rows = std::max<uint64_t>(1, (1ull << 30) / (8 * (1 + W_f)));  // <= 1 GiB of host buffer
+        if (batch_size > max_batch_rows) batch_size = max_batch_rows;
+        if (batch_size == 0) batch_size = 1;
+        vector<uint64_t> buf;
+        double t0 = now_s(), t1;
+        size_t batch_index = 0;
+        for (uint64_t row0 = 0; row0 < n_rows; row0 += batch_size) {
+            const uint64_t n = std::min<uint64_t>(batch_size, n_rows - row0);
+            buf.resize(n * (1 + W_f));
+            ck(kgwas_table_read_rows(tbl, row0, n, buf.data()));
+            t1 = now_s();
+            cerr << "Load [" << batch_index << "]\t" << (t1 - t0) / 60. << "min" << endl;
+            t0 = now_s();
+            ck(kgwas_scan_feed_host(scan, buf.data(), n, row0));
+            for (uint64_t j = 0; j < phenotypes_n; j++) cerr << ".";
+            t1 = now_s();
+            cerr << "Associations [" << batch_index << "]\t" << (t1 - t0) / 60. << "min" << endl;
+            t0 = now_s();
+            batch_index++;
+        }
+        ck(kgwas_scan_finish(scan));
+        kgwas_scan_stats st;
+        ck(kgwas_scan_get_stats(scan, &st));
+
+        // Outputs (:150-205)
+        for (uint64_t j = 0; j < phenotypes_n; j++) {
+            uint64_t n = 0;
+            const uint64_t *kmer = nullptr, *row = nullptr;
+            const double* score = nullptr;
+            ck(kgwas_scan_result(scan, j, &n, &kmer, &score, &row));
+            if (vm.count("k_mers_scores")) {  // output_to_file_with_scores (best_associations_heap.cpp:82-92)
+                ofstream of(fn_base + "." + to_string(j) + ".best_kmers.scores", ios::binary);
+                for (uint64_t i = 0; i < n; i++) {
+                    of.write(reinterpret_cast<const char*>(&kmer[i]), sizeof(uint64_t));
+                    of.write(reinterpret_cast<const char*>(&score[i]), sizeof(double));
+                }
+            }
+            const string out = fn_base + "." + to_string(j) + "." + pname[j];
+            cerr << "Save [" << j << "]" << endl;
+            ck(kgwas_write_plink(out.c_str(), tbl, col.data(), n_accessions, acc.data(), Y + j * n_accessions, n, kmer, row));
+        }
+        {
+            ofstream fout(fn_base + ".tested_kmers");
+            fout << st.rows_tested << endl;
+        }
+        cerr << "[kgwas] kernel=" << (st.kernel_used == KGWAS_KERNEL_MFMA ? "mfma_f32" : "valu")
+             << " direct=" << st.direct_mode << " chunks=" << st.chunks << " score_kernel_ms=" << st.score_kernel_ms
+             << " candidates=" << st.candidates << " heap_pushes=" << st.heap_pushes << endl;
+        kgwas_scan_destroy(scan);
+        kgwas_table_close(tbl);
+        kgwas_pheno_free(ph);
+    } catch (const std::invalid_argument& e) {
+        cerr << "error parsing options: " << e.what() << endl;
+        cerr << vm.help("associate_kmers", desc) << endl;
+        exit(1);
+    }
+    return 0;
+}

@@ -1,0 +1,102 @@
+// emma_kinship_kmers — drop-in for the reference tool of the same name
+// (src/emma_kinship_kmers.cpp): same options (-t/--kmers_table, -k/--kmers_len, --maf, all
+// required), matrix on stdout, progress on stderr; the accumulation runs on the GPU.
+#include <cmath>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "../../include/kgwas.h"
+#include "cli_args.h"
+
+using namespace std;
+
+static bool file_exists(const string& fn) {
+    ifstream f(fn);
+    return f.good();
+}
+static void ck(int rc) {
+    if (rc == KGWAS_OK) return;
+    if (rc == KGWAS_ERR_FORMAT || rc == KGWAS_ERR_IO) {
+        cerr << "terminate called after throwing an instance of 'std::logic_error'\n  what():  " << kgwas_last_error()
+             << endl;
+        abort();
+    }
+    cerr << "emma_kinship_kmers: " << kgwas_last_error() << endl;
+    exit(rc == KGWAS_ERR_DEVICE ? 3 : 1);
+}
+
+int main(int argc, char* argv[]) {
+    CliArgs result({
+        {"kmers_table", 't', true, "k-mers table path", ""},
+        {"kmers_len", 'k', true, "length of k-mers", ""},
+        {"maf", 0, true, "minor allele frequency", ""},
+        {"device", 0, true, "GPU ordinal", "0"},
+        {"help", 0, false, "print help", ""},
+    });
+    const string desc = "Calculate a kinship matrix from the k-mers table (output to stdout)";
+    try {
+        result.parse(argc, argv);
+        if (result.count("help")) {
+            cerr << result.help("emma_kinship_kmers", desc) << endl;
+            exit(0);
+        }
+        for (const char* req : {"kmers_table", "kmers_len", "maf"}) {
+            if (result.count(req) == 0) {
+                cerr << req << " is a required parameter" << endl;
+                cerr << result.help("emma_kinship_kmers", desc) << endl;
+                exit(1);
+            }
+        }
+        const string fn_kmers_table(result.str("kmers_table"));
+        const double MAF = result.f64("maf");
+        const size_t kmer_len = result.u64("kmers_len");
+        for (const string& f : {fn_kmers_table + ".names", fn_kmers_table + ".table"}) {
+            if (!file_exists(f)) {
+                cerr << "Couldn't find file: " << f << endl;
+                exit(1);
+            }
+        }
+        if ((kmer_len > 31) || (kmer_len < 10)) {
+            cerr << "kmer length has to be between 10-31" << endl;
+            exit(1);
+        }
+        kgwas_table* tbl = nullptr;
+        ck(kgwas_table_open(fn_kmers_table.c_str(), (uint32_t)kmer_len, &tbl));
+        uint64_t n_acc = 0, n_rows = 0, W_f = 0;
+        ck(kgwas_table_info(tbl, &n_acc, &n_rows, &W_f, nullptr));
+        const size_t min_count = (size_t)ceil(static_cast<double>(n_acc) * MAF);  // :83
+        cerr << "Min count = " << min_count << endl;
+        kgwas_kinship* kin = nullptr;
+        ck(kgwas_kinship_create((int32_t)result.u64("device", 0), n_acc, min_count, &kin));
+        cerr << "loading..." << endl;
+        const uint64_t batch = 1ull << 20;  // :89
+        vector<uint64_t> buf;
+        for (uint64_t row0 = 0; row0 < n_rows; row0 += batch) {
+            const uint64_t n = std::min<uint64_t>(batch, n_rows - row0);
+            buf.resize(n * (1 + W_f));
+            ck(kgwas_table_read_rows(tbl, row0, n, buf.data()));
+            cerr << ".";
+            cerr.flush();
+            ck(kgwas_kinship_feed_host(kin, buf.data(), n));
+        }
+        vector<uint64_t> H(n_acc * n_acc), K(n_acc * n_acc);
+        uint64_t n_snps = 0;
+        ck(kgwas_kinship_partials(kin, H.data(), &n_snps));
+        ck(kgwas_kinship_from_partials(n_acc, H.data(), n_snps, K.data()));
+        cerr << "#" << n_snps << endl;
+        const uint64_t need = kgwas_kinship_format(n_acc, K.data(), n_snps, nullptr, 0);
+        string text(need, '\0');
+        kgwas_kinship_format(n_acc, K.data(), n_snps, &text[0], need);
+        cout << text;
+        kgwas_kinship_destroy(kin);
+        kgwas_table_close(tbl);
+    } catch (const std::invalid_argument& e) {
+        cerr << "error parsing options: " << e.what() << endl;
+        cerr << result.help("emma_kinship_kmers", desc) << endl;
+        exit(1);
+    }
+    return 0;
+}

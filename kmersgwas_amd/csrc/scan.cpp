@@ -683,8 +683,8 @@ int kgwas_scan_feed_host(kgwas_scan* s, const uint64_t* rows, uint64_t n_rows, u
         if (s->finished) throw Error(KGWAS_ERR_STATE, "scan already finished");
         KGWAS_HIP(hipSetDevice(s->device));
         const uint64_t stride = 1 + s->W_f;
-        const uint64_t piece = s->chunk_max;
-        if (s->d_stage.n < piece * stride) s->d_stage.alloc(piece * stride);
+        const uint64_t piece = std::min<uint64_t>(s->chunk_max, std::max<uint64_t>(n_rows, 1));
+        if (s->d_stage.n < piece * stride) s->d_stage.alloc(piece * stride);  // grows only
         for (uint64_t pos = 0; pos < n_rows; pos += piece) {
             const uint64_t c = std::min<uint64_t>(piece, n_rows - pos);
             KGWAS_HIP(hipMemcpyAsync(s->d_stage.p, rows + pos * stride, c * stride * 8, hipMemcpyHostToDevice, s->stream));
@@ -749,7 +749,7 @@ int kgwas_scan_scores_dense(kgwas_scan* s, const void* rows, int rows_on_device,
         KGWAS_HIP(hipSetDevice(s->device));
         const uint64_t stride = 1 + s->W_f;
         const uint64_t piece = s->dense_rows;
-        if (!rows_on_device && s->d_stage.n < piece * stride) s->d_stage.alloc(std::max<uint64_t>(piece, s->chunk_max) * stride);
+        if (!rows_on_device && s->d_stage.n < piece * stride) s->d_stage.alloc(piece * stride);
         std::vector<double> tmp(s->n_pheno * piece);
         for (uint64_t pos = 0; pos < n_rows; pos += piece) {
             const uint64_t c = std::min<uint64_t>(piece, n_rows - pos);

@@ -1,0 +1,250 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle.
+Integer / index results must be bit-exact; scores must be bit-exact too (the kernels reproduce the
+reference's float32 order), which is stronger than the 1e-6 relative tolerance north_star allows.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import kmersgwas_amd as kg
+from oracle import binding as ob
+from oracle import oracle_np as onp
+from helpers import random_table, phenotypes, synth_rows_numpy
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+KERNELS = [kg.KERNEL_VALU, kg.KERNEL_MFMA]
+
+
+def _check_topn(scan, oracle_res, n_pheno):
+    for j in range(n_pheno):
+        k, s, r = scan.result(j)
+        o = oracle_res["per_pheno"][j]
+        assert (k == o["kmer"]).all(), "k-mer identities differ for column %d" % j
+        assert (r == o["file_row"]).all(), "row ids differ for column %d" % j
+        assert s.tobytes() == o["score"].tobytes(), "scores differ for column %d" % j
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("S_f,S,reorder", [(5, 5, False), (64, 64, False), (127, 127, False), (128, 128, False),
+                                           (129, 129, False), (241, 241, False), (241, 200, True), (1027, 1027, False),
+                                           (1135, 1135, False), (300, 77, True), (2048, 2048, False), (700, 650, False)])
+def test_dense_scores_bit_exact(kernel, S_f, S, reorder):
+    n_rows = 1500 if S < 1000 else 700
+    rows = random_table(n_rows, S_f, seed=S_f * 3 + S)
+    rng = np.random.default_rng(S)
+    col = rng.permutation(S_f)[:S].astype(np.uint64) if reorder else np.arange(S, dtype=np.uint64)
+    P = 21
+    Y = phenotypes(S, P - 1, seed=S + 1)
+    mac = onp.min_count(S, 0.05, 2)
+    exp, kept = ob.scores_dense(rows, S_f, col, Y, mac)
+    scan = kg.AssociationScan(S_f, col, Y, 10, mac, kernel=kernel)
+    got, pc = scan.scores_dense(rows)
+    g, n1, keep = onp.mac_filter(rows, col, mac)
+    assert (pc == n1).all()
+    assert (keep == kept).all()
+    assert got.tobytes() == exp.tobytes()
+    assert scan.stats()["direct_mode"] == (0 if reorder else 1)
+    scan.close()
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_known_answers_on_gpu(kernel):
+    import json
+    cases = json.load(open(os.path.join(GOLD, "known_answers.json")))
+    for c in cases:
+        S = c["S"]
+        words = [0] * ((S + 63) // 64)
+        for i, b in enumerate(c["bits"]):
+            if b:
+                words[i // 64] |= 1 << (i % 64)
+        rows = np.asarray([[1] + words], dtype=np.uint64)
+        Y = np.tile(np.asarray(c["y"], np.float32), (4, 1))
+        scan = kg.AssociationScan(S, np.arange(S), Y, 1, c["mac"], kernel=kernel)
+        got, _ = scan.scores_dense(rows)
+        assert (got[:, 0] == c["expected"]).all()
+        scan.close()
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_golden_vectors(kernel):
+    g = np.load(os.path.join(GOLD, "assoc_small.npz"))
+    rows, col, Y = g["rows"], g["col"], g["Y"]
+    S_f, mac, topn = int(g["S_f"]), int(g["mac"]), int(g["topn"])
+    scan = kg.AssociationScan(S_f, col, Y, topn, mac, kernel=kernel)
+    got, _ = scan.scores_dense(rows)
+    assert got.tobytes() == g["dense"].tobytes()
+    scan.feed_host(rows)
+    scan.finish()
+    for j in range(Y.shape[0]):
+        k, s, r = scan.result(j)
+        assert (k == g["top_kmer"][j]).all() and (r == g["top_row"][j]).all()
+        assert s.tobytes() == g["top_score"][j].tobytes()
+    assert scan.stats()["rows_tested"] == int(g["tested"])
+    scan.close()
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("binary,dup", [(False, 0.0), (True, 0.5), (False, 0.3)])
+def test_topn_identities_with_ties(kernel, binary, dup):
+    """Heavy ties (duplicated patterns, binary trait): survivors, pop order and scores must equal the
+    reference heap's, which depends on the full history of effective pushes."""
+    S_f, S = 260, 241
+    rows = random_table(60000, S_f, seed=77, dup_frac=dup)
+    col = np.arange(S, dtype=np.uint64)
+    P = 9
+    Y = phenotypes(S, P - 1, seed=4, binary=binary)
+    mac = onp.min_count(S, 0.05, 5)
+    topn = np.full(P, 301, np.uint64)
+    topn[0] = 1000  # --first_phenotype_best
+    exp = ob.associate(rows, S_f, col, Y, topn, mac, batch_size=7000, threads=4)
+    # small chunks force dense -> sparse transition, many sparse chunks and the double-buffer path
+    scan = kg.AssociationScan(S_f, col, Y, topn, mac, kernel=kernel, chunk_rows=4096, host_threads=3)
+    scan.feed_host(rows[:25000], 0)
+    scan.feed_host(rows[25000:25001], 25000)
+    scan.feed_host(rows[25001:], 25001)
+    scan.finish()
+    _check_topn(scan, exp, P)
+    st = scan.stats()
+    assert st["rows_tested"] == exp["tested"]
+    assert st["rows_fed"] == len(rows)
+    scan.close()
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_squeezed_mode_topn_and_history_merge(kernel):
+    """Phenotyped subset in shuffled order (squeeze kernel) + cross-shard merge of two scans."""
+    S_f, S = 330, 290
+    rows = random_table(40000, S_f, seed=5, dup_frac=0.2)
+    col = np.random.default_rng(1).permutation(S_f)[:S].astype(np.uint64)
+    P = 6
+    Y = phenotypes(S, P - 1, seed=9)
+    mac = onp.min_count(S, 0.05, 5)
+    topn = 500
+    exp = ob.associate(rows, S_f, col, Y, topn, mac)
+    scan = kg.AssociationScan(S_f, col, Y, topn, mac, kernel=kernel, chunk_rows=8192)
+    scan.feed_host(rows)
+    scan.finish()
+    _check_topn(scan, exp, P)
+    assert scan.stats()["direct_mode"] == 0
+    scan.close()
+    # two shards, each scanned on its own, merged in row order == single scan
+    cut = 17000
+    hist = []
+    for lo, hi in [(0, cut), (cut, len(rows))]:
+        sc = kg.AssociationScan(S_f, col, Y, topn, mac, kernel=kernel, chunk_rows=8192, record_history=True)
+        sc.feed_host(rows[lo:hi], lo)
+        sc.finish()
+        hist.append([sc.history(j) for j in range(P)])
+        sc.close()
+    heaps = kg.merge_shards(topn, hist)
+    for j in range(P):
+        k, s, r = heaps[j].pop_all()
+        o = exp["per_pheno"][j]
+        assert (k == o["kmer"]).all() and (r == o["file_row"]).all() and s.tobytes() == o["score"].tobytes()
+
+
+def test_heap_never_fills_and_tiny_inputs():
+    S = 100
+    rows = random_table(300, S, seed=1)
+    col = np.arange(S, dtype=np.uint64)
+    Y = phenotypes(S, 4, seed=2)
+    mac = 5
+    exp = ob.associate(rows, S, col, Y, 1_000_000, mac)
+    for kernel in KERNELS:
+        scan = kg.AssociationScan(S, col, Y, 1_000_000, mac, kernel=kernel)
+        scan.feed_host(rows)
+        scan.feed_host(rows[:0], len(rows))  # empty feed
+        scan.finish()
+        _check_topn(scan, exp, 5)
+        scan.close()
+    # nothing passes the MAC filter
+    scan = kg.AssociationScan(S, col, Y, 10, 60)
+    scan.feed_host(rows)
+    scan.finish()
+    assert len(scan.result(0)[0]) == 0 and scan.stats()["rows_tested"] == 0
+    scan.close()
+
+
+def test_nonfinite_phenotype_uses_valu_and_matches():
+    S = 130
+    rows = random_table(2000, S, seed=8)
+    col = np.arange(S, dtype=np.uint64)
+    Y = phenotypes(S, 5, seed=3)
+    Y[2, 7] = np.inf
+    Y[4, 100] = np.nan
+    exp, kept = ob.scores_dense(rows, S, col, Y, 5)
+    scan = kg.AssociationScan(S, col, Y, 10, 5)  # AUTO must avoid the multiplicative MFMA form
+    assert scan.stats()["kernel_used"] == kg.KERNEL_VALU
+    got, _ = scan.scores_dense(rows)
+    assert np.array_equal(got, exp, equal_nan=True)
+    with pytest.raises(kg.KgwasError):
+        kg.AssociationScan(S, col, Y, 10, 5, kernel=kg.KERNEL_MFMA)
+    scan.close()
+
+
+def test_synth_device_equals_host_twin_and_numpy():
+    import torch
+    for n_acc in (64, 241, 1024, 1135):
+        W = 1 + (n_acc + 63) // 64
+        n = 3000
+        host = kg.synth_rows_host(12345, n, n_acc, 20240601)
+        assert (host == synth_rows_numpy(12345, n, n_acc, 20240601)).all()
+        t = torch.empty(n * W, dtype=torch.int64, device="cuda")
+        kg.synth_rows_device(t.data_ptr(), 12345, n, n_acc, 20240601, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        dev = t.cpu().numpy().view(np.uint64).reshape(n, W)
+        assert (dev == host).all()
+    # frequency model: ~6 % of rows fail a 5 % MAF filter at 1024 samples
+    rows = kg.synth_rows_host(0, 20000, 1024, 1)
+    n1 = onp.unpack_bits(rows, np.arange(1024, dtype=np.uint64)).sum(axis=1)
+    frac = ((n1 < 52) | (n1 > 1024 - 52)).mean()
+    assert 0.03 < frac < 0.10
+
+
+def test_device_resident_feed_equals_host_feed():
+    import torch
+    S, n, P = 1024, 300_000, 20
+    W = 1 + S // 64
+    Y = phenotypes(S, P - 1, seed=7)
+    mac = onp.min_count(S, 0.05, 5)
+    t = torch.empty(n * W, dtype=torch.int64, device="cuda")
+    kg.synth_rows_device(t.data_ptr(), 0, n, S, 99, torch.cuda.current_stream().cuda_stream)
+    rows = kg.synth_rows_host(0, n, S, 99)
+    res = []
+    for mode in ("dev", "host"):
+        scan = kg.AssociationScan(S, np.arange(S), Y, 2000, mac, chunk_rows=65536)
+        if mode == "dev":
+            scan.feed_device(t.data_ptr(), n, 0, torch.cuda.current_stream().cuda_stream)
+        else:
+            scan.feed_host(rows)
+        scan.finish()
+        res.append([scan.result(j) for j in range(P)])
+        st = scan.stats()
+        assert st["kernel_used"] == kg.KERNEL_MFMA and st["direct_mode"] == 1
+        scan.close()
+    for j in range(P):
+        for a, b in zip(res[0][j], res[1][j]):
+            assert a.tobytes() == b.tobytes()
+    # spot-check against the oracle on the rows that won (size-independent check of a big scan)
+    exp = ob.associate(rows, S, np.arange(S, dtype=np.uint64), Y[:3], 2000, mac, threads=3)
+    for j in range(3):
+        k, s, r = res[0][j]
+        o = exp["per_pheno"][j]
+        assert (k == o["kmer"]).all() and (r == o["file_row"]).all() and s.tobytes() == o["score"].tobytes()
+
+
+@pytest.mark.parametrize("S_f,n_rows", [(5, 100), (64, 700), (77, 2000), (241, 5000), (1135, 3000)])
+def test_kinship_exact(S_f, n_rows):
+    rows = random_table(n_rows, S_f, seed=S_f)
+    mc = int(np.ceil(S_f * 0.05))
+    K, n = ob.kinship(rows, S_f, mc)
+    kin = kg.Kinship(S_f, mc)
+    kin.feed_host(rows[: n_rows // 3])
+    kin.feed_host(rows[n_rows // 3:])
+    Kg, ng = kin.matrix()
+    assert ng == n
+    assert (Kg == K).all()
+    assert kg.kinship_format(Kg, ng) == ob.kinship_text(K, n)
+    kin.close()
