@@ -127,7 +127,9 @@ typedef struct kgwas_scan_stats {
     uint64_t score_launches;    /* launches of the scoring kernel */
     double score_kernel_ms;     /* sum of hipEvent durations of the scoring kernel */
     double squeeze_kernel_ms;   /* sum of hipEvent durations of the squeeze kernel (0 in direct mode) */
-    double replay_ms;           /* host wall time spent replaying candidates (summed over threads) */
+    double replay_ms;           /* host wall time spent replaying candidates (control thread view) */
+    double gpu_wait_ms;         /* host wall time blocked waiting for sparse chunks to finish */
+    double dense_ms;            /* host wall time of the dense (heap-filling) phase, GPU + replay */
     uint32_t kernel_used;       /* KGWAS_KERNEL_VALU or KGWAS_KERNEL_MFMA */
     uint32_t direct_mode;       /* 1 = scorer read the file layout in place (no squeeze pass) */
 } kgwas_scan_stats;
@@ -146,6 +148,9 @@ int kgwas_scan_result(kgwas_scan* s, uint64_t j, uint64_t* n, const uint64_t** k
 int kgwas_scan_history(kgwas_scan* s, uint64_t j, uint64_t* n, const uint64_t** kmer, const double** score,
                        const uint64_t** row);
 int kgwas_scan_get_stats(const kgwas_scan* s, kgwas_scan_stats* st);
+/* Empty the heaps, histories and statistics but keep every device / pinned buffer, so a session can
+ * scan another table (or the same one again) without paying allocation again. */
+int kgwas_scan_reset(kgwas_scan* s);
 void kgwas_scan_destroy(kgwas_scan* s);
 
 /* calculate_kmer_score for every row and phenotype column (src/kmers_multiple_databases.cpp:327-363):

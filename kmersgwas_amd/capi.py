@@ -29,7 +29,7 @@ SYMBOLS = [
     "kgwas_heap_new", "kgwas_heap_add_many", "kgwas_heap_size", "kgwas_heap_pop_all", "kgwas_heap_output_list",
     "kgwas_heap_free",
     "kgwas_scan_create", "kgwas_scan_feed_device", "kgwas_scan_feed_host", "kgwas_scan_finish", "kgwas_scan_result",
-    "kgwas_scan_history", "kgwas_scan_get_stats", "kgwas_scan_destroy", "kgwas_scan_scores_dense",
+    "kgwas_scan_history", "kgwas_scan_get_stats", "kgwas_scan_reset", "kgwas_scan_destroy", "kgwas_scan_scores_dense",
     "kgwas_merge_shards",
     "kgwas_kinship_create", "kgwas_kinship_feed_device", "kgwas_kinship_feed_host", "kgwas_kinship_partials",
     "kgwas_kinship_from_partials", "kgwas_kinship_get_stats", "kgwas_kinship_destroy", "kgwas_kinship_format",
@@ -61,6 +61,7 @@ class ScanStats(C.Structure):
         ("rows_fed", C.c_uint64), ("rows_tested", C.c_uint64), ("candidates", C.c_uint64),
         ("heap_pushes", C.c_uint64), ("chunks", C.c_uint64), ("score_launches", C.c_uint64),
         ("score_kernel_ms", C.c_double), ("squeeze_kernel_ms", C.c_double), ("replay_ms", C.c_double),
+        ("gpu_wait_ms", C.c_double), ("dense_ms", C.c_double),
         ("kernel_used", C.c_uint32), ("direct_mode", C.c_uint32),
     ]
 
@@ -144,6 +145,7 @@ lib.kgwas_scan_finish.argtypes = [_vp]
 lib.kgwas_scan_result.argtypes = [_vp, _u64, _pu64, C.POINTER(_pu64), C.POINTER(_pdbl), C.POINTER(_pu64)]
 lib.kgwas_scan_history.argtypes = [_vp, _u64, _pu64, C.POINTER(_pu64), C.POINTER(_pdbl), C.POINTER(_pu64)]
 lib.kgwas_scan_get_stats.argtypes = [_vp, C.POINTER(ScanStats)]
+lib.kgwas_scan_reset.argtypes = [_vp]
 lib.kgwas_scan_destroy.argtypes = [_vp]
 lib.kgwas_scan_destroy.restype = None
 lib.kgwas_scan_scores_dense.argtypes = [_vp, _vp, C.c_int, _u64, _vp, _vp]

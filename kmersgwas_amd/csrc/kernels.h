@@ -51,7 +51,8 @@ struct ScoreArgs {
 
 // Scoring kernels. rows_per_block only matters for the MFMA kernel (multiple of 128).
 hipError_t launch_score_valu(const ScoreArgs& a, hipStream_t st);
-hipError_t launch_score_mfma(const ScoreArgs& a, uint32_t rows_per_block, hipStream_t st);
+// nb_full = leading 128-sample blocks whose four dwords all exist in the row and need no masking.
+hipError_t launch_score_mfma(const ScoreArgs& a, uint32_t rows_per_block, uint32_t nb_full, hipStream_t st);
 size_t mfma_lds_bytes(uint32_t W_m);
 
 // Squeeze: out[r][2*W_m dwords] bit i = file bit colmap[i] (colmap[i] == 0xFFFFFFFF -> 0).

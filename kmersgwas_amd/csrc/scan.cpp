@@ -172,6 +172,7 @@ struct kgwas_scan {
     uint64_t chunk_max = 0, dense_rows = 0;
     uint32_t cap = 0;
     uint64_t max_topn = 0;
+    uint32_t nb_full = 0;  // leading 128-sample blocks the MFMA scorer may read unmasked
 
     hipStream_t stream = nullptr;
     hipEvent_t ev_user = nullptr, ev_ds = nullptr, ev_d0 = nullptr, ev_d1 = nullptr;  // caller sync + dense-chunk timing
@@ -249,18 +250,20 @@ void fill_args(kgwas_scan* s, ScoreArgs& a, const uint64_t* d_rows, uint64_t n_r
     a.thr = s->d_thr.p;
 }
 
-uint32_t pick_rows_per_block(uint64_t n_rows, uint64_t n_ctiles) {
-    for (uint32_t rpb : {1024u, 512u, 256u}) {
-        const uint64_t blocks = ((n_rows + rpb - 1) / rpb) * n_ctiles;
-        if (blocks >= 1024) return rpb;
+// One block per row block (it walks every column-tile group itself): keep at least ~8 rounds of
+// blocks over the 256 CUs so the last round's imbalance stays small; the launcher rounds up to
+// the rows one pass of the block's waves covers.
+uint32_t pick_rows_per_block(uint64_t n_rows, uint64_t /*n_ctiles*/) {
+    for (uint32_t rpb : {1024u, 512u}) {
+        if ((n_rows + rpb - 1) / rpb >= 2048) return rpb;
     }
-    return 128u;
+    return 256u;
 }
 
 void launch_score(kgwas_scan* s, const ScoreArgs& a) {
     if (s->kernel_used == KGWAS_KERNEL_MFMA) {
         const uint64_t nct = (s->n_pheno + 15) / 16;
-        KGWAS_HIP(launch_score_mfma(a, pick_rows_per_block(a.n_rows, nct), s->stream));
+        KGWAS_HIP(launch_score_mfma(a, pick_rows_per_block(a.n_rows, nct), s->nb_full, s->stream));
     } else {
         KGWAS_HIP(launch_score_valu(a, s->stream));
     }
@@ -290,6 +293,7 @@ void refresh_full(kgwas_scan* s) {
 void run_dense(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, uint64_t first_row, double* out_scores,
                uint32_t* out_n1, bool replay) {
     ScoreArgs a;
+    auto td0 = std::chrono::steady_clock::now();
     hipEvent_t e0 = s->ev_d0, e1 = s->ev_d1, es = s->ev_ds;
     fill_args(s, a, d_rows, n_rows, first_row, !s->direct);
     a.dense = s->d_dense.p;
@@ -352,6 +356,7 @@ void run_dense(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, uint64_t 
     s->rows_done += n_rows;
     refresh_full(s);
     upload_thresholds(s);
+    s->st.dense_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - td0).count();
 }
 
 void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_rows, uint64_t first_row) {
@@ -384,7 +389,11 @@ void process_range_sync(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_
 // Wait for a submitted sparse chunk, replay its candidates in row order, refresh thresholds.
 // Returns false if a candidate list overflowed (nothing was replayed).
 bool reap_sparse(kgwas_scan* s, Slot& sl) {
-    KGWAS_HIP(hipEventSynchronize(sl.ev_done));  // kernel done (mapped candidate writes visible) + counts copied
+    {
+        auto w0 = std::chrono::steady_clock::now();
+        KGWAS_HIP(hipEventSynchronize(sl.ev_done));  // kernel done (mapped candidate writes visible) + counts copied
+        s->st.gpu_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+    }
     sl.busy = false;
     float ms = 0;
     KGWAS_HIP(hipEventElapsedTime(&ms, sl.ev_k0, sl.ev_k1));
@@ -617,6 +626,14 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                     for (uint64_t sx = 0; sx < 32; sx++)
                         Ymfma[(ct * L + (b * 4 + l) * 32 + sx) * 16 + n] = V[128 * b + 32 * l + 31 - sx];
         }
+        {
+            const uint64_t avail = s->direct ? 2 * s->W_f : 2 * W_m;
+            uint32_t nb = 0;
+            while (nb < W_m / 2 && 4ull * nb + 3 < avail && dmask[4 * nb] == 0xFFFFFFFFu &&
+                   dmask[4 * nb + 1] == 0xFFFFFFFFu && dmask[4 * nb + 2] == 0xFFFFFFFFu && dmask[4 * nb + 3] == 0xFFFFFFFFu)
+                nb++;
+            s->nb_full = nb;
+        }
         s->d_dmask.alloc(dmask.size());
         s->d_colmap.alloc(colmap.size());
         s->d_sums.alloc(P);
@@ -730,6 +747,28 @@ int kgwas_scan_history(kgwas_scan* s, uint64_t j, uint64_t* n, const uint64_t** 
         if (kmer) *kmer = s->hist[j].kmer.data();
         if (score) *score = s->hist[j].score.data();
         if (row) *row = s->hist[j].row.data();
+    });
+}
+
+int kgwas_scan_reset(kgwas_scan* s) {
+    return guarded([&] {
+        if (!s) throw Error(KGWAS_ERR_ARG, "kgwas_scan_reset: null");
+        KGWAS_HIP(hipSetDevice(s->device));
+        KGWAS_HIP(hipStreamSynchronize(s->stream));
+        s->heaps.clear();
+        for (uint64_t j = 0; j < s->n_pheno; j++) s->heaps.emplace_back((size_t)s->topn[j]);
+        for (auto& h : s->hist) {
+            h.kmer.clear();
+            h.score.clear();
+            h.row.clear();
+        }
+        s->all_full = false;
+        s->rows_done = 0;
+        s->finished = false;
+        const uint32_t ku = s->st.kernel_used, dm = s->st.direct_mode;
+        s->st = kgwas_scan_stats{};
+        s->st.kernel_used = ku;
+        s->st.direct_mode = dm;
     });
 }
 

@@ -172,6 +172,10 @@ class AssociationScan:
     def finish(self):
         check(lib.kgwas_scan_finish(self._h))
 
+    def reset(self):
+        """Empty heaps / histories / statistics, keep all buffers (session reuse)."""
+        check(lib.kgwas_scan_reset(self._h))
+
     def _lists(self, fn, j):
         n = C.c_uint64()
         k, s, r = C.POINTER(C.c_uint64)(), C.POINTER(C.c_double)(), C.POINTER(C.c_uint64)()
