@@ -36,6 +36,18 @@ def make_phenotypes(S, n_perm, seed):
     return np.ascontiguousarray(np.stack(cols).astype(np.float32))
 
 
+def usable_cpus():
+    """CPUs this process may really use: the cgroup quota if there is one, else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(q) // int(p)))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(S, Y, mac, topn, seed, sample_rows, threads):
     """Oracle (CPU restatement of the reference algorithm: per-bit squeeze loader + SSE-order
     scorer + std::priority_queue, one thread per phenotype column) on a bounded sample."""
@@ -62,7 +74,7 @@ def main():
     ap.add_argument("--topn", type=int, default=10001)
     ap.add_argument("--kernel", type=int, default=0)
     ap.add_argument("--chunk-rows", type=int, default=0)
-    ap.add_argument("--cpu-sample-rows", type=int, default=200_000)
+    ap.add_argument("--cpu-sample-rows", type=int, default=2_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -176,11 +188,11 @@ def main():
                      "chunks_per_step": sum(s["chunks"] for s in stats) // args.steps,
                      "gpu_wait_ms_per_step": sum(s["gpu_wait_ms"] for s in stats) / args.steps,
                      "dense_phase_ms_per_step": sum(s["dense_ms"] for s in stats) / args.steps,
-                     "cores": os.cpu_count()},
+                     "cores": usable_cpus(), "logical_cpus": os.cpu_count()},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S, Y, mac, args.topn, seed_table, args.cpu_sample_rows,
-                                               threads=min(os.cpu_count() or 1, P))
+                                               threads=min(usable_cpus(), P))
         print(json.dumps(out))
     if last is not None:
         last.close()

@@ -20,6 +20,8 @@
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <memory>
@@ -40,7 +42,7 @@ class Pool {
    public:
     explicit Pool(unsigned n) : stop_(false), gen_(0), pending_(0), n_items_(0) {
         if (n < 1) n = 1;
-        for (unsigned i = 1; i < n; i++) th_.emplace_back([this] { loop(); });
+        for (unsigned i = 1; i < n; i++) th_.emplace_back([this, i] { loop(i); });
     }
     ~Pool() {
         {
@@ -51,41 +53,50 @@ class Pool {
         cv_.notify_all();
         for (auto& t : th_) t.join();
     }
+    // Static assignment: item i always runs on worker i % size(), so a phenotype column's heap
+    // (~240 KB at N = 10001) stays in one core's cache from chunk to chunk.
     void parallel_for(size_t n, const std::function<void(size_t)>& fn) {
         if (n == 0) return;
         {
             std::unique_lock<std::mutex> lk(mu_);
             fn_ = &fn;
             n_items_ = n;
-            next_.store(0);
             pending_ = th_.size();
-            gen_++;
+            gen_.fetch_add(1, std::memory_order_release);
         }
         cv_.notify_all();
-        run();
+        run(0);
         std::unique_lock<std::mutex> lk(mu_);
         done_cv_.wait(lk, [this] { return pending_ == 0; });
         fn_ = nullptr;
     }
+    size_t size() const { return th_.size() + 1; }
 
    private:
-    void run() {
-        for (;;) {
-            size_t i = next_.fetch_add(1);
-            if (i >= n_items_) break;
-            (*fn_)(i);
-        }
+    void run(size_t me) {
+        const size_t T = th_.size() + 1;
+        for (size_t i = me; i < n_items_; i += T) (*fn_)(i);
     }
-    void loop() {
+    void loop(size_t me) {
         uint64_t seen = 0;
         for (;;) {
+            // Chunks arrive every few milliseconds while a scan is running: spin briefly before
+            // sleeping so the wake-up does not cost a futex round trip per worker per chunk.
+            bool got = false;
+            for (int spin = 0; spin < 4000; spin++) {
+                if (gen_.load(std::memory_order_acquire) != seen) {
+                    got = true;
+                    break;
+                }
+                __builtin_ia32_pause();
+            }
             {
                 std::unique_lock<std::mutex> lk(mu_);
-                cv_.wait(lk, [&] { return gen_ != seen; });
-                seen = gen_;
+                if (!got) cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen; });
+                seen = gen_.load(std::memory_order_acquire);
                 if (stop_) return;
             }
-            run();
+            run(me);
             {
                 std::unique_lock<std::mutex> lk(mu_);
                 if (--pending_ == 0) done_cv_.notify_all();
@@ -96,12 +107,39 @@ class Pool {
     std::mutex mu_;
     std::condition_variable cv_, done_cv_;
     bool stop_;
-    uint64_t gen_;
+    std::atomic<uint64_t> gen_;
     size_t pending_;
     const std::function<void(size_t)>* fn_ = nullptr;
     size_t n_items_;
-    std::atomic<size_t> next_{0};
 };
+
+// CPUs this process may actually use: the cgroup CPU quota when there is one (containers often
+// expose every host CPU to hardware_concurrency() while capping the quota far lower; running more
+// busy threads than the quota gets the whole process throttled for the rest of the period).
+unsigned usable_cpus() {
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota|max> <period>"
+        char q[64];
+        unsigned long long period = 0;
+        if (fscanf(f, "%63s %llu", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+            const unsigned long long quota = strtoull(q, nullptr, 10);
+            if (quota > 0) n = std::min<unsigned>(n, (unsigned)std::max<unsigned long long>(1, quota / period));
+        }
+        fclose(f);
+    } else {
+        long long quota = -1, period = 0;  // cgroup v1
+        if (FILE* fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+            if (fscanf(fq, "%lld", &quota) != 1) quota = -1;
+            fclose(fq);
+        }
+        if (FILE* fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+            if (fscanf(fp, "%lld", &period) != 1) period = 0;
+            fclose(fp);
+        }
+        if (quota > 0 && period > 0) n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, quota / period));
+    }
+    return n;
+}
 
 struct History {
     std::vector<uint64_t> kmer, row;
@@ -195,6 +233,8 @@ struct kgwas_scan {
 
     std::vector<BestHeap> heaps;
     std::vector<History> hist;
+    std::vector<std::vector<uint64_t>> keys;  // per-column sort scratch for the replay
+    bool trace = false;                       // KGWAS_TRACE=1: one stderr line per sparse chunk
     bool all_full = false;
     uint64_t rows_done = 0;  // rows whose replay is complete
     std::unique_ptr<Pool> pool;
@@ -398,6 +438,7 @@ bool reap_sparse(kgwas_scan* s, Slot& sl) {
     float ms = 0;
     KGWAS_HIP(hipEventElapsedTime(&ms, sl.ev_k0, sl.ev_k1));
     s->st.score_kernel_ms += ms;
+    const float ms_kernel = ms;
     if (!s->direct) {
         KGWAS_HIP(hipEventElapsedTime(&ms, sl.ev_sq0, sl.ev_k0));
         s->st.squeeze_kernel_ms += ms;
@@ -408,20 +449,32 @@ bool reap_sparse(kgwas_scan* s, Slot& sl) {
     auto t0 = std::chrono::steady_clock::now();
     s->st.rows_tested += *sl.h_tested.p;
     std::atomic<uint64_t> pushes(0), cands(0);
+    const uint64_t row0 = sl.first_row;
     s->pool->parallel_for(s->n_pheno, [&](size_t j) {
         const uint32_t n = sl.h_cnt.p[j];
         if (!n) return;
-        Cand* c = sl.cand.p + j * (uint64_t)s->cap;
-        std::sort(c, c + n, [](const Cand& x, const Cand& y) { return x.row < y.row; });
+        const Cand* c = sl.cand.p + j * (uint64_t)s->cap;
         BestHeap& h = s->heaps[j];
+        // The device filtered against a minimum that is one chunk old. Anything not above the
+        // CURRENT minimum would be rejected by add_association whenever it arrives (the minimum only
+        // rises), so it is dropped before the sort. The survivors are put in row order through
+        // compact (row-in-chunk, index) keys.
+        std::vector<uint64_t>& keys = s->keys[j];
+        keys.clear();
+        const bool full = h.full();
+        const double low = h.lowest();
+        for (uint32_t i = 0; i < n; i++)
+            if (!full || c[i].score > low) keys.push_back(((c[i].row - row0) << 32) | i);
+        std::sort(keys.begin(), keys.end());
         uint64_t local = 0;
-        for (uint32_t i = 0; i < n; i++) {
-            if (h.add(c[i].kmer, c[i].score, (size_t)c[i].row)) {
+        for (uint64_t key : keys) {
+            const Cand& e = c[(uint32_t)key];
+            if (h.add(e.kmer, e.score, (size_t)e.row)) {
                 local++;
                 if (s->record_history) {
-                    s->hist[j].kmer.push_back(c[i].kmer);
-                    s->hist[j].score.push_back(c[i].score);
-                    s->hist[j].row.push_back(c[i].row);
+                    s->hist[j].kmer.push_back(e.kmer);
+                    s->hist[j].score.push_back(e.score);
+                    s->hist[j].row.push_back(e.row);
                 }
             }
         }
@@ -430,9 +483,14 @@ bool reap_sparse(kgwas_scan* s, Slot& sl) {
     });
     s->st.heap_pushes += pushes.load();
     s->st.candidates += cands.load();
-    s->st.replay_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    const double rep_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    s->st.replay_ms += rep_ms;
     s->rows_done += sl.n_rows;
     upload_thresholds(s);
+    if (s->trace)
+        fprintf(stderr, "[kgwas] chunk rows=%llu first=%llu kernel=%.3fms cands=%llu pushes=%llu replay=%.3fms\n",
+                (unsigned long long)sl.n_rows, (unsigned long long)sl.first_row, ms_kernel,
+                (unsigned long long)cands.load(), (unsigned long long)pushes.load(), rep_ms);
     return true;
 }
 
@@ -619,12 +677,17 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
             volatile float sum = 0.0f;
             for (uint64_t i = 0; i < L; i++) sum = sum + R[i];
             sums[j] = sum;
-            // MFMA layout: [ct][(b*4+l)*32+s][n] = V[128b+32l+31-s]
+            // MFMA layout (see score_mfma.hip): [ct][(((b*4+l)*2 + t/4)*64 + kk*16+n)*4 + t%4], s = 4t+kk
             const uint64_t ct = j / 16, n = j % 16;
             for (uint64_t b = 0; b < L / 128; b++)
                 for (uint64_t l = 0; l < 4; l++)
                     for (uint64_t sx = 0; sx < 32; sx++)
-                        Ymfma[(ct * L + (b * 4 + l) * 32 + sx) * 16 + n] = V[128 * b + 32 * l + 31 - sx];
+                    {
+                        // chain step sx = 4t + kk; lane = kk*16 + n; four consecutive t sit together
+                        const uint64_t t = sx / 4, kk = sx % 4;
+                        Ymfma[ct * L * 16 + (((b * 4 + l) * 2 + t / 4) * 64 + kk * 16 + n) * 4 + t % 4] =
+                            V[128 * b + 32 * l + 31 - sx];
+                    }
         }
         {
             const uint64_t avail = s->direct ? 2 * s->W_f : 2 * W_m;
@@ -673,7 +736,9 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
 
         for (uint64_t j = 0; j < P; j++) s->heaps.emplace_back((size_t)s->topn[j]);
         s->hist.resize(P);
-        unsigned nt = p->host_threads ? p->host_threads : std::max(1u, std::thread::hardware_concurrency());
+        s->keys.resize(P);
+        s->trace = getenv("KGWAS_TRACE") != nullptr;
+        unsigned nt = p->host_threads ? p->host_threads : usable_cpus();
         nt = (unsigned)std::min<uint64_t>(nt, P);
         s->pool.reset(new Pool(nt));
         s->st.kernel_used = kern;
@@ -875,7 +940,7 @@ int kgwas_merge_shards(uint64_t n_pheno, const uint64_t* topn, uint64_t n_shards
         std::vector<std::vector<uint64_t>> off(n_shards, std::vector<uint64_t>(n_pheno + 1, 0));
         for (uint64_t g = 0; g < n_shards; g++)
             for (uint64_t j = 0; j < n_pheno; j++) off[g][j + 1] = off[g][j] + counts[g * n_pheno + j];
-        unsigned nt = threads ? threads : std::max(1u, std::thread::hardware_concurrency());
+        unsigned nt = threads ? threads : usable_cpus();
         nt = (unsigned)std::min<uint64_t>(nt, n_pheno);
         Pool pool(nt);
         pool.parallel_for(n_pheno, [&](size_t j) {

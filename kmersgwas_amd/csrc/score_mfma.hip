@@ -7,11 +7,12 @@
 // fmaf chain, so the reference's exact scores come straight out of the matrix pipe:
 //
 //   block  = 8 waves sharing NCT (1 or 2) 16-column phenotype tiles in LDS, each [L][16] floats in
-//            chain-step order: ((b*4+l)*32+s)*16+n  ->  y_n[128b+32l+31-s]
+//            chain-step order, four consecutive t per lane contiguous (one ds_read_b128):
+//            (((b*4+l)*2 + t/4)*64 + kk*16+n)*4 + t%4  ->  y_n[128b+32l+31-(4t+kk)]
 //   wave   = 2 row tiles of 16 k-mers x NCT column tiles per pass -> 8*NCT independent accumulators
 //   lane   = (m = lane & 15: k-mer row of the tile, kk = lane >> 4: k index 0..3)
 //   A[m][kk] = bit 31-(4t+kk) of the row's 32-bit SSE-lane word, as 0.0f / 1.0f
-//   B[kk][n] = ylds[c][((b*4+l)*32 + 4t+kk)*16 + n]
+//   B[kk][n] = y_n[128b+32l+31-(4t+kk)]  (k index of the MFMA = kk)
 //   D reg j  = row (lane>>4)*4 + j, column lane & 15
 //
 // What the probes (tools/probe_score.hip) showed and this layout answers:
@@ -72,8 +73,11 @@ __device__ __forceinline__ void mfma_block(f32x4 (&acc)[2][NCT][4], const uint32
     for (int rt = 0; rt < 2; rt++)
 #pragma unroll
         for (int l = 0; l < 4; l++) {
-            const uint32_t e = (w[rt][l] >> sh_e) & 0x01010101u;  // bytes 3..0: t = 0,2,4,6
-            const uint32_t o = (w[rt][l] >> sh_o) & 0x01010101u;  // bytes 3..0: t = 1,3,5,7
+            uint32_t e = (w[rt][l] >> sh_e) & 0x01010101u;  // bytes 3..0: t = 0,2,4,6
+            uint32_t o = (w[rt][l] >> sh_o) & 0x01010101u;  // bytes 3..0: t = 1,3,5,7
+            // Keep e/o as materialised registers: otherwise the compiler folds the byte selects back
+            // into one v_bfe_u32 + v_cvt_f32_ubyte0 per operand instead of a lone v_cvt_f32_ubyteN.
+            asm volatile("" : "+v"(e), "+v"(o));
 #pragma unroll
             for (int h = 0; h < 4; h++) {
                 Af[rt][l][2 * h] = (float)((e >> (8 * (3 - h))) & 0xFFu);      // v_cvt_f32_ubyteN
@@ -81,18 +85,24 @@ __device__ __forceinline__ void mfma_block(f32x4 (&acc)[2][NCT][4], const uint32
             }
         }
     __builtin_amdgcn_sched_barrier(0);  // operands first, then a clean MFMA stream
+    // B operands: one ds_read_b128 per (SSE lane l, half th, tile c) brings this lane's values for
+    // four consecutive t; each chain (rt, c, l) still sees t = 0..7 in ascending order.
 #pragma unroll
-    for (int t = 0; t < 8; t++)
+    for (int th = 0; th < 2; th++)
 #pragma unroll
         for (int l = 0; l < 4; l++) {
-            float Bv[NCT];
-#pragma unroll
-            for (int c = 0; c < NCT; c++) Bv[c] = yb[c * ct_stride + l * 512 + t * 64];
+            f32x4 Bq[NCT];
 #pragma unroll
             for (int c = 0; c < NCT; c++)
+                Bq[c] = *reinterpret_cast<const f32x4*>(yb + c * ct_stride + (l * 2 + th) * 256);
 #pragma unroll
-                for (int rt = 0; rt < 2; rt++)
-                    acc[rt][c][l] = __builtin_amdgcn_mfma_f32_16x16x4f32(Af[rt][l][t], Bv[c], acc[rt][c][l], 0, 0, 0);
+            for (int tq = 0; tq < 4; tq++)
+#pragma unroll
+                for (int c = 0; c < NCT; c++)
+#pragma unroll
+                    for (int rt = 0; rt < 2; rt++)
+                        acc[rt][c][l] = __builtin_amdgcn_mfma_f32_16x16x4f32(Af[rt][l][4 * th + tq], Bq[c][tq],
+                                                                            acc[rt][c][l], 0, 0, 0);
         }
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -182,7 +192,7 @@ __device__ __forceinline__ void score_rows(const ScoreArgs& a, const float* ylds
                 for (int rt = 0; rt < 2; rt++)
 #pragma unroll
                     for (int l = 0; l < 4; l++) w[rt][l] = all[rt][l][qb];
-                mfma_block<NCT>(acc, w, sh_e, sh_o, ylds + (size_t)(4u * g + qb) * 2048u + lane, ct_stride);
+                mfma_block<NCT>(acc, w, sh_e, sh_o, ylds + (size_t)(4u * g + qb) * 2048u + lane * 4u, ct_stride);
             }
         }
         // ---- tail blocks: partial masks and/or dwords beyond the row's data --------------------
@@ -203,7 +213,7 @@ __device__ __forceinline__ void score_rows(const ScoreArgs& a, const float* ylds
                 w[rt][3] = hi.y & k3;
                 n1t[rt] += __popc(w[rt][0]) + __popc(w[rt][1]) + __popc(w[rt][2]) + __popc(w[rt][3]);
             }
-            mfma_block<NCT>(acc, w, sh_e, sh_o, ylds + (size_t)b * 2048u + lane, ct_stride);
+            mfma_block<NCT>(acc, w, sh_e, sh_o, ylds + (size_t)b * 2048u + lane * 4u, ct_stride);
         }
 
         // N1 of each row: the four kk lanes' disjoint pieces plus the common tail.
