@@ -1,0 +1,79 @@
+"""world_size-2 `gloo` test of the multi-GPU plumbing on CPU (kmersgwas_amd/dist.py).
+
+The product's scoring needs a GPU, so each rank's shard-local heap-push history and kinship partials
+are produced here by the oracle (as the checker / stand-in data source); what is under test is the
+N>1 path itself: shard ranges, the history gather over torch.distributed, the in-order replay on rank 0
+(kgwas_merge_shards through the C ABI) and the integer all-reduce of kinship partials."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent("""
+    import os, sys
+    import numpy as np
+    import torch.distributed as dist
+    sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+    import kmersgwas_amd as kg
+    from kmersgwas_amd import dist as kdist
+    from oracle import binding as ob
+    from oracle import oracle_np as onp
+    from helpers import random_table, phenotypes
+    from test_host import _python_history
+
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    S_f, S, P, N, M = 90, 80, 3, 40, 2500
+    rows = random_table(M, S_f, seed=41, dup_frac=0.4)          # same table on every rank
+    col = np.random.default_rng(2).permutation(S_f)[:S].astype(np.uint64)
+    Y = phenotypes(S, P - 1, seed=6, binary=True)
+    mac = onp.min_count(S, 0.05, 5)
+    lo, hi = kdist.shard_range(M, rank, world)
+    assert (lo, hi) == ((M * rank) // world, (M * (rank + 1)) // world)
+    dense, kept = ob.scores_dense(rows[lo:hi], S_f, col, Y, mac)  # stand-in for this rank's GPU scan
+    idx = np.nonzero(kept)[0]
+    hist = [_python_history(rows[lo:hi][idx, 0], dense[j][idx], (idx + lo).astype(np.uint64), N) for j in range(P)]
+    shards = kdist.gather_histories(hist, dst=0)
+    if rank == 0:
+        assert len(shards) == world
+        heaps = kg.merge_shards(N, shards, threads=2)
+        exp = ob.associate(rows, S_f, col, Y, N, mac)
+        for j in range(P):
+            k, s, r = heaps[j].pop_all()
+            o = exp["per_pheno"][j]
+            assert (k == o["kmer"]).all() and (r == o["file_row"]).all() and s.tobytes() == o["score"].tobytes()
+    else:
+        assert shards is None
+    # kinship partials: integer Hamming sums + used-row counts all-reduce to the single-process answer
+    mc = int(np.ceil(S_f * 0.05))
+    g = onp.unpack_bits(rows[lo:hi], np.arange(S_f, dtype=np.uint64)).astype(np.int64)
+    n1 = g.sum(axis=1)
+    g = g[(n1 >= mc) & (n1 <= S_f - mc)]
+    H = (g[:, :, None] ^ g[:, None, :]).sum(axis=0).astype(np.uint64)
+    Hs, n = kdist.allreduce_kinship(H, len(g))
+    K = kg.kinship_from_partials(Hs, n)
+    Ko, no = ob.kinship(rows, S_f, mc)
+    assert n == no and (K == Ko).all()
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.stdout.write("rank%%d-ok\\n" %% rank); sys.stdout.flush()
+""")
+
+
+def test_two_rank_gloo_merge_and_kinship_allreduce(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT})
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("-ok") == 2, r.stdout

@@ -1,0 +1,117 @@
+"""GPU tests of the two drop-in command-line tools at the process boundary (argv + files in, files out),
+byte-for-byte against what the oracle writes for the same inputs."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import kmersgwas_amd as kg
+from oracle import binding as ob
+from oracle import oracle_np as onp
+from helpers import random_table, phenotypes
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "kmersgwas_amd", "bin")
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _oracle_outputs(outdir, base, rows, S_f, names, acc, pnames, Y, topn, mac, k, scores=False):
+    col = onp.column_map(names, acc)
+    res = ob.associate(rows, S_f, col, Y, topn, mac)
+    for j, pn in enumerate(pnames):
+        o = res["per_pheno"][j]
+        ob.write_plink(os.path.join(outdir, "%s.%d.%s" % (base, j, pn)), rows, S_f, col, acc, Y[j], k, o["kmer"], o["file_row"])
+        if scores:
+            with open(os.path.join(outdir, "%s.%d.best_kmers.scores" % (base, j)), "wb") as f:
+                for km, sc in zip(o["kmer"], o["score"]):
+                    f.write(np.uint64(km).tobytes() + np.float64(sc).tobytes())
+    open(os.path.join(outdir, base + ".tested_kmers"), "w").write("%d\n" % res["tested"])
+    return res
+
+
+def _compare_dirs(a, b):
+    fa, fb = sorted(os.listdir(a)), sorted(os.listdir(b))
+    assert fa == fb, (fa, fb)
+    for f in fa:
+        assert open(os.path.join(a, f), "rb").read() == open(os.path.join(b, f), "rb").read(), f
+    return fa
+
+
+def test_associate_kmers_ecoli_shaped_config(tmp_path):
+    """BASELINE.json configs[0]: the E. coli example's phenotype (241 accessions, binary) on a synthetic
+    241-sample table with many duplicated presence/absence patterns, pipeline-style invocation."""
+    names, acc, Y = onp.load_phenotypes(os.path.join(GOLD, "resistence.pheno"))
+    S_f, k = 241, 31
+    table_names = list(reversed(acc))  # table column order differs from the phenotype file's order
+    rows = random_table(200_000, S_f, seed=2024, dup_frac=0.5)
+    base = str(tmp_path / "kmers_table")
+    onp.write_table(base, table_names, k, rows[:, 0], rows[:, 1:])
+    out_p, out_o = tmp_path / "prod", tmp_path / "orc"
+    out_p.mkdir(); out_o.mkdir()
+    cmd = [os.path.join(BIN, "associate_kmers"), "-p", os.path.join(GOLD, "resistence.pheno"), "-b", "pheno", "-o", str(out_p),
+           "-n", "10001", "--parallel", "4", "--kmers_table", base, "--kmer_len", "31", "--maf", "0.050000", "--mac", "5"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Effective minor allele count:\t13" in r.stderr
+    mac = onp.min_count(241, 0.05, 5)
+    _oracle_outputs(str(out_o), "pheno", rows, S_f, table_names, acc, names, Y, 10001, mac, k)
+    files = _compare_dirs(str(out_p), str(out_o))
+    assert files == ["pheno.0.phenotype_value.bed", "pheno.0.phenotype_value.bim", "pheno.0.phenotype_value.fam",
+                     "pheno.tested_kmers"]
+
+
+@pytest.mark.parametrize("kernel", ["1", "2"])
+def test_associate_kmers_permutations_subset_scores(tmp_path, kernel):
+    """Several phenotype columns (value + permutations), phenotyped subset in shuffled order,
+    --first_phenotype_best, --k_mers_scores, small --batch_size: every output file byte-identical."""
+    S_f, S, k, P = 300, 257, 25, 6
+    rows = random_table(30_000, S_f, seed=9, dup_frac=0.2)
+    table_names = ["acc_%d" % i for i in range(S_f)]
+    base = str(tmp_path / "tab")
+    onp.write_table(base, table_names, k, rows[:, 0] & np.uint64((1 << 50) - 1), rows[:, 1:])
+    rows[:, 0] &= np.uint64((1 << 50) - 1)
+    pick = np.random.default_rng(3).permutation(S_f)[:S]
+    acc = [table_names[i] for i in pick]
+    Y = phenotypes(S, P - 1, seed=21)
+    pnames = ["phenotype_value"] + ["P%d" % i for i in range(1, P)]
+    ph = tmp_path / "ph.tsv"
+    with open(ph, "w") as f:
+        f.write("accession_id\t" + "\t".join(pnames) + "\n")
+        for i, a in enumerate(acc):
+            f.write(a + "\t" + "\t".join(repr(float(Y[j, i])) for j in range(P)) + "\n")
+    names2, acc2, Y2 = onp.load_phenotypes(str(ph))
+    assert Y2.tobytes() == Y.tobytes()
+    out_p, out_o = tmp_path / "prod", tmp_path / "orc"
+    out_p.mkdir(); out_o.mkdir()
+    cmd = [os.path.join(BIN, "associate_kmers"), "--phenotype_file", str(ph), "--base_name", "x", "--output_dir", str(out_p),
+           "--best", "500", "--first_phenotype_best", "1500", "--kmers_table", base, "--kmer_len", "25", "--maf=0.05",
+           "--mac", "5", "--k_mers_scores", "--batch_size", "7001", "--kernel", kernel]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    topn = np.full(P, 500, np.uint64)
+    topn[0] = 1500
+    _oracle_outputs(str(out_o), "x", rows, S_f, table_names, acc, pnames, Y, topn, onp.min_count(S, 0.05, 5), k, scores=True)
+    files = _compare_dirs(str(out_p), str(out_o))
+    assert len(files) == 3 * P + P + 1
+    # unknown accession -> the reference's uncaught logic_error (abort)
+    with open(ph, "a") as f:
+        f.write("not_in_table\t" + "\t".join(["1"] * P) + "\n")
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode != 0 and "Couldn't find path for DB: not_in_table" in r.stderr
+
+
+def test_emma_kinship_kmers_stdout(tmp_path):
+    S_f, k = 241, 31
+    rows = random_table(50_000, S_f, seed=77)
+    names = ["s%d" % i for i in range(S_f)]
+    base = str(tmp_path / "tab")
+    onp.write_table(base, names, k, rows[:, 0], rows[:, 1:])
+    r = subprocess.run([os.path.join(BIN, "emma_kinship_kmers"), "-t", base, "-k", "31", "--maf", "0.05"], capture_output=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    mc = int(np.ceil(S_f * 0.05))
+    K, n = ob.kinship(rows, S_f, mc)
+    assert r.stdout == ob.kinship_text(K, n)
+    err = r.stderr.decode()
+    assert "Min count = %d" % mc in err and "#%d" % n in err

@@ -1,0 +1,278 @@
+"""CPU tests of the product's host side (no GPU, no compute calls): the C-ABI library loads and
+exports every symbol include/kgwas.h declares, the .table/.names/.pheno readers and their error
+behaviour, the BestAssociationsHeap mirror, the cross-shard merge, the PLINK and kinship writers,
+the synthetic-row generator's host twin, the CLIs' argument handling — each against the oracle."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import kmersgwas_amd as kg
+from kmersgwas_amd import capi
+from oracle import binding as ob
+from oracle import oracle_np as onp
+from helpers import random_table, phenotypes, synth_rows_numpy
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+BIN = os.path.join(ROOT, "kmersgwas_amd", "bin")
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "kgwas.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(kgwas_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared == sorted(capi.SYMBOLS), "capi.SYMBOLS must list exactly what kgwas.h declares"
+    for s in declared:
+        assert hasattr(capi.lib, s), "libkgwas.so does not export " + s
+    assert capi.lib.kgwas_version() >= 100
+    # one HIP runtime per process: the library itself must not pull a second one in
+    out = subprocess.check_output(["readelf", "-d", capi.LIB_PATH]).decode()
+    assert "libamdhip64" not in out
+
+
+def _write_table(tmp_path, n_rows=50, S=70, k=31, seed=2):
+    rows = random_table(n_rows, S, seed=seed)
+    names = ["acc%03d" % i for i in range(S)]
+    base = str(tmp_path / "t")
+    onp.write_table(base, names, k, rows[:, 0], rows[:, 1:])
+    return base, names, rows
+
+
+def test_table_reader_and_guards(tmp_path):
+    base, names, rows = _write_table(tmp_path)
+    t = kg.KmersTable(base, 31)
+    assert (t.n_acc, t.n_rows, t.words_per_row, t.kmer_len) == (70, 50, 2, 31)
+    assert t.names == names
+    assert (t.read_rows(0, 50) == rows).all()
+    assert (t.read_rows(7, 5) == rows[7:12]).all()
+    with pytest.raises(kg.KgwasError) as e:
+        t.read_rows(48, 3)
+    assert e.value.code == capi.KGWAS_ERR_ARG
+    assert (t.column_map(["acc005", "acc000", "acc069"]) == [5, 0, 69]).all()
+    with pytest.raises(kg.KgwasError, match="Couldn't find path for DB: nope") as e:
+        t.column_map(["acc001", "nope"])
+    assert e.value.code == capi.KGWAS_ERR_FORMAT
+    t.close()
+    assert kg.KmersTable(base, 0).kmer_len == 31  # k = 0 skips the check
+    # the reference's logic_error messages (src/kmers_multiple_databases.cpp:65-93)
+    with pytest.raises(kg.KgwasError, match="Kmer length not as defined in class"):
+        kg.KmersTable(base, 25)
+    raw = bytearray(open(base + ".table", "rb").read())
+    open(base + ".table", "wb").write(raw[:-8])
+    with pytest.raises(kg.KgwasError, match="size of file not valid"):
+        kg.KmersTable(base, 31)
+    open(base + ".table", "wb").write(raw[:16])
+    with pytest.raises(kg.KgwasError, match="Kmer table size is too small"):
+        kg.KmersTable(base, 31)
+    bad = bytearray(raw)
+    bad[0] = 0
+    open(base + ".table", "wb").write(bad)
+    with pytest.raises(kg.KgwasError, match="Incorrect prefix"):
+        kg.KmersTable(base, 31)
+    open(base + ".table", "wb").write(raw)
+    open(base + ".names", "a").write("extra\n")
+    with pytest.raises(kg.KgwasError, match="Number of accession in file not as defined in class"):
+        kg.KmersTable(base, 31)
+    with pytest.raises(kg.KgwasError, match="Couldn't open kmer table file") as e:
+        kg.KmersTable(str(tmp_path / "missing"), 31)
+    assert e.value.code == capi.KGWAS_ERR_IO
+
+
+def test_duplicate_accession_in_names(tmp_path):
+    base, names, rows = _write_table(tmp_path)
+    names2 = list(names)
+    names2[3] = names2[9]
+    open(base + ".names", "w").write("\n".join(names2) + "\n")
+    t = kg.KmersTable(base, 31)
+    with pytest.raises(kg.KgwasError, match="Two DBs with the same name! acc009"):
+        t.column_map(["acc009"])
+
+
+@pytest.mark.parametrize("fname", ["resistence.pheno", "FT10.pheno"])
+def test_phenotype_loader_on_the_reference_examples(fname):
+    path = os.path.join(GOLD, fname)
+    p = kg.Phenotypes(path)
+    names, acc, Y = onp.load_phenotypes(path)
+    assert p.names == names == ["phenotype_value"]
+    assert p.accessions == acc
+    assert p.Y.tobytes() == Y.tobytes()
+    assert len(acc) == (241 if fname.startswith("res") else 1162)
+
+
+def test_phenotype_loader_multi_column_and_errors(tmp_path):
+    f = tmp_path / "p.tsv"
+    f.write_text("accession_id\tphenotype_value\tP1\tP2\nA\t1.5\t-2e-3\t7\nB\t0.1\t3.25\t1e10\nC\t71.6666666667\t0\t-0")
+    p = kg.Phenotypes(str(f))
+    names, acc, Y = onp.load_phenotypes(str(f))
+    assert p.names == names == ["phenotype_value", "P1", "P2"] and p.accessions == acc == ["A", "B", "C"]
+    assert p.Y.tobytes() == Y.tobytes()
+    f.write_text("accession_id\tv\nA\t1\nB\n")
+    with pytest.raises(kg.KgwasError, match="same number of fields") as e:
+        kg.Phenotypes(str(f))
+    assert e.value.code == capi.KGWAS_ERR_FORMAT
+    f.write_text("accession_id\tv\nA\tabc\n")
+    with pytest.raises(kg.KgwasError):
+        kg.Phenotypes(str(f))
+    with pytest.raises(kg.KgwasError) as e:
+        kg.Phenotypes(str(tmp_path / "none.tsv"))
+    assert e.value.code == capi.KGWAS_ERR_IO
+
+
+def test_min_count_matches_the_reference_rule():
+    for S, maf, mac in [(241, 0.05, 5), (1024, 0.05, 5), (2048, 0.05, 5), (1135, 0.05, 5), (20, 0.05, 5), (100, 0.0, 0),
+                        (1000, 0.051, 3)]:
+        assert kg.min_count(S, maf, mac) == onp.min_count(S, maf, mac) == int(ob.lib().orc_min_count(S, maf, mac))
+    assert kg.min_count(241, 0.05, 5) == 13 and kg.min_count(1024, 0.05, 5) == 52 and kg.min_count(2048, 0.05, 5) == 103
+
+
+@pytest.mark.parametrize("N,n,levels", [(1, 60, 3), (10, 500, 4), (64, 4000, 9), (200, 150, 5), (33, 3000, 2)])
+def test_heap_mirror_equals_oracle_heap_under_ties(N, n, levels):
+    rng = np.random.default_rng(N * 31 + n)
+    k = np.arange(n, dtype=np.uint64) + 7
+    s = rng.integers(0, levels, size=n).astype(np.float64) / 8.0
+    s[rng.random(n) < 0.01] = np.nan
+    r = np.arange(n, dtype=np.uint64) * 3
+    h = kg.BestAssociationsHeap(N)
+    h.add_associations(k[: n // 2], s[: n // 2], r[: n // 2])
+    h.add_associations(k[n // 2:], s[n // 2:], r[n // 2:])
+    o = ob.Heap(N)
+    o.add_many(k, s, r)
+    for a, b in zip(h.pop_all(), o.pop_all()):
+        assert a.tobytes() == b.tobytes()
+    for a, b in zip(h.get_kmers_for_output(), o.output_list()):
+        assert (a == b).all()
+    assert len(h) == min(N, n)
+
+
+def _python_history(kmer, score, row, N):
+    """Effective pushes of a shard-local heap (what kgwas_scan_history returns), via the pure-Python heap."""
+    h = onp.BestHeap(N)
+    hist = ([], [], [])
+    for i in range(len(kmer)):
+        before = (len(h.q), h.lowest)
+        h.add(int(kmer[i]), float(score[i]), int(row[i]))
+        changed = len(h.q) != before[0] or (before[0] == N and score[i] > before[1])
+        if changed:
+            hist[0].append(kmer[i]); hist[1].append(score[i]); hist[2].append(row[i])
+    return (np.asarray(hist[0], np.uint64), np.asarray(hist[1], np.float64), np.asarray(hist[2], np.uint64))
+
+
+def test_merge_shards_equals_single_pass():
+    """The union of shard-local effective pushes, replayed shard by shard, reproduces the single heap."""
+    rng = np.random.default_rng(3)
+    P, N, M = 4, 25, 3000
+    kmer = np.arange(M, dtype=np.uint64) + 1000
+    row = np.arange(M, dtype=np.uint64)
+    scores = [rng.integers(0, 40, size=M).astype(np.float64) / 4 for _ in range(P)]  # many ties
+    cuts = [0, 700, 701, 2200, M]
+    shards = []
+    for g in range(len(cuts) - 1):
+        lo, hi = cuts[g], cuts[g + 1]
+        shards.append([_python_history(kmer[lo:hi], scores[j][lo:hi], row[lo:hi], N) for j in range(P)])
+    heaps = kg.merge_shards(N, shards, threads=2)
+    for j in range(P):
+        o = ob.Heap(N)
+        o.add_many(kmer, scores[j], row)
+        for a, b in zip(heaps[j].pop_all(), o.pop_all()):
+            assert a.tobytes() == b.tobytes()
+
+
+def test_plink_writer_matches_oracle_bytes(tmp_path):
+    S_f, S = 150, 131
+    rows = random_table(400, S_f, seed=12)
+    names = ["s%d" % i for i in range(S_f)]
+    base = str(tmp_path / "tab")
+    onp.write_table(base, names, 31, rows[:, 0], rows[:, 1:])
+    col = np.random.default_rng(4).permutation(S_f)[:S].astype(np.uint64)
+    acc = [names[c] for c in col]
+    y = np.asarray([71.6666666667, 1e-05, 100000, 1234567, -0.0, 0.5, 3] + list(np.linspace(-2, 2, S - 7)), np.float32)
+    rng = np.random.default_rng(6)
+    pick = rng.choice(400, size=60, replace=False)
+    kmer_pop, row_pop = rows[pick, 0], pick.astype(np.uint64)
+    t = kg.KmersTable(base, 31)
+    kg.write_plink(str(tmp_path / "prod"), t, col, acc, y, kmer_pop, row_pop)
+    ob.write_plink(str(tmp_path / "orc"), rows, S_f, col, acc, y, 31, kmer_pop, row_pop)
+    for ext in (".bed", ".bim", ".fam"):
+        a = open(str(tmp_path / "prod") + ext, "rb").read()
+        b = open(str(tmp_path / "orc") + ext, "rb").read()
+        assert a == b, ext
+    bed = open(str(tmp_path / "prod.bed"), "rb").read()
+    assert bed[:3] == b"\x6c\x1b\x01" and len(bed) == 3 + 60 * ((S + 3) // 4)
+    bim = open(str(tmp_path / "prod.bim")).read().split("\n")
+    assert bim[0].startswith("0\t") and re.match(r"^0\t[ACGT]{31}_\d+\t0\t0\t0\t1$", bim[0])
+
+
+def test_kinship_text_and_from_partials():
+    S = 50
+    rows = random_table(300, S, seed=5)
+    K, n = ob.kinship(rows, S, 3)
+    g = onp.unpack_bits(rows, np.arange(S, dtype=np.uint64)).astype(np.int64)
+    n1 = g.sum(axis=1)
+    g = g[(n1 >= 3) & (n1 <= S - 3)]
+    H = ((g[:, :, None] ^ g[:, None, :]).sum(axis=0)).astype(np.uint64)  # Hamming distances
+    K2 = kg.kinship_from_partials(H, len(g))
+    assert len(g) == n and (K2 == K).all()
+    assert kg.kinship_format(K2, n) == ob.kinship_text(K, n)
+
+
+def test_synth_host_twin_matches_numpy_statement():
+    for n_acc in (1, 63, 64, 65, 241, 1024, 1135):
+        a = kg.synth_rows_host(999, 500, n_acc, 20240601)
+        assert (a == synth_rows_numpy(999, 500, n_acc, 20240601)).all()
+        assert (a[:, 0] == np.arange(1000, 1500)).all()
+    a = kg.synth_rows_host(0, 100, 70, 1)
+    b = kg.synth_rows_host(40, 60, 70, 1)
+    assert (a[40:] == b).all()  # any shard can be generated independently
+
+
+def test_compute_fails_loudly_without_a_gpu(have_gpu):
+    if have_gpu:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(kg.KgwasError) as e:
+        kg.AssociationScan(64, np.arange(64), np.zeros((1, 64), np.float32), 10, 3)
+    assert e.value.code == capi.KGWAS_ERR_DEVICE and "no CPU fallback" in e.value.msg
+    with pytest.raises(kg.KgwasError) as e:
+        kg.Kinship(64, 3)
+    assert e.value.code == capi.KGWAS_ERR_DEVICE
+
+
+def _run(args):
+    return subprocess.run(args, capture_output=True, text=True)
+
+
+def test_cli_argument_handling(tmp_path):
+    a = os.path.join(BIN, "associate_kmers")
+    e = os.path.join(BIN, "emma_kinship_kmers")
+    r = _run([a, "--help"])
+    assert r.returncode == 0 and "--kmers_table" in r.stderr and "--first_phenotype_best" in r.stderr
+    r = _run([a, "-p", "x", "-b", "y", "--kmers_table", "t", "--kmer_len", "9"])
+    assert r.returncode == 1 and "kmer length has to be between 10-31" in r.stderr
+    r = _run([a, "-p", "x"])
+    assert r.returncode == 1 and "error parsing options" in r.stderr
+    r = _run([a, "--nonsense"])
+    assert r.returncode == 1 and "error parsing options" in r.stderr
+    r = _run([e, "-t", "x", "-k", "31"])
+    assert r.returncode == 1 and "maf is a required parameter" in r.stderr
+    r = _run([e, "-t", str(tmp_path / "nope"), "-k", "31", "--maf", "0.05"])
+    assert r.returncode == 1 and "Couldn't find file: " in r.stderr and r.stdout == ""
+    base, names, rows = _write_table(tmp_path)
+    r = _run([e, "-t", base, "-k", "40", "--maf", "0.05"])
+    assert r.returncode == 1 and "kmer length has to be between 10-31" in r.stderr
+    # data errors abort like the reference's uncaught std::logic_error
+    r = _run([e, "-t", base, "-k", "25", "--maf", "0.05"])
+    assert r.returncode != 0 and "Kmer length not as defined in class" in r.stderr
+
+
+def test_cli_fails_loudly_without_a_gpu(tmp_path, have_gpu):
+    if have_gpu:
+        pytest.skip("a HIP device is present")
+    base, names, rows = _write_table(tmp_path)
+    ph = tmp_path / "p.tsv"
+    ph.write_text("accession_id\tphenotype_value\n" + "".join("%s\t%d\n" % (n, i % 3) for i, n in enumerate(names)))
+    r = _run([os.path.join(BIN, "associate_kmers"), "-p", str(ph), "-b", "out", "-o", str(tmp_path), "--kmers_table", base,
+              "--kmer_len", "31"])
+    assert r.returncode == 3 and "no HIP device" in r.stderr
+    assert "Effective minor allele count:\t5" in r.stderr
