@@ -162,6 +162,18 @@ def main():
         # sanity on the final result of the last step: ascending pops, full heaps
         k, sc, r = (heaps[0].pop_all() if world > 1 else last.result(0))
         assert (np.diff(sc) >= 0).all() and len(k) == min(args.topn, tested)
+        # HBM traffic per launch cannot be read from inside the process; it comes from the committed
+        # rocprofv3 PMC passes of this same workload (FETCH_SIZE x2 on gfx950 + WRITE_SIZE).
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+        if S == 1024 and P == 101 and os.path.exists(pmc):
+            try:
+                j = json.load(open(pmc))
+                # bytes per 4 194 304-row launch -> GB per average launch of this run (rows-proportional)
+                traffic = j["traffic_bytes_per_4194304_row_launch"] / 4194304 * (rows_scored / max(k_launch, 1)) / 1e9
+                traffic_src = "profiles/r01_pmc_hbm_traffic.json"
+            except Exception:
+                pass
         out = {
             "metric": "k-mers x permutations scored/sec", "value": value, "unit": "kmer*phenotype/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -177,7 +189,9 @@ def main():
             "rows_tested": int(tested),
             "roofline": {"bound": "mfma" if stats[-1]["kernel_used"] == 2 else "valu", "kernel": kernel_name,
                          "achieved": achieved_tflops, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved_tflops / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved_tflops / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_unit": "GB per average launch (HBM-side, PMC)", "traffic_source": traffic_src,
+                         "algorithmic_GB_per_launch": rows_scored / max(k_launch, 1) * 8.0 * W / 1e9,
                          "launches": k_launch, "avg_launch_ms": avg_ms,
                          "kernel_ms_per_step": k_ms / args.steps,
                          "hbm_frac_of_8TBps": (rows_scored * 8.0 * W / (k_ms * 1e-3) / 1e9) / HBM_PEAK_GBPS
