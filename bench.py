@@ -88,8 +88,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        ndev = torch.cuda.device_count()
+        torch.cuda.set_device(local_rank % ndev)
+        # KGWAS_DIST_BACKEND=gloo lets several ranks share one GPU (used to exercise the N>1 path on a 1-GPU box)
+        backend = os.environ.get("KGWAS_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank % ndev))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     dev = torch.cuda.current_device()
@@ -121,7 +127,7 @@ def main():
         st = scan.stats()
         heaps = None
         if world > 1:
-            heaps, tested = kdist.merge_on_root(scan, args.topn)
+            tested = kdist.merge_on_root(scan)  # rank 0's session now holds the global heaps
         else:
             tested = st["rows_tested"]
         return scan, st, heaps, tested
@@ -144,7 +150,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=kdist._dev())
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -160,7 +166,7 @@ def main():
         achieved_tflops = flop_per_row * rows_scored / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         kernel_name = {1: "score_valu_kernel", 2: "score_mfma_kernel"}[stats[-1]["kernel_used"]]
         # sanity on the final result of the last step: ascending pops, full heaps
-        k, sc, r = (heaps[0].pop_all() if world > 1 else last.result(0))
+        k, sc, r = last.result(0)
         assert (np.diff(sc) >= 0).all() and len(k) == min(args.topn, tested)
         # HBM traffic per launch cannot be read from inside the process; it comes from the committed
         # rocprofv3 PMC passes of this same workload (FETCH_SIZE x2 on gfx950 + WRITE_SIZE).

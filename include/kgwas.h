@@ -153,6 +153,16 @@ int kgwas_scan_get_stats(const kgwas_scan* s, kgwas_scan_stats* st);
 int kgwas_scan_reset(kgwas_scan* s);
 void kgwas_scan_destroy(kgwas_scan* s);
 
+/* Cross-shard merge without re-playing shard 0: current heap minima (lowest_score) and fullness of
+ * every column, and in-order replay of later shards' (pre-filtered) histories INTO this scan's heaps.
+ * Exactness: the heap of shard 0 is what a single scan holds after those rows; an entry of shard g >= 1
+ * whose score is not above max(final minima of the full heaps of shards < g) is rejected by
+ * add_association whenever it arrives, so the sender may drop it. counts/kmer/score/row as in
+ * kgwas_merge_shards (shards in row order, all after this scan's rows). Call kgwas_scan_finish again. */
+int kgwas_scan_lowest(const kgwas_scan* s, double* lowest, uint8_t* full);
+int kgwas_scan_absorb(kgwas_scan* s, uint64_t n_shards, const uint64_t* counts, const uint64_t* const* kmer,
+                      const double* const* score, const uint64_t* const* row);
+
 /* calculate_kmer_score for every row and phenotype column (src/kmers_multiple_databases.cpp:327-363):
  * scores[j*n_rows + r] (0 for rows the MAC filter drops), popcnt[r] = masked popcount N1,
  * outputs in host memory. rows_on_device selects how `rows` is interpreted. */

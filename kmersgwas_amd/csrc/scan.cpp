@@ -815,6 +815,47 @@ int kgwas_scan_history(kgwas_scan* s, uint64_t j, uint64_t* n, const uint64_t** 
     });
 }
 
+int kgwas_scan_lowest(const kgwas_scan* s, double* lowest, uint8_t* full) {
+    return guarded([&] {
+        if (!s || !lowest || !full) throw Error(KGWAS_ERR_ARG, "kgwas_scan_lowest: null argument");
+        for (uint64_t j = 0; j < s->n_pheno; j++) {
+            lowest[j] = s->heaps[j].lowest();
+            full[j] = s->heaps[j].full() ? 1 : 0;
+        }
+    });
+}
+
+int kgwas_scan_absorb(kgwas_scan* s, uint64_t n_shards, const uint64_t* counts, const uint64_t* const* kmer,
+                      const double* const* score, const uint64_t* const* row) {
+    return guarded([&] {
+        if (!s || (n_shards && (!counts || !kmer || !score || !row))) throw Error(KGWAS_ERR_ARG, "kgwas_scan_absorb: null argument");
+        const uint64_t P = s->n_pheno;
+        std::vector<std::vector<uint64_t>> off(n_shards, std::vector<uint64_t>(P + 1, 0));
+        for (uint64_t g = 0; g < n_shards; g++)
+            for (uint64_t j = 0; j < P; j++) off[g][j + 1] = off[g][j] + counts[g * P + j];
+        std::atomic<uint64_t> pushes(0);
+        s->pool->parallel_for(P, [&](size_t j) {
+            BestHeap& h = s->heaps[j];
+            uint64_t local = 0;
+            for (uint64_t g = 0; g < n_shards; g++) {  // shards in row order
+                const uint64_t o = off[g][j], n = counts[g * P + j];
+                for (uint64_t i = 0; i < n; i++)
+                    if (h.add(kmer[g][o + i], score[g][o + i], (size_t)row[g][o + i])) {
+                        local++;
+                        if (s->record_history) {
+                            s->hist[j].kmer.push_back(kmer[g][o + i]);
+                            s->hist[j].score.push_back(score[g][o + i]);
+                            s->hist[j].row.push_back(row[g][o + i]);
+                        }
+                    }
+            }
+            pushes += local;
+        });
+        s->st.heap_pushes += pushes.load();
+        s->finished = false;
+    });
+}
+
 int kgwas_scan_reset(kgwas_scan* s) {
     return guarded([&] {
         if (!s) throw Error(KGWAS_ERR_ARG, "kgwas_scan_reset: null");

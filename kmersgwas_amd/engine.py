@@ -176,6 +176,33 @@ class AssociationScan:
         """Empty heaps / histories / statistics, keep all buffers (session reuse)."""
         check(lib.kgwas_scan_reset(self._h))
 
+    def lowest(self):
+        """(lowest_score[n_pheno], full[n_pheno]) of the heaps as they stand."""
+        low = np.zeros(self.n_pheno, np.float64)
+        full = np.zeros(self.n_pheno, np.uint8)
+        check(lib.kgwas_scan_lowest(self._h, ptr(low), ptr(full)))
+        return low, full.astype(bool)
+
+    def absorb(self, shard_histories):
+        """Replay later shards' (pre-filtered) histories, in shard order, into this scan's heaps.
+        shard_histories[g][j] = (kmer, score, row). Call finish() again afterwards."""
+        G = len(shard_histories)
+        if G == 0:
+            return
+        P = self.n_pheno
+        counts = np.zeros((G, P), np.uint64)
+        ks, ss, rs = [], [], []
+        for g in range(G):
+            for j in range(P):
+                counts[g, j] = len(shard_histories[g][j][0])
+            ks.append(np.ascontiguousarray(np.concatenate([np.asarray(h[0], np.uint64) for h in shard_histories[g]])))
+            ss.append(np.ascontiguousarray(np.concatenate([np.asarray(h[1], np.float64) for h in shard_histories[g]])))
+            rs.append(np.ascontiguousarray(np.concatenate([np.asarray(h[2], np.uint64) for h in shard_histories[g]])))
+        kp = (C.c_void_p * G)(*[a.ctypes.data for a in ks])
+        sp = (C.c_void_p * G)(*[a.ctypes.data for a in ss])
+        rp = (C.c_void_p * G)(*[a.ctypes.data for a in rs])
+        check(lib.kgwas_scan_absorb(self._h, G, ptr(counts), kp, sp, rp))
+
     def _lists(self, fn, j):
         n = C.c_uint64()
         k, s, r = C.POINTER(C.c_uint64)(), C.POINTER(C.c_double)(), C.POINTER(C.c_uint64)()

@@ -49,6 +49,27 @@ WORKER = textwrap.dedent("""
             assert (k == o["kmer"]).all() and (r == o["file_row"]).all() and s.tobytes() == o["score"].tobytes()
     else:
         assert shards is None
+    # The cheap exchange bench.py uses: final minima all-gathered, later shards pre-filtered by
+    # score > max(minima of earlier full heaps); shard 0 is sent in full here only because this CPU test
+    # has no scan session to absorb into (on GPUs rank 0 keeps its heaps and absorbs shards 1..).
+    py = [onp.BestHeap(N) for _ in range(P)]
+    for j in range(P):
+        for kk_, ss_, rr_ in zip(*hist[j]):
+            py[j].add(int(kk_), float(ss_), int(rr_))
+    low = np.asarray([h.lowest for h in py]); full = np.asarray([len(h.q) >= N for h in py])
+    lows, fulls = kdist.exchange_minima(low, full)
+    thr = kdist.prefix_thresholds(lows, fulls)
+    assert (thr[0] == -np.inf).all()
+    filt = hist if rank == 0 else kdist.filter_history(hist, thr[rank])
+    if rank > 0:
+        assert sum(len(h[0]) for h in filt) < sum(len(h[0]) for h in hist)
+    shards2 = kdist.gather_histories(filt, dst=0)
+    if rank == 0:
+        heaps2 = kg.merge_shards(N, shards2, threads=2)
+        for j in range(P):
+            k, s, r = heaps2[j].pop_all()
+            o = exp["per_pheno"][j]
+            assert (k == o["kmer"]).all() and (r == o["file_row"]).all() and s.tobytes() == o["score"].tobytes()
     # kinship partials: integer Hamming sums + used-row counts all-reduce to the single-process answer
     mc = int(np.ceil(S_f * 0.05))
     g = onp.unpack_bits(rows[lo:hi], np.arange(S_f, dtype=np.uint64)).astype(np.int64)

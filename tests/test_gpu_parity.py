@@ -145,6 +145,39 @@ def test_squeezed_mode_topn_and_history_merge(kernel):
         assert (k == o["kmer"]).all() and (r == o["file_row"]).all() and s.tobytes() == o["score"].tobytes()
 
 
+@pytest.mark.parametrize("topn", [300, 30000])
+def test_shard_merge_by_absorbing_filtered_histories(topn):
+    """The multi-GPU merge, emulated with three sequential shard scans on one GPU: shard 0's session keeps
+    its heaps and absorbs the later shards' histories pre-filtered by the earlier shards' final minima
+    (kmersgwas_amd/dist.py). topn=30000 leaves shard 0's heaps unfilled (no filtering possible there)."""
+    from kmersgwas_amd import dist as kdist
+    S_f = S = 200
+    rows = random_table(90000, S_f, seed=15, dup_frac=0.3)
+    col = np.arange(S, dtype=np.uint64)
+    P = 5
+    Y = phenotypes(S, P - 1, seed=31, binary=True)
+    mac = onp.min_count(S, 0.05, 5)
+    exp = ob.associate(rows, S_f, col, Y, topn, mac, threads=4)
+    cuts = [0, 20000, 55000, 90000]
+    scans = []
+    for g in range(3):
+        sc = kg.AssociationScan(S_f, col, Y, topn, mac, chunk_rows=8192, record_history=True)
+        sc.feed_host(rows[cuts[g]:cuts[g + 1]], cuts[g])
+        sc.finish()
+        scans.append(sc)
+    lows, fulls = zip(*[sc.lowest() for sc in scans])
+    thr = kdist.prefix_thresholds(np.stack(lows), np.stack(fulls))
+    later = [kdist.filter_history([scans[g].history(j) for j in range(P)], thr[g]) for g in (1, 2)]
+    if topn == 300:
+        assert sum(len(h[0]) for h in later[0]) < sum(len(scans[1].history(j)[0]) for j in range(P))
+    scans[0].absorb(later)
+    scans[0].finish()
+    _check_topn(scans[0], exp, P)
+    assert sum(sc.stats()["rows_tested"] for sc in scans) == exp["tested"]
+    for sc in scans:
+        sc.close()
+
+
 def test_heap_never_fills_and_tiny_inputs():
     S = 100
     rows = random_table(300, S, seed=1)
