@@ -184,8 +184,67 @@ __global__ void __launch_bounds__(256) kin_gram_kernel(const uint32_t* T, uint64
 }
 
 // ------------------------------------------------------------------------------------------
+// Device-side threshold tracking. BestAssociationsHeap::add_association only changes a full heap
+// when score > lowest_score (src/best_associations_heap.cpp:49-58); lowest_score after some rows is
+// the N-th largest score seen, so ANY value v with at least N seen scores >= v is a lower bound of it.
+// The scorers count every shipped candidate's score in a per-column histogram of its top bits;
+// this kernel (one block per column, run between chunks) picks the highest bin boundary with >= N
+// counted scores at or above it and raises thr[p] to it — no host round trip, so the GPU never waits
+// for the replay. thr_host[p] (the exact minimum of the host heap as far as it has replayed) is
+// folded in whenever it is higher. A NaN minimum (NaN inside a full heap) freezes the column:
+// `score > NaN` is false on both sides.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) thr_update_kernel(const uint32_t* hist, const uint32_t* hist_base,
+                                                         uint32_t bins, const uint64_t* topn, const double* thr_host,
+                                                         double* thr) {
+    __shared__ unsigned long long part[256];
+    const uint32_t p = blockIdx.x, t = threadIdx.x;
+    const uint32_t per = bins / 256u;
+    const uint32_t* h = hist + (uint64_t)p * bins;
+    unsigned long long s = 0;
+    for (uint32_t i = 0; i < per; i++) s += h[t * per + i];
+    part[t] = s;
+    __syncthreads();
+    if (t == 0) {
+        const unsigned long long N = topn[p];
+        unsigned long long run = 0;
+        int seg = -1;
+        for (int u = 255; u >= 0; u--) {
+            if (run + part[u] >= N) {
+                seg = u;
+                break;
+            }
+            run += part[u];
+        }
+        double cur = thr[p];
+        const double th = thr_host[p];
+        if (seg >= 0) {
+            uint32_t b = seg * per + per - 1;
+            for (;; b--) {  // run = counted scores above this segment; walk down inside it
+                run += h[b];
+                if (run >= N || b == (uint32_t)seg * per) break;
+            }
+            const double v = __longlong_as_double((long long)((unsigned long long)(hist_base[p] + b) << HIST_SHIFT));
+            if (v > cur) cur = v;
+        }
+        if (th != th || cur != cur)
+            cur = __longlong_as_double(0x7FF8000000000000LL);
+        else if (th > cur)
+            cur = th;
+        thr[p] = cur;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Launchers
 // ------------------------------------------------------------------------------------------
+hipError_t launch_thr_update(const uint32_t* hist, const uint32_t* hist_base, uint32_t bins, const uint64_t* topn,
+                             const double* thr_host, double* thr, uint32_t n_pheno, hipStream_t st) {
+    if (n_pheno == 0 || bins % 256u) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(thr_update_kernel, dim3(n_pheno), dim3(256), 0, st, hist, hist_base, bins, topn, thr_host, thr);
+    return hipGetLastError();
+}
+
 hipError_t launch_squeeze(const uint64_t* file_rows, uint64_t file_stride_w, uint64_t n_rows, const uint32_t* colmap,
                           uint32_t W_m, uint32_t W_f, uint32_t* out, hipStream_t st) {
     if (n_rows == 0) return hipSuccess;

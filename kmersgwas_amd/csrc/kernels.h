@@ -47,7 +47,20 @@ struct ScoreArgs {
     uint32_t* cand_cnt;   // [n_pheno]
     uint32_t cap;
     unsigned long long* tested;  // MAC-passing rows, accumulated
+    // Device-side threshold tracking (sparse mode, optional): every shipped candidate is counted in a
+    // per-column histogram over the top bits of its score; thr_update_kernel raises thr[p] between
+    // chunks to the largest bin boundary with >= topn[p] candidates at or above it.
+    uint32_t* hist;             // [n_pheno][hist_bins] or null
+    const uint32_t* hist_base;  // [n_pheno] (bits(score) >> HIST_SHIFT) of bin 0
+    uint32_t hist_bins;
 };
+
+constexpr int HIST_SHIFT = 44;          // 8 mantissa bits per bin: 0.4 % score resolution
+constexpr uint32_t HIST_BINS = 16384;   // 64 binades above the threshold at sparse start
+
+// thr[p] = max(thr[p], thr_host[p], largest bin boundary with >= topn[p] counted scores at or above it).
+hipError_t launch_thr_update(const uint32_t* hist, const uint32_t* hist_base, uint32_t bins, const uint64_t* topn,
+                             const double* thr_host, double* thr, uint32_t n_pheno, hipStream_t st);
 
 // Scoring kernels. rows_per_block only matters for the MFMA kernel (multiple of 128).
 hipError_t launch_score_valu(const ScoreArgs& a, hipStream_t st);

@@ -20,6 +20,7 @@
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
+#include <deque>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -184,6 +185,8 @@ struct PinBuf {
     ~PinBuf() { release(); }
 };
 
+constexpr int NSLOT = 8;  // sparse chunks the GPU may run ahead of the host replay
+
 struct Slot {
     PinBuf<Cand> cand;  // written by the GPU straight into mapped host memory
     Cand* d_cand = nullptr;
@@ -219,7 +222,14 @@ struct kgwas_scan {
     DevBuf<double> d_thr;
     PinBuf<double> h_thr;  // two halves, alternated, so an in-flight upload is never overwritten
     uint32_t thr_flip = 0;
-    Slot slot[2];
+    // device-side threshold tracking (thr_update_kernel)
+    DevBuf<uint32_t> d_hist, d_hist_base;
+    PinBuf<uint32_t> h_hist_base;
+    DevBuf<uint64_t> d_topn;
+    DevBuf<double> d_thr_host;
+    bool hist_ready = false;
+    uint64_t rows_submitted = 0;  // rows handed to the GPU (replayed or still in flight)
+    Slot slot[NSLOT];
     // dense mode
     DevBuf<double> d_dense;
     DevBuf<uint32_t> d_n1;
@@ -316,11 +326,29 @@ void maybe_squeeze(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows) {
                              s->stream));
 }
 
+// The exact heap minima as far as the host has replayed. They go to thr_host, which thr_update_kernel
+// folds into the device's own thresholds; before the sparse phase starts they are the thresholds.
 void upload_thresholds(kgwas_scan* s) {
-    double* h = s->h_thr.p + (s->thr_flip & 1u) * s->n_pheno;
+    double* h = s->h_thr.p + (s->thr_flip % 8u) * s->n_pheno;  // ring: uploads may queue behind long kernels
     s->thr_flip++;
     for (uint64_t j = 0; j < s->n_pheno; j++) h[j] = s->heaps[j].lowest();
-    KGWAS_HIP(hipMemcpyAsync(s->d_thr.p, h, s->n_pheno * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    KGWAS_HIP(hipMemcpyAsync(s->d_thr_host.p, h, s->n_pheno * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    if (!s->hist_ready)
+        KGWAS_HIP(hipMemcpyAsync(s->d_thr.p, h, s->n_pheno * sizeof(double), hipMemcpyHostToDevice, s->stream));
+}
+
+// First sparse chunk: histogram bin 0 of every column starts at its current exact minimum.
+void start_histograms(kgwas_scan* s) {
+    for (uint64_t j = 0; j < s->n_pheno; j++) {
+        const double low = s->heaps[j].lowest();
+        uint64_t bits = 0;
+        if (low == low && low > 0) memcpy(&bits, &low, 8);
+        s->h_hist_base.p[j] = (uint32_t)(bits >> HIST_SHIFT);
+    }
+    KGWAS_HIP(hipMemcpyAsync(s->d_hist_base.p, s->h_hist_base.p, s->n_pheno * sizeof(uint32_t), hipMemcpyHostToDevice,
+                             s->stream));
+    KGWAS_HIP(hipMemsetAsync(s->d_hist.p, 0, s->n_pheno * (size_t)HIST_BINS * sizeof(uint32_t), s->stream));
+    s->hist_ready = true;
 }
 
 void refresh_full(kgwas_scan* s) {
@@ -394,18 +422,28 @@ void run_dense(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, uint64_t 
     s->st.heap_pushes += pushes.load();
     s->st.replay_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     s->rows_done += n_rows;
+    s->rows_submitted = std::max(s->rows_submitted, s->rows_done);
     refresh_full(s);
     upload_thresholds(s);
     s->st.dense_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - td0).count();
 }
 
-void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_rows, uint64_t first_row) {
+// count_hist: first (and only) scoring of these rows in the sparse phase -> their candidates feed the
+// device-side threshold histograms. Overflow re-runs must not count the same rows twice.
+void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_rows, uint64_t first_row,
+                   bool count_hist) {
     ScoreArgs a;
     fill_args(s, a, d_rows, n_rows, first_row, !s->direct);
     a.cand = sl.d_cand;
     a.cand_cnt = sl.d_cnt.p;
     a.cap = s->cap;
     a.tested = sl.d_tested.p;
+    if (count_hist) {
+        if (!s->hist_ready) start_histograms(s);
+        a.hist = s->d_hist.p;
+        a.hist_base = s->d_hist_base.p;
+        a.hist_bins = HIST_BINS;
+    }
     KGWAS_HIP(hipMemsetAsync(sl.d_cnt.p, 0, s->n_pheno * sizeof(uint32_t), s->stream));
     KGWAS_HIP(hipMemsetAsync(sl.d_tested.p, 0, sizeof(unsigned long long), s->stream));
     KGWAS_HIP(hipEventRecord(sl.ev_sq0, s->stream));
@@ -413,6 +451,9 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
     KGWAS_HIP(hipEventRecord(sl.ev_k0, s->stream));
     launch_score(s, a);
     KGWAS_HIP(hipEventRecord(sl.ev_k1, s->stream));
+    if (s->hist_ready)  // raise the thresholds for whatever is queued next; no host round trip
+        KGWAS_HIP(launch_thr_update(s->d_hist.p, s->d_hist_base.p, HIST_BINS, s->d_topn.p, s->d_thr_host.p, s->d_thr.p,
+                                    (uint32_t)s->n_pheno, s->stream));
     KGWAS_HIP(hipMemcpyAsync(sl.h_cnt.p, sl.d_cnt.p, s->n_pheno * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     KGWAS_HIP(hipMemcpyAsync(sl.h_tested.p, sl.d_tested.p, sizeof(unsigned long long), hipMemcpyDeviceToHost,
                              s->stream));
@@ -502,7 +543,7 @@ void process_range_sync(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_
         run_dense(s, d_rows, n_rows, first_row, nullptr, nullptr, true);
         return;
     }
-    submit_sparse(s, sl, d_rows, n_rows, first_row);
+    submit_sparse(s, sl, d_rows, n_rows, first_row, /*count_hist=*/false);
     if (reap_sparse(s, sl)) return;
     const uint64_t half = n_rows / 2;
     process_range_sync(s, sl, d_rows, half, first_row);
@@ -510,59 +551,55 @@ void process_range_sync(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_
 }
 
 uint64_t next_sparse_chunk(const kgwas_scan* s) {
-    // Expected candidates per column for a chunk of c rows against thresholds that reflect
-    // rows_done rows: about topn * c / rows_done. Keep that under cap / 4.
-    const double m = (double)std::max<uint64_t>(s->rows_done, 1);
-    double c = m * (double)s->cap / (4.0 * (double)std::max<uint64_t>(s->max_topn, 1));
+    // The device keeps its thresholds current with everything submitted so far (thr_update_kernel), so a
+    // chunk of c rows ships about topn * c / rows_submitted records per column. Keep that under cap / 3.
+    const double m = (double)std::max<uint64_t>(s->rows_submitted, 1);
+    double c = m * (double)s->cap / (3.0 * (double)std::max<uint64_t>(s->max_topn, 1));
     uint64_t ci = (uint64_t)std::min<double>(c, (double)s->chunk_max);
     ci = std::max<uint64_t>(ci, std::min<uint64_t>(s->dense_rows, s->chunk_max));
     ci = std::min<uint64_t>(ci, s->chunk_max);
     return (ci + 127) / 128 * 128;
 }
 
+// The GPU runs up to NSLOT chunks ahead of the host replay. Heap pushes are front-loaded (60 % of them
+// belong to the first 10 % of a 100 M-row table) and inherently serial per column, so the host lags during
+// that part; instead of idling, the GPU keeps scoring later chunks against the thresholds it has (staler
+// thresholds only mean more records for the host to discard, never a wrong result) and the replay catches
+// up while the long steady chunks run.
 void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, uint64_t first_row) {
     const uint64_t stride = 1 + s->W_f;
     uint64_t pos = 0;
-    int pending = -1, k = 0;
-    auto drain = [&]() {
-        if (pending < 0) return;
-        Slot& sl = s->slot[pending];
-        pending = -1;
+    std::deque<int> inflight;  // slot indices, oldest first
+    uint64_t n_submitted = 0;
+    auto reap_oldest = [&]() {
+        Slot& sl = s->slot[inflight.front()];
+        inflight.pop_front();
         if (!reap_sparse(s, sl)) {
+            // A candidate list overflowed. Let the younger chunks finish (their lists stay in their own
+            // slots and are reaped in order afterwards) and redo this range synchronously in halves.
             KGWAS_HIP(hipStreamSynchronize(s->stream));
             process_range_sync(s, sl, sl.rows, sl.n_rows, sl.first_row);
         }
     };
+    const size_t depth = s->direct ? (size_t)NSLOT : 1;  // squeezed mode has a single squeeze buffer
     while (pos < n_rows) {
         if (!s->all_full) {
-            drain();
+            while (!inflight.empty()) reap_oldest();
             const uint64_t c = std::min<uint64_t>(s->dense_rows, n_rows - pos);
             run_dense(s, d_rows + pos * stride, c, first_row + pos, nullptr, nullptr, true);
             pos += c;
             continue;
         }
+        if (inflight.size() >= depth) reap_oldest();
         const uint64_t c = std::min<uint64_t>(next_sparse_chunk(s), n_rows - pos);
-        if (!s->direct && pending >= 0) drain();  // the squeeze buffer is single: no overlap in squeezed mode
-        Slot& sl = s->slot[k & 1];
-        submit_sparse(s, sl, d_rows + pos * stride, c, first_row + pos);
-        const int mine = k & 1;
-        k++;
+        const int idx = (int)(n_submitted % NSLOT);  // FIFO order: this slot was reaped NSLOT submissions ago
+        submit_sparse(s, s->slot[idx], d_rows + pos * stride, c, first_row + pos, /*count_hist=*/true);
+        s->rows_submitted += c;
+        inflight.push_back(idx);
+        n_submitted++;
         pos += c;
-        if (pending >= 0) {
-            // reap the older chunk while the one just submitted runs
-            Slot& old = s->slot[pending];
-            pending = -1;
-            if (!reap_sparse(s, old)) {
-                // overflow: let the newer chunk finish, redo the older range synchronously, then
-                // the newer one is reaped in order below.
-                KGWAS_HIP(hipStreamSynchronize(s->stream));
-                Slot& spare = old;
-                process_range_sync(s, spare, old.rows, old.n_rows, old.first_row);
-            }
-        }
-        pending = mine;
     }
-    drain();
+    while (!inflight.empty()) reap_oldest();
     s->st.rows_fed += n_rows;
 }
 
@@ -640,7 +677,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         s->chunk_max = p->chunk_rows ? p->chunk_rows : (4ull << 20);
         s->chunk_max = std::max<uint64_t>(128, (s->chunk_max + 127) / 128 * 128);
         s->dense_rows = std::min<uint64_t>(16384, s->chunk_max);
-        const uint64_t budget = 4ull << 20;  // candidate records per slot
+        const uint64_t budget = 4ull << 20;  // candidate records per slot (x 24 B x NSLOT of mapped pinned memory)
         uint64_t cap = std::min<uint64_t>(2 * s->max_topn + 4096, std::max<uint64_t>(budget / s->n_pheno, 1024));
         s->cap = (uint32_t)std::min<uint64_t>(cap, 0x7FFFFFFFull);
 
@@ -701,7 +738,13 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         s->d_colmap.alloc(colmap.size());
         s->d_sums.alloc(P);
         s->d_thr.alloc(P);
-        s->h_thr.alloc(2 * P);
+        s->h_thr.alloc(8 * P);
+        s->d_thr_host.alloc(P);
+        s->d_hist.alloc(P * (size_t)HIST_BINS);
+        s->d_hist_base.alloc(P);
+        s->h_hist_base.alloc(P);
+        s->d_topn.alloc(P);
+        KGWAS_HIP(hipMemcpy(s->d_topn.p, s->topn.data(), P * 8, hipMemcpyHostToDevice));
         KGWAS_HIP(hipMemcpy(s->d_dmask.p, dmask.data(), dmask.size() * 4, hipMemcpyHostToDevice));
         KGWAS_HIP(hipMemcpy(s->d_colmap.p, colmap.data(), colmap.size() * 4, hipMemcpyHostToDevice));
         KGWAS_HIP(hipMemcpy(s->d_sums.p, sums.data(), P * 4, hipMemcpyHostToDevice));
@@ -869,6 +912,8 @@ int kgwas_scan_reset(kgwas_scan* s) {
             h.row.clear();
         }
         s->all_full = false;
+        s->hist_ready = false;
+        s->rows_submitted = 0;
         s->rows_done = 0;
         s->finished = false;
         const uint32_t ku = s->st.kernel_used, dm = s->st.direct_mode;

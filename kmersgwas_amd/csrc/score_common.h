@@ -36,6 +36,15 @@ __device__ __forceinline__ void finish_pair(const ScoreArgs& a, uint64_t r, uint
     if (q >= lim) {
         const double s = q / d;  // correctly rounded IEEE division, as divsd on the host
         if (s > thr_p) {
+            if (a.hist) {
+                // Count the score in its bin (positive doubles order like their bit patterns; s > thr_p >= 0
+                // here, +inf lands in the clamped top bin, NaN never gets here).
+                const uint32_t b = (uint32_t)((unsigned long long)__double_as_longlong(s) >> HIST_SHIFT);
+                const uint32_t base = a.hist_base[p];
+                uint32_t idx = b > base ? b - base : 0u;
+                if (idx >= a.hist_bins) idx = a.hist_bins - 1u;
+                atomicAdd(&a.hist[(uint64_t)p * a.hist_bins + idx], 1u);
+            }
             const uint32_t slot = atomicAdd(&a.cand_cnt[p], 1u);
             if (slot < a.cap) {
                 Cand c;
