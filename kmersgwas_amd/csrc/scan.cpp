@@ -226,7 +226,8 @@ struct kgwas_scan {
     DevBuf<uint32_t> d_hist, d_hist_base;
     PinBuf<uint32_t> h_hist_base;
     DevBuf<uint64_t> d_topn;
-    DevBuf<double> d_thr_host;
+    DevBuf<double> d_thr_host, d_thr_redo;
+    PinBuf<double> h_thr_redo;
     bool hist_ready = false;
     uint64_t rows_submitted = 0;  // rows handed to the GPU (replayed or still in flight)
     Slot slot[NSLOT];
@@ -443,6 +444,15 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
         a.hist = s->d_hist.p;
         a.hist_base = s->d_hist_base.p;
         a.hist_bins = HIST_BINS;
+    } else {
+        // Overflow re-run of rows the device has ALREADY counted in its histograms: d_thr may by now
+        // reflect these very rows (or later ones), which is only valid for rows after them. The re-run is
+        // synchronous and in order, so the host heaps hold exactly the rows before this range: use their
+        // minima, nothing newer.
+        for (uint64_t j = 0; j < s->n_pheno; j++) s->h_thr_redo.p[j] = s->heaps[j].lowest();
+        KGWAS_HIP(hipMemcpyAsync(s->d_thr_redo.p, s->h_thr_redo.p, s->n_pheno * sizeof(double), hipMemcpyHostToDevice,
+                                 s->stream));
+        a.thr = s->d_thr_redo.p;
     }
     KGWAS_HIP(hipMemsetAsync(sl.d_cnt.p, 0, s->n_pheno * sizeof(uint32_t), s->stream));
     KGWAS_HIP(hipMemsetAsync(sl.d_tested.p, 0, sizeof(unsigned long long), s->stream));
@@ -740,6 +750,8 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         s->d_thr.alloc(P);
         s->h_thr.alloc(8 * P);
         s->d_thr_host.alloc(P);
+        s->d_thr_redo.alloc(P);
+        s->h_thr_redo.alloc(P);
         s->d_hist.alloc(P * (size_t)HIST_BINS);
         s->d_hist_base.alloc(P);
         s->h_hist_base.alloc(P);

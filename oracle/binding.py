@@ -54,7 +54,7 @@ def lib():
         L.orc_associate.restype = C.c_uint64
         L.orc_associate.argtypes = [u64p, C.c_uint64, C.c_uint64, u64p, C.c_uint64, f32p, C.c_uint64, u64p,
                                     C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, u64p, u64p, f64p, u64p, u64p,
-                                    C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+                                    C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         L.orc_write_plink.restype = C.c_int
         L.orc_write_plink.argtypes = [C.c_char_p, u64p, C.c_uint64, C.c_uint64, u64p, C.c_uint64,
                                       C.POINTER(C.c_char_p), f32p, C.c_uint64, C.c_uint64, u64p, u64p]
@@ -105,17 +105,19 @@ def associate(rows, S_f, col, Y, topn, mac, batch_size=10_000_000, threads=1, co
     out_ref = np.zeros(P * cap, np.uint64)
     out_file = np.zeros(P * cap, np.uint64)
     npat = C.c_uint64(0)
+    pushes = C.c_uint64(0)
     timing = (C.c_double * 2)()
     tested = lib().orc_associate(rows.reshape(-1), n_rows, S_f, col, len(col), Y.reshape(-1), P, topn, mac,
                                  batch_size, threads, cap, out_n, out_kmer, out_score, out_ref, out_file,
-                                 1 if count_patterns else 0, C.byref(npat), timing)
+                                 1 if count_patterns else 0, C.byref(npat), timing, C.byref(pushes))
     res = []
     for j in range(P):
         n = int(out_n[j])
         sl = slice(j * cap, j * cap + n)
         res.append(dict(kmer=out_kmer[sl].copy(), score=out_score[sl].copy(), ref_row=out_ref[sl].copy(),
                         file_row=out_file[sl].copy()))
-    return dict(tested=int(tested), per_pheno=res, patterns=int(npat.value), t_load=timing[0], t_score=timing[1])
+    return dict(tested=int(tested), per_pheno=res, patterns=int(npat.value), pushes=int(pushes.value),
+                t_load=timing[0], t_score=timing[1])
 
 
 def kinship(rows, S_f, min_count):

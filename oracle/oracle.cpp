@@ -407,7 +407,7 @@ uint64_t orc_associate(const uint64_t* rows, uint64_t n_rows, uint64_t S_f, cons
                        const float* Y, uint64_t n_pheno, const uint64_t* topn, uint64_t mac, uint64_t batch_size,
                        uint64_t threads, uint64_t cap, uint64_t* out_n, uint64_t* out_kmer, double* out_score,
                        uint64_t* out_refrow, uint64_t* out_filerow, int count_patterns, uint64_t* n_patterns,
-                       double* timing) {
+                       double* timing, uint64_t* pushes_out) {
     ColMap m = make_map(col, S, S_f);
     std::vector<OrcHeap> heaps;
     for (size_t j = 0; j < n_pheno; j++) heaps.emplace_back((size_t)topn[j]);
@@ -486,6 +486,10 @@ uint64_t orc_associate(const uint64_t* rows, uint64_t n_rows, uint64_t S_f, cons
                 }
             }
         }
+    }
+    if (pushes_out) {  // effective pushes over all heaps (cnt_push, src/best_associations_heap.cpp:47,54)
+        *pushes_out = 0;
+        for (auto& h : heaps) *pushes_out += h.cnt_push;
     }
     return heaps.empty() ? 0 : heaps[0].cnt_kmers;
 }

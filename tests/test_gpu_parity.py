@@ -17,7 +17,9 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 KERNELS = [kg.KERNEL_VALU, kg.KERNEL_MFMA]
 
 
-def _check_topn(scan, oracle_res, n_pheno):
+def _check_topn(scan, oracle_res, n_pheno, check_pushes=True):
+    if check_pushes:  # no effective add_association lost or invented on the way (ties make this visible)
+        assert scan.stats()["heap_pushes"] == oracle_res["pushes"], (scan.stats()["heap_pushes"], oracle_res["pushes"])
     for j in range(n_pheno):
         k, s, r = scan.result(j)
         o = oracle_res["per_pheno"][j]
@@ -176,6 +178,33 @@ def test_shard_merge_by_absorbing_filtered_histories(topn):
     assert sum(sc.stats()["rows_tested"] for sc in scans) == exp["tested"]
     for sc in scans:
         sc.close()
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_adversarial_order_overflows_candidate_lists(kernel):
+    """Rows sorted by ascending score of column 0: every row beats every threshold, so the sparse chunks'
+    candidate lists overflow and the session has to fall back (halving, then dense chunks) without ever
+    counting a row twice in the device-side threshold histograms. Results must still be exact."""
+    S = 128
+    rows = random_table(120_000, S, seed=23)
+    col = np.arange(S, dtype=np.uint64)
+    Y = phenotypes(S, 3, seed=12)
+    mac = onp.min_count(S, 0.05, 5)
+    dense, kept = ob.scores_dense(rows, S, col, Y[:1], mac)
+    order = np.argsort(dense[0], kind="stable")
+    kmers = rows[:, 0].copy()
+    rows = rows[order]
+    rows[:, 0] = kmers  # keep k-mers ascending
+    topn = 10
+    exp = ob.associate(rows, S, col, Y, topn, mac)
+    scan = kg.AssociationScan(S, col, Y, topn, mac, kernel=kernel)
+    scan.feed_host(rows)
+    scan.finish()
+    _check_topn(scan, exp, 4)
+    st = scan.stats()
+    assert st["rows_tested"] == exp["tested"]
+    assert st["heap_pushes"] >= int(0.9 * kept.sum())  # column 0 pushes on (almost) every kept row
+    scan.close()
 
 
 def test_heap_never_fills_and_tiny_inputs():
