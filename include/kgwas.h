@@ -115,7 +115,7 @@ typedef struct kgwas_scan_params {
     uint32_t host_threads;   /* replay threads; 0 = hardware concurrency */
     uint32_t kernel;         /* KGWAS_KERNEL_* */
     uint32_t record_history; /* keep every effective heap push (for cross-shard merges) */
-    uint32_t reserved;
+    uint32_t count_patterns; /* --pattern_counter: count distinct presence/absence patterns of tested rows */
 } kgwas_scan_params;
 
 typedef struct kgwas_scan_stats {
@@ -132,6 +132,7 @@ typedef struct kgwas_scan_stats {
     double dense_ms;            /* host wall time of the dense (heap-filling) phase, GPU + replay */
     uint32_t kernel_used;       /* KGWAS_KERNEL_VALU or KGWAS_KERNEL_MFMA */
     uint32_t direct_mode;       /* 1 = scorer read the file layout in place (no squeeze pass) */
+    uint64_t patterns;          /* distinct pattern hashes among tested rows (count_patterns; valid after finish) */
 } kgwas_scan_stats;
 
 int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out);

@@ -52,7 +52,7 @@ class ScanParams(C.Structure):
         ("n_pheno", C.c_uint64), ("Y", C.POINTER(C.c_float)), ("topn", C.POINTER(C.c_uint64)),
         ("min_count", C.c_uint64), ("chunk_rows", C.c_uint64),
         ("host_threads", C.c_uint32), ("kernel", C.c_uint32), ("record_history", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("count_patterns", C.c_uint32),
     ]
 
 
@@ -62,7 +62,7 @@ class ScanStats(C.Structure):
         ("heap_pushes", C.c_uint64), ("chunks", C.c_uint64), ("score_launches", C.c_uint64),
         ("score_kernel_ms", C.c_double), ("squeeze_kernel_ms", C.c_double), ("replay_ms", C.c_double),
         ("gpu_wait_ms", C.c_double), ("dense_ms", C.c_double),
-        ("kernel_used", C.c_uint32), ("direct_mode", C.c_uint32),
+        ("kernel_used", C.c_uint32), ("direct_mode", C.c_uint32), ("patterns", C.c_uint64),
     ]
 
     def as_dict(self):

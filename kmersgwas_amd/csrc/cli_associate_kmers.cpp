@@ -82,10 +82,6 @@ int main(int argc, char* argv[]) {
         const size_t mac = vm.u64("mac", 5);
         const string table_base = vm.str("kmers_table");
         const string pheno_file = vm.str("phenotype_file");
-        if (vm.count("pattern_counter")) {
-            cerr << "associate_kmers: --pattern_counter is not implemented by this engine yet" << endl;
-            exit(1);
-        }
 
         // Phenotypes (load_phenotypes_file) and the table they must all be present in.
         kgwas_pheno* ph = nullptr;
@@ -127,7 +123,7 @@ int main(int argc, char* argv[]) {
         sp.host_threads = (uint32_t)threads;
         sp.kernel = (uint32_t)vm.u64("kernel", 0);
         sp.record_history = 0;
-        sp.reserved = 0;
+        sp.count_patterns = vm.count("pattern_counter") ? 1 : 0;
         kgwas_scan* scan = nullptr;
         ck(kgwas_scan_create(&sp, &scan));
 
@@ -172,6 +168,11 @@ int main(int argc, char* argv[]) {
             const string out = fn_base + "." + to_string(j) + "." + pname[j];
             cerr << "Save [" << j << "]" << endl;
             ck(kgwas_write_plink(out.c_str(), tbl, col.data(), n_accessions, acc.data(), Y + j * n_accessions, n, kmer, row));
+        }
+        if (vm.count("pattern_counter")) {  // :143-144, :197-201
+            cerr << "Total patterns\t" << st.patterns << endl;
+            ofstream fout(fn_base + ".pattern_counter");
+            fout << st.patterns << endl;
         }
         {
             ofstream fout(fn_base + ".tested_kmers");

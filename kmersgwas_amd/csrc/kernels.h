@@ -68,6 +68,12 @@ hipError_t launch_score_valu(const ScoreArgs& a, hipStream_t st);
 hipError_t launch_score_mfma(const ScoreArgs& a, uint32_t rows_per_block, uint32_t nb_full, hipStream_t st);
 size_t mfma_lds_bytes(uint32_t W_m);
 
+// --pattern_counter: append hash_presence_absence_pattern of every MAC-passing row to out[*out_count ...];
+// count_distinct_u64 sorts the collected hashes in place (device) and returns how many are distinct.
+hipError_t launch_pattern_hash(const RowSrc& src, const uint32_t* dmask, uint64_t n_rows, uint32_t S, uint32_t W_m,
+                               uint32_t min_count, uint64_t* out, unsigned long long* out_count, hipStream_t st);
+hipError_t count_distinct_u64(uint64_t* keys, uint64_t n, uint64_t* result, hipStream_t st);
+
 // Squeeze: out[r][2*W_m dwords] bit i = file bit colmap[i] (colmap[i] == 0xFFFFFFFF -> 0).
 hipError_t launch_squeeze(const uint64_t* file_rows, uint64_t file_stride_w, uint64_t n_rows, const uint32_t* colmap,
                           uint32_t W_m, uint32_t W_f, uint32_t* out, hipStream_t st);

@@ -230,6 +230,11 @@ struct kgwas_scan {
     PinBuf<double> h_thr_redo;
     bool hist_ready = false;
     uint64_t rows_submitted = 0;  // rows handed to the GPU (replayed or still in flight)
+    // --pattern_counter
+    bool count_patterns = false;
+    DevBuf<uint64_t> d_pat;                // pattern hashes of the tested rows seen so far
+    DevBuf<unsigned long long> d_pat_cnt;  // how many
+    uint64_t pat_upper = 0;                // host-side upper bound of that count (rows fed)
     Slot slot[NSLOT];
     // dense mode
     DevBuf<double> d_dense;
@@ -325,6 +330,33 @@ void maybe_squeeze(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows) {
     if (s->direct) return;
     KGWAS_HIP(launch_squeeze(d_rows, 1 + s->W_f, n_rows, s->d_colmap.p, (uint32_t)s->W_m, (uint32_t)s->W_f, s->d_sq.p,
                              s->stream));
+}
+
+// --pattern_counter: hash the presence/absence pattern of every MAC-passing row of this feed
+// (update_presence_absence_pattern_counter, src/kmers_multiple_databases.cpp:376-380). A separate,
+// bandwidth-bound pass over the fed rows; the distinct count is taken at finish.
+void hash_patterns(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows) {
+    const uint64_t need = s->pat_upper + n_rows;
+    if (need > s->d_pat.n) {  // grow (amortised doubling); keep what is there
+        DevBuf<uint64_t> bigger;
+        bigger.alloc(std::max<uint64_t>(need, 2 * s->d_pat.n));
+        if (s->d_pat.n) {
+            KGWAS_HIP(hipMemcpyAsync(bigger.p, s->d_pat.p, s->d_pat.n * 8, hipMemcpyDeviceToDevice, s->stream));
+            KGWAS_HIP(hipStreamSynchronize(s->stream));
+        }
+        std::swap(bigger.p, s->d_pat.p);
+        std::swap(bigger.n, s->d_pat.n);
+    }
+    const uint64_t stride = 1 + s->W_f;
+    for (uint64_t pos = 0; pos < n_rows; pos += s->chunk_max) {
+        const uint64_t c = std::min<uint64_t>(s->chunk_max, n_rows - pos);
+        ScoreArgs a;
+        fill_args(s, a, d_rows + pos * stride, c, 0, !s->direct);
+        maybe_squeeze(s, d_rows + pos * stride, c);
+        KGWAS_HIP(launch_pattern_hash(a.src, s->d_dmask.p, c, (uint32_t)s->S, (uint32_t)s->W_m, a.min_count, s->d_pat.p,
+                                      s->d_pat_cnt.p, s->stream));
+    }
+    s->pat_upper += n_rows;
 }
 
 // The exact heap minima as far as the host has replayed. They go to thr_host, which thr_update_kernel
@@ -579,6 +611,7 @@ uint64_t next_sparse_chunk(const kgwas_scan* s) {
 void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, uint64_t first_row) {
     const uint64_t stride = 1 + s->W_f;
     uint64_t pos = 0;
+    if (s->count_patterns) hash_patterns(s, d_rows, n_rows);
     std::deque<int> inflight;  // slot indices, oldest first
     uint64_t n_submitted = 0;
     auto reap_oldest = [&]() {
@@ -659,6 +692,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         s->topn.assign(p->topn, p->topn + s->n_pheno);
         s->Y.assign(p->Y, p->Y + s->n_pheno * s->S);
         s->record_history = p->record_history != 0;
+        s->count_patterns = p->count_patterns != 0;
         std::vector<bool> seen(s->S_f, false);
         for (uint64_t i = 0; i < s->S; i++) {
             if (s->col[i] >= s->S_f) throw Error(KGWAS_ERR_ARG, "column index out of range");
@@ -755,6 +789,8 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         s->d_hist.alloc(P * (size_t)HIST_BINS);
         s->d_hist_base.alloc(P);
         s->h_hist_base.alloc(P);
+        s->d_pat_cnt.alloc(1);
+        KGWAS_HIP(hipMemset(s->d_pat_cnt.p, 0, 8));
         s->d_topn.alloc(P);
         KGWAS_HIP(hipMemcpy(s->d_topn.p, s->topn.data(), P * 8, hipMemcpyHostToDevice));
         KGWAS_HIP(hipMemcpy(s->d_dmask.p, dmask.data(), dmask.size() * 4, hipMemcpyHostToDevice));
@@ -842,6 +878,13 @@ int kgwas_scan_finish(kgwas_scan* s) {
         s->res_score.resize(s->n_pheno);
         s->pool->parallel_for(s->n_pheno,
                               [&](size_t j) { s->heaps[j].pop_all(s->res_kmer[j], s->res_score[j], s->res_row[j]); });
+        if (s->count_patterns) {
+            unsigned long long n_hashes = 0;
+            KGWAS_HIP(hipMemcpy(&n_hashes, s->d_pat_cnt.p, 8, hipMemcpyDeviceToHost));
+            uint64_t distinct = 0;
+            KGWAS_HIP(count_distinct_u64(s->d_pat.p, n_hashes, &distinct, s->stream));
+            s->st.patterns = distinct;
+        }
         s->finished = true;
     });
 }
@@ -926,6 +969,8 @@ int kgwas_scan_reset(kgwas_scan* s) {
         s->all_full = false;
         s->hist_ready = false;
         s->rows_submitted = 0;
+        s->pat_upper = 0;
+        KGWAS_HIP(hipMemset(s->d_pat_cnt.p, 0, 8));
         s->rows_done = 0;
         s->finished = false;
         const uint32_t ku = s->st.kernel_used, dm = s->st.direct_mode;

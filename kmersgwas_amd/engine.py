@@ -133,7 +133,8 @@ class AssociationScan:
     """Pass 1 of associate_kmers for all phenotype columns at once."""
 
     def __init__(self, n_acc_file: int, col, Y, topn, min_count: int, device: int = 0, kernel: int = capi.KERNEL_AUTO,
-                 chunk_rows: int = 0, host_threads: int = 0, record_history: bool = False):
+                 chunk_rows: int = 0, host_threads: int = 0, record_history: bool = False,
+                 count_patterns: bool = False):
         self.col = np.ascontiguousarray(col, np.uint64)
         self.Y = np.ascontiguousarray(Y, np.float32)
         if self.Y.ndim == 1:
@@ -156,6 +157,7 @@ class AssociationScan:
         p.host_threads = host_threads
         p.kernel = kernel
         p.record_history = 1 if record_history else 0
+        p.count_patterns = 1 if count_patterns else 0
         self._h = C.c_void_p()
         check(lib.kgwas_scan_create(C.byref(p), C.byref(self._h)))
 

@@ -51,15 +51,19 @@ def test_associate_kmers_ecoli_shaped_config(tmp_path):
     out_p, out_o = tmp_path / "prod", tmp_path / "orc"
     out_p.mkdir(); out_o.mkdir()
     cmd = [os.path.join(BIN, "associate_kmers"), "-p", os.path.join(GOLD, "resistence.pheno"), "-b", "pheno", "-o", str(out_p),
-           "-n", "10001", "--parallel", "4", "--kmers_table", base, "--kmer_len", "31", "--maf", "0.050000", "--mac", "5"]
+           "-n", "10001", "--parallel", "4", "--kmers_table", base, "--kmer_len", "31", "--maf", "0.050000", "--mac", "5",
+           "--pattern_counter"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "Effective minor allele count:\t13" in r.stderr
     mac = onp.min_count(241, 0.05, 5)
-    _oracle_outputs(str(out_o), "pheno", rows, S_f, table_names, acc, names, Y, 10001, mac, k)
+    res = _oracle_outputs(str(out_o), "pheno", rows, S_f, table_names, acc, names, Y, 10001, mac, k)
+    pat = ob.associate(rows, S_f, onp.column_map(table_names, acc), Y, 10001, mac, count_patterns=True)["patterns"]
+    open(os.path.join(str(out_o), "pheno.pattern_counter"), "w").write("%d\n" % pat)  # src/associate_kmers.cpp:197-201
+    assert "Total patterns\t%d" % pat in r.stderr
     files = _compare_dirs(str(out_p), str(out_o))
     assert files == ["pheno.0.phenotype_value.bed", "pheno.0.phenotype_value.bim", "pheno.0.phenotype_value.fam",
-                     "pheno.tested_kmers"]
+                     "pheno.pattern_counter", "pheno.tested_kmers"]
 
 
 @pytest.mark.parametrize("kernel", ["1", "2"])

@@ -207,6 +207,26 @@ def test_adversarial_order_overflows_candidate_lists(kernel):
     scan.close()
 
 
+@pytest.mark.parametrize("S_f,S,reorder", [(241, 241, False), (300, 257, True), (64, 64, False), (1030, 1030, False)])
+def test_pattern_counter(S_f, S, reorder):
+    """--pattern_counter: distinct hash_presence_absence_pattern values over the tested rows, with many
+    duplicated patterns, direct and squeezed mode, several feeds."""
+    rows = random_table(50_000, S_f, seed=S_f + 1, dup_frac=0.6)
+    rng = np.random.default_rng(S)
+    col = rng.permutation(S_f)[:S].astype(np.uint64) if reorder else np.arange(S, dtype=np.uint64)
+    Y = phenotypes(S, 2, seed=3)
+    mac = onp.min_count(S, 0.05, 5)
+    exp = ob.associate(rows, S_f, col, Y, 100, mac, count_patterns=True)
+    assert 0 < exp["patterns"] < exp["tested"]
+    scan = kg.AssociationScan(S_f, col, Y, 100, mac, count_patterns=True, chunk_rows=16384)
+    scan.feed_host(rows[:30_000], 0)
+    scan.feed_host(rows[30_000:], 30_000)
+    scan.finish()
+    _check_topn(scan, exp, 3)
+    assert scan.stats()["patterns"] == exp["patterns"]
+    scan.close()
+
+
 def test_heap_never_fills_and_tiny_inputs():
     S = 100
     rows = random_table(300, S, seed=1)
