@@ -185,7 +185,7 @@ struct PinBuf {
     ~PinBuf() { release(); }
 };
 
-constexpr int NSLOT = 8;  // sparse chunks the GPU may run ahead of the host replay
+constexpr int MAX_SLOTS = 16;  // upper bound on sparse chunks the GPU may run ahead of the host replay
 
 struct Slot {
     PinBuf<Cand> cand;  // written by the GPU straight into mapped host memory
@@ -235,7 +235,8 @@ struct kgwas_scan {
     DevBuf<uint64_t> d_pat;                // pattern hashes of the tested rows seen so far
     DevBuf<unsigned long long> d_pat_cnt;  // how many
     uint64_t pat_upper = 0;                // host-side upper bound of that count (rows fed)
-    Slot slot[NSLOT];
+    Slot slot[MAX_SLOTS];
+    int n_slots = MAX_SLOTS;  // as many as fit 1 GiB of mapped pinned candidate memory (at least 4)
     // dense mode
     DevBuf<double> d_dense;
     DevBuf<uint32_t> d_n1;
@@ -310,7 +311,9 @@ void fill_args(kgwas_scan* s, ScoreArgs& a, const uint64_t* d_rows, uint64_t n_r
 // blocks over the 256 CUs so the last round's imbalance stays small; the launcher rounds up to
 // the rows one pass of the block's waves covers.
 uint32_t pick_rows_per_block(uint64_t n_rows, uint64_t /*n_ctiles*/) {
-    for (uint32_t rpb : {1024u, 512u}) {
+    // Bigger row blocks amortise the per-group LDS refills and barriers (probe: 78.0 / 79.2 / 80.3 % of
+    // peak at 1024 / 2048 / 4096 rows per block on 4 M rows x 96 columns).
+    for (uint32_t rpb : {4096u, 2048u, 1024u, 512u}) {
         if ((n_rows + rpb - 1) / rpb >= 2048) return rpb;
     }
     return 256u;
@@ -603,7 +606,7 @@ uint64_t next_sparse_chunk(const kgwas_scan* s) {
     return (ci + 127) / 128 * 128;
 }
 
-// The GPU runs up to NSLOT chunks ahead of the host replay. Heap pushes are front-loaded (60 % of them
+// The GPU runs up to n_slots chunks ahead of the host replay. Heap pushes are front-loaded (60 % of them
 // belong to the first 10 % of a 100 M-row table) and inherently serial per column, so the host lags during
 // that part; instead of idling, the GPU keeps scoring later chunks against the thresholds it has (staler
 // thresholds only mean more records for the host to discard, never a wrong result) and the replay catches
@@ -624,7 +627,7 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
             process_range_sync(s, sl, sl.rows, sl.n_rows, sl.first_row);
         }
     };
-    const size_t depth = s->direct ? (size_t)NSLOT : 1;  // squeezed mode has a single squeeze buffer
+    const size_t depth = s->direct ? (size_t)s->n_slots : 1;  // squeezed mode has a single squeeze buffer
     while (pos < n_rows) {
         if (!s->all_full) {
             while (!inflight.empty()) reap_oldest();
@@ -635,7 +638,7 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
         }
         if (inflight.size() >= depth) reap_oldest();
         const uint64_t c = std::min<uint64_t>(next_sparse_chunk(s), n_rows - pos);
-        const int idx = (int)(n_submitted % NSLOT);  // FIFO order: this slot was reaped NSLOT submissions ago
+        const int idx = (int)(n_submitted % (uint64_t)s->n_slots);  // FIFO: reaped n_slots submissions ago
         submit_sparse(s, s->slot[idx], d_rows + pos * stride, c, first_row + pos, /*count_hist=*/true);
         s->rows_submitted += c;
         inflight.push_back(idx);
@@ -718,10 +721,10 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         if (kern != KGWAS_KERNEL_MFMA && kern != KGWAS_KERNEL_VALU) throw Error(KGWAS_ERR_ARG, "unknown kernel id");
         s->kernel_used = kern;
 
-        s->chunk_max = p->chunk_rows ? p->chunk_rows : (4ull << 20);
+        s->chunk_max = p->chunk_rows ? p->chunk_rows : (8ull << 20);
         s->chunk_max = std::max<uint64_t>(128, (s->chunk_max + 127) / 128 * 128);
         s->dense_rows = std::min<uint64_t>(16384, s->chunk_max);
-        const uint64_t budget = 4ull << 20;  // candidate records per slot (x 24 B x NSLOT of mapped pinned memory)
+        const uint64_t budget = 4ull << 20;  // candidate records per slot (x 24 B x n_slots of mapped pinned memory)
         uint64_t cap = std::min<uint64_t>(2 * s->max_topn + 4096, std::max<uint64_t>(budget / s->n_pheno, 1024));
         s->cap = (uint32_t)std::min<uint64_t>(cap, 0x7FFFFFFFull);
 
@@ -805,7 +808,12 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         }
         if (!s->direct) s->d_sq.alloc(s->chunk_max * 2 * W_m);
 
-        for (auto& sl : s->slot) {
+        {
+            const uint64_t slot_bytes = (uint64_t)s->cap * P * sizeof(Cand);
+            s->n_slots = (int)std::min<uint64_t>(MAX_SLOTS, std::max<uint64_t>(4, (1ull << 30) / std::max<uint64_t>(slot_bytes, 1)));
+        }
+        for (int si = 0; si < s->n_slots; si++) {
+            Slot& sl = s->slot[si];
             sl.cand.alloc((uint64_t)s->cap * P);
             sl.d_cand = sl.cand.dev();
             sl.d_cnt.alloc(P);

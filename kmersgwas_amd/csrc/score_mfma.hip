@@ -80,8 +80,13 @@ __device__ __forceinline__ void mfma_block(f32x4 (&acc)[2][NCT][4], const uint32
             asm volatile("" : "+v"(e), "+v"(o));
 #pragma unroll
             for (int h = 0; h < 4; h++) {
+#if defined(KGWAS_ABLATE) && (KGWAS_ABLATE & 16)  // probe: operands without the per-operand conversion
+                Af[rt][l][2 * h] = __int_as_float(e);
+                Af[rt][l][2 * h + 1] = __int_as_float(o);
+#else
                 Af[rt][l][2 * h] = (float)((e >> (8 * (3 - h))) & 0xFFu);      // v_cvt_f32_ubyteN
                 Af[rt][l][2 * h + 1] = (float)((o >> (8 * (3 - h))) & 0xFFu);
+#endif
             }
         }
     __builtin_amdgcn_sched_barrier(0);  // operands first, then a clean MFMA stream
