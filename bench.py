@@ -175,8 +175,8 @@ def main():
         if S == 1024 and P == 101 and os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
-                # bytes per 4 194 304-row launch -> GB per average launch of this run (rows-proportional)
-                traffic = j["traffic_bytes_per_4194304_row_launch"] / 4194304 * (rows_scored / max(k_launch, 1)) / 1e9
+                # PMC bytes per row of the steady launches -> GB per average launch of this run
+                traffic = j["traffic_bytes_per_row"] * (rows_scored / max(k_launch, 1)) / 1e9
                 traffic_src = "profiles/r01_pmc_hbm_traffic.json"
             except Exception:
                 pass
