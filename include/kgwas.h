@@ -100,6 +100,8 @@ typedef struct kgwas_scan kgwas_scan;
 #define KGWAS_KERNEL_AUTO 0
 #define KGWAS_KERNEL_VALU 1 /* exact-order select+add on the vector ALU */
 #define KGWAS_KERNEL_MFMA 2 /* exact-order f32 MFMA (v_mfma_f32_16x16x4_f32) */
+#define KGWAS_KERNEL_COARSE 3 /* int8-MFMA coarse filter with a rigorous bound + exact re-scoring of survivors;
+                                the dense phase and overflow re-runs use an exact kernel. Same results. */
 
 typedef struct kgwas_scan_params {
     uint32_t struct_size;    /* sizeof(kgwas_scan_params) */

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libkgwas.so")
 
 KGWAS_OK = 0
 KGWAS_ERR_ARG, KGWAS_ERR_IO, KGWAS_ERR_FORMAT, KGWAS_ERR_DEVICE, KGWAS_ERR_STATE, KGWAS_ERR_NOMEM = -1, -2, -3, -4, -5, -6
-KERNEL_AUTO, KERNEL_VALU, KERNEL_MFMA = 0, 1, 2
+KERNEL_AUTO, KERNEL_VALU, KERNEL_MFMA, KERNEL_COARSE = 0, 1, 2, 3
 
 # Every symbol include/kgwas.h declares (tests check the library exports each one).
 SYMBOLS = [

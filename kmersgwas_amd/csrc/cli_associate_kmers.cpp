@@ -59,7 +59,7 @@ int main(int argc, char* argv[]) {
         {"k_mers_scores", 0, false, "output the best k_mers scores in binary format", ""},
         {"pattern_counter", 0, false, "Count the number of unique presence/absence patterns", ""},
         {"device", 0, true, "GPU ordinal", "0"},
-        {"kernel", 0, true, "scoring kernel: 0 auto, 1 vector ALU, 2 f32 MFMA", "0"},
+        {"kernel", 0, true, "scoring kernel: 0 auto, 1 vector ALU, 2 f32 MFMA, 3 int8 coarse filter + exact re-score", "0"},
         {"help", 0, false, "print help", ""},
     });
     const string desc = "Associate k-mers presence/absence pattern with a phenotype of interest";

@@ -68,6 +68,33 @@ hipError_t launch_score_valu(const ScoreArgs& a, hipStream_t st);
 hipError_t launch_score_mfma(const ScoreArgs& a, uint32_t rows_per_block, uint32_t nb_full, hipStream_t st);
 size_t mfma_lds_bytes(uint32_t W_m);
 
+// Coarse int8 filter (score_coarse.hip). Survivors of column p are listed as chunk-local row indices in
+// surv[p*surv_cap ...]; launch_rescore then scores them exactly (it takes the sparse-mode ScoreArgs,
+// with Yperm set).
+struct CoarseArgs {
+    RowSrc src;
+    const uint32_t* dmask;  // [2*W_m]
+    uint32_t all_ones;      // 1: no masking needed (every dmask word is ~0 and rows hold no other bits)
+    uint64_t n_rows;
+    uint32_t S, W_m, n_pheno, min_count;
+    uint32_t n_kgroups;     // 512-sample groups = ceil(W_m / 8)
+    uint32_t n_lgroups;     // LDS groups of T/2 x 16 phenotype columns
+    const int8_t* Bq;       // [n_lgroups][n_kgroups][8][T][64 lanes][16] int8 slices, see score_coarse.hip
+    const double* scale0;   // [n_pheno]
+    const double* scale1;   // [n_pheno]
+    const double* E;        // [n_pheno] bound on |yigi_ref - yc|
+    const float* sums;      // [n_pheno]
+    const double* thr;      // [n_pheno]
+    uint32_t* surv;         // [n_pheno][surv_cap]
+    uint32_t* surv_cnt;     // [n_pheno]
+    uint32_t surv_cap;
+    unsigned long long* tested;
+};
+size_t coarse_lds_bytes(uint32_t n_kgroups, uint32_t T);
+hipError_t launch_coarse(const CoarseArgs& a, uint32_t T, uint32_t rows_per_block, hipStream_t st);
+hipError_t launch_rescore(const ScoreArgs& a, const uint32_t* surv, const uint32_t* surv_cnt, uint32_t surv_cap,
+                          hipStream_t st);
+
 // --pattern_counter: append hash_presence_absence_pattern of every MAC-passing row to out[*out_count ...];
 // count_distinct_u64 sorts the collected hashes in place (device) and returns how many are distinct.
 hipError_t launch_pattern_hash(const RowSrc& src, const uint32_t* dmask, uint64_t n_rows, uint32_t S, uint32_t W_m,

@@ -192,6 +192,7 @@ struct Slot {
     Cand* d_cand = nullptr;
     DevBuf<uint32_t> d_cnt;
     PinBuf<uint32_t> h_cnt;
+    PinBuf<uint32_t> h_surv_cnt;  // coarse filter: survivors per column (overflow check)
     DevBuf<unsigned long long> d_tested;
     PinBuf<unsigned long long> h_tested;
     hipEvent_t ev_sq0 = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_done = nullptr;
@@ -230,6 +231,12 @@ struct kgwas_scan {
     PinBuf<double> h_thr_redo;
     bool hist_ready = false;
     uint64_t rows_submitted = 0;  // rows handed to the GPU (replayed or still in flight)
+    // coarse int8 filter (sparse phase)
+    bool coarse = false;
+    uint32_t coarse_T = 0, n_kgroups = 0, n_lgroups = 0, coarse_all_ones = 0;
+    DevBuf<int8_t> d_Bq;
+    DevBuf<double> d_s0, d_s1, d_E;
+    DevBuf<uint32_t> d_surv, d_surv_cnt;  // shared by all chunks: consumed by the re-score kernel in stream order
     // --pattern_counter
     bool count_patterns = false;
     DevBuf<uint64_t> d_pat;                // pattern hashes of the tested rows seen so far
@@ -494,7 +501,41 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
     KGWAS_HIP(hipEventRecord(sl.ev_sq0, s->stream));
     maybe_squeeze(s, d_rows, n_rows);
     KGWAS_HIP(hipEventRecord(sl.ev_k0, s->stream));
-    launch_score(s, a);
+    const bool use_coarse = s->coarse && count_hist;
+    if (use_coarse) {
+        CoarseArgs c;
+        memset(&c, 0, sizeof(c));
+        c.src = a.src;
+        c.dmask = a.dmask;
+        c.all_ones = s->coarse_all_ones;
+        c.n_rows = n_rows;
+        c.S = a.S;
+        c.W_m = a.W_m;
+        c.n_pheno = a.n_pheno;
+        c.min_count = a.min_count;
+        c.n_kgroups = s->n_kgroups;
+        c.n_lgroups = s->n_lgroups;
+        c.Bq = s->d_Bq.p;
+        c.scale0 = s->d_s0.p;
+        c.scale1 = s->d_s1.p;
+        c.E = s->d_E.p;
+        c.sums = a.sums;
+        c.thr = a.thr;
+        c.surv = s->d_surv.p;
+        c.surv_cnt = s->d_surv_cnt.p;
+        c.surv_cap = s->cap;
+        c.tested = a.tested;
+        KGWAS_HIP(hipMemsetAsync(s->d_surv_cnt.p, 0, s->n_pheno * sizeof(uint32_t), s->stream));
+        KGWAS_HIP(launch_coarse(c, s->coarse_T, n_rows >= (1u << 20) ? 2048u : 512u, s->stream));
+        a.tested = nullptr;  // counted by the coarse pass
+        KGWAS_HIP(launch_rescore(a, s->d_surv.p, s->d_surv_cnt.p, s->cap, s->stream));
+        KGWAS_HIP(hipMemcpyAsync(sl.h_surv_cnt.p, s->d_surv_cnt.p, s->n_pheno * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                 s->stream));
+        s->st.score_launches++;
+    } else {
+        if (s->coarse) memset(sl.h_surv_cnt.p, 0, s->n_pheno * sizeof(uint32_t));
+        launch_score(s, a);
+    }
     KGWAS_HIP(hipEventRecord(sl.ev_k1, s->stream));
     if (s->hist_ready)  // raise the thresholds for whatever is queued next; no host round trip
         KGWAS_HIP(launch_thr_update(s->d_hist.p, s->d_hist_base.p, HIST_BINS, s->d_topn.p, s->d_thr_host.p, s->d_thr.p,
@@ -530,7 +571,7 @@ bool reap_sparse(kgwas_scan* s, Slot& sl) {
         s->st.squeeze_kernel_ms += ms;
     }
     for (uint64_t j = 0; j < s->n_pheno; j++)
-        if (sl.h_cnt.p[j] > s->cap) return false;
+        if (sl.h_cnt.p[j] > s->cap || (s->coarse && sl.h_surv_cnt.p[j] > s->cap)) return false;
 
     auto t0 = std::chrono::steady_clock::now();
     s->st.rows_tested += *sl.h_tested.p;
@@ -713,6 +754,23 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         for (float v : s->Y) finite = finite && std::isfinite(v);
         uint32_t kern = p->kernel;
         const bool mfma_fits = mfma_lds_bytes((uint32_t)s->W_m) <= 160u * 1024u;
+        // Coarse int8 filter + exact re-scoring for the sparse phase (score_coarse.hip): needs finite values,
+        // an exact kernel for the dense phase / re-runs, and T >= 2 int8 tiles of the whole sample axis in LDS.
+        const uint32_t n_kgroups = (uint32_t)((s->W_m + 7) / 8);
+        uint32_t coarse_T = 0;
+        for (uint32_t T : {8u, 6u, 4u, 2u})
+            if (coarse_lds_bytes(n_kgroups, T) <= 152u * 1024u) {
+                coarse_T = T;
+                break;
+            }
+        bool want_coarse = false;
+        if (kern == KGWAS_KERNEL_COARSE) {
+            if (!finite || !coarse_T) throw Error(KGWAS_ERR_ARG, "coarse filter needs finite phenotype values and <= 5120 accessions");
+            want_coarse = true;
+            kern = KGWAS_KERNEL_AUTO;
+        } else if (kern == KGWAS_KERNEL_AUTO && finite && coarse_T && s->n_pheno >= 8) {
+            want_coarse = true;
+        }
         if (kern == KGWAS_KERNEL_AUTO) kern = (s->n_pheno >= 4 && finite && mfma_fits) ? KGWAS_KERNEL_MFMA : KGWAS_KERNEL_VALU;
         if (kern == KGWAS_KERNEL_MFMA && !mfma_fits)
             throw Error(KGWAS_ERR_ARG, "MFMA scorer: phenotype tile does not fit LDS for this many accessions");
@@ -720,6 +778,9 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
             throw Error(KGWAS_ERR_ARG, "MFMA scorer needs finite phenotype values (0*inf); use the VALU scorer");
         if (kern != KGWAS_KERNEL_MFMA && kern != KGWAS_KERNEL_VALU) throw Error(KGWAS_ERR_ARG, "unknown kernel id");
         s->kernel_used = kern;
+        s->coarse = want_coarse;
+        s->coarse_T = coarse_T;
+        s->n_kgroups = n_kgroups;
 
         s->chunk_max = p->chunk_rows ? p->chunk_rows : (8ull << 20);
         s->chunk_max = std::max<uint64_t>(128, (s->chunk_max + 127) / 128 * 128);
@@ -802,9 +863,73 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         if (kern == KGWAS_KERNEL_MFMA) {
             s->d_Ymfma.alloc(Ymfma.size());
             KGWAS_HIP(hipMemcpy(s->d_Ymfma.p, Ymfma.data(), Ymfma.size() * 4, hipMemcpyHostToDevice));
-        } else {
+        }
+        if (kern != KGWAS_KERNEL_MFMA || s->coarse) {
             s->d_Yperm.alloc(Yperm.size());
             KGWAS_HIP(hipMemcpy(s->d_Yperm.p, Yperm.data(), Yperm.size() * 4, hipMemcpyHostToDevice));
+        }
+        if (s->coarse) {
+            // Two int8 slices per column: y ~ s0*q0 + s1*q1, and E >= |yigi_ref - (s0*D0 + s1*D1)| for every row:
+            //   float32 summation error of the reference chain  <= gamma_{L/4+3} * sum|y_i|   (Higham, recursive sums)
+            //   quantisation residual                            <= sum_i |y_i - s0 q0_i - s1 q1_i|
+            // plus a small pad for the double arithmetic of the device-side combination.
+            const uint32_t T = s->coarse_T, PG = T / 2;
+            const uint64_t n_lgroups = (P + 16ull * PG - 1) / (16ull * PG);
+            s->n_lgroups = (uint32_t)n_lgroups;
+            std::vector<int8_t> Bq(n_lgroups * n_kgroups * 8ull * T * 1024ull, 0);
+            std::vector<double> sc0(P), sc1(P), Eb(P);
+            const double u32 = std::ldexp(1.0, -24);
+            const double nterms = (double)L / 4.0 + 3.0;
+            const double gamma = nterms * u32 / (1.0 - nterms * u32);
+            std::vector<int> q0(S), q1(S);
+            for (uint64_t j = 0; j < P; j++) {
+                double mx = 0, A = 0;
+                for (uint64_t i = 0; i < S; i++) {
+                    mx = std::max(mx, std::fabs((double)s->Y[j * S + i]));
+                    A += std::fabs((double)s->Y[j * S + i]);
+                }
+                const double a0 = mx > 0 ? mx / 127.0 : 1.0, a1 = a0 / 254.0;
+                double resid = 0;
+                for (uint64_t i = 0; i < S; i++) {
+                    const double y = (double)s->Y[j * S + i];
+                    int v0 = (int)std::lrint(y / a0);
+                    v0 = std::max(-127, std::min(127, v0));
+                    const double r1 = y - a0 * v0;
+                    int v1 = (int)std::lrint(r1 / a1);
+                    v1 = std::max(-127, std::min(127, v1));
+                    q0[i] = v0;
+                    q1[i] = v1;
+                    resid += std::fabs(r1 - a1 * v1);
+                }
+                sc0[j] = a0;
+                sc1[j] = a1;
+                Eb[j] = (gamma * A + resid) * (1.0 + 1e-6) + 1e-12 * (1.0 + A);
+                const uint64_t lg = j / (16ull * PG), pgl = (j / 16) % PG, n = j % 16;
+                for (uint64_t g = 0; g < n_kgroups; g++)
+                    for (uint64_t jj = 0; jj < 8; jj++)
+                        for (uint64_t kg = 0; kg < 4; kg++)
+                            for (uint64_t e = 0; e < 16; e++) {
+                                const uint64_t smp = 512 * g + 128 * kg + 16 * jj + e;
+                                if (smp >= S) continue;
+                                const uint64_t lane = kg * 16 + n;
+                                const uint64_t base = (((lg * n_kgroups + g) * 8 + jj) * T);
+                                Bq[((base + 2 * pgl) * 64 + lane) * 16 + e] = (int8_t)q0[smp];
+                                Bq[((base + 2 * pgl + 1) * 64 + lane) * 16 + e] = (int8_t)q1[smp];
+                            }
+            }
+            s->d_Bq.alloc(Bq.size());
+            s->d_s0.alloc(P);
+            s->d_s1.alloc(P);
+            s->d_E.alloc(P);
+            KGWAS_HIP(hipMemcpy(s->d_Bq.p, Bq.data(), Bq.size(), hipMemcpyHostToDevice));
+            KGWAS_HIP(hipMemcpy(s->d_s0.p, sc0.data(), P * 8, hipMemcpyHostToDevice));
+            KGWAS_HIP(hipMemcpy(s->d_s1.p, sc1.data(), P * 8, hipMemcpyHostToDevice));
+            KGWAS_HIP(hipMemcpy(s->d_E.p, Eb.data(), P * 8, hipMemcpyHostToDevice));
+            bool ones = (s->direct ? 2 * s->W_f : 2 * W_m) <= 2 * W_m;
+            for (uint32_t v : dmask) ones = ones && (v == 0xFFFFFFFFu);
+            s->coarse_all_ones = ones ? 1u : 0u;
+            s->d_surv.alloc((uint64_t)s->cap * P);
+            s->d_surv_cnt.alloc(P);
         }
         if (!s->direct) s->d_sq.alloc(s->chunk_max * 2 * W_m);
 
@@ -818,6 +943,8 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
             sl.d_cand = sl.cand.dev();
             sl.d_cnt.alloc(P);
             sl.h_cnt.alloc(P);
+            sl.h_surv_cnt.alloc(P);
+            memset(sl.h_surv_cnt.p, 0, P * sizeof(uint32_t));
             sl.d_tested.alloc(1);
             sl.h_tested.alloc(1);
             KGWAS_HIP(hipEventCreate(&sl.ev_sq0));
@@ -840,7 +967,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         unsigned nt = p->host_threads ? p->host_threads : usable_cpus();
         nt = (unsigned)std::min<uint64_t>(nt, P);
         s->pool.reset(new Pool(nt));
-        s->st.kernel_used = kern;
+        s->st.kernel_used = s->coarse ? (uint32_t)KGWAS_KERNEL_COARSE : kern;
         s->st.direct_mode = s->direct ? 1 : 0;
         *out = s.release();
     });

@@ -66,7 +66,7 @@ def test_associate_kmers_ecoli_shaped_config(tmp_path):
                      "pheno.pattern_counter", "pheno.tested_kmers"]
 
 
-@pytest.mark.parametrize("kernel", ["1", "2"])
+@pytest.mark.parametrize("kernel", ["1", "2", "3"])
 def test_associate_kmers_permutations_subset_scores(tmp_path, kernel):
     """Several phenotype columns (value + permutations), phenotyped subset in shuffled order,
     --first_phenotype_best, --k_mers_scores, small --batch_size: every output file byte-identical."""

@@ -14,7 +14,7 @@ from helpers import random_table, phenotypes, synth_rows_numpy
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-KERNELS = [kg.KERNEL_VALU, kg.KERNEL_MFMA]
+KERNELS = [kg.KERNEL_VALU, kg.KERNEL_MFMA, kg.KERNEL_COARSE]
 
 
 def _check_topn(scan, oracle_res, n_pheno, check_pushes=True):
@@ -304,7 +304,7 @@ def test_device_resident_feed_equals_host_feed():
         scan.finish()
         res.append([scan.result(j) for j in range(P)])
         st = scan.stats()
-        assert st["kernel_used"] == kg.KERNEL_MFMA and st["direct_mode"] == 1
+        assert st["kernel_used"] == kg.KERNEL_COARSE and st["direct_mode"] == 1  # AUTO: >= 8 finite columns
         scan.close()
     for j in range(P):
         for a, b in zip(res[0][j], res[1][j]):
