@@ -132,6 +132,8 @@ typedef struct kgwas_scan_stats {
     double replay_ms;           /* host wall time spent replaying candidates (control thread view) */
     double gpu_wait_ms;         /* host wall time blocked waiting for sparse chunks to finish */
     double dense_ms;            /* host wall time of the dense (heap-filling) phase, GPU + replay */
+    double coarse_kernel_ms;    /* sum of hipEvent durations of coarse_kernel alone (KGWAS_KERNEL_COARSE) */
+    uint64_t coarse_launches;   /* its launches */
     uint32_t kernel_used;       /* KGWAS_KERNEL_VALU or KGWAS_KERNEL_MFMA */
     uint32_t direct_mode;       /* 1 = scorer read the file layout in place (no squeeze pass) */
     uint64_t patterns;          /* distinct pattern hashes among tested rows (count_patterns; valid after finish) */

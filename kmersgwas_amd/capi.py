@@ -62,6 +62,7 @@ class ScanStats(C.Structure):
         ("heap_pushes", C.c_uint64), ("chunks", C.c_uint64), ("score_launches", C.c_uint64),
         ("score_kernel_ms", C.c_double), ("squeeze_kernel_ms", C.c_double), ("replay_ms", C.c_double),
         ("gpu_wait_ms", C.c_double), ("dense_ms", C.c_double),
+        ("coarse_kernel_ms", C.c_double), ("coarse_launches", C.c_uint64),
         ("kernel_used", C.c_uint32), ("direct_mode", C.c_uint32), ("patterns", C.c_uint64),
     ]
 

@@ -195,7 +195,8 @@ struct Slot {
     PinBuf<uint32_t> h_surv_cnt;  // coarse filter: survivors per column (overflow check)
     DevBuf<unsigned long long> d_tested;
     PinBuf<unsigned long long> h_tested;
-    hipEvent_t ev_sq0 = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_done = nullptr;
+    hipEvent_t ev_sq0 = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_done = nullptr, ev_mid = nullptr;
+    bool used_coarse = false;
     const uint64_t* rows = nullptr;
     uint64_t first_row = 0, n_rows = 0;
     bool squeezed = false, busy = false;
@@ -274,6 +275,7 @@ struct kgwas_scan {
             if (s.ev_k0) (void)hipEventDestroy(s.ev_k0);
             if (s.ev_k1) (void)hipEventDestroy(s.ev_k1);
             if (s.ev_done) (void)hipEventDestroy(s.ev_done);
+            if (s.ev_mid) (void)hipEventDestroy(s.ev_mid);
         }
         if (ev_user) (void)hipEventDestroy(ev_user);
         if (ev_ds) (void)hipEventDestroy(ev_ds);
@@ -502,6 +504,7 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
     maybe_squeeze(s, d_rows, n_rows);
     KGWAS_HIP(hipEventRecord(sl.ev_k0, s->stream));
     const bool use_coarse = s->coarse && count_hist;
+    sl.used_coarse = use_coarse;
     if (use_coarse) {
         CoarseArgs c;
         memset(&c, 0, sizeof(c));
@@ -527,6 +530,7 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
         c.tested = a.tested;
         KGWAS_HIP(hipMemsetAsync(s->d_surv_cnt.p, 0, s->n_pheno * sizeof(uint32_t), s->stream));
         KGWAS_HIP(launch_coarse(c, s->coarse_T, n_rows >= (1u << 20) ? 2048u : 512u, s->stream));
+        KGWAS_HIP(hipEventRecord(sl.ev_mid, s->stream));
         a.tested = nullptr;  // counted by the coarse pass
         KGWAS_HIP(launch_rescore(a, s->d_surv.p, s->d_surv_cnt.p, s->cap, s->stream));
         KGWAS_HIP(hipMemcpyAsync(sl.h_surv_cnt.p, s->d_surv_cnt.p, s->n_pheno * sizeof(uint32_t), hipMemcpyDeviceToHost,
@@ -566,6 +570,12 @@ bool reap_sparse(kgwas_scan* s, Slot& sl) {
     KGWAS_HIP(hipEventElapsedTime(&ms, sl.ev_k0, sl.ev_k1));
     s->st.score_kernel_ms += ms;
     const float ms_kernel = ms;
+    if (sl.used_coarse) {
+        float mc = 0;
+        KGWAS_HIP(hipEventElapsedTime(&mc, sl.ev_k0, sl.ev_mid));
+        s->st.coarse_kernel_ms += mc;
+        s->st.coarse_launches++;
+    }
     if (!s->direct) {
         KGWAS_HIP(hipEventElapsedTime(&ms, sl.ev_sq0, sl.ev_k0));
         s->st.squeeze_kernel_ms += ms;
@@ -951,6 +961,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
             KGWAS_HIP(hipEventCreate(&sl.ev_k0));
             KGWAS_HIP(hipEventCreate(&sl.ev_k1));
             KGWAS_HIP(hipEventCreate(&sl.ev_done));
+            KGWAS_HIP(hipEventCreate(&sl.ev_mid));
         }
         s->d_dense.alloc(P * s->dense_rows);
         s->h_dense.alloc(P * s->dense_rows);
