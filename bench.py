@@ -64,6 +64,15 @@ def cpu_baseline(S, Y, mac, topn, seed, sample_rows, threads):
                 seconds=dt)
 
 
+def cgroup_throttle():
+    """(nr_throttled, throttled_usec) of this container's CPU controller, (0, 0) if unreadable."""
+    try:
+        kv = dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat"))
+        return int(kv.get("nr_throttled", 0)), int(kv.get("throttled_usec", 0))
+    except Exception:
+        return 0, 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -142,14 +151,19 @@ def main():
     for _ in range(args.warmup):
         scan, st, heaps, tested = one_step()
     sync()
+    thr0 = cgroup_throttle()
     t0 = time.perf_counter()
     stats = []
+    step_ms = []
     last = None
     for _ in range(args.steps):
+        ts = time.perf_counter()
         last, st, heaps, tested = one_step()
         stats.append(st)
+        step_ms.append((time.perf_counter() - ts) * 1e3)
     sync()
     dt = time.perf_counter() - t0
+    thr1 = cgroup_throttle()
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=kdist._dev())
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -229,7 +243,10 @@ def main():
                      "chunks_per_step": sum(s["chunks"] for s in stats) // args.steps,
                      "gpu_wait_ms_per_step": sum(s["gpu_wait_ms"] for s in stats) / args.steps,
                      "dense_phase_ms_per_step": sum(s["dense_ms"] for s in stats) / args.steps,
-                     "cores": usable_cpus(), "logical_cpus": os.cpu_count()},
+                     "cores": usable_cpus(), "logical_cpus": os.cpu_count(),
+                     "step_ms": [round(x, 2) for x in step_ms],
+                     # CFS bandwidth throttling of this container during the timed region (cpu.stat deltas)
+                     "cgroup_nr_throttled": thr1[0] - thr0[0], "cgroup_throttled_ms": (thr1[1] - thr0[1]) / 1e3},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S, Y, mac, args.topn, seed_table, args.cpu_sample_rows,

@@ -14,6 +14,7 @@
 // every comparison, and therefore every move, is the one the reference's 24-byte tuples would
 // make, at 2/3 of the memory traffic of the replay (the hot loop of the host side).
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 #include <algorithm>
@@ -21,7 +22,9 @@
 
 namespace kgwas {
 
-class BestHeap {
+// alignas: neighbouring heaps are replayed by different worker threads; their counters and minima are written
+// on every call, so each object gets its own cache lines (no false sharing).
+class alignas(128) BestHeap {
     struct Ent {
         double score;
         uint32_t slot;
@@ -47,18 +50,54 @@ class BestHeap {
             return true;
         }
         if (score > lowest_) {
-            std::pop_heap(v_.begin(), v_.end(), Greater());
-            const uint32_t slot = v_.back().slot;  // the evicted minimum's slot is reused
-            v_.pop_back();
+            const uint32_t slot = v_.front().slot;  // the evicted minimum's slot is reused
             kmer_[slot] = kmer;
             row_[slot] = row;
-            v_.push_back(Ent{score, slot});
-            std::push_heap(v_.begin(), v_.end(), Greater());
+            replace_top(v_.data(), (ptrdiff_t)v_.size(), Ent{score, slot});
             pushes_++;
             lowest_ = v_.front().score;
             return true;
         }
         return false;
+    }
+
+    // pop() followed by push(x) on a full heap a[0..n), written out: the element moves are exactly those of
+    // libstdc++'s std::pop_heap (value = a[n-1]; __adjust_heap: the hole at the root walks down to a leaf
+    // taking the child that does NOT compare greater, the right one on a tie; __push_heap: value climbs from
+    // that leaf while its parent compares greater) and std::push_heap (x climbs from index n-1), in that
+    // order, with the comparator Greater. Only the child choice is made branch-free (it is a coin flip for
+    // the branch predictor, 13 levels deep at N = 10001). tests/test_host.py drives this against a literal
+    // std::priority_queue on tie-heavy streams.
+    static inline void replace_top(Ent* a, ptrdiff_t n, Ent x) {
+        const Ent value = a[n - 1];
+        const ptrdiff_t len = n - 1;
+        ptrdiff_t hole = 0, child = 0;
+        while (child < (len - 1) / 2) {
+            child = 2 * (child + 1);
+            child -= (a[child].score > a[child - 1].score) ? 1 : 0;
+            a[hole] = a[child];
+            hole = child;
+        }
+        if ((len & 1) == 0 && child == (len - 2) / 2) {
+            child = 2 * (child + 1);
+            a[hole] = a[child - 1];
+            hole = child - 1;
+        }
+        ptrdiff_t parent = (hole - 1) / 2;
+        while (hole > 0 && a[parent].score > value.score) {
+            a[hole] = a[parent];
+            hole = parent;
+            parent = (hole - 1) / 2;
+        }
+        a[hole] = value;
+        hole = n - 1;
+        parent = (hole - 1) / 2;
+        while (hole > 0 && a[parent].score > x.score) {
+            a[hole] = a[parent];
+            hole = parent;
+            parent = (hole - 1) / 2;
+        }
+        a[hole] = x;
     }
     inline bool full() const { return v_.size() >= n_res_; }
     inline size_t size() const { return v_.size(); }
@@ -70,16 +109,44 @@ class BestHeap {
     // output_to_file_with_scores order (:82-92): ascending pops from a copy.
     void pop_all(std::vector<uint64_t>& kmer, std::vector<double>& score, std::vector<uint64_t>& row) const {
         std::vector<Ent> tmp(v_);
-        kmer.clear();
-        score.clear();
-        row.clear();
-        while (!tmp.empty()) {
-            kmer.push_back(kmer_[tmp.front().slot]);
-            score.push_back(tmp.front().score);
-            row.push_back(row_[tmp.front().slot]);
-            std::pop_heap(tmp.begin(), tmp.end(), Greater());
-            tmp.pop_back();
+        const size_t n = tmp.size();
+        kmer.resize(n);
+        score.resize(n);
+        row.resize(n);
+        Ent* a = tmp.data();
+        for (size_t i = 0; i < n; i++) {
+            kmer[i] = kmer_[a[0].slot];
+            score[i] = a[0].score;
+            row[i] = row_[a[0].slot];
+            pop_top(a, (ptrdiff_t)(n - i));
         }
+    }
+
+    // std::pop_heap(a, a + n, Greater()) minus the store of the old top into a[n-1] (the caller drops it):
+    // same hole walk and climb as in replace_top.
+    static inline void pop_top(Ent* a, ptrdiff_t n) {
+        if (n <= 1) return;
+        const Ent value = a[n - 1];
+        const ptrdiff_t len = n - 1;
+        ptrdiff_t hole = 0, child = 0;
+        while (child < (len - 1) / 2) {
+            child = 2 * (child + 1);
+            child -= (a[child].score > a[child - 1].score) ? 1 : 0;
+            a[hole] = a[child];
+            hole = child;
+        }
+        if ((len & 1) == 0 && child == (len - 2) / 2) {
+            child = 2 * (child + 1);
+            a[hole] = a[child - 1];
+            hole = child - 1;
+        }
+        ptrdiff_t parent = (hole - 1) / 2;
+        while (hole > 0 && a[parent].score > value.score) {
+            a[hole] = a[parent];
+            hole = parent;
+            parent = (hole - 1) / 2;
+        }
+        a[hole] = value;
     }
 
    private:

@@ -53,6 +53,11 @@ struct ScoreArgs {
     uint32_t* hist;             // [n_pheno][hist_bins] or null
     const uint32_t* hist_base;  // [n_pheno] (bits(score) >> HIST_SHIFT) of bin 0
     uint32_t hist_bins;
+    // Ordered output of the re-score kernel (coarse path): entry i of column p describes the i-th survivor in
+    // row order; score is -inf for a survivor that is not a candidate (score <= thr or MAC-filtered).
+    double* so_score;    // [n_pheno][cap] or null
+    uint64_t* so_kmer;   // [n_pheno][cap]
+    uint32_t* so_row;    // [n_pheno][cap] chunk-local row
 };
 
 constexpr int HIST_SHIFT = 44;          // 8 mantissa bits per bin: 0.4 % score resolution
@@ -94,6 +99,13 @@ size_t coarse_lds_bytes(uint32_t n_kgroups, uint32_t T);
 hipError_t launch_coarse(const CoarseArgs& a, uint32_t T, uint32_t rows_per_block, hipStream_t st);
 hipError_t launch_rescore(const ScoreArgs& a, const uint32_t* surv, const uint32_t* surv_cnt, uint32_t surv_cap,
                           hipStream_t st);
+
+// Row-order sort of the survivor lists, one segment per column (surv_sort.hip).
+hipError_t surv_sort_temp_bytes(uint32_t n_pheno, uint32_t cap, size_t* bytes);
+hipError_t launch_seg_begin(uint32_t cap, uint32_t n_pheno, uint32_t* seg_beg, hipStream_t st);
+hipError_t launch_surv_sort(const uint32_t* surv, uint32_t* surv_sorted, const uint32_t* surv_cnt, const uint32_t* seg_beg,
+                            uint32_t* seg_end, uint32_t n_pheno, uint32_t cap, uint32_t key_bits, void* temp,
+                            size_t temp_bytes, hipStream_t st);
 
 // --pattern_counter: append hash_presence_absence_pattern of every MAC-passing row to out[*out_count ...];
 // count_distinct_u64 sorts the collected hashes in place (device) and returns how many are distinct.

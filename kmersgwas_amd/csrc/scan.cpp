@@ -21,14 +21,20 @@
 #include <cmath>
 #include <condition_variable>
 #include <deque>
+#include <limits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <memory>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
+
+#include <dirent.h>
+#include <pthread.h>
+#include <sched.h>
 
 #include "common.h"
 #include "heap.h"
@@ -38,12 +44,27 @@ using namespace kgwas;
 
 namespace {
 
-// Minimal persistent worker pool: parallel_for over phenotype columns.
+// Minimal persistent worker pool: parallel_for over phenotype columns. The caller does not take part: it
+// sleeps until the workers are done, so exactly size() threads are busy (sized to the CPU quota).
 class Pool {
    public:
-    explicit Pool(unsigned n) : stop_(false), gen_(0), pending_(0), n_items_(0) {
+    // cpus: optional CPU to pin worker i to (empty = leave placement to the scheduler).
+    explicit Pool(unsigned n, const std::vector<std::vector<int>>& cpus = {})
+        : stop_(false), gen_(0), pending_(0), n_items_(0) {
         if (n < 1) n = 1;
-        for (unsigned i = 1; i < n; i++) th_.emplace_back([this, i] { loop(i); });
+        for (unsigned i = 0; i < n; i++) {
+            const std::vector<int> mine = i < cpus.size() ? cpus[i] : std::vector<int>();
+            th_.emplace_back([this, i, mine] {
+                if (!mine.empty()) {
+                    cpu_set_t set;
+                    CPU_ZERO(&set);
+                    for (int c : mine)
+                        if (c >= 0 && c < CPU_SETSIZE) CPU_SET(c, &set);
+                    (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+                }
+                loop(i);
+            });
+        }
     }
     ~Pool() {
         {
@@ -55,28 +76,40 @@ class Pool {
         for (auto& t : th_) t.join();
     }
     // Static assignment: item i always runs on worker i % size(), so a phenotype column's heap
-    // (~240 KB at N = 10001) stays in one core's cache from chunk to chunk.
+    // (~320 KB at N = 10001) stays in one core's cache from chunk to chunk.
     void parallel_for(size_t n, const std::function<void(size_t)>& fn) {
         if (n == 0) return;
         {
             std::unique_lock<std::mutex> lk(mu_);
             fn_ = &fn;
             n_items_ = n;
+            if (claimed_.size() < n) claimed_ = std::vector<std::atomic<uint8_t>>(n);
+            for (size_t i = 0; i < n; i++) claimed_[i].store(0, std::memory_order_relaxed);
             pending_ = th_.size();
+            done_.store(0, std::memory_order_relaxed);
             gen_.fetch_add(1, std::memory_order_release);
         }
         cv_.notify_all();
-        run(0);
+        for (int spin = 0; spin < 20000; spin++) {  // replays take a few ms at most: spin before sleeping
+            if (done_.load(std::memory_order_acquire)) break;
+            __builtin_ia32_pause();
+        }
         std::unique_lock<std::mutex> lk(mu_);
         done_cv_.wait(lk, [this] { return pending_ == 0; });
         fn_ = nullptr;
     }
-    size_t size() const { return th_.size() + 1; }
+    size_t size() const { return th_.size(); }
 
    private:
+    // Own items first, in increasing order; then take whatever nobody has started yet, from the far end
+    // (with 101 columns on 16 workers the five workers that own a seventh column give it away to a worker
+    // that is done with its six). An item runs exactly once, on one thread.
     void run(size_t me) {
-        const size_t T = th_.size() + 1;
-        for (size_t i = me; i < n_items_; i += T) (*fn_)(i);
+        const size_t T = th_.size();
+        for (size_t i = me; i < n_items_; i += T)
+            if (!claimed_[i].exchange(1, std::memory_order_acq_rel)) (*fn_)(i);
+        for (size_t i = n_items_; i-- > 0;)
+            if (!claimed_[i].load(std::memory_order_relaxed) && !claimed_[i].exchange(1, std::memory_order_acq_rel)) (*fn_)(i);
     }
     void loop(size_t me) {
         uint64_t seen = 0;
@@ -100,7 +133,10 @@ class Pool {
             run(me);
             {
                 std::unique_lock<std::mutex> lk(mu_);
-                if (--pending_ == 0) done_cv_.notify_all();
+                if (--pending_ == 0) {
+                    done_.store(1, std::memory_order_release);
+                    done_cv_.notify_all();
+                }
             }
         }
     }
@@ -109,10 +145,146 @@ class Pool {
     std::condition_variable cv_, done_cv_;
     bool stop_;
     std::atomic<uint64_t> gen_;
+    std::atomic<int> done_{0};
+    std::vector<std::atomic<uint8_t>> claimed_;
     size_t pending_;
     const std::function<void(size_t)>* fn_ = nullptr;
     size_t n_items_;
 };
+
+std::vector<int> parse_cpulist(const char* path) {
+    std::vector<int> out;
+    FILE* f = fopen(path, "r");
+    if (!f) return out;
+    char buf[4096];
+    if (fgets(buf, sizeof(buf), f)) {
+        for (char* tok = strtok(buf, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+            int a = 0, b = 0;
+            const int k = sscanf(tok, "%d-%d", &a, &b);
+            if (k == 1) b = a;
+            if (k >= 1)
+                for (int c = a; c <= b; c++) out.push_back(c);
+        }
+    }
+    fclose(f);
+    return out;
+}
+
+// One CPU per replay worker: distinct physical cores of the NUMA node the GPU hangs off (where its mapped
+// host buffers are best read), spread evenly over that node's cores (= over its L3 slices). A worker owns a
+// fixed set of heaps (static assignment above), ~2 MB of state that should stay in that core's L2/L3 from
+// chunk to chunk instead of following the scheduler around a 256-CPU host. Returns {} (no pinning) whenever
+// the topology cannot be read or does not offer n allowed cores; KGWAS_PIN_THREADS=0 turns it off.
+std::vector<std::vector<int>> pick_replay_cpus(unsigned n, int device) {
+    std::vector<std::vector<int>> none;
+    int mode = 1;  // 0 off, 1 one core each, 2 the GPU's share of its NUMA node for all, 3 the core's L3 domain
+    if (const char* e = getenv("KGWAS_PIN_THREADS")) mode = atoi(e);
+    if (mode == 0) return none;
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return none;
+    int node = -1;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) == hipSuccess) {
+        for (char* c = bus; *c; c++) *c = (char)tolower(*c);
+        char path[256];
+        snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus);
+        if (FILE* f = fopen(path, "r")) {
+            if (fscanf(f, "%d", &node) != 1) node = -1;
+            fclose(f);
+        }
+    }
+    std::vector<int> cand;
+    if (node >= 0) {
+        char path[256];
+        snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+        cand = parse_cpulist(path);
+    }
+    if (cand.empty())
+        for (int c = 0; c < CPU_SETSIZE; c++)
+            if (CPU_ISSET(c, &allowed)) cand.push_back(c);
+    std::vector<int> cores;  // first hardware thread of every allowed core
+    for (int c : cand) {
+        if (c < 0 || c >= CPU_SETSIZE || !CPU_ISSET(c, &allowed)) continue;
+        char path[256];
+        snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", c);
+        const std::vector<int> sib = parse_cpulist(path);
+        if (sib.empty() || sib[0] == c) cores.push_back(c);
+    }
+    // Several GPUs usually share a NUMA node and each has its own process (one rank per GPU): give every
+    // GPU of the node its own contiguous share of the node's cores, by PCI order, so ranks never stack.
+    size_t n_gpus = 1, ordinal = 0;
+    if (node >= 0 && bus[0]) {
+        std::vector<std::string> gpus;
+        if (DIR* d = opendir("/sys/bus/pci/devices")) {
+            while (struct dirent* de = readdir(d)) {
+                if (de->d_name[0] == '.') continue;
+                char path[512];
+                unsigned vendor = 0, cls = 0;
+                int nn = -2;
+                snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/vendor", de->d_name);
+                if (FILE* f = fopen(path, "r")) {
+                    if (fscanf(f, "%x", &vendor) != 1) vendor = 0;
+                    fclose(f);
+                }
+                if (vendor != 0x1002) continue;
+                snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/class", de->d_name);
+                if (FILE* f = fopen(path, "r")) {
+                    if (fscanf(f, "%x", &cls) != 1) cls = 0;
+                    fclose(f);
+                }
+                if ((cls >> 8) != 0x0380 && (cls >> 8) != 0x1200 && (cls >> 8) != 0x0300) continue;
+                snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", de->d_name);
+                if (FILE* f = fopen(path, "r")) {
+                    if (fscanf(f, "%d", &nn) != 1) nn = -2;
+                    fclose(f);
+                }
+                if (nn == node) gpus.push_back(de->d_name);
+            }
+            closedir(d);
+        }
+        std::sort(gpus.begin(), gpus.end());
+        for (size_t i = 0; i < gpus.size(); i++)
+            if (gpus[i] == bus) {
+                n_gpus = gpus.size();
+                ordinal = i;
+            }
+    }
+    const size_t share = cores.size() / n_gpus;
+    if (share < n || n == 0) return none;
+    std::vector<std::vector<int>> out;
+    auto with_siblings = [&](int c, std::vector<int>& dst) {
+        char path[256];
+        snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", c);
+        std::vector<int> sib = parse_cpulist(path);
+        if (sib.empty()) sib.push_back(c);
+        for (int x : sib)
+            if (x >= 0 && x < CPU_SETSIZE && CPU_ISSET(x, &allowed)) dst.push_back(x);
+    };
+    for (unsigned i = 0; i < n; i++) {
+        const int core = cores[ordinal * share + (size_t)i * share / n];
+        std::vector<int> set;
+        if (mode == 1) {
+            set.push_back(core);
+        } else if (mode == 2) {
+            for (size_t k = 0; k < share; k++) with_siblings(cores[ordinal * share + k], set);
+        } else {
+            char path[256];
+            snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", core);
+            for (int x : parse_cpulist(path))
+                if (x >= 0 && x < CPU_SETSIZE && CPU_ISSET(x, &allowed)) set.push_back(x);
+            if (set.empty()) set.push_back(core);
+        }
+        out.push_back(set);
+    }
+    if (getenv("KGWAS_TRACE")) {
+        fprintf(stderr, "[kgwas] replay workers placed (mode %d, numa node %d, gpu %zu of %zu on it):", mode, node, ordinal,
+                n_gpus);
+        for (auto& v : out) fprintf(stderr, " %d%s", v[0], v.size() > 1 ? "+" : "");
+        fprintf(stderr, "\n");
+    }
+    return out;
+}
 
 // CPUs this process may actually use: the cgroup CPU quota when there is one (containers often
 // expose every host CPU to hardware_concurrency() while capping the quota far lower; running more
@@ -193,6 +365,13 @@ struct Slot {
     DevBuf<uint32_t> d_cnt;
     PinBuf<uint32_t> h_cnt;
     PinBuf<uint32_t> h_surv_cnt;  // coarse filter: survivors per column (overflow check)
+    // coarse filter: the re-score kernel's row-ordered records, written straight into mapped host memory
+    PinBuf<double> so_score;
+    PinBuf<uint64_t> so_kmer;
+    PinBuf<uint32_t> so_row;
+    double* d_so_score = nullptr;
+    uint64_t* d_so_kmer = nullptr;
+    uint32_t* d_so_row = nullptr;
     DevBuf<unsigned long long> d_tested;
     PinBuf<unsigned long long> h_tested;
     hipEvent_t ev_sq0 = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_done = nullptr, ev_mid = nullptr;
@@ -238,12 +417,16 @@ struct kgwas_scan {
     DevBuf<int8_t> d_Bq;
     DevBuf<double> d_s0, d_s1, d_E;
     DevBuf<uint32_t> d_surv, d_surv_cnt;  // shared by all chunks: consumed by the re-score kernel in stream order
+    DevBuf<uint32_t> d_surv_sorted, d_seg_beg, d_seg_end;
+    DevBuf<uint8_t> d_sort_tmp;
+    uint32_t row_key_bits = 32;
     // --pattern_counter
     bool count_patterns = false;
     DevBuf<uint64_t> d_pat;                // pattern hashes of the tested rows seen so far
     DevBuf<unsigned long long> d_pat_cnt;  // how many
     uint64_t pat_upper = 0;                // host-side upper bound of that count (rows fed)
     Slot slot[MAX_SLOTS];
+    Slot redo;  // coarse mode: the only slot with exact-scorer candidate records (synchronous overflow re-runs)
     int n_slots = MAX_SLOTS;  // as many as fit 1 GiB of mapped pinned candidate memory (at least 4)
     // dense mode
     DevBuf<double> d_dense;
@@ -260,6 +443,7 @@ struct kgwas_scan {
     std::vector<History> hist;
     std::vector<std::vector<uint64_t>> keys;  // per-column sort scratch for the replay
     bool trace = false;                       // KGWAS_TRACE=1: one stderr line per sparse chunk
+    std::vector<double> col_ms;               // trace only: replay time per column of the last chunk
     bool all_full = false;
     uint64_t rows_done = 0;  // rows whose replay is complete
     std::unique_ptr<Pool> pool;
@@ -270,13 +454,15 @@ struct kgwas_scan {
 
     ~kgwas_scan() {
         (void)hipSetDevice(device);
-        for (auto& s : slot) {
+        auto drop_events = [](Slot& s) {
             if (s.ev_sq0) (void)hipEventDestroy(s.ev_sq0);
             if (s.ev_k0) (void)hipEventDestroy(s.ev_k0);
             if (s.ev_k1) (void)hipEventDestroy(s.ev_k1);
             if (s.ev_done) (void)hipEventDestroy(s.ev_done);
             if (s.ev_mid) (void)hipEventDestroy(s.ev_mid);
-        }
+        };
+        for (auto& s : slot) drop_events(s);
+        drop_events(redo);
         if (ev_user) (void)hipEventDestroy(ev_user);
         if (ev_ds) (void)hipEventDestroy(ev_ds);
         if (ev_d0) (void)hipEventDestroy(ev_d0);
@@ -532,7 +718,13 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
         KGWAS_HIP(launch_coarse(c, s->coarse_T, n_rows >= (1u << 20) ? 2048u : 512u, s->stream));
         KGWAS_HIP(hipEventRecord(sl.ev_mid, s->stream));
         a.tested = nullptr;  // counted by the coarse pass
-        KGWAS_HIP(launch_rescore(a, s->d_surv.p, s->d_surv_cnt.p, s->cap, s->stream));
+        KGWAS_HIP(launch_surv_sort(s->d_surv.p, s->d_surv_sorted.p, s->d_surv_cnt.p, s->d_seg_beg.p, s->d_seg_end.p,
+                                   (uint32_t)s->n_pheno, s->cap, s->row_key_bits, s->d_sort_tmp.p, s->d_sort_tmp.n,
+                                   s->stream));
+        a.so_score = sl.d_so_score;
+        a.so_kmer = sl.d_so_kmer;
+        a.so_row = sl.d_so_row;
+        KGWAS_HIP(launch_rescore(a, s->d_surv_sorted.p, s->d_surv_cnt.p, s->cap, s->stream));
         KGWAS_HIP(hipMemcpyAsync(sl.h_surv_cnt.p, s->d_surv_cnt.p, s->n_pheno * sizeof(uint32_t), hipMemcpyDeviceToHost,
                                  s->stream));
         s->st.score_launches++;
@@ -587,6 +779,39 @@ bool reap_sparse(kgwas_scan* s, Slot& sl) {
     s->st.rows_tested += *sl.h_tested.p;
     std::atomic<uint64_t> pushes(0), cands(0);
     const uint64_t row0 = sl.first_row;
+    if (sl.used_coarse) {
+        // Records arrive in row order (sorted on the device): one forward scan, add_association's own
+        // test against the current minimum does the rest.
+        s->pool->parallel_for(s->n_pheno, [&](size_t j) {
+            const uint32_t n = sl.h_surv_cnt.p[j];
+            if (!n) return;
+            const auto tc0 = std::chrono::steady_clock::now();
+            const uint64_t o = j * (uint64_t)s->cap;
+            const double* sc = sl.so_score.p + o;
+            const uint64_t* km = sl.so_kmer.p + o;
+            const uint32_t* rw = sl.so_row.p + o;
+            BestHeap& h = s->heaps[j];
+            const double none = -std::numeric_limits<double>::infinity();
+            uint64_t local = 0, nc = 0;
+            for (uint32_t i = 0; i < n; i++) {
+                const double v = sc[i];
+                if (v == none) continue;  // a survivor of the coarse bound that is not a candidate
+                nc++;
+                if (h.add(km[i], v, (size_t)(row0 + rw[i]))) {
+                    local++;
+                    if (s->record_history) {
+                        s->hist[j].kmer.push_back(km[i]);
+                        s->hist[j].score.push_back(v);
+                        s->hist[j].row.push_back(row0 + rw[i]);
+                    }
+                }
+            }
+            pushes += local;
+            cands += nc;
+            if (s->trace)
+                s->col_ms[j] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count();
+        });
+    } else
     s->pool->parallel_for(s->n_pheno, [&](size_t j) {
         const uint32_t n = sl.h_cnt.p[j];
         if (!n) return;
@@ -624,10 +849,22 @@ bool reap_sparse(kgwas_scan* s, Slot& sl) {
     s->st.replay_ms += rep_ms;
     s->rows_done += sl.n_rows;
     upload_thresholds(s);
-    if (s->trace)
-        fprintf(stderr, "[kgwas] chunk rows=%llu first=%llu kernel=%.3fms cands=%llu pushes=%llu replay=%.3fms\n",
+    if (s->trace) {
+        const size_t T = s->pool->size();
+        std::vector<double> busy(T, 0.0);
+        double tot = 0, mx = 0;
+        for (uint64_t j = 0; j < s->n_pheno; j++) {
+            busy[j % T] += s->col_ms[j];
+            tot += s->col_ms[j];
+            s->col_ms[j] = 0;
+        }
+        for (double b : busy) mx = std::max(mx, b);
+        fprintf(stderr,
+                "[kgwas] chunk rows=%llu first=%llu kernel=%.3fms cands=%llu pushes=%llu replay=%.3fms (worker busy: max %.3f "
+                "mean %.3f)\n",
                 (unsigned long long)sl.n_rows, (unsigned long long)sl.first_row, ms_kernel,
-                (unsigned long long)cands.load(), (unsigned long long)pushes.load(), rep_ms);
+                (unsigned long long)cands.load(), (unsigned long long)pushes.load(), rep_ms, mx, tot / (double)T);
+    }
     return true;
 }
 
@@ -639,8 +876,9 @@ void process_range_sync(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_
         run_dense(s, d_rows, n_rows, first_row, nullptr, nullptr, true);
         return;
     }
-    submit_sparse(s, sl, d_rows, n_rows, first_row, /*count_hist=*/false);
-    if (reap_sparse(s, sl)) return;
+    Slot& rs = s->coarse ? s->redo : sl;  // coarse-mode slots carry no exact-scorer candidate buffers
+    submit_sparse(s, rs, d_rows, n_rows, first_row, /*count_hist=*/false);
+    if (reap_sparse(s, rs)) return;
     const uint64_t half = n_rows / 2;
     process_range_sync(s, sl, d_rows, half, first_row);
     process_range_sync(s, sl, d_rows + half * stride, n_rows - half, first_row + half);
@@ -940,17 +1178,36 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
             s->coarse_all_ones = ones ? 1u : 0u;
             s->d_surv.alloc((uint64_t)s->cap * P);
             s->d_surv_cnt.alloc(P);
+            s->d_surv_sorted.alloc((uint64_t)s->cap * P);
+            s->d_seg_beg.alloc(P);
+            s->d_seg_end.alloc(P);
+            size_t tb = 0;
+            KGWAS_HIP(surv_sort_temp_bytes((uint32_t)P, s->cap, &tb));
+            s->d_sort_tmp.alloc(std::max<size_t>(tb, 16));
+            KGWAS_HIP(launch_seg_begin(s->cap, (uint32_t)P, s->d_seg_beg.p, s->stream));
+            s->row_key_bits = 1;
+            while (s->row_key_bits < 32 && (1ull << s->row_key_bits) < s->chunk_max) s->row_key_bits++;
         }
         if (!s->direct) s->d_sq.alloc(s->chunk_max * 2 * W_m);
 
         {
-            const uint64_t slot_bytes = (uint64_t)s->cap * P * sizeof(Cand);
+            const uint64_t slot_bytes = (uint64_t)s->cap * P * (s->coarse ? 20 : sizeof(Cand));
             s->n_slots = (int)std::min<uint64_t>(MAX_SLOTS, std::max<uint64_t>(4, (1ull << 30) / std::max<uint64_t>(slot_bytes, 1)));
         }
-        for (int si = 0; si < s->n_slots; si++) {
-            Slot& sl = s->slot[si];
-            sl.cand.alloc((uint64_t)s->cap * P);
-            sl.d_cand = sl.cand.dev();
+        for (int si = 0; si < s->n_slots + (s->coarse ? 1 : 0); si++) {
+            const bool is_redo = si == s->n_slots;
+            Slot& sl = is_redo ? s->redo : s->slot[si];
+            if (s->coarse && !is_redo) {
+                sl.so_score.alloc((uint64_t)s->cap * P);
+                sl.so_kmer.alloc((uint64_t)s->cap * P);
+                sl.so_row.alloc((uint64_t)s->cap * P);
+                sl.d_so_score = sl.so_score.dev();
+                sl.d_so_kmer = sl.so_kmer.dev();
+                sl.d_so_row = sl.so_row.dev();
+            } else {
+                sl.cand.alloc((uint64_t)s->cap * P);
+                sl.d_cand = sl.cand.dev();
+            }
             sl.d_cnt.alloc(P);
             sl.h_cnt.alloc(P);
             sl.h_surv_cnt.alloc(P);
@@ -974,10 +1231,13 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         for (uint64_t j = 0; j < P; j++) s->heaps.emplace_back((size_t)s->topn[j]);
         s->hist.resize(P);
         s->keys.resize(P);
+        s->col_ms.assign(P, 0.0);
         s->trace = getenv("KGWAS_TRACE") != nullptr;
         unsigned nt = p->host_threads ? p->host_threads : usable_cpus();
+        if (const char* e = getenv("KGWAS_HOST_THREADS"))
+            if (atoi(e) > 0) nt = (unsigned)atoi(e);
         nt = (unsigned)std::min<uint64_t>(nt, P);
-        s->pool.reset(new Pool(nt));
+        s->pool.reset(new Pool(nt, pick_replay_cpus(nt, s->device)));
         s->st.kernel_used = s->coarse ? (uint32_t)KGWAS_KERNEL_COARSE : kern;
         s->st.direct_mode = s->direct ? 1 : 0;
         *out = s.release();

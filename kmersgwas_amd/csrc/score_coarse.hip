@@ -150,12 +150,17 @@ __global__ void __launch_bounds__(512) coarse_kernel(CoarseArgs a, uint32_t rows
                 }
             }
             // Conservative test per (row, column): the column constants are fetched here (L1-resident),
-            // not kept in registers across the MFMA loop.
+            // not kept in registers across the MFMA loop. A lane holds 16 (row, column p) pairs per column
+            // group, and the four kg lanes of one m share the column: survivors are counted over those 64 pairs
+            // first and the column's counter is bumped once (early chunks have ~1e6 survivors on ~100 counters;
+            // one atomic per survivor serialises in the L2).
 #pragma unroll
             for (int g = 0; g < PG; g++) {
                 const uint32_t p = (lg * PG + g) * 16u + m;
-                if (p >= a.n_pheno) continue;
-                const double s0 = a.scale0[p], s1 = a.scale1[p], NE = N * a.E[p], thr = a.thr[p], sum = (double)a.sums[p];
+                const bool pvalid = p < a.n_pheno;
+                const uint32_t pc = pvalid ? p : 0u;
+                const double s0 = a.scale0[pc], s1 = a.scale1[pc], NE = N * a.E[pc], thr = a.thr[pc], sum = (double)a.sums[pc];
+                uint32_t mbits = 0;
 #pragma unroll
                 for (int rt = 0; rt < RT; rt++) {
 #pragma unroll
@@ -163,7 +168,7 @@ __global__ void __launch_bounds__(512) coarse_kernel(CoarseArgs a, uint32_t rows
                         const uint32_t trow = kg * 4u + jj;  // D row held in register jj
                         const uint32_t n1r = n1rows[rt][jj];
                         const uint64_t r = rbase + rt * 16u + trow;
-                        const bool pass = (r < a.n_rows) && (a.S >= a.min_count) && (n1r >= a.min_count) &&
+                        const bool pass = pvalid && (r < a.n_rows) && (a.S >= a.min_count) && (n1r >= a.min_count) &&
                                           (n1r <= a.S - a.min_count);
                         const double N1 = (double)n1r;
                         const double d = N1 * (N - N1);
@@ -171,10 +176,24 @@ __global__ void __launch_bounds__(512) coarse_kernel(CoarseArgs a, uint32_t rows
                         const double u = fabs(N * yc - N1 * sum) + NE;
                         double lim = thr * d;
                         lim = lim - fabs(lim) * 0x1p-40;
-                        if (pass && (u * u >= lim)) {
-                            const uint32_t slot = atomicAdd(&a.surv_cnt[p], 1u);
-                            if (slot < a.surv_cap) a.surv[(uint64_t)p * a.surv_cap + slot] = (uint32_t)(r);
-                        }
+                        if (pass && (u * u >= lim)) mbits |= 1u << (rt * 4 + jj);
+                    }
+                }
+                if (__any(mbits != 0u)) {  // wave-uniform
+                    const uint32_t cnt = __popc(mbits);
+                    const uint32_t c0 = __shfl(cnt, (int)m), c1 = __shfl(cnt, (int)(m + 16u)), c2 = __shfl(cnt, (int)(m + 32u)),
+                                   c3 = __shfl(cnt, (int)(m + 48u));
+                    const uint32_t total = c0 + c1 + c2 + c3;
+                    uint32_t base = 0;
+                    if (kg == 0 && total) base = atomicAdd(&a.surv_cnt[p], total);
+                    base = __shfl(base, (int)m);
+                    uint32_t slot = base + (kg > 0 ? c0 : 0u) + (kg > 1 ? c1 : 0u) + (kg > 2 ? c2 : 0u);
+                    while (mbits) {
+                        const uint32_t b = __ffs(mbits) - 1u;
+                        mbits &= mbits - 1u;
+                        const uint64_t r = rbase + (b >> 2) * 16u + kg * 4u + (b & 3u);
+                        if (slot < a.surv_cap) a.surv[(uint64_t)p * a.surv_cap + slot] = (uint32_t)r;
+                        slot++;
                     }
                 }
             }
@@ -196,7 +215,10 @@ __global__ void __launch_bounds__(256) rescore_kernel(ScoreArgs a, const uint32_
                                                       uint32_t surv_cap) {
     const uint32_t p = blockIdx.y;
     uint32_t n = surv_cnt[p];
-    if (n > surv_cap) n = surv_cap;
+    if (n > surv_cap) {
+        if (a.so_score) return;  // overflow: the list was not sorted; the host redoes this chunk
+        n = surv_cap;
+    }
     if (blockIdx.x * 256u >= n) return;  // block-uniform
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     const bool valid = i < n;
@@ -227,7 +249,18 @@ __global__ void __launch_bounds__(256) rescore_kernel(ScoreArgs a, const uint32_
     }
     if (!valid) return;
     const float yf = ((acc[0] + acc[1]) + acc[2]) + acc[3];
-    finish_pair(a, r, p, yf, n1, mac_pass(a, n1), a.sums[p], a.thr[p]);
+    if (!a.so_score) {
+        finish_pair(a, r, p, yf, n1, mac_pass(a, n1), a.sums[p], a.thr[p]);
+        return;
+    }
+    // Ordered mode: the survivor list is sorted by row, entry i goes to position i (coalesced).
+    double q, d, s, out = -__builtin_huge_val();
+    score_terms(a, yf, n1, a.sums[p], q, d);
+    if (mac_pass(a, n1) && candidate_score(a, p, q, d, a.thr[p], s)) out = s;
+    const uint64_t o = (uint64_t)p * surv_cap + i;
+    a.so_score[o] = out;
+    a.so_kmer[o] = a.file_rows[r * a.file_stride_w];
+    a.so_row[o] = (uint32_t)r;
 }
 
 size_t coarse_lds_bytes(uint32_t n_kgroups, uint32_t T) { return (size_t)n_kgroups * 8u * T * 1024u; }

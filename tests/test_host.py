@@ -128,7 +128,8 @@ def test_min_count_matches_the_reference_rule():
     assert kg.min_count(241, 0.05, 5) == 13 and kg.min_count(1024, 0.05, 5) == 52 and kg.min_count(2048, 0.05, 5) == 103
 
 
-@pytest.mark.parametrize("N,n,levels", [(1, 60, 3), (10, 500, 4), (64, 4000, 9), (200, 150, 5), (33, 3000, 2)])
+@pytest.mark.parametrize("N,n,levels", [(1, 60, 3), (2, 100, 3), (3, 200, 2), (10, 500, 4), (64, 4000, 9), (200, 150, 5), (33, 3000, 2),
+                                        (1000, 30000, 40), (1001, 30000, 2000)])
 def test_heap_mirror_equals_oracle_heap_under_ties(N, n, levels):
     rng = np.random.default_rng(N * 31 + n)
     k = np.arange(n, dtype=np.uint64) + 7

@@ -1,0 +1,145 @@
+// heap_bench.cpp — host-side microbenchmark for the replay's inner loop (not part of the product).
+// T threads x H heaps of N entries each; every heap receives a stream of "effective pushes" (score above the
+// current minimum), as in the ramp part of a pass. Variants:
+//   0: std::pop_heap/push_heap on 16-byte entries (what heap.h does)
+//   1: hand-written replace with the same element moves (branchless child choice)
+//   2: variant 1, the thread's H heaps advanced in lockstep (memory-level parallelism across columns)
+// build: g++ -O3 -std=c++17 -pthread tools/heap_bench.cpp -o tools/bin/heap_bench
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <chrono>
+#include <random>
+#include <thread>
+#include <vector>
+
+struct Ent {
+    double score;
+    uint32_t slot;
+};
+struct Greater {
+    bool operator()(const Ent& l, const Ent& r) const { return l.score > r.score; }
+};
+
+static inline void replace_std(std::vector<Ent>& v, Ent x) {
+    std::pop_heap(v.begin(), v.end(), Greater());
+    x.slot = v.back().slot;
+    v.pop_back();
+    v.push_back(x);
+    std::push_heap(v.begin(), v.end(), Greater());
+}
+
+// Same moves as pop_heap (libstdc++ __adjust_heap + __push_heap) followed by push_heap of x.
+static inline void replace_hand(Ent* a, ptrdiff_t n, Ent x) {
+    const Ent value = a[n - 1];
+    x.slot = a[0].slot;
+    const ptrdiff_t len = n - 1;
+    ptrdiff_t hole = 0, child = 0;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        child -= (a[child].score > a[child - 1].score) ? 1 : 0;
+        a[hole] = a[child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        a[hole] = a[child - 1];
+        hole = child - 1;
+    }
+    ptrdiff_t parent = (hole - 1) / 2;
+    while (hole > 0 && a[parent].score > value.score) {
+        a[hole] = a[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    a[hole] = value;
+    hole = n - 1;
+    parent = (hole - 1) / 2;
+    while (hole > 0 && a[parent].score > x.score) {
+        a[hole] = a[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    a[hole] = x;
+}
+
+int main(int argc, char** argv) {
+    const int T = argc > 1 ? atoi(argv[1]) : 16;
+    const int H = argc > 2 ? atoi(argv[2]) : 7;
+    const int N = argc > 3 ? atoi(argv[3]) : 10001;
+    const int pushes = argc > 4 ? atoi(argv[4]) : 400000;
+    for (int variant = 0; variant < 3; variant++) {
+        std::vector<double> ns(T);
+        std::vector<uint64_t> chk(T);
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; t++)
+            th.emplace_back([&, t]() {
+                std::mt19937_64 rng(1234 + t);
+                std::uniform_real_distribution<double> U(0.0, 1.0);
+                std::vector<std::vector<Ent>> heaps(H);
+                std::vector<std::vector<uint64_t>> km(H), rw(H);
+                for (int h = 0; h < H; h++) {
+                    for (int i = 0; i < N; i++) {
+                        heaps[h].push_back(Ent{U(rng), (uint32_t)i});
+                        std::push_heap(heaps[h].begin(), heaps[h].end(), Greater());
+                    }
+                    km[h].resize(N);
+                    rw[h].resize(N);
+                }
+                // effective pushes: min + a random gap distribution similar to an order statistic stream
+                std::vector<double> u((size_t)pushes * H);
+                for (auto& x : u) x = U(rng);
+                auto t0 = std::chrono::steady_clock::now();
+                if (variant == 0) {
+                    for (int h = 0; h < H; h++)
+                        for (int i = 0; i < pushes; i++) {
+                            auto& v = heaps[h];
+                            const double lo = v.front().score;
+                            Ent x{lo + (1.0 - lo) * u[(size_t)h * pushes + i], 0};
+                            replace_std(v, x);
+                            km[h][v.back().slot] = i;
+                            rw[h][v.back().slot] = i;
+                        }
+                } else if (variant == 1) {
+                    for (int h = 0; h < H; h++)
+                        for (int i = 0; i < pushes; i++) {
+                            Ent* a = heaps[h].data();
+                            const double lo = a[0].score;
+                            Ent x{lo + (1.0 - lo) * u[(size_t)h * pushes + i], 0};
+                            const uint32_t slot = a[0].slot;
+                            replace_hand(a, N, x);
+                            km[h][slot] = i;
+                            rw[h][slot] = i;
+                        }
+                } else {
+                    for (int i = 0; i < pushes; i++)
+                        for (int h = 0; h < H; h++) {
+                            Ent* a = heaps[h].data();
+                            const double lo = a[0].score;
+                            Ent x{lo + (1.0 - lo) * u[(size_t)h * pushes + i], 0};
+                            const uint32_t slot = a[0].slot;
+                            replace_hand(a, N, x);
+                            km[h][slot] = i;
+                            rw[h][slot] = i;
+                        }
+                }
+                ns[t] = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count() /
+                        ((double)pushes * H);
+                uint64_t c = 0;
+                for (int h = 0; h < H; h++)
+                    for (int i = 0; i < N; i++) c = c * 1315423911u + heaps[h][i].slot + (uint64_t)(heaps[h][i].score * 1e9);
+                chk[t] = c;
+            });
+        for (auto& x : th) x.join();
+        double mx = 0, av = 0;
+        for (double x : ns) {
+            mx = std::max(mx, x);
+            av += x / T;
+        }
+        printf("variant %d: T=%d H=%d N=%d  ns/push avg %.1f max %.1f  chk %llx\n", variant, T, H, N, av, mx,
+               (unsigned long long)chk[0]);
+    }
+    return 0;
+}
