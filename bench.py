@@ -204,13 +204,14 @@ def main():
         # HBM traffic per launch cannot be read from inside the process; it comes from the committed
         # rocprofv3 PMC passes of this same workload (FETCH_SIZE x2 on gfx950 + WRITE_SIZE).
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-        if S == 1024 and P == 101 and os.path.exists(pmc):
+        pmc_name = "r01b_coarse_pmc_hbm_traffic.json" if ku == 3 else "r01a_exactmfma_pmc_hbm_traffic.json"
+        pmc = os.path.join(ROOT, "profiles", pmc_name)
+        if S == 1024 and P == 101 and ku in (2, 3) and os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
                 # PMC bytes per row of the steady launches -> GB per average launch of this run
                 traffic = j["traffic_bytes_per_row"] * (rows_scored / max(k_launch, 1)) / 1e9
-                traffic_src = "profiles/r01_pmc_hbm_traffic.json"
+                traffic_src = "profiles/" + pmc_name
             except Exception:
                 pass
         out = {

@@ -1032,7 +1032,12 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
 
         s->chunk_max = p->chunk_rows ? p->chunk_rows : (8ull << 20);
         s->chunk_max = std::max<uint64_t>(128, (s->chunk_max + 127) / 128 * 128);
-        s->dense_rows = std::min<uint64_t>(16384, s->chunk_max);
+        if (s->coarse) {  // the coarse kernel addresses a chunk's rows with 32-bit dword offsets
+            const uint64_t stride_dw = 2 * (1 + std::max<uint64_t>(s->W_f, s->W_m));
+            const uint64_t lim = ((1ull << 32) - (1ull << 20)) / stride_dw / 128 * 128;
+            s->chunk_max = std::max<uint64_t>(128, std::min<uint64_t>(s->chunk_max, lim));
+        }
+        s->dense_rows =std::min<uint64_t>(16384, s->chunk_max);
         const uint64_t budget = 4ull << 20;  // candidate records per slot (x 24 B x n_slots of mapped pinned memory)
         uint64_t cap = std::min<uint64_t>(2 * s->max_topn + 4096, std::max<uint64_t>(budget / s->n_pheno, 1024));
         s->cap = (uint32_t)std::min<uint64_t>(cap, 0x7FFFFFFFull);

@@ -71,12 +71,13 @@ __global__ void __launch_bounds__(512) coarse_kernel(CoarseArgs a, uint32_t rows
         for (uint32_t ps = 0; ps * rows_per_pass < rows_per_block; ps++) {
             const uint64_t rbase = blk_row0 + (uint64_t)ps * rows_per_pass + wave * (RT * 16u);
             if (rbase >= a.n_rows) break;  // wave-uniform
-            const uint32_t* rp[RT];
+            // 32-bit dword offsets from the (uniform) base: launch_coarse guarantees n_rows * stride < 2^32
+            uint32_t ro[RT];
 #pragma unroll
             for (int rt = 0; rt < RT; rt++) {
                 uint64_t r = rbase + rt * 16u + m;
                 if (r >= a.n_rows) r = a.n_rows - 1;
-                rp[rt] = a.src.base + r * a.src.stride_dw + a.src.off_dw;
+                ro[rt] = (uint32_t)r * (uint32_t)a.src.stride_dw + a.src.off_dw;
             }
             i32x4 acc[RT][T];
 #pragma unroll
@@ -94,7 +95,8 @@ __global__ void __launch_bounds__(512) coarse_kernel(CoarseArgs a, uint32_t rows
 #pragma unroll
                     for (int h = 0; h < 2; h++) {
                         uint2 v = make_uint2(0u, 0u);
-                        if (d0 + 2u * h + 1u < a.src.avail_dw) v = *reinterpret_cast<const uint2*>(rp[rt] + d0 + 2u * h);
+                        if (d0 + 2u * h + 1u < a.src.avail_dw)
+                            v = *reinterpret_cast<const uint2*>(a.src.base + (ro[rt] + d0 + 2u * h));
                         piece[rt][2 * h] = v.x;
                         piece[rt][2 * h + 1] = v.y;
                     }
@@ -136,11 +138,6 @@ __global__ void __launch_bounds__(512) coarse_kernel(CoarseArgs a, uint32_t rows
                 v += __shfl_xor(v, 32);
                 n1[rt] = v;
             }
-            uint32_t n1rows[RT][4];  // N1 of the row each accumulator register belongs to
-#pragma unroll
-            for (int rt = 0; rt < RT; rt++)
-#pragma unroll
-                for (int jj = 0; jj < 4; jj++) n1rows[rt][jj] = __shfl(n1[rt], (int)(kg * 4u + jj));
             if (lg == 0 && kg == 0) {
 #pragma unroll
                 for (int rt = 0; rt < RT; rt++) {
@@ -158,7 +155,8 @@ __global__ void __launch_bounds__(512) coarse_kernel(CoarseArgs a, uint32_t rows
             for (int g = 0; g < PG; g++) {
                 const uint32_t p = (lg * PG + g) * 16u + m;
                 const bool pvalid = p < a.n_pheno;
-                const uint32_t pc = pvalid ? p : 0u;
+                uint32_t pc = pvalid ? p : 0u;
+                asm volatile("" : "+v"(pc));  // keep the constants' loads here: hoisted out of the pass loop they spill
                 const double s0 = a.scale0[pc], s1 = a.scale1[pc], NE = N * a.E[pc], thr = a.thr[pc], sum = (double)a.sums[pc];
                 uint32_t mbits = 0;
 #pragma unroll
@@ -166,7 +164,12 @@ __global__ void __launch_bounds__(512) coarse_kernel(CoarseArgs a, uint32_t rows
 #pragma unroll
                     for (int jj = 0; jj < 4; jj++) {
                         const uint32_t trow = kg * 4u + jj;  // D row held in register jj
-                        const uint32_t n1r = n1rows[rt][jj];
+                        // N1 of the row accumulator register jj belongs to; fetched per use (a cross-lane read
+                        // is cheap next to the MFMAs, 16 more live registers are not: the kernel sits at the
+                        // 256-register limit of two waves per SIMD)
+                        uint32_t n1src = n1[rt];
+                        asm volatile("" : "+v"(n1src));
+                        const uint32_t n1r = __shfl(n1src, (int)trow);
                         const uint64_t r = rbase + rt * 16u + trow;
                         const bool pass = pvalid && (r < a.n_rows) && (a.S >= a.min_count) && (n1r >= a.min_count) &&
                                           (n1r <= a.S - a.min_count);
@@ -270,6 +273,7 @@ hipError_t launch_coarse(const CoarseArgs& a, uint32_t T, uint32_t rows_per_bloc
     const size_t lds = coarse_lds_bytes(a.n_kgroups, T);
     if (lds > 160u * 1024u) return hipErrorInvalidValue;
     const uint32_t threads = 512;
+    if (a.n_rows * a.src.stride_dw + a.src.off_dw + a.src.avail_dw >= (1ull << 32)) return hipErrorInvalidValue;  // 32-bit row offsets
     const uint32_t rpp = (threads >> 6) * 64u;
     rows_per_block = (rows_per_block + rpp - 1) / rpp * rpp;
     const uint32_t n_rowblocks = (uint32_t)((a.n_rows + rows_per_block - 1) / rows_per_block);

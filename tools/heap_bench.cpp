@@ -65,12 +65,48 @@ static inline void replace_hand(Ent* a, ptrdiff_t n, Ent x) {
     a[hole] = x;
 }
 
+// variant 3: like replace_hand, the array based at 16 mod 64 bytes (sibling pairs never straddle a line, the four
+// grandchildren of a node share one line) and the grandchildren line prefetched one level ahead.
+static inline void replace_pf(Ent* a, ptrdiff_t n, Ent x) {
+    const Ent value = a[n - 1];
+    x.slot = a[0].slot;
+    const ptrdiff_t len = n - 1;
+    ptrdiff_t hole = 0, child = 0;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        __builtin_prefetch(&a[2 * child - 1]);  // children of (child-1) and of child: 4 consecutive entries
+        child -= (a[child].score > a[child - 1].score) ? 1 : 0;
+        a[hole] = a[child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        a[hole] = a[child - 1];
+        hole = child - 1;
+    }
+    ptrdiff_t parent = (hole - 1) / 2;
+    while (hole > 0 && a[parent].score > value.score) {
+        a[hole] = a[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    a[hole] = value;
+    hole = n - 1;
+    parent = (hole - 1) / 2;
+    while (hole > 0 && a[parent].score > x.score) {
+        a[hole] = a[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    a[hole] = x;
+}
+
 int main(int argc, char** argv) {
     const int T = argc > 1 ? atoi(argv[1]) : 16;
     const int H = argc > 2 ? atoi(argv[2]) : 7;
     const int N = argc > 3 ? atoi(argv[3]) : 10001;
     const int pushes = argc > 4 ? atoi(argv[4]) : 400000;
-    for (int variant = 0; variant < 3; variant++) {
+    for (int variant = 0; variant < 5; variant++) {
         std::vector<double> ns(T);
         std::vector<uint64_t> chk(T);
         std::vector<std::thread> th;
@@ -113,6 +149,30 @@ int main(int argc, char** argv) {
                             km[h][slot] = i;
                             rw[h][slot] = i;
                         }
+                } else if (variant >= 3) {
+                    // copy every heap into a buffer based at 16 mod 64
+                    std::vector<std::vector<char>> raw(H);
+                    std::vector<Ent*> base(H);
+                    for (int h = 0; h < H; h++) {
+                        raw[h].resize((size_t)N * sizeof(Ent) + 256);
+                        uintptr_t p = (uintptr_t)raw[h].data();
+                        p = (p + 63) / 64 * 64 + (variant == 3 ? 16 : 0);
+                        base[h] = (Ent*)p;
+                        for (int i = 0; i < N; i++) base[h][i] = heaps[h][i];
+                    }
+                    t0 = std::chrono::steady_clock::now();
+                    for (int h = 0; h < H; h++)
+                        for (int i = 0; i < pushes; i++) {
+                            Ent* a = base[h];
+                            const double lo = a[0].score;
+                            Ent x{lo + (1.0 - lo) * u[(size_t)h * pushes + i], 0};
+                            const uint32_t slot = a[0].slot;
+                            if (variant == 3) replace_pf(a, N, x); else replace_hand(a, N, x);
+                            km[h][slot] = i;
+                            rw[h][slot] = i;
+                        }
+                    for (int h = 0; h < H; h++)
+                        for (int i = 0; i < N; i++) heaps[h][i] = base[h][i];
                 } else {
                     for (int i = 0; i < pushes; i++)
                         for (int h = 0; h < H; h++) {
