@@ -780,36 +780,110 @@ bool reap_sparse(kgwas_scan* s, Slot& sl) {
     std::atomic<uint64_t> pushes(0), cands(0);
     const uint64_t row0 = sl.first_row;
     if (sl.used_coarse) {
-        // Records arrive in row order (sorted on the device): one forward scan, add_association's own
-        // test against the current minimum does the rest.
-        s->pool->parallel_for(s->n_pheno, [&](size_t j) {
-            const uint32_t n = sl.h_surv_cnt.p[j];
-            if (!n) return;
+        // Records arrive in row order (sorted on the device). A worker owns the columns w, w+T, ... and advances
+        // all of them together: per round, every column scans forward to its next record that beats the column's
+        // current minimum (everything else is a no-op for add_association), then the heaps of equal size take
+        // their replacements in lockstep (heap.h). Columns are independent, so interleaving them changes nothing
+        // in any column's own sequence of pushes.
+        const size_t T = s->pool->size();
+        const double none = -std::numeric_limits<double>::infinity();
+        s->pool->parallel_for(std::min<size_t>(T, s->n_pheno), [&](size_t w) {
+            struct Cur {
+                const double* sc;
+                const uint64_t* km;
+                const uint32_t* rw;
+                uint32_t i, n;
+                BestHeap* h;
+                size_t j;
+            };
+            constexpr int MK = BestHeap::MAX_LOCKSTEP;
             const auto tc0 = std::chrono::steady_clock::now();
-            const uint64_t o = j * (uint64_t)s->cap;
-            const double* sc = sl.so_score.p + o;
-            const uint64_t* km = sl.so_kmer.p + o;
-            const uint32_t* rw = sl.so_row.p + o;
-            BestHeap& h = s->heaps[j];
-            const double none = -std::numeric_limits<double>::infinity();
+            std::vector<Cur> cols;
+            for (size_t j = w; j < s->n_pheno; j += T) {
+                const uint32_t n = sl.h_surv_cnt.p[j];
+                if (!n) continue;
+                const uint64_t o = j * (uint64_t)s->cap;
+                cols.push_back(Cur{sl.so_score.p + o, sl.so_kmer.p + o, sl.so_row.p + o, 0, n, &s->heaps[j], j});
+            }
             uint64_t local = 0, nc = 0;
-            for (uint32_t i = 0; i < n; i++) {
-                const double v = sc[i];
-                if (v == none) continue;  // a survivor of the coarse bound that is not a candidate
-                nc++;
-                if (h.add(km[i], v, (size_t)(row0 + rw[i]))) {
-                    local++;
-                    if (s->record_history) {
-                        s->hist[j].kmer.push_back(km[i]);
-                        s->hist[j].score.push_back(v);
-                        s->hist[j].row.push_back(row0 + rw[i]);
+            while (!cols.empty()) {
+                // next effective record of every column still active
+                for (size_t c = 0; c < cols.size();) {
+                    Cur& cu = cols[c];
+                    bool ready = false;
+                    while (cu.i < cu.n) {
+                        const double v = cu.sc[cu.i];
+                        if (v == none) {  // a survivor of the coarse bound that is not a candidate
+                            cu.i++;
+                            continue;
+                        }
+                        if (!cu.h->full() || v > cu.h->lowest()) {
+                            ready = true;
+                            break;
+                        }
+                        nc++;
+                        cu.h->note_rejected();
+                        cu.i++;
                     }
+                    if (ready) {
+                        c++;
+                    } else {
+                        cols[c] = cols.back();
+                        cols.pop_back();
+                    }
+                }
+                // lockstep groups of equal heap size (columns that differ, or are not full, go one at a time)
+                size_t done = 0;
+                while (done < cols.size()) {
+                    BestHeap* hp[MK];
+                    uint64_t km[MK], rw[MK];
+                    double sc[MK];
+                    Cur* who[MK];
+                    int K = 0;
+                    const size_t cap0 = cols[done].h->capacity();
+                    const bool full0 = cols[done].h->full();
+                    size_t c = done;
+                    for (; c < cols.size() && K < MK; c++) {
+                        Cur& cu = cols[c];
+                        if (cu.h->capacity() != cap0 || !cu.h->full() || !full0) break;
+                        hp[K] = cu.h;
+                        km[K] = cu.km[cu.i];
+                        sc[K] = cu.sc[cu.i];
+                        rw[K] = row0 + cu.rw[cu.i];
+                        who[K] = &cu;
+                        K++;
+                    }
+                    if (K == 0) {  // not full: plain add_association
+                        Cur& cu = cols[done];
+                        hp[0] = cu.h;
+                        km[0] = cu.km[cu.i];
+                        sc[0] = cu.sc[cu.i];
+                        rw[0] = row0 + cu.rw[cu.i];
+                        who[0] = &cu;
+                        cu.h->add(km[0], sc[0], (size_t)rw[0]);
+                        K = 1;
+                        c = done + 1;
+                    } else {
+                        BestHeap::replace_top_n(K, hp, km, sc, rw);
+                    }
+                    for (int k = 0; k < K; k++) {
+                        if (s->record_history) {
+                            History& hi = s->hist[who[k]->j];
+                            hi.kmer.push_back(km[k]);
+                            hi.score.push_back(sc[k]);
+                            hi.row.push_back(rw[k]);
+                        }
+                        who[k]->i++;
+                    }
+                    local += (uint64_t)K;
+                    nc += (uint64_t)K;
+                    done = c;
                 }
             }
             pushes += local;
             cands += nc;
             if (s->trace)
-                s->col_ms[j] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count();
+                s->col_ms[w] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count();
         });
     } else
     s->pool->parallel_for(s->n_pheno, [&](size_t j) {

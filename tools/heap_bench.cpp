@@ -101,12 +101,171 @@ static inline void replace_pf(Ent* a, ptrdiff_t n, Ent x) {
     a[hole] = x;
 }
 
+// variant 5: two equal-size heaps advanced in lockstep inside ONE loop (two independent dependency chains per
+// iteration); the element moves of each heap are those of replace_hand.
+static inline void replace_pair(Ent* a, Ent* b, ptrdiff_t n, Ent xa, Ent xb) {
+    const Ent va = a[n - 1], vb = b[n - 1];
+    xa.slot = a[0].slot;
+    xb.slot = b[0].slot;
+    const ptrdiff_t len = n - 1;
+    ptrdiff_t ha = 0, ca = 0, hb = 0, cb = 0;
+    const ptrdiff_t lim = (len - 1) / 2;
+    while (ca < lim && cb < lim) {
+        ca = 2 * (ca + 1);
+        cb = 2 * (cb + 1);
+        ca -= (a[ca].score > a[ca - 1].score) ? 1 : 0;
+        cb -= (b[cb].score > b[cb - 1].score) ? 1 : 0;
+        a[ha] = a[ca];
+        b[hb] = b[cb];
+        ha = ca;
+        hb = cb;
+    }
+    while (ca < lim) {
+        ca = 2 * (ca + 1);
+        ca -= (a[ca].score > a[ca - 1].score) ? 1 : 0;
+        a[ha] = a[ca];
+        ha = ca;
+    }
+    while (cb < lim) {
+        cb = 2 * (cb + 1);
+        cb -= (b[cb].score > b[cb - 1].score) ? 1 : 0;
+        b[hb] = b[cb];
+        hb = cb;
+    }
+    if ((len & 1) == 0 && ca == (len - 2) / 2) {
+        ca = 2 * (ca + 1);
+        a[ha] = a[ca - 1];
+        ha = ca - 1;
+    }
+    if ((len & 1) == 0 && cb == (len - 2) / 2) {
+        cb = 2 * (cb + 1);
+        b[hb] = b[cb - 1];
+        hb = cb - 1;
+    }
+    ptrdiff_t pa = (ha - 1) / 2, pb = (hb - 1) / 2;
+    while (ha > 0 && a[pa].score > va.score) {
+        a[ha] = a[pa];
+        ha = pa;
+        pa = (ha - 1) / 2;
+    }
+    a[ha] = va;
+    while (hb > 0 && b[pb].score > vb.score) {
+        b[hb] = b[pb];
+        hb = pb;
+        pb = (hb - 1) / 2;
+    }
+    b[hb] = vb;
+    ha = n - 1;
+    pa = (ha - 1) / 2;
+    while (ha > 0 && a[pa].score > xa.score) {
+        a[ha] = a[pa];
+        ha = pa;
+        pa = (ha - 1) / 2;
+    }
+    a[ha] = xa;
+    hb = n - 1;
+    pb = (hb - 1) / 2;
+    while (hb > 0 && b[pb].score > xb.score) {
+        b[hb] = b[pb];
+        hb = pb;
+        pb = (hb - 1) / 2;
+    }
+    b[hb] = xb;
+}
+
+// variants 6,7,8: K = 3, 4, 6 equal-size heaps in lockstep (generic form of replace_pair).
+template <int K>
+static inline void replace_multi(Ent* const* a, ptrdiff_t n, Ent* x) {
+    Ent v[K];
+    ptrdiff_t h[K], c[K];
+    const ptrdiff_t len = n - 1, lim = (len - 1) / 2;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        v[k] = a[k][n - 1];
+        x[k].slot = a[k][0].slot;
+        h[k] = 0;
+        c[k] = 0;
+    }
+    // every hole walks to the leaf level; the walks differ by at most one step (left vs right subtree depth)
+    for (;;) {
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if (c[k] < lim) {
+                ptrdiff_t cc = 2 * (c[k] + 1);
+                cc -= (a[k][cc].score > a[k][cc - 1].score) ? 1 : 0;
+                a[k][h[k]] = a[k][cc];
+                h[k] = cc;
+                c[k] = cc;
+                any = true;
+            }
+        }
+        if (!any) break;
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        if ((len & 1) == 0 && c[k] == (len - 2) / 2) {
+            c[k] = 2 * (c[k] + 1);
+            a[k][h[k]] = a[k][c[k] - 1];
+            h[k] = c[k] - 1;
+        }
+        ptrdiff_t hh = h[k], p = (hh - 1) / 2;
+        while (hh > 0 && a[k][p].score > v[k].score) {
+            a[k][hh] = a[k][p];
+            hh = p;
+            p = (hh - 1) / 2;
+        }
+        a[k][hh] = v[k];
+        hh = n - 1;
+        p = (hh - 1) / 2;
+        while (hh > 0 && a[k][p].score > x[k].score) {
+            a[k][hh] = a[k][p];
+            hh = p;
+            p = (hh - 1) / 2;
+        }
+        a[k][hh] = x[k];
+    }
+}
+
+template <int K>
+static void run_multi(std::vector<std::vector<Ent>>& heaps, std::vector<std::vector<uint64_t>>& km,
+                      std::vector<std::vector<uint64_t>>& rw, const std::vector<double>& u, int H, int N, int pushes) {
+    int h = 0;
+    for (; h + K <= H; h += K)
+        for (int i = 0; i < pushes; i++) {
+            Ent* a[K];
+            Ent x[K];
+            uint32_t sl[K];
+            for (int k = 0; k < K; k++) {
+                a[k] = heaps[h + k].data();
+                const double lo = a[k][0].score;
+                x[k] = Ent{lo + (1.0 - lo) * u[(size_t)(h + k) * pushes + i], 0};
+                sl[k] = a[k][0].slot;
+            }
+            replace_multi<K>(a, N, x);
+            for (int k = 0; k < K; k++) {
+                km[h + k][sl[k]] = i;
+                rw[h + k][sl[k]] = i;
+            }
+        }
+    for (; h < H; h++)
+        for (int i = 0; i < pushes; i++) {
+            Ent* a = heaps[h].data();
+            const double lo = a[0].score;
+            Ent x{lo + (1.0 - lo) * u[(size_t)h * pushes + i], 0};
+            const uint32_t slot = a[0].slot;
+            replace_hand(a, N, x);
+            km[h][slot] = i;
+            rw[h][slot] = i;
+        }
+}
+
 int main(int argc, char** argv) {
     const int T = argc > 1 ? atoi(argv[1]) : 16;
     const int H = argc > 2 ? atoi(argv[2]) : 7;
     const int N = argc > 3 ? atoi(argv[3]) : 10001;
     const int pushes = argc > 4 ? atoi(argv[4]) : 400000;
-    for (int variant = 0; variant < 5; variant++) {
+    for (int variant = 0; variant < 9; variant++) {
         std::vector<double> ns(T);
         std::vector<uint64_t> chk(T);
         std::vector<std::thread> th;
@@ -140,6 +299,38 @@ int main(int argc, char** argv) {
                         }
                 } else if (variant == 1) {
                     for (int h = 0; h < H; h++)
+                        for (int i = 0; i < pushes; i++) {
+                            Ent* a = heaps[h].data();
+                            const double lo = a[0].score;
+                            Ent x{lo + (1.0 - lo) * u[(size_t)h * pushes + i], 0};
+                            const uint32_t slot = a[0].slot;
+                            replace_hand(a, N, x);
+                            km[h][slot] = i;
+                            rw[h][slot] = i;
+                        }
+                } else if (variant == 6) {
+                    run_multi<3>(heaps, km, rw, u, H, N, pushes);
+                } else if (variant == 7) {
+                    run_multi<4>(heaps, km, rw, u, H, N, pushes);
+                } else if (variant == 8) {
+                    run_multi<6>(heaps, km, rw, u, H, N, pushes);
+                } else if (variant == 5) {
+                    int h = 0;
+                    for (; h + 1 < H; h += 2)
+                        for (int i = 0; i < pushes; i++) {
+                            Ent* a = heaps[h].data();
+                            Ent* b = heaps[h + 1].data();
+                            const double la = a[0].score, lb = b[0].score;
+                            Ent xa{la + (1.0 - la) * u[(size_t)h * pushes + i], 0};
+                            Ent xb{lb + (1.0 - lb) * u[(size_t)(h + 1) * pushes + i], 0};
+                            const uint32_t sa = a[0].slot, sb = b[0].slot;
+                            replace_pair(a, b, N, xa, xb);
+                            km[h][sa] = i;
+                            rw[h][sa] = i;
+                            km[h + 1][sb] = i;
+                            rw[h + 1][sb] = i;
+                        }
+                    for (; h < H; h++)
                         for (int i = 0; i < pushes; i++) {
                             Ent* a = heaps[h].data();
                             const double lo = a[0].score;
