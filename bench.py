@@ -126,8 +126,11 @@ def main():
 
     # One scan session per process, reused across steps (kgwas_scan_reset empties heaps and statistics
     # but keeps device / pinned buffers): a step is one full pass of the hot path, not buffer set-up.
+    # Host replay pool: this rank's share of the CPUs the job may use (one rank per GPU on one node).
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    host_threads = max(1, usable_cpus() // max(local_world, 1))
     session = kg.AssociationScan(S, col, Y, args.topn, mac, device=dev, kernel=args.kernel,
-                                 chunk_rows=args.chunk_rows, record_history=(world > 1))
+                                 chunk_rows=args.chunk_rows, record_history=(world > 1), host_threads=host_threads)
 
     def one_step():
         scan = session
@@ -195,9 +198,14 @@ def main():
             peak, peak_unit, dtype = I8_MFMA_PEAK_TOPS, "TOP/s (int8 MFMA dense)", "i8 filter + f32/f64 exact re-score"
             Wm = 2 * ((S + 127) // 128)
             kgroups = (Wm + 7) // 8
-            T = next(t for t in (8, 6, 4, 2) if kgroups * 8 * t * 1024 <= 152 * 1024)
-            lgroups = (P + 8 * T - 1) // (8 * T)
-            executed = 2.0 * (kgroups * 512) * (lgroups * T * 16) * rows_scored / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+            # executed int8 work: per operand set, padded samples x padded operand columns x rows filtered with it
+            ex_ops = 0.0
+            for mi in range(2):
+                T, lgroups = stats[-1]["coarse_mode_tiles"][mi], stats[-1]["coarse_mode_lgroups"][mi]
+                ex_ops += 2.0 * (kgroups * 512) * (lgroups * T * 16) * sum(st_["coarse_mode_rows"][mi] for st_ in stats)
+            rows_scored = sum(sum(st_["coarse_mode_rows"]) for st_ in stats)
+            achieved_tflops = flop_per_row * rows_scored / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+            executed = ex_ops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         # sanity on the final result of the last step: ascending pops, full heaps
         k, sc, r = last.result(0)
         assert (np.diff(sc) >= 0).all() and len(k) == min(args.topn, tested)
@@ -230,6 +238,12 @@ def main():
             "roofline": {"bound": "mfma" if ku in (2, 3) else "valu", "kernel": kernel_name,
                          "achieved": achieved_tflops, "peak": peak, "unit": peak_unit,
                          "frac": achieved_tflops / peak, "executed_TOPs": executed,
+                         "coarse_sets": ([{"int8_slices": mi + 1, "tiles_per_lds_group": stats[-1]["coarse_mode_tiles"][mi],
+                                            "lds_groups": stats[-1]["coarse_mode_lgroups"][mi],
+                                            "launches_per_step": sum(st_["coarse_mode_launches"][mi] for st_ in stats) / args.steps,
+                                            "rows_per_step": sum(st_["coarse_mode_rows"][mi] for st_ in stats) // args.steps,
+                                            "ms_per_step": sum(st_["coarse_mode_ms"][mi] for st_ in stats) / args.steps}
+                                           for mi in range(2) if stats[-1]["coarse_mode_tiles"][mi]] if ku == 3 else None),
                          "executed_frac": (executed / peak) if executed else None, "traffic": traffic,
                          "traffic_unit": "GB per average launch (HBM-side, PMC)", "traffic_source": traffic_src,
                          "algorithmic_GB_per_launch": rows_scored / max(k_launch, 1) * 8.0 * W / 1e9,
@@ -244,7 +258,7 @@ def main():
                      "chunks_per_step": sum(s["chunks"] for s in stats) // args.steps,
                      "gpu_wait_ms_per_step": sum(s["gpu_wait_ms"] for s in stats) / args.steps,
                      "dense_phase_ms_per_step": sum(s["dense_ms"] for s in stats) / args.steps,
-                     "cores": usable_cpus(), "logical_cpus": os.cpu_count(),
+                     "cores": usable_cpus(), "replay_threads_per_rank": host_threads, "logical_cpus": os.cpu_count(),
                      "step_ms": [round(x, 2) for x in step_ms],
                      # CFS bandwidth throttling of this container during the timed region (cpu.stat deltas)
                      "cgroup_nr_throttled": thr1[0] - thr0[0], "cgroup_throttled_ms": (thr1[1] - thr0[1]) / 1e3},

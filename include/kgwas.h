@@ -134,9 +134,15 @@ typedef struct kgwas_scan_stats {
     double dense_ms;            /* host wall time of the dense (heap-filling) phase, GPU + replay */
     double coarse_kernel_ms;    /* sum of hipEvent durations of coarse_kernel alone (KGWAS_KERNEL_COARSE) */
     uint64_t coarse_launches;   /* its launches */
-    uint32_t kernel_used;       /* KGWAS_KERNEL_VALU or KGWAS_KERNEL_MFMA */
+    uint32_t kernel_used;       /* KGWAS_KERNEL_VALU, _MFMA or _COARSE */
     uint32_t direct_mode;       /* 1 = scorer read the file layout in place (no squeeze pass) */
     uint64_t patterns;          /* distinct pattern hashes among tested rows (count_patterns; valid after finish) */
+    /* coarse filter, per operand set: [0] = one int8 slice per phenotype column, [1] = two slices */
+    uint32_t coarse_mode_tiles[2];     /* 16-column int8 operand tiles per LDS group (0 = set not built) */
+    uint32_t coarse_mode_lgroups[2];   /* LDS groups a block walks */
+    uint64_t coarse_mode_launches[2];
+    uint64_t coarse_mode_rows[2];      /* rows filtered with this set */
+    double coarse_mode_ms[2];          /* hipEvent time of its coarse_kernel launches */
 } kgwas_scan_stats;
 
 int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out);

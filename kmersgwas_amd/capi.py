@@ -64,10 +64,17 @@ class ScanStats(C.Structure):
         ("gpu_wait_ms", C.c_double), ("dense_ms", C.c_double),
         ("coarse_kernel_ms", C.c_double), ("coarse_launches", C.c_uint64),
         ("kernel_used", C.c_uint32), ("direct_mode", C.c_uint32), ("patterns", C.c_uint64),
+        ("coarse_mode_tiles", C.c_uint32 * 2), ("coarse_mode_lgroups", C.c_uint32 * 2),
+        ("coarse_mode_launches", C.c_uint64 * 2), ("coarse_mode_rows", C.c_uint64 * 2),
+        ("coarse_mode_ms", C.c_double * 2),
     ]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_}
+        d = {}
+        for k, _ in self._fields_:
+            v = getattr(self, k)
+            d[k] = list(v) if hasattr(v, "__len__") else v
+        return d
 
 
 if not os.path.exists(LIB_PATH):

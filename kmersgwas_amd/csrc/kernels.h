@@ -76,6 +76,16 @@ size_t mfma_lds_bytes(uint32_t W_m);
 // Coarse int8 filter (score_coarse.hip). Survivors of column p are listed as chunk-local row indices in
 // surv[p*surv_cap ...]; launch_rescore then scores them exactly (it takes the sparse-mode ScoreArgs,
 // with Yperm set).
+// Per-column constants of the coarse filter (score_coarse.hip): y_i ~ c + u*(254*q0_i + q1_i) (two slices) or
+// c + u*q0_i (one slice), c = sum/N. A pair survives iff |Dc| >= sqrt(thr)*kalpha*sqrt(d) - eg - min(rall, N1*rmax),
+// everything in units of u and already rounded in the conservative direction by the host.
+struct CoarseCol {
+    double kalpha;  // (1 - 2^-19) / (N * u)
+    float eg;       // (Eg + rho/N) / u, rounded up, + absolute pad   (Eg: float32 summation error of the reference chains)
+    float rall;     // max(sum of positive residuals, sum of |negative residuals|) / u, rounded up
+    float rmax;     // max |residual| / u, rounded up
+    float pad;
+};
 struct CoarseArgs {
     RowSrc src;
     const uint32_t* dmask;  // [2*W_m]
@@ -84,10 +94,9 @@ struct CoarseArgs {
     uint32_t S, W_m, n_pheno, min_count;
     uint32_t n_kgroups;     // 512-sample groups = ceil(W_m / 8)
     uint32_t n_lgroups;     // LDS groups of T/2 x 16 phenotype columns
+    uint32_t n_slices;      // int8 slices per column: 1 or 2
     const int8_t* Bq;       // [n_lgroups][n_kgroups][8][T][64 lanes][16] int8 slices, see score_coarse.hip
-    const double* scale0;   // [n_pheno]
-    const double* scale1;   // [n_pheno]
-    const double* E;        // [n_pheno] bound on |yigi_ref - yc|
+    const CoarseCol* cols;  // [n_pheno]
     const float* sums;      // [n_pheno]
     const double* thr;      // [n_pheno]
     uint32_t* surv;         // [n_pheno][surv_cap]

@@ -376,6 +376,7 @@ struct Slot {
     PinBuf<unsigned long long> h_tested;
     hipEvent_t ev_sq0 = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_done = nullptr, ev_mid = nullptr;
     bool used_coarse = false;
+    int coarse_mode = 0;
     const uint64_t* rows = nullptr;
     uint64_t first_row = 0, n_rows = 0;
     bool squeezed = false, busy = false;
@@ -413,9 +414,15 @@ struct kgwas_scan {
     uint64_t rows_submitted = 0;  // rows handed to the GPU (replayed or still in flight)
     // coarse int8 filter (sparse phase)
     bool coarse = false;
-    uint32_t coarse_T = 0, n_kgroups = 0, n_lgroups = 0, coarse_all_ones = 0;
-    DevBuf<int8_t> d_Bq;
-    DevBuf<double> d_s0, d_s1, d_E;
+    uint32_t coarse_T = 0, n_kgroups = 0, coarse_all_ones = 0;  // coarse_T: most operand tiles the LDS can hold
+    // Operand sets of the filter: mode[0] = one int8 slice per column (half the matrix work, ~2.5 survivors per
+    // candidate), mode[1] = two slices (~1). Both may be resident; each chunk picks one (pick_coarse_mode).
+    struct CoarseMode {
+        bool ready = false;
+        uint32_t T = 0, n_lgroups = 0, slices = 0;
+        DevBuf<int8_t> d_Bq;
+        DevBuf<CoarseCol> d_cols;
+    } cmode[2];
     DevBuf<uint32_t> d_surv, d_surv_cnt;  // shared by all chunks: consumed by the re-score kernel in stream order
     DevBuf<uint32_t> d_surv_sorted, d_seg_beg, d_seg_end;
     DevBuf<uint8_t> d_sort_tmp;
@@ -661,6 +668,16 @@ void run_dense(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, uint64_t 
 
 // count_hist: first (and only) scoring of these rows in the sparse phase -> their candidates feed the
 // device-side threshold histograms. Overflow re-runs must not count the same rows twice.
+// Which operand set a sparse chunk of n_rows uses: the one-slice filter when its ~2.5x longer survivor lists
+// still fit the per-column capacity with room to spare (the long steady chunks), the two-slice one otherwise
+// (the ramp, where chunks are sized to fill a third of the capacity with candidates alone).
+int pick_coarse_mode(const kgwas_scan* s, uint64_t n_rows) {
+    if (!s->cmode[0].ready) return 1;
+    if (!s->cmode[1].ready) return 0;
+    const double per_col = (double)s->max_topn * (double)n_rows / (double)std::max<uint64_t>(s->rows_submitted, 1);
+    return 2.5 * per_col <= 0.6 * (double)s->cap ? 0 : 1;
+}
+
 void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_rows, uint64_t first_row,
                    bool count_hist) {
     ScoreArgs a;
@@ -703,11 +720,13 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
         c.n_pheno = a.n_pheno;
         c.min_count = a.min_count;
         c.n_kgroups = s->n_kgroups;
-        c.n_lgroups = s->n_lgroups;
-        c.Bq = s->d_Bq.p;
-        c.scale0 = s->d_s0.p;
-        c.scale1 = s->d_s1.p;
-        c.E = s->d_E.p;
+        const int cm = pick_coarse_mode(s, n_rows);
+        const kgwas_scan::CoarseMode& M = s->cmode[cm];
+        sl.coarse_mode = cm;
+        c.n_lgroups = M.n_lgroups;
+        c.Bq = M.d_Bq.p;
+        c.n_slices = M.slices;
+        c.cols = M.d_cols.p;
         c.sums = a.sums;
         c.thr = a.thr;
         c.surv = s->d_surv.p;
@@ -715,7 +734,7 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
         c.surv_cap = s->cap;
         c.tested = a.tested;
         KGWAS_HIP(hipMemsetAsync(s->d_surv_cnt.p, 0, s->n_pheno * sizeof(uint32_t), s->stream));
-        KGWAS_HIP(launch_coarse(c, s->coarse_T, n_rows >= (1u << 20) ? 2048u : 512u, s->stream));
+        KGWAS_HIP(launch_coarse(c, M.T, n_rows >= (1u << 20) ? 2048u : 512u, s->stream));
         KGWAS_HIP(hipEventRecord(sl.ev_mid, s->stream));
         a.tested = nullptr;  // counted by the coarse pass
         KGWAS_HIP(launch_surv_sort(s->d_surv.p, s->d_surv_sorted.p, s->d_surv_cnt.p, s->d_seg_beg.p, s->d_seg_end.p,
@@ -767,13 +786,28 @@ bool reap_sparse(kgwas_scan* s, Slot& sl) {
         KGWAS_HIP(hipEventElapsedTime(&mc, sl.ev_k0, sl.ev_mid));
         s->st.coarse_kernel_ms += mc;
         s->st.coarse_launches++;
+        s->st.coarse_mode_ms[sl.coarse_mode] += mc;
+        s->st.coarse_mode_launches[sl.coarse_mode]++;
+        s->st.coarse_mode_rows[sl.coarse_mode] += sl.n_rows;
     }
     if (!s->direct) {
         KGWAS_HIP(hipEventElapsedTime(&ms, sl.ev_sq0, sl.ev_k0));
         s->st.squeeze_kernel_ms += ms;
     }
     for (uint64_t j = 0; j < s->n_pheno; j++)
-        if (sl.h_cnt.p[j] > s->cap || (s->coarse && sl.h_surv_cnt.p[j] > s->cap)) return false;
+        if (sl.h_cnt.p[j] > s->cap || (s->coarse && sl.h_surv_cnt.p[j] > s->cap)) {
+            if (s->trace) {
+                uint64_t tot = 0, mx = 0;
+                for (uint64_t q = 0; q < s->n_pheno; q++) {
+                    tot += sl.h_surv_cnt.p[q];
+                    mx = std::max<uint64_t>(mx, sl.h_surv_cnt.p[q]);
+                }
+                fprintf(stderr, "[kgwas] chunk rows=%llu first=%llu OVERFLOW: survivors total %llu, max per column %llu, cap %u\n",
+                        (unsigned long long)sl.n_rows, (unsigned long long)sl.first_row, (unsigned long long)tot,
+                        (unsigned long long)mx, s->cap);
+            }
+            return false;
+        }
 
     auto t0 = std::chrono::steady_clock::now();
     s->st.rows_tested += *sl.h_tested.p;
@@ -805,8 +839,17 @@ bool reap_sparse(kgwas_scan* s, Slot& sl) {
                 const uint64_t o = j * (uint64_t)s->cap;
                 cols.push_back(Cur{sl.so_score.p + o, sl.so_kmer.p + o, sl.so_row.p + o, 0, n, &s->heaps[j], j});
             }
+            // The records were just written by the GPU (no CPU cache holds them) and the replay walks ~20 short
+            // streams at once, more than the hardware prefetchers track: pull them in up front, a line at a time.
+            for (const Cur& cu : cols) {
+                for (uint32_t i = 0; i < cu.n; i += 8) __builtin_prefetch(cu.sc + i);
+                for (uint32_t i = 0; i < cu.n; i += 8) __builtin_prefetch(cu.km + i);
+                for (uint32_t i = 0; i < cu.n; i += 16) __builtin_prefetch(cu.rw + i);
+            }
             uint64_t local = 0, nc = 0;
+            uint64_t tsc_scan = 0, tsc_heap = 0, rounds = 0;
             while (!cols.empty()) {
+                const uint64_t q0 = s->trace ? __builtin_ia32_rdtsc() : 0;
                 // next effective record of every column still active
                 for (size_t c = 0; c < cols.size();) {
                     Cur& cu = cols[c];
@@ -833,6 +876,7 @@ bool reap_sparse(kgwas_scan* s, Slot& sl) {
                     }
                 }
                 // lockstep groups of equal heap size (columns that differ, or are not full, go one at a time)
+                const uint64_t q1 = s->trace ? __builtin_ia32_rdtsc() : 0;
                 size_t done = 0;
                 while (done < cols.size()) {
                     BestHeap* hp[MK];
@@ -879,7 +923,16 @@ bool reap_sparse(kgwas_scan* s, Slot& sl) {
                     nc += (uint64_t)K;
                     done = c;
                 }
+                if (s->trace) {
+                    const uint64_t q2 = __builtin_ia32_rdtsc();
+                    tsc_scan += q1 - q0;
+                    tsc_heap += q2 - q1;
+                    rounds++;
+                }
             }
+            if (s->trace && w == 0)
+                fprintf(stderr, "[kgwas]   worker 0: %llu rounds, %llu pushes, scan %.0f heap %.0f kcycles (tsc)\n",
+                        (unsigned long long)rounds, (unsigned long long)local, tsc_scan / 1e3, tsc_heap / 1e3);
             pushes += local;
             cands += nc;
             if (s->trace)
@@ -962,7 +1015,9 @@ uint64_t next_sparse_chunk(const kgwas_scan* s) {
     // The device keeps its thresholds current with everything submitted so far (thr_update_kernel), so a
     // chunk of c rows ships about topn * c / rows_submitted records per column. Keep that under cap / 3.
     const double m = (double)std::max<uint64_t>(s->rows_submitted, 1);
-    double c = m * (double)s->cap / (3.0 * (double)std::max<uint64_t>(s->max_topn, 1));
+    // (the one-slice coarse filter lists ~2.5 survivors per candidate, the two-slice one ~1)
+    const double infl = (s->coarse && !s->cmode[1].ready) ? 2.5 : 1.0;
+    double c = m * (double)s->cap / (3.0 * infl * (double)std::max<uint64_t>(s->max_topn, 1));
     uint64_t ci = (uint64_t)std::min<double>(c, (double)s->chunk_max);
     ci = std::max<uint64_t>(ci, std::min<uint64_t>(s->dense_rows, s->chunk_max));
     ci = std::min<uint64_t>(ci, s->chunk_max);
@@ -1080,7 +1135,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         // an exact kernel for the dense phase / re-runs, and T >= 2 int8 tiles of the whole sample axis in LDS.
         const uint32_t n_kgroups = (uint32_t)((s->W_m + 7) / 8);
         uint32_t coarse_T = 0;
-        for (uint32_t T : {8u, 6u, 4u, 2u})
+        for (uint32_t T : {8u, 7u, 6u, 5u, 4u, 3u, 2u})
             if (coarse_lds_bytes(n_kgroups, T) <= 152u * 1024u) {
                 coarse_T = T;
                 break;
@@ -1196,62 +1251,121 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
             KGWAS_HIP(hipMemcpy(s->d_Yperm.p, Yperm.data(), Yperm.size() * 4, hipMemcpyHostToDevice));
         }
         if (s->coarse) {
-            // Two int8 slices per column: y ~ s0*q0 + s1*q1, and E >= |yigi_ref - (s0*D0 + s1*D1)| for every row:
-            //   float32 summation error of the reference chain  <= gamma_{L/4+3} * sum|y_i|   (Higham, recursive sums)
-            //   quantisation residual                            <= sum_i |y_i - s0 q0_i - s1 q1_i|
-            // plus a small pad for the double arithmetic of the device-side combination.
-            const uint32_t T = s->coarse_T, PG = T / 2;
-            const uint64_t n_lgroups = (P + 16ull * PG - 1) / (16ull * PG);
-            s->n_lgroups = (uint32_t)n_lgroups;
-            std::vector<int8_t> Bq(n_lgroups * n_kgroups * 8ull * T * 1024ull, 0);
-            std::vector<double> sc0(P), sc1(P), Eb(P);
+            // int8 slices per column: y_i ~ c + u*(254*q0_i + q1_i) (two slices, ~15 bits) or c + u*q0_i (one),
+            // centred at c = sum/N, sum being the reference's float32 sum of the column: then
+            //   r_c = N*yc - N1*sum = N*u*Dc + N1*(N*c - sum),   |N1*(N*c - sum)| <= rho  (rounding of c only),
+            // i.e. an exact integer Dc times a constant. For every row
+            //   |yigi_ref - yc| <= Eg + |sum_{i in row} resid_i| <= Eg + min(Rall, N1 * rmax):
+            //   Eg   = gamma_{L/4+3} * sum|y_i|  float32 summation error of the reference chains (Higham, recursive sums)
+            //   Rall = max(sum of the positive resid_i, sum of the |negative resid_i|)  (a row's residuals cannot
+            //          add up to more than all residuals of one sign), rmax = max_i |resid_i|,
+            //          resid_i = y_i - c - u*(254 q0_i + q1_i)
+            // so score_ref > thr needs (N*u*|Dc| + rho + N*E)^2 >= thr*d*(1 - 2^-40), i.e.
+            //   |Dc| >= sqrt(thr)*kalpha*sqrt(d) - eg - min(rall, N1*rmax)       (units of u; score_coarse.hip)
+            // with kalpha rounded down by 2^-19 relative and the error terms rounded up and padded: the device
+            // evaluates the right-hand side in float32, and these margins dominate its rounding.
             const double u32 = std::ldexp(1.0, -24);
             const double nterms = (double)L / 4.0 + 3.0;
             const double gamma = nterms * u32 / (1.0 - nterms * u32);
             std::vector<int> q0(S), q1(S);
-            for (uint64_t j = 0; j < P; j++) {
+            auto up = [](double x) { return std::nextafter((float)x, std::numeric_limits<float>::infinity()); };
+            auto quantise = [&](uint64_t j, int ns, CoarseCol& cc) {
+                const double Nd = (double)S, sum = (double)sums[j];
+                const double c = sum / Nd;
                 double mx = 0, A = 0;
                 for (uint64_t i = 0; i < S; i++) {
-                    mx = std::max(mx, std::fabs((double)s->Y[j * S + i]));
-                    A += std::fabs((double)s->Y[j * S + i]);
-                }
-                const double a0 = mx > 0 ? mx / 127.0 : 1.0, a1 = a0 / 254.0;
-                double resid = 0;
-                for (uint64_t i = 0; i < S; i++) {
                     const double y = (double)s->Y[j * S + i];
+                    mx = std::max(mx, std::fabs(y - c));
+                    A += std::fabs(y);
+                }
+                // unit u: one slice spans +-127 u, two slices +-(127*254 + 127) u
+                const double u = mx > 0 ? (ns == 2 ? mx / (127.0 * 254.0) : mx / 127.0) : 1.0;
+                const double a0 = ns == 2 ? 254.0 * u : u;
+                double rpos = 0, rneg = 0, rmax = 0;
+                for (uint64_t i = 0; i < S; i++) {
+                    const double y = (double)s->Y[j * S + i] - c;
                     int v0 = (int)std::lrint(y / a0);
                     v0 = std::max(-127, std::min(127, v0));
-                    const double r1 = y - a0 * v0;
-                    int v1 = (int)std::lrint(r1 / a1);
-                    v1 = std::max(-127, std::min(127, v1));
+                    double r = y - a0 * v0;
+                    int v1 = 0;
+                    if (ns == 2) {
+                        v1 = (int)std::lrint(r / u);
+                        v1 = std::max(-127, std::min(127, v1));
+                        r -= u * v1;
+                    }
                     q0[i] = v0;
                     q1[i] = v1;
-                    resid += std::fabs(r1 - a1 * v1);
+                    if (r > 0) rpos += r; else rneg -= r;
+                    rmax = std::max(rmax, std::fabs(r));
                 }
-                sc0[j] = a0;
-                sc1[j] = a1;
-                Eb[j] = (gamma * A + resid) * (1.0 + 1e-6) + 1e-12 * (1.0 + A);
-                const uint64_t lg = j / (16ull * PG), pgl = (j / 16) % PG, n = j % 16;
-                for (uint64_t g = 0; g < n_kgroups; g++)
-                    for (uint64_t jj = 0; jj < 8; jj++)
-                        for (uint64_t kg = 0; kg < 4; kg++)
-                            for (uint64_t e = 0; e < 16; e++) {
-                                const uint64_t smp = 512 * g + 128 * kg + 16 * jj + e;
-                                if (smp >= S) continue;
-                                const uint64_t lane = kg * 16 + n;
-                                const uint64_t base = (((lg * n_kgroups + g) * 8 + jj) * T);
-                                Bq[((base + 2 * pgl) * 64 + lane) * 16 + e] = (int8_t)q0[smp];
-                                Bq[((base + 2 * pgl + 1) * 64 + lane) * 16 + e] = (int8_t)q1[smp];
-                            }
+                const double rho = Nd * std::fabs(Nd * c - sum) * 2.0 + 1e-9 * (1.0 + std::fabs(sum));
+                const double Eg = gamma * A * (1.0 + 1e-6) + 1e-12 * (1.0 + A);
+                cc.kalpha = (1.0 - std::ldexp(1.0, -19)) / (Nd * u);
+                cc.eg = up((Eg + rho / Nd) / u * (1.0 + 1e-6) + 1e-2);
+                cc.rall = up(std::max(rpos, rneg) / u * (1.0 + 1e-6));
+                cc.rmax = up(rmax / u * (1.0 + 1e-6));
+                cc.pad = 0.0f;
+            };
+            // One slice halves the matrix work but widens the bound; it is offered when, for every column, the bound
+            // at N1 = S/2 stays below 15 % of the deviation of yigi a z = 4 association needs (2*sigma*sqrt(S)), so the
+            // survivors stay within a small multiple of the true candidates. KGWAS_COARSE_SLICES=1|2 forces one set.
+            bool one_ok = true;
+            for (uint64_t j = 0; j < P && one_ok; j++) {
+                CoarseCol cc;
+                quantise(j, 1, cc);
+                double mean = 0, var = 0;
+                for (uint64_t i = 0; i < S; i++) mean += (double)s->Y[j * S + i];
+                mean /= (double)S;
+                for (uint64_t i = 0; i < S; i++) var += ((double)s->Y[j * S + i] - mean) * ((double)s->Y[j * S + i] - mean);
+                const double sigma = std::sqrt(var / (double)S);
+                const double u = 1.0 / (cc.kalpha * (double)S);  // up to the 2^-19 slack
+                const double e_half = u * ((double)cc.eg + std::min((double)cc.rall, 0.5 * (double)S * (double)cc.rmax));
+                if (!(e_half <= 0.15 * 2.0 * sigma * std::sqrt((double)S))) one_ok = false;
             }
-            s->d_Bq.alloc(Bq.size());
-            s->d_s0.alloc(P);
-            s->d_s1.alloc(P);
-            s->d_E.alloc(P);
-            KGWAS_HIP(hipMemcpy(s->d_Bq.p, Bq.data(), Bq.size(), hipMemcpyHostToDevice));
-            KGWAS_HIP(hipMemcpy(s->d_s0.p, sc0.data(), P * 8, hipMemcpyHostToDevice));
-            KGWAS_HIP(hipMemcpy(s->d_s1.p, sc1.data(), P * 8, hipMemcpyHostToDevice));
-            KGWAS_HIP(hipMemcpy(s->d_E.p, Eb.data(), P * 8, hipMemcpyHostToDevice));
+            bool want[2] = {one_ok, true};
+            if (const char* e = getenv("KGWAS_COARSE_SLICES")) {
+                if (atoi(e) == 1) want[0] = true, want[1] = false;
+                if (atoi(e) == 2) want[0] = false, want[1] = true;
+            }
+            for (int mi = 0; mi < 2; mi++) {
+                if (!want[mi]) continue;
+                const int ns = mi + 1;
+                kgwas_scan::CoarseMode& M = s->cmode[mi];
+                const uint64_t tiles = (uint64_t)ns * ((P + 15) / 16);
+                uint32_t Tmax = s->coarse_T;  // largest tile count whose operands fit the LDS
+                if (ns == 2) Tmax &= ~1u;
+                const uint64_t n_lgroups = (tiles + Tmax - 1) / Tmax;
+                uint32_t T = (uint32_t)((tiles + n_lgroups - 1) / n_lgroups);
+                if (ns == 2 && (T & 1u)) T++;
+                const uint32_t PG = T / (uint32_t)ns;
+                M.T = T;
+                M.slices = (uint32_t)ns;
+                M.n_lgroups = (uint32_t)n_lgroups;
+                s->st.coarse_mode_tiles[mi] = T;
+                s->st.coarse_mode_lgroups[mi] = (uint32_t)n_lgroups;
+                std::vector<int8_t> Bq(n_lgroups * n_kgroups * 8ull * T * 1024ull, 0);
+                std::vector<CoarseCol> cols(P);
+                for (uint64_t j = 0; j < P; j++) {
+                    quantise(j, ns, cols[j]);
+                    const uint64_t lg = j / (16ull * PG), pgl = (j / 16) % PG, n = j % 16;
+                    for (uint64_t g = 0; g < n_kgroups; g++)
+                        for (uint64_t jj = 0; jj < 8; jj++)
+                            for (uint64_t kg = 0; kg < 4; kg++)
+                                for (uint64_t e = 0; e < 16; e++) {
+                                    const uint64_t smp = 512 * g + 128 * kg + 16 * jj + e;
+                                    if (smp >= S) continue;
+                                    const uint64_t lane = kg * 16 + n;
+                                    const uint64_t base = (((lg * n_kgroups + g) * 8 + jj) * T);
+                                    Bq[((base + ns * pgl) * 64 + lane) * 16 + e] = (int8_t)q0[smp];
+                                    if (ns == 2) Bq[((base + 2 * pgl + 1) * 64 + lane) * 16 + e] = (int8_t)q1[smp];
+                                }
+                }
+                M.d_Bq.alloc(Bq.size());
+                M.d_cols.alloc(P);
+                KGWAS_HIP(hipMemcpy(M.d_Bq.p, Bq.data(), Bq.size(), hipMemcpyHostToDevice));
+                KGWAS_HIP(hipMemcpy(M.d_cols.p, cols.data(), P * sizeof(CoarseCol), hipMemcpyHostToDevice));
+                M.ready = true;
+            }
             bool ones = (s->direct ? 2 * s->W_f : 2 * W_m) <= 2 * W_m;
             for (uint32_t v : dmask) ones = ones && (v == 0xFFFFFFFFu);
             s->coarse_all_ones = ones ? 1u : 0u;
@@ -1458,10 +1572,14 @@ int kgwas_scan_reset(kgwas_scan* s) {
         KGWAS_HIP(hipMemset(s->d_pat_cnt.p, 0, 8));
         s->rows_done = 0;
         s->finished = false;
-        const uint32_t ku = s->st.kernel_used, dm = s->st.direct_mode;
+        const kgwas_scan_stats old = s->st;
         s->st = kgwas_scan_stats{};
-        s->st.kernel_used = ku;
-        s->st.direct_mode = dm;
+        s->st.kernel_used = old.kernel_used;
+        s->st.direct_mode = old.direct_mode;
+        for (int mi = 0; mi < 2; mi++) {
+            s->st.coarse_mode_tiles[mi] = old.coarse_mode_tiles[mi];
+            s->st.coarse_mode_lgroups[mi] = old.coarse_mode_lgroups[mi];
+        }
     });
 }
 

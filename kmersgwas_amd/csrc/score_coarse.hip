@@ -43,11 +43,21 @@ __device__ __forceinline__ i32x4 expand16(uint32_t x) {
     return r;
 }
 
-// T = column tiles per LDS group (two int8 slices x T/2 groups of 16 phenotype columns).
-template <int T>
+// T  = operand tiles (16 columns of one int8 slice each) per LDS group,
+// NS = int8 slices per column (1: tile t of a group = column tile; 2: tiles 2g, 2g+1 = the two slices of column group g).
+//
+// The conservative test. The host centres the quantisation at c = sum/N (sum = the reference's float32 sum), so
+//   r_c = N*yc - N1*sum = N*u*Dc            Dc = D0 (one slice) or 254*D0 + D1 (two slices, s0 = 254*s1), u = s0 or s1,
+// an exact integer times a column constant. A pair can only have score_ref > thr if
+//   |Dc| >= alpha_p * sqrt(d(N1)) - e_p(N1),    alpha_p = sqrt(thr_p)/(N*u),  e_p(N1) = (Eg + min(Rall, N1*rmax))/u
+// (score_coarse.hip header for Eg, Rall, rmax). The right-hand side is evaluated in float32 from constants the host
+// rounded in the safe direction (alpha down by 2^-19 relative, sqrt(d) down by 2^-20, the error terms up, plus an
+// absolute pad), which dominates the float32 rounding of the three operations: the computed limit never exceeds the
+// true one, so no possible candidate is dropped. 8 cheap lane-ops per pair instead of 14 double-precision ones.
+template <int T, int NS>
 __global__ void __launch_bounds__(512) coarse_kernel(CoarseArgs a, uint32_t rows_per_block, uint32_t n_rowblocks) {
-    extern __shared__ i32x4 blds[];  // [n_kgroups][8][T][64] x 16 bytes
-    constexpr int PG = T / 2;
+    extern __shared__ i32x4 blds[];  // [n_kgroups][8][T][64] x 16 bytes, then float colc[4][PG*16]
+    constexpr int PG = T / NS;       // column groups (of 16) per LDS group
     constexpr int RT = 4;
     const uint32_t rb = blockIdx.x;
     if (rb >= n_rowblocks) return;
@@ -55,9 +65,10 @@ __global__ void __launch_bounds__(512) coarse_kernel(CoarseArgs a, uint32_t rows
     const uint32_t kg = lane >> 4, m = lane & 15u;
     const uint32_t n_kgroups = a.n_kgroups;
     const uint32_t group_vec = n_kgroups * 8u * T * 64u;  // i32x4 elements per LDS group
+    float* colc = reinterpret_cast<float*>(blds + group_vec);
     const uint32_t rows_per_pass = (blockDim.x >> 6) * (RT * 16u);
     const uint64_t blk_row0 = (uint64_t)rb * rows_per_block;
-    const double N = (double)a.S;
+    const float Nf = (float)a.S;
     uint32_t tested_local = 0;
 
     for (uint32_t lg = 0; lg < a.n_lgroups; lg++) {
@@ -65,6 +76,21 @@ __global__ void __launch_bounds__(512) coarse_kernel(CoarseArgs a, uint32_t rows
         {
             const i32x4* src = reinterpret_cast<const i32x4*>(a.Bq) + (size_t)lg * group_vec;
             for (uint32_t i = threadIdx.x; i < group_vec; i += blockDim.x) blds[i] = src[i];
+            if (threadIdx.x < PG * 16u) {
+                const uint32_t p = lg * (PG * 16u) + threadIdx.x;
+                float al = __builtin_huge_valf(), eg = 0.0f, ra = 0.0f, rm = 0.0f;  // padding column: nothing survives
+                if (p < a.n_pheno) {
+                    const CoarseCol cc = a.cols[p];
+                    al = (float)(sqrt(a.thr[p]) * cc.kalpha);  // NaN threshold (frozen column) -> NaN -> nothing survives
+                    eg = cc.eg;
+                    ra = cc.rall;
+                    rm = cc.rmax;
+                }
+                colc[threadIdx.x] = al;
+                colc[PG * 16u + threadIdx.x] = eg;
+                colc[2u * PG * 16u + threadIdx.x] = ra;
+                colc[3u * PG * 16u + threadIdx.x] = rm;
+            }
         }
         __syncthreads();
 
@@ -146,42 +172,41 @@ __global__ void __launch_bounds__(512) coarse_kernel(CoarseArgs a, uint32_t rows
                         tested_local++;
                 }
             }
-            // Conservative test per (row, column): the column constants are fetched here (L1-resident),
-            // not kept in registers across the MFMA loop. A lane holds 16 (row, column p) pairs per column
-            // group, and the four kg lanes of one m share the column: survivors are counted over those 64 pairs
-            // first and the column's counter is bumped once (early chunks have ~1e6 survivors on ~100 counters;
-            // one atomic per survivor serialises in the L2).
+            // Per-row terms of the 16 rows whose accumulator registers this lane holds (row kg*4+jj of tile rt):
+            // N1, sqrt(d) rounded down, and whether the row exists and passes the MAC filter.
+            float n1f[RT * 4], sqd[RT * 4];
+            uint32_t rowok = 0;
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) {
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) {
+                    const uint32_t trow = kg * 4u + jj;
+                    const uint32_t n1r = __shfl(n1[rt], (int)trow);
+                    const uint64_t r = rbase + rt * 16u + trow;
+                    if ((r < a.n_rows) && (a.S >= a.min_count) && (n1r >= a.min_count) && (n1r <= a.S - a.min_count))
+                        rowok |= 1u << (rt * 4 + jj);
+                    const float f = (float)n1r;
+                    n1f[rt * 4 + jj] = f;
+                    sqd[rt * 4 + jj] = __builtin_sqrtf(f * (Nf - f)) * 0.99999905f;  // d < 2^24 is exact; (1 - 2^-20)
+                }
+            }
+            // A lane holds 16 (row, column p) pairs per column group, and the four kg lanes of one m share the
+            // column: survivors are counted over those 64 pairs first and the column's counter is bumped once
+            // (early chunks have ~1e6 survivors on ~100 counters; one atomic per survivor serialises in the L2).
 #pragma unroll
             for (int g = 0; g < PG; g++) {
                 const uint32_t p = (lg * PG + g) * 16u + m;
-                const bool pvalid = p < a.n_pheno;
-                uint32_t pc = pvalid ? p : 0u;
-                asm volatile("" : "+v"(pc));  // keep the constants' loads here: hoisted out of the pass loop they spill
-                const double s0 = a.scale0[pc], s1 = a.scale1[pc], NE = N * a.E[pc], thr = a.thr[pc], sum = (double)a.sums[pc];
+                const float al = colc[g * 16 + m], eg = colc[PG * 16 + g * 16 + m], ra = colc[2 * PG * 16 + g * 16 + m],
+                            rm = colc[3 * PG * 16 + g * 16 + m];
                 uint32_t mbits = 0;
 #pragma unroll
-                for (int rt = 0; rt < RT; rt++) {
-#pragma unroll
-                    for (int jj = 0; jj < 4; jj++) {
-                        const uint32_t trow = kg * 4u + jj;  // D row held in register jj
-                        // N1 of the row accumulator register jj belongs to; fetched per use (a cross-lane read
-                        // is cheap next to the MFMAs, 16 more live registers are not: the kernel sits at the
-                        // 256-register limit of two waves per SIMD)
-                        uint32_t n1src = n1[rt];
-                        asm volatile("" : "+v"(n1src));
-                        const uint32_t n1r = __shfl(n1src, (int)trow);
-                        const uint64_t r = rbase + rt * 16u + trow;
-                        const bool pass = pvalid && (r < a.n_rows) && (a.S >= a.min_count) && (n1r >= a.min_count) &&
-                                          (n1r <= a.S - a.min_count);
-                        const double N1 = (double)n1r;
-                        const double d = N1 * (N - N1);
-                        const double yc = s0 * (double)acc[rt][2 * g][jj] + s1 * (double)acc[rt][2 * g + 1][jj];
-                        const double u = fabs(N * yc - N1 * sum) + NE;
-                        double lim = thr * d;
-                        lim = lim - fabs(lim) * 0x1p-40;
-                        if (pass && (u * u >= lim)) mbits |= 1u << (rt * 4 + jj);
-                    }
+                for (int i = 0; i < RT * 4; i++) {
+                    int dc = acc[i >> 2][NS * g][i & 3];
+                    if (NS == 2) dc = dc * 254 + acc[i >> 2][NS * g + NS - 1][i & 3];
+                    const float lim = fmaf(al, sqd[i], -eg) - fminf(ra, n1f[i] * rm);
+                    if (fabsf((float)dc) >= lim) mbits |= 1u << i;
                 }
+                mbits &= rowok;
                 if (__any(mbits != 0u)) {  // wave-uniform
                     const uint32_t cnt = __popc(mbits);
                     const uint32_t c0 = __shfl(cnt, (int)m), c1 = __shfl(cnt, (int)(m + 16u)), c2 = __shfl(cnt, (int)(m + 32u)),
@@ -266,7 +291,20 @@ __global__ void __launch_bounds__(256) rescore_kernel(ScoreArgs a, const uint32_
     a.so_row[o] = (uint32_t)r;
 }
 
-size_t coarse_lds_bytes(uint32_t n_kgroups, uint32_t T) { return (size_t)n_kgroups * 8u * T * 1024u; }
+// B operands of one LDS group + the group's per-column float constants (4 x up to 128 floats)
+size_t coarse_lds_bytes(uint32_t n_kgroups, uint32_t T) { return (size_t)n_kgroups * 8u * T * 1024u + 2048u; }
+
+template <int T, int NS>
+static hipError_t launch_coarse_t(const CoarseArgs& a, uint32_t rows_per_block, uint32_t n_rowblocks, size_t lds,
+                                  hipStream_t st) {
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)coarse_kernel<T, NS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((coarse_kernel<T, NS>), dim3(n_rowblocks), dim3(512), lds, st, a, rows_per_block, n_rowblocks);
+    return hipGetLastError();
+}
 
 hipError_t launch_coarse(const CoarseArgs& a, uint32_t T, uint32_t rows_per_block, hipStream_t st) {
     if (a.n_rows == 0) return hipSuccess;
@@ -277,20 +315,25 @@ hipError_t launch_coarse(const CoarseArgs& a, uint32_t T, uint32_t rows_per_bloc
     const uint32_t rpp = (threads >> 6) * 64u;
     rows_per_block = (rows_per_block + rpp - 1) / rpp * rpp;
     const uint32_t n_rowblocks = (uint32_t)((a.n_rows + rows_per_block - 1) / rows_per_block);
-    hipError_t e;
-#define KGWAS_COARSE_LAUNCH(TT)                                                                                          \
-    if (T == TT) {                                                                                                       \
-        if (lds > 64 * 1024 && (e = hipFuncSetAttribute((const void*)coarse_kernel<TT>,                                  \
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) \
-            return e;                                                                                                    \
-        hipLaunchKernelGGL(coarse_kernel<TT>, dim3(n_rowblocks), dim3(threads), lds, st, a, rows_per_block, n_rowblocks); \
-        return hipGetLastError();                                                                                        \
+    if (a.n_slices == 1) {
+        switch (T) {
+            case 1: return launch_coarse_t<1, 1>(a, rows_per_block, n_rowblocks, lds, st);
+            case 2: return launch_coarse_t<2, 1>(a, rows_per_block, n_rowblocks, lds, st);
+            case 3: return launch_coarse_t<3, 1>(a, rows_per_block, n_rowblocks, lds, st);
+            case 4: return launch_coarse_t<4, 1>(a, rows_per_block, n_rowblocks, lds, st);
+            case 5: return launch_coarse_t<5, 1>(a, rows_per_block, n_rowblocks, lds, st);
+            case 6: return launch_coarse_t<6, 1>(a, rows_per_block, n_rowblocks, lds, st);
+            case 7: return launch_coarse_t<7, 1>(a, rows_per_block, n_rowblocks, lds, st);
+            case 8: return launch_coarse_t<8, 1>(a, rows_per_block, n_rowblocks, lds, st);
+        }
+    } else if (a.n_slices == 2) {
+        switch (T) {
+            case 2: return launch_coarse_t<2, 2>(a, rows_per_block, n_rowblocks, lds, st);
+            case 4: return launch_coarse_t<4, 2>(a, rows_per_block, n_rowblocks, lds, st);
+            case 6: return launch_coarse_t<6, 2>(a, rows_per_block, n_rowblocks, lds, st);
+            case 8: return launch_coarse_t<8, 2>(a, rows_per_block, n_rowblocks, lds, st);
+        }
     }
-    KGWAS_COARSE_LAUNCH(8)
-    KGWAS_COARSE_LAUNCH(6)
-    KGWAS_COARSE_LAUNCH(4)
-    KGWAS_COARSE_LAUNCH(2)
-#undef KGWAS_COARSE_LAUNCH
     return hipErrorInvalidValue;
 }
 

@@ -114,6 +114,32 @@ def test_topn_identities_with_ties(kernel, binary, dup):
     scan.close()
 
 
+@pytest.mark.parametrize("slices", [1, 2])
+@pytest.mark.parametrize("S,P,shift", [(241, 5, 0.0), (241, 40, 100.0), (1024, 101, 0.0), (1024, 130, -7.5), (1500, 23, 3.0)])
+def test_coarse_filter_shapes(monkeypatch, slices, S, P, shift):
+    """The int8 filter in every operand-tile shape (1..8 tiles per LDS group, one or two LDS groups, 1..3
+    512-sample groups), with one and with two int8 slices per column, on shifted phenotypes (the quantisation is
+    centred) and duplicated patterns: survivors, pop order, scores and push counts equal the oracle's."""
+    monkeypatch.setenv("KGWAS_COARSE_SLICES", str(slices))
+    rows = random_table(40000, S, seed=S + P, dup_frac=0.2)
+    col = np.arange(S, dtype=np.uint64)
+    Y = (phenotypes(S, P - 1, seed=P) + np.float32(shift)).astype(np.float32)
+    mac = onp.min_count(S, 0.05, 5)
+    topn = 257
+    exp = ob.associate(rows, S, col, Y, topn, mac, batch_size=9000, threads=4)
+    scan = kg.AssociationScan(S, col, Y, topn, mac, kernel=kg.KERNEL_COARSE, chunk_rows=8192)
+    scan.feed_host(rows)
+    scan.finish()
+    st = scan.stats()
+    assert st["kernel_used"] == kg.KERNEL_COARSE
+    mi = slices - 1  # the forced operand set is the only one built, and it covers all columns
+    assert st["coarse_mode_tiles"][1 - mi] == 0 and st["coarse_mode_launches"][mi] > 0
+    assert st["coarse_mode_tiles"][mi] * st["coarse_mode_lgroups"][mi] >= slices * ((P + 15) // 16)
+    _check_topn(scan, exp, P)
+    assert st["rows_tested"] == exp["tested"]
+    scan.close()
+
+
 @pytest.mark.parametrize("kernel", KERNELS)
 def test_squeezed_mode_topn_and_history_merge(kernel):
     """Phenotyped subset in shuffled order (squeeze kernel) + cross-shard merge of two scans."""
