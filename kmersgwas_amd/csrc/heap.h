@@ -233,6 +233,69 @@ class alignas(128) BestHeap {
         a[hole] = value;
     }
 
+    // pop_all for K heaps of equal size() at once: the K pop sequences advance in lockstep (same idea as
+    // replace_top_multi; each heap's moves are those of pop_top).
+    template <int K>
+    static void pop_all_multi(const BestHeap* const* hp, std::vector<uint64_t>* const* kmer, std::vector<double>* const* score,
+                              std::vector<uint64_t>* const* row) {
+        std::vector<Ent> tmp[K];
+        Ent* a[K];
+        const size_t n = hp[0]->v_.size();
+        for (int k = 0; k < K; k++) {
+            tmp[k] = hp[k]->v_;
+            a[k] = tmp[k].data();
+            kmer[k]->resize(n);
+            score[k]->resize(n);
+            row[k]->resize(n);
+        }
+        for (size_t i = 0; i < n; i++) {
+            const ptrdiff_t m = (ptrdiff_t)(n - i);
+            Ent v[K];
+            ptrdiff_t h[K], c[K];
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                (*kmer[k])[i] = hp[k]->kmer_[a[k][0].slot];
+                (*score[k])[i] = a[k][0].score;
+                (*row[k])[i] = hp[k]->row_[a[k][0].slot];
+                v[k] = a[k][m - 1];
+                h[k] = 0;
+                c[k] = 0;
+            }
+            if (m <= 1) continue;
+            const ptrdiff_t len = m - 1, lim = (len - 1) / 2;
+            for (;;) {
+                bool any = false;
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    if (c[k] < lim) {
+                        ptrdiff_t cc = 2 * (c[k] + 1);
+                        cc -= (a[k][cc].score > a[k][cc - 1].score) ? 1 : 0;
+                        a[k][h[k]] = a[k][cc];
+                        h[k] = cc;
+                        c[k] = cc;
+                        any = true;
+                    }
+                }
+                if (!any) break;
+            }
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                if ((len & 1) == 0 && c[k] == (len - 2) / 2) {
+                    c[k] = 2 * (c[k] + 1);
+                    a[k][h[k]] = a[k][c[k] - 1];
+                    h[k] = c[k] - 1;
+                }
+                ptrdiff_t hh = h[k], p = (hh - 1) / 2;
+                while (hh > 0 && a[k][p].score > v[k].score) {
+                    a[k][hh] = a[k][p];
+                    hh = p;
+                    p = (hh - 1) / 2;
+                }
+                a[k][hh] = v[k];
+            }
+        }
+    }
+
    private:
     size_t n_res_;
     std::vector<Ent> v_;

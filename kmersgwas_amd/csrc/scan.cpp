@@ -392,7 +392,7 @@ struct kgwas_scan {
     bool direct = false;
     uint32_t kernel_used = 0;
     bool record_history = false;
-    uint64_t chunk_max = 0, dense_rows = 0;
+    uint64_t chunk_max = 0, dense_rows = 0, dense_chunk = 0;
     uint32_t cap = 0;
     uint64_t max_topn = 0;
     uint32_t nb_full = 0;  // leading 128-sample blocks the MFMA scorer may read unmasked
@@ -1049,7 +1049,7 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
     while (pos < n_rows) {
         if (!s->all_full) {
             while (!inflight.empty()) reap_oldest();
-            const uint64_t c = std::min<uint64_t>(s->dense_rows, n_rows - pos);
+            const uint64_t c = std::min<uint64_t>(s->dense_chunk, n_rows - pos);
             run_dense(s, d_rows + pos * stride, c, first_row + pos, nullptr, nullptr, true);
             pos += c;
             continue;
@@ -1166,7 +1166,10 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
             const uint64_t lim = ((1ull << 32) - (1ull << 20)) / stride_dw / 128 * 128;
             s->chunk_max = std::max<uint64_t>(128, std::min<uint64_t>(s->chunk_max, lim));
         }
-        s->dense_rows =std::min<uint64_t>(16384, s->chunk_max);
+        s->dense_rows = std::min<uint64_t>(16384, s->chunk_max);
+        // Dense chunks of a feed: enough rows to fill the largest heap with a margin for the MAC filter (more
+        // dense chunks follow while a heap is still short); everything after goes through the sparse path.
+        s->dense_chunk = std::min<uint64_t>(s->dense_rows, std::max<uint64_t>(1024, (s->max_topn + s->max_topn / 8 + 512 + 127) / 128 * 128));
         const uint64_t budget = 4ull << 20;  // candidate records per slot (x 24 B x n_slots of mapped pinned memory)
         uint64_t cap = std::min<uint64_t>(2 * s->max_topn + 4096, std::max<uint64_t>(budget / s->n_pheno, 1024));
         s->cap = (uint32_t)std::min<uint64_t>(cap, 0x7FFFFFFFull);
@@ -1475,8 +1478,32 @@ int kgwas_scan_finish(kgwas_scan* s) {
         s->res_kmer.resize(s->n_pheno);
         s->res_row.resize(s->n_pheno);
         s->res_score.resize(s->n_pheno);
-        s->pool->parallel_for(s->n_pheno,
-                              [&](size_t j) { s->heaps[j].pop_all(s->res_kmer[j], s->res_score[j], s->res_row[j]); });
+        // A worker pops its columns (w, w+T, ...) four at a time in lockstep where their sizes agree.
+        const size_t Tw = s->pool->size();
+        s->pool->parallel_for(std::min<size_t>(Tw, s->n_pheno), [&](size_t w) {
+            std::vector<size_t> mine;
+            for (size_t j = w; j < s->n_pheno; j += Tw) mine.push_back(j);
+            size_t i = 0;
+            while (i < mine.size()) {
+                size_t K = 1;
+                while (K < 4 && i + K < mine.size() && s->heaps[mine[i + K]].size() == s->heaps[mine[i]].size()) K++;
+                const BestHeap* hp[4];
+                std::vector<uint64_t>*km[4], *rw[4];
+                std::vector<double>* sc[4];
+                for (size_t k = 0; k < K; k++) {
+                    const size_t j = mine[i + k];
+                    hp[k] = &s->heaps[j];
+                    km[k] = &s->res_kmer[j];
+                    sc[k] = &s->res_score[j];
+                    rw[k] = &s->res_row[j];
+                }
+                if (K == 4) BestHeap::pop_all_multi<4>(hp, km, sc, rw);
+                else if (K == 3) BestHeap::pop_all_multi<3>(hp, km, sc, rw);
+                else if (K == 2) BestHeap::pop_all_multi<2>(hp, km, sc, rw);
+                else s->heaps[mine[i]].pop_all(s->res_kmer[mine[i]], s->res_score[mine[i]], s->res_row[mine[i]]);
+                i += K;
+            }
+        });
         if (s->count_patterns) {
             unsigned long long n_hashes = 0;
             KGWAS_HIP(hipMemcpy(&n_hashes, s->d_pat_cnt.p, 8, hipMemcpyDeviceToHost));
