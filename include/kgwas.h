@@ -148,8 +148,13 @@ typedef struct kgwas_scan_stats {
 int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out);
 /* Rows already resident in HBM (file layout, 8-byte aligned). hip_stream may be NULL. */
 int kgwas_scan_feed_device(kgwas_scan* s, const void* d_rows, uint64_t n_rows, uint64_t first_row, void* hip_stream);
-/* Rows in host memory; copied to the device through pinned double buffers. */
+/* Rows in host memory (file layout). Chunked, double-buffered: a producer thread stages 128 MiB pieces into pinned
+ * memory and piece k+1 is copied (own stream) while piece k is scored and replayed. */
 int kgwas_scan_feed_host(kgwas_scan* s, const uint64_t* rows, uint64_t n_rows, uint64_t first_row);
+/* Rows [row0, row0 + n_rows) straight from an open .table: the same pipeline with the producer thread reading the
+ * file (pread) into the pinned pieces, so disk, PCIe and GPU + replay overlap. Replaces the reference's
+ * load-a-batch-then-compute loop (src/associate_kmers.cpp:104-148); first_row of the feed is row0. */
+int kgwas_scan_feed_table(kgwas_scan* s, kgwas_table* t, uint64_t row0, uint64_t n_rows);
 int kgwas_scan_finish(kgwas_scan* s);
 /* Heap of phenotype j in heap-pop (ascending score) order: rank of entry i is n - i.
  * row = file row index. Valid after kgwas_scan_finish. */

@@ -28,7 +28,7 @@ SYMBOLS = [
     "kgwas_pheno_free", "kgwas_min_count",
     "kgwas_heap_new", "kgwas_heap_add_many", "kgwas_heap_size", "kgwas_heap_pop_all", "kgwas_heap_output_list",
     "kgwas_heap_free",
-    "kgwas_scan_create", "kgwas_scan_feed_device", "kgwas_scan_feed_host", "kgwas_scan_finish", "kgwas_scan_result",
+    "kgwas_scan_create", "kgwas_scan_feed_device", "kgwas_scan_feed_host", "kgwas_scan_feed_table", "kgwas_scan_finish", "kgwas_scan_result",
     "kgwas_scan_history", "kgwas_scan_get_stats", "kgwas_scan_reset", "kgwas_scan_lowest", "kgwas_scan_absorb", "kgwas_scan_destroy", "kgwas_scan_scores_dense",
     "kgwas_merge_shards",
     "kgwas_kinship_create", "kgwas_kinship_feed_device", "kgwas_kinship_feed_host", "kgwas_kinship_partials",
@@ -149,6 +149,7 @@ lib.kgwas_heap_free.restype = None
 lib.kgwas_scan_create.argtypes = [C.POINTER(ScanParams), _pp]
 lib.kgwas_scan_feed_device.argtypes = [_vp, _vp, _u64, _u64, _vp]
 lib.kgwas_scan_feed_host.argtypes = [_vp, _vp, _u64, _u64]
+lib.kgwas_scan_feed_table.argtypes = [_vp, _vp, _u64, _u64]
 lib.kgwas_scan_finish.argtypes = [_vp]
 lib.kgwas_scan_result.argtypes = [_vp, _u64, _pu64, C.POINTER(_pu64), C.POINTER(_pdbl), C.POINTER(_pu64)]
 lib.kgwas_scan_history.argtypes = [_vp, _u64, _pu64, C.POINTER(_pu64), C.POINTER(_pdbl), C.POINTER(_pu64)]

@@ -167,6 +167,10 @@ class AssociationScan:
         n = rows.size // (1 + self.words_per_row)
         check(lib.kgwas_scan_feed_host(self._h, ptr(rows), n, first_row))
 
+    def feed_table(self, table: "KmersTable", row0: int, n_rows: int):
+        """Rows [row0, row0 + n_rows) of an open table, read / copied / scored in overlapping 128 MiB pieces."""
+        check(lib.kgwas_scan_feed_table(self._h, table._h, row0, n_rows))
+
     # device pointer to rows already resident in HBM (e.g. torch tensor .data_ptr())
     def feed_device(self, d_ptr: int, n_rows: int, first_row: int = 0, stream: int = 0):
         check(lib.kgwas_scan_feed_device(self._h, C.c_void_p(d_ptr), n_rows, first_row, C.c_void_p(stream)))

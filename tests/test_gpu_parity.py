@@ -292,6 +292,41 @@ def test_nonfinite_phenotype_uses_valu_and_matches():
     scan.close()
 
 
+@pytest.mark.parametrize("piece", [1000, 5000, 0])
+def test_double_buffered_ingest_from_file_and_host(monkeypatch, tmp_path, piece):
+    """kgwas_scan_feed_table / kgwas_scan_feed_host stream the rows in pinned pieces (producer thread, copy
+    stream, two device pieces): many small pieces, a ragged last piece, several feeds, and the default 64 MiB
+    piece all give the oracle's heaps, push for push."""
+    if piece:
+        monkeypatch.setenv("KGWAS_INGEST_PIECE_ROWS", str(piece))
+    S_f, S, k, P = 200, 200, 31, 12
+    rows = random_table(47_001, S_f, seed=piece + 5, dup_frac=0.3)
+    names = ["a%d" % i for i in range(S_f)]
+    base = str(tmp_path / "t")
+    onp.write_table(base, names, k, rows[:, 0], rows[:, 1:])
+    col = np.arange(S, dtype=np.uint64)
+    Y = phenotypes(S, P - 1, seed=3)
+    mac = onp.min_count(S, 0.05, 5)
+    exp = ob.associate(rows, S_f, col, Y, 401, mac, batch_size=11000, threads=3)
+    tbl = kg.KmersTable(base, k)
+    for mode in ("table", "host"):
+        scan = kg.AssociationScan(S_f, col, Y, 401, mac, chunk_rows=4096)
+        if mode == "table":
+            scan.feed_table(tbl, 0, 20_000)
+            scan.feed_table(tbl, 20_000, 0)
+            scan.feed_table(tbl, 20_000, 27_001)
+            with pytest.raises(kg.KgwasError):
+                scan.feed_table(tbl, 40_000, 10_000)  # beyond the table
+        else:
+            scan.feed_host(rows[:33_333], 0)
+            scan.feed_host(rows[33_333:], 33_333)
+        scan.finish()
+        _check_topn(scan, exp, P)
+        assert scan.stats()["rows_tested"] == exp["tested"] and scan.stats()["rows_fed"] == len(rows)
+        scan.close()
+    tbl.close()
+
+
 def test_synth_device_equals_host_twin_and_numpy():
     import torch
     for n_acc in (64, 241, 1024, 1135):
