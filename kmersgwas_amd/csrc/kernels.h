@@ -73,48 +73,47 @@ hipError_t launch_score_valu(const ScoreArgs& a, hipStream_t st);
 hipError_t launch_score_mfma(const ScoreArgs& a, uint32_t rows_per_block, uint32_t nb_full, hipStream_t st);
 size_t mfma_lds_bytes(uint32_t W_m);
 
-// Coarse int8 filter (score_coarse.hip). Survivors of column p are listed as chunk-local row indices in
-// surv[p*surv_cap ...]; launch_rescore then scores them exactly (it takes the sparse-mode ScoreArgs,
-// with Yperm set).
-// Per-column constants of the coarse filter (score_coarse.hip): y_i ~ c + u*(254*q0_i + q1_i) (two slices) or
-// c + u*q0_i (one slice), c = sum/N. A pair survives iff |Dc| >= sqrt(thr)*kalpha*sqrt(d) - eg - min(rall, N1*rmax),
-// everything in units of u and already rounded in the conservative direction by the host.
+// Coarse int8 filter (score_coarse.hip). Survivors are appended to one key list; after launch_surv_sort,
+// launch_rescore scores them exactly, column by column in row order (it takes the sparse-mode ScoreArgs, with
+// Yperm set).
+// Per-slot constants of the coarse filter (score_coarse.hip); a slot is one of the PG*16 operand columns of an LDS
+// group. y_i ~ c + u*(254*q0_i + q1_i) (two slices) or c + u*q0_i (one slice), c = sum/N. A pair survives iff
+// |Dc| >= sqrt(thr)*kalpha*sqrt(d) - iu*E(N1), constants already rounded in the conservative direction by the host.
 struct CoarseCol {
     double kalpha;  // (1 - 2^-19) / (N * u)
-    float eg;       // (Eg + rho/N) / u, rounded up, + absolute pad   (Eg: float32 summation error of the reference chains)
-    float rall;     // max(sum of positive residuals, sum of |negative residuals|) / u, rounded up
-    float rmax;     // max |residual| / u, rounded up
-    float pad;
+    float iu;       // 1 / u, rounded up
+    int32_t pheno;  // phenotype column in this slot; -1: padding or the group's ones column (slot PG*16-1 -> N1)
 };
 struct CoarseArgs {
     RowSrc src;
-    const uint32_t* dmask;  // [2*W_m]
-    uint32_t all_ones;      // 1: no masking needed (every dmask word is ~0 and rows hold no other bits)
     uint64_t n_rows;
-    uint32_t S, W_m, n_pheno, min_count;
+    uint32_t S, n_pheno, min_count;
     uint32_t n_kgroups;     // 512-sample groups = ceil(W_m / 8)
-    uint32_t n_lgroups;     // LDS groups of T/2 x 16 phenotype columns
+    uint32_t n_lgroups;     // LDS groups of T/NS x 16 operand columns
     uint32_t n_slices;      // int8 slices per column: 1 or 2
     const int8_t* Bq;       // [n_lgroups][n_kgroups][8][T][64 lanes][16] int8 slices, see score_coarse.hip
-    const CoarseCol* cols;  // [n_pheno]
-    const float* sums;      // [n_pheno]
+    const CoarseCol* cols;  // [n_lgroups][T/NS*16]
     const double* thr;      // [n_pheno]
-    uint32_t* surv;         // [n_pheno][surv_cap]
-    uint32_t* surv_cnt;     // [n_pheno]
-    uint32_t surv_cap;
+    uint32_t* keys;         // survivor keys (column << row_bits | chunk-local row), one global list
+    uint32_t* key_count;    // keys appended (may exceed key_cap: then the list overflowed)
+    uint32_t key_cap;
+    uint32_t row_bits;
     unsigned long long* tested;
+    // E(N1) = eg_max + min(rall_max, N1 * rmax_max) bounds |yigi_ref - yc| for every column (phenotype units, each
+    // the maximum over the columns, rounded up): float32 summation error of the reference chains, the larger
+    // one-sign sum of the quantisation residuals, the largest residual.
+    float eg_max, rall_max, rmax_max;
 };
 size_t coarse_lds_bytes(uint32_t n_kgroups, uint32_t T);
 hipError_t launch_coarse(const CoarseArgs& a, uint32_t T, uint32_t rows_per_block, hipStream_t st);
-hipError_t launch_rescore(const ScoreArgs& a, const uint32_t* surv, const uint32_t* surv_cnt, uint32_t surv_cap,
-                          hipStream_t st);
+hipError_t launch_rescore(const ScoreArgs& a, const uint32_t* keys, const uint32_t* surv_off, const uint32_t* surv_cnt,
+                          uint32_t surv_cap, uint32_t row_bits, hipStream_t st);
 
-// Row-order sort of the survivor lists, one segment per column (surv_sort.hip).
-hipError_t surv_sort_temp_bytes(uint32_t n_pheno, uint32_t cap, size_t* bytes);
-hipError_t launch_seg_begin(uint32_t cap, uint32_t n_pheno, uint32_t* seg_beg, hipStream_t st);
-hipError_t launch_surv_sort(const uint32_t* surv, uint32_t* surv_sorted, const uint32_t* surv_cnt, const uint32_t* seg_beg,
-                            uint32_t* seg_end, uint32_t n_pheno, uint32_t cap, uint32_t key_bits, void* temp,
-                            size_t temp_bytes, hipStream_t st);
+// Survivor keys -> (column, row) order + each column's range (surv_sort.hip). n_slots = size of the key arrays.
+hipError_t surv_sort_temp_bytes(uint32_t n_slots, size_t* bytes);
+hipError_t launch_surv_sort(const uint32_t* keys, uint32_t* keys_sorted, uint32_t n_slots, const uint32_t* key_count,
+                            uint32_t key_cap, uint32_t n_pheno, uint32_t row_bits, uint32_t key_bits, uint32_t* off,
+                            uint32_t* cnt, void* temp, size_t temp_bytes, hipStream_t st);
 
 // --pattern_counter: append hash_presence_absence_pattern of every MAC-passing row to out[*out_count ...];
 // count_distinct_u64 sorts the collected hashes in place (device) and returns how many are distinct.

@@ -364,7 +364,7 @@ struct Slot {
     Cand* d_cand = nullptr;
     DevBuf<uint32_t> d_cnt;
     PinBuf<uint32_t> h_cnt;
-    PinBuf<uint32_t> h_surv_cnt;  // coarse filter: survivors per column (overflow check)
+    PinBuf<uint32_t> h_surv_cnt;  // coarse filter: survivors per column (overflow check), [n_pheno] = all of them
     // coarse filter: the re-score kernel's row-ordered records, written straight into mapped host memory
     PinBuf<double> so_score;
     PinBuf<uint64_t> so_kmer;
@@ -414,17 +414,20 @@ struct kgwas_scan {
     uint64_t rows_submitted = 0;  // rows handed to the GPU (replayed or still in flight)
     // coarse int8 filter (sparse phase)
     bool coarse = false;
-    uint32_t coarse_T = 0, n_kgroups = 0, coarse_all_ones = 0;  // coarse_T: most operand tiles the LDS can hold
+    uint32_t coarse_T = 0, n_kgroups = 0;  // coarse_T: most operand tiles the LDS can hold
     // Operand sets of the filter: mode[0] = one int8 slice per column (half the matrix work, ~2.5 survivors per
     // candidate), mode[1] = two slices (~1). Both may be resident; each chunk picks one (pick_coarse_mode).
     struct CoarseMode {
         bool ready = false;
         uint32_t T = 0, n_lgroups = 0, slices = 0;
+        float eg_max = 0, rall_max = 0, rmax_max = 0;  // row error term, maxima over the columns (kernels.h)
         DevBuf<int8_t> d_Bq;
         DevBuf<CoarseCol> d_cols;
     } cmode[2];
-    DevBuf<uint32_t> d_surv, d_surv_cnt;  // shared by all chunks: consumed by the re-score kernel in stream order
-    DevBuf<uint32_t> d_surv_sorted, d_seg_beg, d_seg_end;
+    // survivor keys of the chunk being filtered, their sorted copy, each column's range in it; shared by all chunks
+    // (consumed by the re-score kernel in stream order)
+    DevBuf<uint32_t> d_surv, d_surv_sorted, d_surv_cnt, d_surv_off, d_key_count;
+    uint32_t key_slots = 0;  // capacity of the key list = n_pheno * cap
     DevBuf<uint8_t> d_sort_tmp;
     uint32_t row_key_bits = 32;
     // --pattern_counter
@@ -721,11 +724,8 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
         CoarseArgs c;
         memset(&c, 0, sizeof(c));
         c.src = a.src;
-        c.dmask = a.dmask;
-        c.all_ones = s->coarse_all_ones;
         c.n_rows = n_rows;
         c.S = a.S;
-        c.W_m = a.W_m;
         c.n_pheno = a.n_pheno;
         c.min_count = a.min_count;
         c.n_kgroups = s->n_kgroups;
@@ -736,28 +736,34 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
         c.Bq = M.d_Bq.p;
         c.n_slices = M.slices;
         c.cols = M.d_cols.p;
-        c.sums = a.sums;
+        c.eg_max = M.eg_max;
+        c.rall_max = M.rall_max;
+        c.rmax_max = M.rmax_max;
         c.thr = a.thr;
-        c.surv = s->d_surv.p;
-        c.surv_cnt = s->d_surv_cnt.p;
-        c.surv_cap = s->cap;
+        c.keys = s->d_surv.p;
+        c.key_count = s->d_key_count.p;
+        c.key_cap = s->key_slots;
+        c.row_bits = s->row_key_bits;
         c.tested = a.tested;
-        KGWAS_HIP(hipMemsetAsync(s->d_surv_cnt.p, 0, s->n_pheno * sizeof(uint32_t), s->stream));
+        KGWAS_HIP(hipMemsetAsync(s->d_key_count.p, 0, sizeof(uint32_t), s->stream));
+        KGWAS_HIP(hipMemsetAsync(s->d_surv.p, 0xFF, (size_t)s->key_slots * sizeof(uint32_t), s->stream));  // sorts last
         KGWAS_HIP(launch_coarse(c, M.T, n_rows >= (1u << 20) ? 2048u : 512u, s->stream));
         KGWAS_HIP(hipEventRecord(sl.ev_mid, s->stream));
         a.tested = nullptr;  // counted by the coarse pass
-        KGWAS_HIP(launch_surv_sort(s->d_surv.p, s->d_surv_sorted.p, s->d_surv_cnt.p, s->d_seg_beg.p, s->d_seg_end.p,
-                                   (uint32_t)s->n_pheno, s->cap, s->row_key_bits, s->d_sort_tmp.p, s->d_sort_tmp.n,
-                                   s->stream));
+        KGWAS_HIP(launch_surv_sort(s->d_surv.p, s->d_surv_sorted.p, s->key_slots, s->d_key_count.p, s->key_slots,
+                                   (uint32_t)s->n_pheno, s->row_key_bits, 32, s->d_surv_off.p, s->d_surv_cnt.p,
+                                   s->d_sort_tmp.p, s->d_sort_tmp.n, s->stream));
         a.so_score = sl.d_so_score;
         a.so_kmer = sl.d_so_kmer;
         a.so_row = sl.d_so_row;
-        KGWAS_HIP(launch_rescore(a, s->d_surv_sorted.p, s->d_surv_cnt.p, s->cap, s->stream));
+        KGWAS_HIP(launch_rescore(a, s->d_surv_sorted.p, s->d_surv_off.p, s->d_surv_cnt.p, s->cap, s->row_key_bits, s->stream));
+        KGWAS_HIP(hipMemcpyAsync(sl.h_surv_cnt.p + s->n_pheno, s->d_key_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost,
+                                 s->stream));
         KGWAS_HIP(hipMemcpyAsync(sl.h_surv_cnt.p, s->d_surv_cnt.p, s->n_pheno * sizeof(uint32_t), hipMemcpyDeviceToHost,
                                  s->stream));
         s->st.score_launches++;
     } else {
-        if (s->coarse) memset(sl.h_surv_cnt.p, 0, s->n_pheno * sizeof(uint32_t));
+        if (s->coarse) memset(sl.h_surv_cnt.p, 0, (s->n_pheno + 1) * sizeof(uint32_t));
         launch_score(s, a);
     }
     KGWAS_HIP(hipEventRecord(sl.ev_k1, s->stream));
@@ -804,7 +810,8 @@ bool reap_sparse(kgwas_scan* s, Slot& sl) {
         s->st.squeeze_kernel_ms += ms;
     }
     for (uint64_t j = 0; j < s->n_pheno; j++)
-        if (sl.h_cnt.p[j] > s->cap || (s->coarse && sl.h_surv_cnt.p[j] > s->cap)) {
+        if (sl.h_cnt.p[j] > s->cap ||
+            (s->coarse && (sl.h_surv_cnt.p[j] > s->cap || sl.h_surv_cnt.p[s->n_pheno] > s->key_slots))) {
             if (s->trace) {
                 uint64_t tot = 0, mx = 0;
                 for (uint64_t q = 0; q < s->n_pheno; q++) {
@@ -1170,9 +1177,15 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
 
         s->chunk_max = p->chunk_rows ? p->chunk_rows : (8ull << 20);
         s->chunk_max = std::max<uint64_t>(128, (s->chunk_max + 127) / 128 * 128);
-        if (s->coarse) {  // the coarse kernel addresses a chunk's rows with 32-bit dword offsets
+        if (s->coarse) {  // survivor keys are (column << row_bits | row) in 32 bits, the 0xFFFFFFFF fill included
+            uint32_t pbits = 1;
+            while ((1ull << pbits) < s->n_pheno + 1) pbits++;
+            if (pbits > 22) throw Error(KGWAS_ERR_ARG, "coarse filter: too many phenotype columns for 32-bit survivor keys");
+            s->chunk_max = std::max<uint64_t>(128, std::min<uint64_t>(s->chunk_max, 1ull << (32 - pbits)));
+        }
+        if (s->coarse) {  // the coarse kernel addresses a chunk's rows with 32-bit byte offsets
             const uint64_t stride_dw = 2 * (1 + std::max<uint64_t>(s->W_f, s->W_m));
-            const uint64_t lim = ((1ull << 32) - (1ull << 20)) / stride_dw / 128 * 128;
+            const uint64_t lim = ((1ull << 32) - (1ull << 20)) / (4 * stride_dw) / 128 * 128;
             s->chunk_max = std::max<uint64_t>(128, std::min<uint64_t>(s->chunk_max, lim));
         }
         s->dense_rows = std::min<uint64_t>(16384, s->chunk_max);
@@ -1281,7 +1294,10 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
             const double gamma = nterms * u32 / (1.0 - nterms * u32);
             std::vector<int> q0(S), q1(S);
             auto up = [](double x) { return std::nextafter((float)x, std::numeric_limits<float>::infinity()); };
-            auto quantise = [&](uint64_t j, int ns, CoarseCol& cc) {
+            struct ErrBound {
+                float eg, rall, rmax;  // phenotype units, rounded up
+            };
+            auto quantise = [&](uint64_t j, int ns, CoarseCol& cc, ErrBound& eb) {
                 const double Nd = (double)S, sum = (double)sums[j];
                 const double c = sum / Nd;
                 double mx = 0, A = 0;
@@ -1313,10 +1329,10 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                 const double rho = Nd * std::fabs(Nd * c - sum) * 2.0 + 1e-9 * (1.0 + std::fabs(sum));
                 const double Eg = gamma * A * (1.0 + 1e-6) + 1e-12 * (1.0 + A);
                 cc.kalpha = (1.0 - std::ldexp(1.0, -19)) / (Nd * u);
-                cc.eg = up((Eg + rho / Nd) / u * (1.0 + 1e-6) + 1e-2);
-                cc.rall = up(std::max(rpos, rneg) / u * (1.0 + 1e-6));
-                cc.rmax = up(rmax / u * (1.0 + 1e-6));
-                cc.pad = 0.0f;
+                cc.iu = up(1.0 / u * (1.0 + 1e-6));
+                eb.eg = up((Eg + rho / Nd) * (1.0 + 1e-6) + 1e-30);
+                eb.rall = up(std::max(rpos, rneg) * (1.0 + 1e-6));
+                eb.rmax = up(rmax * (1.0 + 1e-6));
             };
             // One slice halves the matrix work but widens the bound; it is offered when, for every column, the bound
             // at N1 = S/2 stays below 15 % of the deviation of yigi a z = 4 association needs (2*sigma*sqrt(S)), so the
@@ -1324,14 +1340,14 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
             bool one_ok = true;
             for (uint64_t j = 0; j < P && one_ok; j++) {
                 CoarseCol cc;
-                quantise(j, 1, cc);
+                ErrBound eb;
+                quantise(j, 1, cc, eb);
                 double mean = 0, var = 0;
                 for (uint64_t i = 0; i < S; i++) mean += (double)s->Y[j * S + i];
                 mean /= (double)S;
                 for (uint64_t i = 0; i < S; i++) var += ((double)s->Y[j * S + i] - mean) * ((double)s->Y[j * S + i] - mean);
                 const double sigma = std::sqrt(var / (double)S);
-                const double u = 1.0 / (cc.kalpha * (double)S);  // up to the 2^-19 slack
-                const double e_half = u * ((double)cc.eg + std::min((double)cc.rall, 0.5 * (double)S * (double)cc.rmax));
+                const double e_half = (double)eb.eg + std::min((double)eb.rall, 0.5 * (double)S * (double)eb.rmax);
                 if (!(e_half <= 0.15 * 2.0 * sigma * std::sqrt((double)S))) one_ok = false;
             }
             bool want[2] = {one_ok, true};
@@ -1343,23 +1359,31 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                 if (!want[mi]) continue;
                 const int ns = mi + 1;
                 kgwas_scan::CoarseMode& M = s->cmode[mi];
-                const uint64_t tiles = (uint64_t)ns * ((P + 15) / 16);
+                // Operand columns ("slots") per LDS group: the group's share of the phenotype columns, padding, and
+                // the ones column in the last slot (its dot product is the row's masked popcount N1).
                 uint32_t Tmax = s->coarse_T;  // largest tile count whose operands fit the LDS
                 if (ns == 2) Tmax &= ~1u;
-                const uint64_t n_lgroups = (tiles + Tmax - 1) / Tmax;
-                uint32_t T = (uint32_t)((tiles + n_lgroups - 1) / n_lgroups);
-                if (ns == 2 && (T & 1u)) T++;
-                const uint32_t PG = T / (uint32_t)ns;
+                uint64_t n_lgroups = 1, cper = P;
+                uint32_t T = 0;
+                for (;; n_lgroups++) {
+                    cper = (P + n_lgroups - 1) / n_lgroups;  // phenotype columns per group
+                    T = (uint32_t)(ns * ((cper + 1 + 15) / 16));
+                    if (T <= Tmax) break;
+                }
+                const uint32_t PG = T / (uint32_t)ns, slots = PG * 16;
                 M.T = T;
                 M.slices = (uint32_t)ns;
                 M.n_lgroups = (uint32_t)n_lgroups;
                 s->st.coarse_mode_tiles[mi] = T;
                 s->st.coarse_mode_lgroups[mi] = (uint32_t)n_lgroups;
                 std::vector<int8_t> Bq(n_lgroups * n_kgroups * 8ull * T * 1024ull, 0);
-                std::vector<CoarseCol> cols(P);
-                for (uint64_t j = 0; j < P; j++) {
-                    quantise(j, ns, cols[j]);
-                    const uint64_t lg = j / (16ull * PG), pgl = (j / 16) % PG, n = j % 16;
+                std::vector<CoarseCol> cols(n_lgroups * slots);
+                for (auto& cc : cols) {
+                    memset(&cc, 0, sizeof(cc));
+                    cc.pheno = -1;
+                }
+                auto put = [&](uint64_t lg, uint64_t slot, const std::vector<int>& v0, const std::vector<int>& v1) {
+                    const uint64_t pgl = slot / 16, n = slot % 16;
                     for (uint64_t g = 0; g < n_kgroups; g++)
                         for (uint64_t jj = 0; jj < 8; jj++)
                             for (uint64_t kg = 0; kg < 4; kg++)
@@ -1368,28 +1392,44 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                                     if (smp >= S) continue;
                                     const uint64_t lane = kg * 16 + n;
                                     const uint64_t base = (((lg * n_kgroups + g) * 8 + jj) * T);
-                                    Bq[((base + ns * pgl) * 64 + lane) * 16 + e] = (int8_t)q0[smp];
-                                    if (ns == 2) Bq[((base + 2 * pgl + 1) * 64 + lane) * 16 + e] = (int8_t)q1[smp];
+                                    if (ns == 1) {
+                                        Bq[((base + pgl) * 64 + lane) * 16 + e] = (int8_t)v0[smp];
+                                    } else {
+                                        Bq[((base + 2 * pgl) * 64 + lane) * 16 + e] = (int8_t)v0[smp];
+                                        Bq[((base + 2 * pgl + 1) * 64 + lane) * 16 + e] = (int8_t)v1[smp];
+                                    }
                                 }
+                };
+                for (uint64_t j = 0; j < P; j++) {
+                    const uint64_t lg = j / cper, slot = j % cper;
+                    CoarseCol& cc = cols[lg * slots + slot];
+                    ErrBound eb;
+                    quantise(j, ns, cc, eb);
+                    M.eg_max = std::max(M.eg_max, eb.eg);
+                    M.rall_max = std::max(M.rall_max, eb.rall);
+                    M.rmax_max = std::max(M.rmax_max, eb.rmax);
+                    cc.pheno = (int32_t)j;
+                    put(lg, slot, q0, q1);
+                }
+                {  // ones column: Dc = N1 (one slice: q0 = 1; two slices: Dc = 254*D0 + D1 with q0 = 0, q1 = 1)
+                    std::vector<int> ones(S, 1), zeros(S, 0);
+                    for (uint64_t lg = 0; lg < n_lgroups; lg++) put(lg, slots - 1, ns == 1 ? ones : zeros, ones);
                 }
                 M.d_Bq.alloc(Bq.size());
-                M.d_cols.alloc(P);
+                M.d_cols.alloc(cols.size());
                 KGWAS_HIP(hipMemcpy(M.d_Bq.p, Bq.data(), Bq.size(), hipMemcpyHostToDevice));
-                KGWAS_HIP(hipMemcpy(M.d_cols.p, cols.data(), P * sizeof(CoarseCol), hipMemcpyHostToDevice));
+                KGWAS_HIP(hipMemcpy(M.d_cols.p, cols.data(), cols.size() * sizeof(CoarseCol), hipMemcpyHostToDevice));
                 M.ready = true;
             }
-            bool ones = (s->direct ? 2 * s->W_f : 2 * W_m) <= 2 * W_m;
-            for (uint32_t v : dmask) ones = ones && (v == 0xFFFFFFFFu);
-            s->coarse_all_ones = ones ? 1u : 0u;
-            s->d_surv.alloc((uint64_t)s->cap * P);
+            s->key_slots = (uint32_t)std::min<uint64_t>((uint64_t)s->cap * P, 0x7FFFFFFFull);
+            s->d_surv.alloc(s->key_slots);
+            s->d_surv_sorted.alloc(s->key_slots);
             s->d_surv_cnt.alloc(P);
-            s->d_surv_sorted.alloc((uint64_t)s->cap * P);
-            s->d_seg_beg.alloc(P);
-            s->d_seg_end.alloc(P);
+            s->d_surv_off.alloc(P);
+            s->d_key_count.alloc(1);
             size_t tb = 0;
-            KGWAS_HIP(surv_sort_temp_bytes((uint32_t)P, s->cap, &tb));
+            KGWAS_HIP(surv_sort_temp_bytes(s->key_slots, &tb));
             s->d_sort_tmp.alloc(std::max<size_t>(tb, 16));
-            KGWAS_HIP(launch_seg_begin(s->cap, (uint32_t)P, s->d_seg_beg.p, s->stream));
             s->row_key_bits = 1;
             while (s->row_key_bits < 32 && (1ull << s->row_key_bits) < s->chunk_max) s->row_key_bits++;
         }
@@ -1415,8 +1455,8 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
             }
             sl.d_cnt.alloc(P);
             sl.h_cnt.alloc(P);
-            sl.h_surv_cnt.alloc(P);
-            memset(sl.h_surv_cnt.p, 0, P * sizeof(uint32_t));
+            sl.h_surv_cnt.alloc(P + 1);
+            memset(sl.h_surv_cnt.p, 0, (P + 1) * sizeof(uint32_t));
             sl.d_tested.alloc(1);
             sl.h_tested.alloc(1);
             KGWAS_HIP(hipEventCreate(&sl.ev_sq0));

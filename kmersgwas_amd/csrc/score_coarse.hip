@@ -29,6 +29,17 @@
 // each expanded operand feeds T column tiles, each B operand (ds_read_b128) four row tiles.
 #include "score_common.h"
 
+#ifndef KGWAS_COARSE_PF
+#define KGWAS_COARSE_PF 0  // 0: load each unit when it starts, 1: prefetch the next sample group, 2: also across passes
+#endif                     // (measured: 12.3 / 12.5 / 13.4 ms per pass of one-slice launches; 1 and 2 cost registers)
+#define COARSE_SBUF 2048u  // survivor keys a block buffers in LDS
+#ifndef KGWAS_COARSE_PHASES
+#define KGWAS_COARSE_PHASES 1  // pin the per-step order: LDS reads, operand expansion, MFMAs
+#endif
+#ifndef KGWAS_COARSE_ABLATE
+#define KGWAS_COARSE_ABLATE 0  // timing experiments only (wrong results): 1 no test, 2 no expansion, 4 no LDS reads, 8 no row loads
+#endif
+
 namespace kgwas {
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -49,16 +60,22 @@ __device__ __forceinline__ i32x4 expand16(uint32_t x) {
 // The conservative test. The host centres the quantisation at c = sum/N (sum = the reference's float32 sum), so
 //   r_c = N*yc - N1*sum = N*u*Dc            Dc = D0 (one slice) or 254*D0 + D1 (two slices, s0 = 254*s1), u = s0 or s1,
 // an exact integer times a column constant. A pair can only have score_ref > thr if
-//   |Dc| >= alpha_p * sqrt(d(N1)) - e_p(N1),    alpha_p = sqrt(thr_p)/(N*u),  e_p(N1) = (Eg + min(Rall, N1*rmax))/u
-// (score_coarse.hip header for Eg, Rall, rmax). The right-hand side is evaluated in float32 from constants the host
-// rounded in the safe direction (alpha down by 2^-19 relative, sqrt(d) down by 2^-20, the error terms up, plus an
-// absolute pad), which dominates the float32 rounding of the three operations: the computed limit never exceeds the
-// true one, so no possible candidate is dropped. 8 cheap lane-ops per pair instead of 14 double-precision ones.
+//   |Dc| >= alpha_p * sqrt(d(N1)) - E(N1)/u_p,    alpha_p = sqrt(thr_p)/(N*u_p),  E(N1) = Eg + min(Rall, N1*rmax)
+// with Eg, Rall, rmax (header) taken as their maxima over all columns, so E is a per-ROW term (permutation columns
+// share them anyway). The right-hand side is evaluated in float32 from constants the host rounded in the safe
+// direction (alpha down by 2^-19 relative, sqrt(d) down by 2^-20, E and 1/u up by 1e-6), which dominates the
+// float32 rounding of the three operations: the computed limit never exceeds the true one, so no possible
+// candidate is dropped. 5 cheap lane-ops per pair instead of 14 double-precision ones.
+//
+// N1 comes out of the matrix pipe as well: the last operand column of every LDS group holds 1 for each phenotyped
+// sample (0 elsewhere), so its dot product IS the masked popcount - no masks, no popcounts, no mask loads in the
+// main loop, and bits of unphenotyped samples or row padding meet zeros in every operand column.
 template <int T, int NS>
 __global__ void __launch_bounds__(512) coarse_kernel(CoarseArgs a, uint32_t rows_per_block, uint32_t n_rowblocks) {
-    extern __shared__ i32x4 blds[];  // [n_kgroups][8][T][64] x 16 bytes, then float colc[4][PG*16]
+    extern __shared__ i32x4 blds[];  // [n_kgroups][8][T][64] x 16 bytes, colc[3][PG*16] (alpha, 1/u, column index), survivor buffer
     constexpr int PG = T / NS;       // column groups (of 16) per LDS group
     constexpr int RT = 4;
+    constexpr int SLOTS = PG * 16;
     const uint32_t rb = blockIdx.x;
     if (rb >= n_rowblocks) return;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -66,9 +83,21 @@ __global__ void __launch_bounds__(512) coarse_kernel(CoarseArgs a, uint32_t rows
     const uint32_t n_kgroups = a.n_kgroups;
     const uint32_t group_vec = n_kgroups * 8u * T * 64u;  // i32x4 elements per LDS group
     float* colc = reinterpret_cast<float*>(blds + group_vec);
+    const int* colp = reinterpret_cast<const int*>(colc + 2 * SLOTS);
+    // Survivors are keys (column << row_bits | chunk-local row). A block collects them in LDS and appends them to the
+    // global list with ONE atomic at its end (per-column counters bumped once per wave pass were ~9e5 device-scope
+    // atomics per launch on ~100 addresses: they serialise at the memory side and cost more than the MFMAs).
+    uint32_t* sctl = reinterpret_cast<uint32_t*>(colc + 3 * SLOTS);  // [0] reserved, [1] start of the first reservation that did not fit, [2] global base, [3] n
+    uint32_t* sbuf = sctl + 4;
+    if (threadIdx.x == 0) {
+        sctl[0] = 0u;
+        sctl[1] = 0xFFFFFFFFu;
+    }
     const uint32_t rows_per_pass = (blockDim.x >> 6) * (RT * 16u);
     const uint64_t blk_row0 = (uint64_t)rb * rows_per_block;
     const float Nf = (float)a.S;
+    const char* rows_base = reinterpret_cast<const char*>(a.src.base);
+    const uint32_t avail_b = a.src.avail_dw * 4u;
     uint32_t tested_local = 0;
 
     for (uint32_t lg = 0; lg < a.n_lgroups; lg++) {
@@ -76,181 +105,245 @@ __global__ void __launch_bounds__(512) coarse_kernel(CoarseArgs a, uint32_t rows
         {
             const i32x4* src = reinterpret_cast<const i32x4*>(a.Bq) + (size_t)lg * group_vec;
             for (uint32_t i = threadIdx.x; i < group_vec; i += blockDim.x) blds[i] = src[i];
-            if (threadIdx.x < PG * 16u) {
-                const uint32_t p = lg * (PG * 16u) + threadIdx.x;
-                float al = __builtin_huge_valf(), eg = 0.0f, ra = 0.0f, rm = 0.0f;  // padding column: nothing survives
-                if (p < a.n_pheno) {
-                    const CoarseCol cc = a.cols[p];
-                    al = (float)(sqrt(a.thr[p]) * cc.kalpha);  // NaN threshold (frozen column) -> NaN -> nothing survives
-                    eg = cc.eg;
-                    ra = cc.rall;
-                    rm = cc.rmax;
-                }
+            if (threadIdx.x < SLOTS) {
+                const CoarseCol cc = a.cols[lg * SLOTS + threadIdx.x];
+                float al = __builtin_huge_valf();  // padding / N1 column: nothing survives
+                if (cc.pheno >= 0) al = (float)(sqrt(a.thr[cc.pheno]) * cc.kalpha);  // NaN threshold (frozen column) -> NaN -> nothing survives
                 colc[threadIdx.x] = al;
-                colc[PG * 16u + threadIdx.x] = eg;
-                colc[2u * PG * 16u + threadIdx.x] = ra;
-                colc[3u * PG * 16u + threadIdx.x] = rm;
+                colc[SLOTS + threadIdx.x] = cc.iu;
+                reinterpret_cast<int*>(colc + 2 * SLOTS)[threadIdx.x] = cc.pheno;
             }
         }
         __syncthreads();
 
-        for (uint32_t ps = 0; ps * rows_per_pass < rows_per_block; ps++) {
-            const uint64_t rbase = blk_row0 + (uint64_t)ps * rows_per_pass + wave * (RT * 16u);
-            if (rbase >= a.n_rows) break;  // wave-uniform
-            // 32-bit dword offsets from the (uniform) base: launch_coarse guarantees n_rows * stride < 2^32
-            uint32_t ro[RT];
+        // piece[rt][q] = dword q of this lane's 16 bytes of row tile rt for the current (pass, sample group) unit
+        // (bytes 64g + 16kg .. +15 of the row's bits; zero beyond its data). The pieces of the NEXT unit - the next
+        // sample group, or group 0 of the wave's next 64 rows - are fetched into the same registers as soon as the
+        // current unit has expanded them (first half after step 3, second half after step 7): ~4 steps (2000 cycles)
+        // ahead of their use, and across the epilogue, which two waves per SIMD could not hide otherwise.
+        uint32_t piece[RT][4];
+        uint32_t ro[RT];  // 32-bit byte offsets (launch_coarse guarantees the chunk spans < 4 GiB) of the rows to fetch next
+        auto set_rows = [&](uint64_t rb0) {
 #pragma unroll
             for (int rt = 0; rt < RT; rt++) {
-                uint64_t r = rbase + rt * 16u + m;
+                uint64_t r = rb0 + rt * 16u + m;
                 if (r >= a.n_rows) r = a.n_rows - 1;
-                ro[rt] = (uint32_t)r * (uint32_t)a.src.stride_dw + a.src.off_dw;
+                ro[rt] = ((uint32_t)r * (uint32_t)a.src.stride_dw + a.src.off_dw + 4u * kg) * 4u;
+            }
+        };
+        auto load_half = [&](uint32_t g, int h) {
+            const uint32_t b0 = 64u * g + 8u * h;  // + 16*kg is part of ro
+#pragma unroll
+            for (int rt = 0; rt < RT; rt++) {
+                uint2 v = make_uint2(0u, 0u);
+                if ((KGWAS_COARSE_ABLATE & 8) == 0 && b0 + 16u * kg + 8u <= avail_b)
+                    v = *reinterpret_cast<const uint2*>(rows_base + (ro[rt] + b0));
+                if (KGWAS_COARSE_ABLATE & 8) v = make_uint2(ro[rt] + b0, lane * 2654435761u);
+                piece[rt][2 * h] = v.x;
+                piece[rt][2 * h + 1] = v.y;
+            }
+        };
+        const uint64_t wave_row0 = blk_row0 + wave * (RT * 16u);
+        if (KGWAS_COARSE_PF == 2 && wave_row0 < a.n_rows) {
+            set_rows(wave_row0);
+            load_half(0, 0);
+            load_half(0, 1);
+        }
+
+        for (uint32_t ps = 0; ps * rows_per_pass < rows_per_block; ps++) {
+            const uint64_t rbase = wave_row0 + (uint64_t)ps * rows_per_pass;
+            if (rbase >= a.n_rows) break;  // wave-uniform
+            const uint64_t rnext = rbase + rows_per_pass;
+            const bool next_pass = (KGWAS_COARSE_PF == 2) && ((ps + 1) * rows_per_pass < rows_per_block) && (rnext < a.n_rows);  // wave-uniform
+            if (KGWAS_COARSE_PF < 2) {
+                set_rows(rbase);
+                load_half(0, 0);
+                load_half(0, 1);
             }
             i32x4 acc[RT][T];
 #pragma unroll
             for (int rt = 0; rt < RT; rt++)
 #pragma unroll
                 for (int t = 0; t < T; t++) acc[rt][t] = (i32x4){0, 0, 0, 0};
-            uint32_t n1p[RT] = {0u, 0u, 0u, 0u};
 
             for (uint32_t g = 0; g < n_kgroups; g++) {
-                // this lane's 16 bytes of each row: dwords 16g + 4kg .. +3 (zero beyond the row's data, masked)
-                uint32_t piece[RT][4];
-                const uint32_t d0 = 16u * g + 4u * kg;
-#pragma unroll
-                for (int rt = 0; rt < RT; rt++) {
-#pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        uint2 v = make_uint2(0u, 0u);
-                        if (d0 + 2u * h + 1u < a.src.avail_dw)
-                            v = *reinterpret_cast<const uint2*>(a.src.base + (ro[rt] + d0 + 2u * h));
-                        piece[rt][2 * h] = v.x;
-                        piece[rt][2 * h + 1] = v.y;
-                    }
-                }
-                if (!a.all_ones) {
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const uint32_t mk = (d0 + q < 2u * a.W_m) ? a.dmask[d0 + q] : 0u;
-#pragma unroll
-                        for (int rt = 0; rt < RT; rt++) piece[rt][q] &= mk;
-                    }
-                }
-#pragma unroll
-                for (int rt = 0; rt < RT; rt++)
-                    n1p[rt] += __popc(piece[rt][0]) + __popc(piece[rt][1]) + __popc(piece[rt][2]) + __popc(piece[rt][3]);
-
+                const bool last_g = g + 1 == n_kgroups;
+                const bool fetch = (KGWAS_COARSE_PF >= 1) && (!last_g || next_pass);  // is there a next unit (wave-uniform)
+                const uint32_t gn = last_g ? 0u : g + 1u;
                 const i32x4* bg = blds + (size_t)g * 8u * T * 64u + lane;
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    i32x4 A[RT];
-#pragma unroll
-                    for (int rt = 0; rt < RT; rt++) A[rt] = expand16((piece[rt][j >> 1] >> ((j & 1) * 16)) & 0xFFFFu);
+                    if (KGWAS_COARSE_PF == 0 && j == 0 && g > 0) {
+                        load_half(g, 0);
+                        load_half(g, 1);
+                    }
+                    // Phase order per step: all B operands of the step are requested from LDS first, the A operands are
+                    // expanded while those reads are in flight, then the T x 4 MFMAs issue back to back (the wave's
+                    // partner on the SIMD runs its own load/expand phase underneath them).
+                    i32x4 B[T];
 #pragma unroll
                     for (int t = 0; t < T; t++) {
-                        const i32x4 B = bg[(j * T + t) * 64];
+                        if (KGWAS_COARSE_ABLATE & 4)
+                            B[t] = (i32x4){(int)lane, t, j, (int)g};
+                        else
+                            B[t] = bg[(j * T + t) * 64];
+                    }
+#if KGWAS_COARSE_PHASES
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
+                    i32x4 A[RT];
+#pragma unroll
+                    for (int rt = 0; rt < RT; rt++) {
+                        if (KGWAS_COARSE_ABLATE & 2)
+                            A[rt] = (i32x4){(int)piece[rt][0], (int)piece[rt][1], (int)piece[rt][2], (int)piece[rt][3] + j};
+                        else
+                            A[rt] = expand16((piece[rt][j >> 1] >> ((j & 1) * 16)) & 0xFFFFu);
+                    }
+                    if (j == 3 && fetch) {  // dwords 0,1 served j = 0..3
+                        if (last_g) set_rows(rnext);
+                        load_half(gn, 0);
+                    }
+                    if (j == 7 && fetch) load_half(gn, 1);  // dwords 2,3 served j = 4..7
+#if KGWAS_COARSE_PHASES
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+                    for (int t = 0; t < T; t++) {
 #pragma unroll
                         for (int rt = 0; rt < RT; rt++)
-                            acc[rt][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[rt], B, acc[rt][t], 0, 0, 0);
+                            acc[rt][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[rt], B[t], acc[rt][t], 0, 0, 0);
                     }
+#if KGWAS_COARSE_PHASES
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
                 }
             }
 
-            // N1 of each row: the four kg lanes hold disjoint pieces.
-            uint32_t n1[RT];
-#pragma unroll
-            for (int rt = 0; rt < RT; rt++) {
-                uint32_t v = n1p[rt];
-                v += __shfl_xor(v, 16);
-                v += __shfl_xor(v, 32);
-                n1[rt] = v;
-            }
-            if (lg == 0 && kg == 0) {
-#pragma unroll
-                for (int rt = 0; rt < RT; rt++) {
-                    const uint64_t r = rbase + rt * 16u + m;
-                    if (r < a.n_rows && a.S >= a.min_count && n1[rt] >= a.min_count && n1[rt] <= a.S - a.min_count)
-                        tested_local++;
-                }
-            }
             // Per-row terms of the 16 rows whose accumulator registers this lane holds (row kg*4+jj of tile rt):
-            // N1, sqrt(d) rounded down, and whether the row exists and passes the MAC filter.
-            float n1f[RT * 4], sqd[RT * 4];
-            uint32_t rowok = 0;
-#pragma unroll
-            for (int rt = 0; rt < RT; rt++) {
-#pragma unroll
-                for (int jj = 0; jj < 4; jj++) {
-                    const uint32_t trow = kg * 4u + jj;
-                    const uint32_t n1r = __shfl(n1[rt], (int)trow);
-                    const uint64_t r = rbase + rt * 16u + trow;
-                    if ((r < a.n_rows) && (a.S >= a.min_count) && (n1r >= a.min_count) && (n1r <= a.S - a.min_count))
-                        rowok |= 1u << (rt * 4 + jj);
-                    const float f = (float)n1r;
-                    n1f[rt * 4 + jj] = f;
-                    sqd[rt * 4 + jj] = __builtin_sqrtf(f * (Nf - f)) * 0.99999905f;  // d < 2^24 is exact; (1 - 2^-20)
-                }
-            }
-            // A lane holds 16 (row, column p) pairs per column group, and the four kg lanes of one m share the
-            // column: survivors are counted over those 64 pairs first and the column's counter is bumped once
-            // (early chunks have ~1e6 survivors on ~100 counters; one atomic per survivor serialises in the L2).
-#pragma unroll
-            for (int g = 0; g < PG; g++) {
-                const uint32_t p = (lg * PG + g) * 16u + m;
-                const float al = colc[g * 16 + m], eg = colc[PG * 16 + g * 16 + m], ra = colc[2 * PG * 16 + g * 16 + m],
-                            rm = colc[3 * PG * 16 + g * 16 + m];
-                uint32_t mbits = 0;
+            // N1 from the ones column (slot 15 of the last column group: lane kg*16+15 holds it for these rows),
+            // sqrt(d) rounded down (+inf for a row that does not exist or fails the MAC filter: nothing survives),
+            // and the row's error term E(N1) rounded up.
+            float sqd[RT * 4], er[RT * 4];
+            {
+                const uint64_t left = a.n_rows - rbase;
+                const uint32_t rows_here = left < 64u ? (uint32_t)left : 64u;
+                const bool mac_any = a.S >= 2u * a.min_count;  // else no N1 can satisfy mc <= N1 <= S - mc
+                const uint32_t span = a.S - 2u * a.min_count;
+                uint32_t n_ok = 0;
 #pragma unroll
                 for (int i = 0; i < RT * 4; i++) {
+                    const int rt = i >> 2, jj = i & 3;
+                    const uint32_t n1r = (uint32_t)__shfl(acc[rt][T - 1][jj], (int)(kg * 16u + 15u));
+                    const bool ok = mac_any & ((uint32_t)(rt * 16 + jj) + kg * 4u < rows_here) & ((n1r - a.min_count) <= span);
+                    n_ok += ok ? 1u : 0u;
+                    const float f = (float)n1r;
+                    const float sq = __builtin_amdgcn_sqrtf(f * (Nf - f)) * 0.99999905f;  // d < 2^24 is exact; 1 ulp sqrt; (1 - 2^-20)
+                    sqd[i] = ok ? sq : __builtin_huge_valf();
+                    er[i] = (a.eg_max + fminf(a.rall_max, f * a.rmax_max)) * 1.000001f;
+                    if (KGWAS_COARSE_ABLATE & 16) {
+                        sqd[i] = 1000.0f + i;
+                        er[i] = 1.0f;
+                    }
+                }
+                if (lg == 0 && m == 15u) tested_local += n_ok;  // the four m = 15 lanes cover the wave's 64 rows
+            }
+            // A lane holds 16 (row, column) pairs per column group; the four kg lanes of one m share the column.
+            // All groups are tested first; then, if the wave has survivors at all, each column's list counter is bumped
+            // ONCE for the 64 pairs the wave holds for it, all the (returning) atomics are issued back to back, and
+            // only then are the rows written: one L2 round trip per wave pass instead of one per group (that was 55 %
+            // of the kernel), and no atomic per survivor (which serialised the early chunks in the L2).
+            uint32_t mb[PG];
+            uint32_t any_bits = 0;
+#pragma unroll
+            for (int g = 0; g < PG; g++) {
+                const float al = colc[g * 16 + m], iu = colc[SLOTS + g * 16 + m];
+                uint32_t mbits = 0;
+#pragma unroll
+                for (int i = RT * 4 - 1; i >= 0; i--) {
                     int dc = acc[i >> 2][NS * g][i & 3];
                     if (NS == 2) dc = dc * 254 + acc[i >> 2][NS * g + NS - 1][i & 3];
-                    const float lim = fmaf(al, sqd[i], -eg) - fminf(ra, n1f[i] * rm);
-                    if (fabsf((float)dc) >= lim) mbits |= 1u << i;
+                    const float lim = fmaf(al, sqd[i], -(iu * er[i]));
+                    mbits = (mbits << 1) | ((fabsf((float)dc) >= lim) ? 1u : 0u);
                 }
-                mbits &= rowok;
-                if (__any(mbits != 0u)) {  // wave-uniform
-                    const uint32_t cnt = __popc(mbits);
-                    const uint32_t c0 = __shfl(cnt, (int)m), c1 = __shfl(cnt, (int)(m + 16u)), c2 = __shfl(cnt, (int)(m + 32u)),
-                                   c3 = __shfl(cnt, (int)(m + 48u));
-                    const uint32_t total = c0 + c1 + c2 + c3;
-                    uint32_t base = 0;
-                    if (kg == 0 && total) base = atomicAdd(&a.surv_cnt[p], total);
-                    base = __shfl(base, (int)m);
-                    uint32_t slot = base + (kg > 0 ? c0 : 0u) + (kg > 1 ? c1 : 0u) + (kg > 2 ? c2 : 0u);
+                if (KGWAS_COARSE_ABLATE & 1) mbits = (acc[0][NS * g][0] == 0x7fffffff) ? 1u : 0u;  // keeps the accumulators alive
+                mb[g] = mbits;
+                any_bits |= mbits;
+            }
+            if (KGWAS_COARSE_ABLATE & 32) any_bits = (any_bits == 0x12345678u) ? 1u : 0u;
+            if ((KGWAS_COARSE_ABLATE & 128) && lane == 0 && any_bits) atomicAdd(&sctl[0], 0u);
+            if (!(KGWAS_COARSE_ABLATE & 128) && __any(any_bits != 0u)) {  // wave-uniform
+                uint32_t lane_cnt = 0;
+#pragma unroll
+                for (int g = 0; g < PG; g++) lane_cnt += __popc(mb[g]);
+                uint32_t incl = lane_cnt;  // inclusive scan over the wave
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t t = __shfl_up(incl, d);
+                    if ((int)lane >= d) incl += t;
+                }
+                const uint32_t total = __shfl(incl, 63);
+                uint32_t wbase = 0;
+                if (lane == 0) wbase = atomicAdd(&sctl[0], total);  // LDS
+                wbase = __shfl(wbase, 0);
+                const bool fits = wbase + total <= COARSE_SBUF;  // wave-uniform
+                uint32_t gb = 0;
+                if (!fits) {  // dense survivors (ramp chunks): this wave appends to the global list itself
+                    if (lane == 0) {
+                        atomicMin(&sctl[1], wbase);
+                        gb = atomicAdd(a.key_count, total);
+                    }
+                    gb = __shfl(gb, 0);
+                }
+                uint32_t k = (fits ? wbase : gb) + (incl - lane_cnt);
+#pragma unroll
+                for (int g = 0; g < PG; g++) {
+                    uint32_t mbits = (KGWAS_COARSE_ABLATE & 64) ? 0u : mb[g];
+                    const uint32_t pk = (uint32_t)colp[g * 16 + m] << a.row_bits;  // column >= 0 wherever a bit is set
                     while (mbits) {
                         const uint32_t b = __ffs(mbits) - 1u;
                         mbits &= mbits - 1u;
-                        const uint64_t r = rbase + (b >> 2) * 16u + kg * 4u + (b & 3u);
-                        if (slot < a.surv_cap) a.surv[(uint64_t)p * a.surv_cap + slot] = (uint32_t)r;
-                        slot++;
+                        const uint32_t key = pk | (uint32_t)(rbase + (b >> 2) * 16u + kg * 4u + (b & 3u));
+                        if (fits)
+                            sbuf[k] = key;
+                        else if (k < a.key_cap)
+                            a.keys[k] = key;
+                        k++;
                     }
                 }
             }
         }
     }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t n = sctl[0] < sctl[1] ? sctl[0] : sctl[1];
+        sctl[3] = n;
+        sctl[2] = n ? atomicAdd(a.key_count, n) : 0u;
+    }
+    __syncthreads();
+    {
+        const uint32_t n = sctl[3], gb = sctl[2];
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
+            if (gb + i < a.key_cap) a.keys[gb + i] = sbuf[i];
+    }
     if (a.tested) {
         uint32_t v = tested_local;
-        v += __shfl_xor(v, 1);
-        v += __shfl_xor(v, 2);
-        v += __shfl_xor(v, 4);
-        v += __shfl_xor(v, 8);
-        if (lane == 0 && v) atomicAdd(a.tested, (unsigned long long)v);
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (lane == 15u && v) atomicAdd(a.tested, (unsigned long long)v);
     }
 }
 
 // Exact re-scoring of the survivors of one phenotype column (blockIdx.y), one lane per survivor.
 // Same arithmetic as score_valu_kernel: the reference's select-and-add chains, then finish_pair.
-__global__ void __launch_bounds__(256) rescore_kernel(ScoreArgs a, const uint32_t* surv, const uint32_t* surv_cnt,
-                                                      uint32_t surv_cap) {
+__global__ void __launch_bounds__(256) rescore_kernel(ScoreArgs a, const uint32_t* keys, const uint32_t* surv_off,
+                                                      const uint32_t* surv_cnt, uint32_t surv_cap, uint32_t row_mask) {
     const uint32_t p = blockIdx.y;
-    uint32_t n = surv_cnt[p];
-    if (n > surv_cap) {
-        if (a.so_score) return;  // overflow: the list was not sorted; the host redoes this chunk
-        n = surv_cap;
-    }
+    const uint32_t n = surv_cnt[p];
+    if (n > surv_cap) return;  // overflow: the host redoes this chunk
     if (blockIdx.x * 256u >= n) return;  // block-uniform
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     const bool valid = i < n;
-    const uint64_t r = surv[(uint64_t)p * surv_cap + (valid ? i : 0u)];
+    const uint64_t r = keys[surv_off[p] + (valid ? i : 0u)] & row_mask;
     const uint32_t* rp = a.src.base + r * a.src.stride_dw + a.src.off_dw;
     const uint32_t L = 64u * a.W_m;
     const uint32_t nblk = a.W_m / 2u;
@@ -291,8 +384,8 @@ __global__ void __launch_bounds__(256) rescore_kernel(ScoreArgs a, const uint32_
     a.so_row[o] = (uint32_t)r;
 }
 
-// B operands of one LDS group + the group's per-column float constants (4 x up to 128 floats)
-size_t coarse_lds_bytes(uint32_t n_kgroups, uint32_t T) { return (size_t)n_kgroups * 8u * T * 1024u + 2048u; }
+// B operands of one LDS group + the group's per-column constants (3 x up to 128 words) + the block's survivor buffer
+size_t coarse_lds_bytes(uint32_t n_kgroups, uint32_t T) { return (size_t)n_kgroups * 8u * T * 1024u + 1536u + 16u + 4u * COARSE_SBUF; }
 
 template <int T, int NS>
 static hipError_t launch_coarse_t(const CoarseArgs& a, uint32_t rows_per_block, uint32_t n_rowblocks, size_t lds,
@@ -311,10 +404,15 @@ hipError_t launch_coarse(const CoarseArgs& a, uint32_t T, uint32_t rows_per_bloc
     const size_t lds = coarse_lds_bytes(a.n_kgroups, T);
     if (lds > 160u * 1024u) return hipErrorInvalidValue;
     const uint32_t threads = 512;
-    if (a.n_rows * a.src.stride_dw + a.src.off_dw + a.src.avail_dw >= (1ull << 32)) return hipErrorInvalidValue;  // 32-bit row offsets
+    if ((a.n_rows * a.src.stride_dw + a.src.off_dw + a.src.avail_dw) * 4ull >= (1ull << 32)) return hipErrorInvalidValue;  // 32-bit byte offsets
     const uint32_t rpp = (threads >> 6) * 64u;
     rows_per_block = (rows_per_block + rpp - 1) / rpp * rpp;
     const uint32_t n_rowblocks = (uint32_t)((a.n_rows + rows_per_block - 1) / rows_per_block);
+#ifdef KGWAS_COARSE_BENCH_ONLY  // experiments: only the two shapes of the 1024 x 101 bench (fast compiles)
+    if (a.n_slices == 1 && T == 7) return launch_coarse_t<7, 1>(a, rows_per_block, n_rowblocks, lds, st);
+    if (a.n_slices == 2 && T == 8) return launch_coarse_t<8, 2>(a, rows_per_block, n_rowblocks, lds, st);
+    return hipErrorInvalidValue;
+#else
     if (a.n_slices == 1) {
         switch (T) {
             case 1: return launch_coarse_t<1, 1>(a, rows_per_block, n_rowblocks, lds, st);
@@ -335,12 +433,15 @@ hipError_t launch_coarse(const CoarseArgs& a, uint32_t T, uint32_t rows_per_bloc
         }
     }
     return hipErrorInvalidValue;
+#endif
 }
 
-hipError_t launch_rescore(const ScoreArgs& a, const uint32_t* surv, const uint32_t* surv_cnt, uint32_t surv_cap,
-                          hipStream_t st) {
+hipError_t launch_rescore(const ScoreArgs& a, const uint32_t* keys, const uint32_t* surv_off, const uint32_t* surv_cnt,
+                          uint32_t surv_cap, uint32_t row_bits, hipStream_t st) {
     if (a.n_pheno == 0 || surv_cap == 0) return hipSuccess;
-    hipLaunchKernelGGL(rescore_kernel, dim3((surv_cap + 255u) / 256u, a.n_pheno), dim3(256), 0, st, a, surv, surv_cnt, surv_cap);
+    const uint32_t row_mask = row_bits >= 32 ? 0xFFFFFFFFu : ((1u << row_bits) - 1u);
+    hipLaunchKernelGGL(rescore_kernel, dim3((surv_cap + 255u) / 256u, a.n_pheno), dim3(256), 0, st, a, keys, surv_off, surv_cnt,
+                       surv_cap, row_mask);
     return hipGetLastError();
 }
 

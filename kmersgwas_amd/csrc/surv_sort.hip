@@ -1,10 +1,10 @@
-// surv_sort.hip — put the coarse filter's survivor lists in row order on the device.
+// surv_sort.hip — put the coarse filter's survivor keys in (column, row) order on the device.
 //
 // BestAssociationsHeap::add_association (src/best_associations_heap.cpp:43-59) is order dependent, so the
-// host replays a column's candidates in file-row order. The coarse kernel appends survivors with atomics
-// (arbitrary order); sorting the chunk-local row indices here (one segment per phenotype column, keys are
-// distinct) lets the re-score kernel emit its records already ordered, with coalesced writes, and the host
-// replay becomes a single forward scan.
+// host replays a column's candidates in file-row order. The coarse kernel appends keys
+// (column << row_bits | chunk-local row) to one global list in arbitrary order; one radix sort of the list
+// groups them by column and orders them by row, a tiny kernel finds each column's range, and the re-score kernel
+// then emits its records already ordered, with coalesced writes: the host replay is a single forward scan.
 #include <hipcub/hipcub.hpp>
 
 #include "kernels.h"
@@ -12,42 +12,48 @@
 namespace kgwas {
 
 namespace {
-__global__ void seg_end_kernel(const uint32_t* cnt, uint32_t cap, uint32_t n_pheno, uint32_t* seg_end) {
+// off[p] = first sorted key of column p, cnt[p] = how many (keys beyond n_keys are the 0xFFFFFFFF fill).
+__global__ void surv_ranges_kernel(const uint32_t* keys, uint32_t n_slots, const uint32_t* key_count, uint32_t key_cap,
+                                   uint32_t n_pheno, uint32_t row_bits, uint32_t* off, uint32_t* cnt) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pheno) return;
-    const uint32_t n = cnt[p];
-    seg_end[p] = p * cap + (n > cap ? 0u : n);  // an overflowing list is redone by the host anyway: skip it
-}
-__global__ void seg_begin_kernel(uint32_t cap, uint32_t n_pheno, uint32_t* seg_beg) {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < n_pheno) seg_beg[p] = p * cap;
+    uint32_t n = *key_count;
+    if (n > key_cap) n = key_cap;  // the list overflowed: the host redoes the chunk (it reads key_count too)
+    if (n > n_slots) n = n_slots;
+    auto lower = [&](uint64_t v) {  // first index with key >= v
+        uint32_t lo = 0, hi = n;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((uint64_t)keys[mid] < v) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    };
+    const uint32_t a = lower((uint64_t)p << row_bits), b = lower((uint64_t)(p + 1) << row_bits);
+    off[p] = a;
+    cnt[p] = b - a;
 }
 }  // namespace
 
-hipError_t surv_sort_temp_bytes(uint32_t n_pheno, uint32_t cap, size_t* bytes) {
+hipError_t surv_sort_temp_bytes(uint32_t n_slots, size_t* bytes) {
     *bytes = 0;
     const uint32_t* kin = nullptr;
     uint32_t* kout = nullptr;
-    const uint32_t* off = nullptr;
-    return hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, *bytes, kin, kout, (int)((uint64_t)n_pheno * cap),
-                                                      (int)n_pheno, off, off, 0, 32, 0);
+    return hipcub::DeviceRadixSort::SortKeys(nullptr, *bytes, kin, kout, (int)n_slots, 0, 32, 0);
 }
 
-hipError_t launch_seg_begin(uint32_t cap, uint32_t n_pheno, uint32_t* seg_beg, hipStream_t st) {
-    hipLaunchKernelGGL(seg_begin_kernel, dim3((n_pheno + 255u) / 256u), dim3(256), 0, st, cap, n_pheno, seg_beg);
-    return hipGetLastError();
-}
-
-hipError_t launch_surv_sort(const uint32_t* surv, uint32_t* surv_sorted, const uint32_t* surv_cnt, const uint32_t* seg_beg,
-                            uint32_t* seg_end, uint32_t n_pheno, uint32_t cap, uint32_t key_bits, void* temp,
-                            size_t temp_bytes, hipStream_t st) {
-    hipLaunchKernelGGL(seg_end_kernel, dim3((n_pheno + 255u) / 256u), dim3(256), 0, st, surv_cnt, cap, n_pheno, seg_end);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
+hipError_t launch_surv_sort(const uint32_t* keys, uint32_t* keys_sorted, uint32_t n_slots, const uint32_t* key_count,
+                            uint32_t key_cap, uint32_t n_pheno, uint32_t row_bits, uint32_t key_bits, uint32_t* off,
+                            uint32_t* cnt, void* temp, size_t temp_bytes, hipStream_t st) {
     if (key_bits < 1) key_bits = 1;
     if (key_bits > 32) key_bits = 32;
-    return hipcub::DeviceSegmentedRadixSort::SortKeys(temp, temp_bytes, surv, surv_sorted, (int)((uint64_t)n_pheno * cap),
-                                                      (int)n_pheno, seg_beg, (const uint32_t*)seg_end, 0, (int)key_bits, st);
+    // the whole slot array is sorted (its tail is the 0xFFFFFFFF fill): the number of live keys is only known on
+    // the device, and a few million 32-bit keys sort in well under 0.1 ms
+    hipError_t e = hipcub::DeviceRadixSort::SortKeys(temp, temp_bytes, keys, keys_sorted, (int)n_slots, 0, 32, st);
+    if (e != hipSuccess) return e;
+    (void)key_bits;
+    hipLaunchKernelGGL(surv_ranges_kernel, dim3((n_pheno + 127u) / 128u), dim3(128), 0, st, keys_sorted, n_slots, key_count,
+                       key_cap, n_pheno, row_bits, off, cnt);
+    return hipGetLastError();
 }
 
 }  // namespace kgwas
