@@ -99,6 +99,10 @@ def main():
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         ndev = torch.cuda.device_count()
+        if ndev < int(os.environ.get("LOCAL_WORLD_SIZE", str(world))):
+            # several ranks on one GPU (only done to exercise the N>1 path on a 1-GPU box): the library would pin
+            # every rank's replay workers to the same cores of that GPU's NUMA share
+            os.environ.setdefault("KGWAS_PIN_THREADS", "0")
         torch.cuda.set_device(local_rank % ndev)
         # KGWAS_DIST_BACKEND=gloo lets several ranks share one GPU (used to exercise the N>1 path on a 1-GPU box)
         backend = os.environ.get("KGWAS_DIST_BACKEND", "nccl")
@@ -130,17 +134,24 @@ def main():
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     host_threads = max(1, usable_cpus() // max(local_world, 1))
     session = kg.AssociationScan(S, col, Y, args.topn, mac, device=dev, kernel=args.kernel,
-                                 chunk_rows=args.chunk_rows, record_history=(world > 1), host_threads=host_threads)
+                                 chunk_rows=args.chunk_rows, record_history=(world > 1 and rank > 0), host_threads=host_threads)
+
+    merge_ms = []
 
     def one_step():
         scan = session
         scan.reset()
         scan.feed_device(table.data_ptr(), M, first_row, stream)
-        scan.finish()
+        if world == 1:
+            scan.finish()  # with several ranks the merge finishes rank 0's session once, at its end
         st = scan.stats()
         heaps = None
         if world > 1:
-            tested = kdist.merge_on_root(scan)  # rank 0's session now holds the global heaps
+            if os.environ.get("KGWAS_BENCH_MERGE_DIAG"):  # diagnostics: separate "waiting for the slowest rank" from the merge
+                dist.barrier()
+            tm = time.perf_counter()
+            tested = kdist.merge_by_column(scan)  # rank 0's session now holds the global heaps
+            merge_ms.append((time.perf_counter() - tm) * 1e3)
         else:
             tested = st["rows_tested"]
         return scan, st, heaps, tested
@@ -260,6 +271,8 @@ def main():
                      "dense_phase_ms_per_step": sum(s["dense_ms"] for s in stats) / args.steps,
                      "cores": usable_cpus(), "replay_threads_per_rank": host_threads, "logical_cpus": os.cpu_count(),
                      "step_ms": [round(x, 2) for x in step_ms],
+                     # cross-shard merge on rank 0's clock (includes waiting for the slowest rank's scan)
+                     "merge_ms": [round(x, 2) for x in merge_ms[args.warmup:]],
                      # CFS bandwidth throttling of this container during the timed region (cpu.stat deltas)
                      "cgroup_nr_throttled": thr1[0] - thr0[0], "cgroup_throttled_ms": (thr1[1] - thr0[1]) / 1e3},
         }

@@ -178,6 +178,18 @@ void kgwas_scan_destroy(kgwas_scan* s);
 int kgwas_scan_lowest(const kgwas_scan* s, double* lowest, uint8_t* full);
 int kgwas_scan_absorb(kgwas_scan* s, uint64_t n_shards, const uint64_t* counts, const uint64_t* const* kmer,
                       const double* const* score, const uint64_t* const* row);
+/* The part of the recorded history that can still matter after heaps whose minima are thr[j]: entries with
+ * score > thr[j] (thr[j] = -inf keeps all), column by column, flat: counts[j] entries of column j follow those of
+ * column j-1. The arrays stay valid until the next call of this function or of kgwas_scan_heaps_export. */
+int kgwas_scan_history_above(kgwas_scan* s, const double* thr, uint64_t* counts, const uint64_t** kmer,
+                             const double** score, const uint64_t** row);
+/* Column-distributed merge: the state of heaps cols[0..n_cols) in heap-array order (sizes[c] entries each, flat),
+ * and its exact re-creation in another scan session of the same shape - layout included, so the heap goes on
+ * there exactly as it would have here (column j of a multi-GPU job is merged on rank j mod G). */
+int kgwas_scan_heaps_export(kgwas_scan* s, uint64_t n_cols, const uint64_t* cols, uint64_t* sizes, const uint64_t** kmer,
+                            const double** score, const uint64_t** row);
+int kgwas_scan_heaps_import(kgwas_scan* s, uint64_t n_cols, const uint64_t* cols, const uint64_t* sizes, const uint64_t* kmer,
+                            const double* score, const uint64_t* row);
 
 /* calculate_kmer_score for every row and phenotype column (src/kmers_multiple_databases.cpp:327-363):
  * scores[j*n_rows + r] (0 for rows the MAC filter drops), popcnt[r] = masked popcount N1,

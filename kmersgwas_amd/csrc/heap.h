@@ -187,6 +187,27 @@ class alignas(128) BestHeap {
             default: replace_top_multi<8>(hp, kmer, score, row); break;
         }
     }
+    // The heap's state in heap-array order (entry i = array position i): shipping these three arrays and importing
+    // them elsewhere reproduces the layout exactly, so every later push/pop behaves as it would have here
+    // (multi-GPU merge: column j continues on the rank that owns it).
+    void export_state(uint64_t* kmer, double* score, uint64_t* row) const {  // size() entries each
+        size_t i = 0;
+        for (const Ent& e : v_) {
+            kmer[i] = kmer_[e.slot];
+            score[i] = e.score;
+            row[i] = row_[e.slot];
+            i++;
+        }
+    }
+    void import_state(size_t n, const uint64_t* kmer, const double* score, const uint64_t* row) {
+        if (n > n_res_) n = n_res_;
+        v_.clear();
+        kmer_.assign(kmer, kmer + n);
+        row_.assign(row, row + n);
+        for (size_t i = 0; i < n; i++) v_.push_back(Ent{score[i], (uint32_t)i});
+        lowest_ = n ? v_.front().score : 0;
+    }
+
     // add_association for a record that is known not to beat a full heap's minimum: only the call counter moves.
     inline void note_rejected() { inserted_++; }
 

@@ -457,6 +457,8 @@ struct kgwas_scan {
 
     std::vector<BestHeap> heaps;
     std::vector<History> hist;
+    std::vector<uint64_t> exp_kmer, exp_row;  // scratch of kgwas_scan_history_above / kgwas_scan_heaps_export
+    std::vector<double> exp_score;
     std::vector<std::vector<uint64_t>> keys;  // per-column sort scratch for the replay
     bool trace = false;                       // KGWAS_TRACE=1: one stderr line per sparse chunk
     std::vector<double> col_ms;               // trace only: replay time per column of the last chunk
@@ -1700,6 +1702,82 @@ int kgwas_scan_history(kgwas_scan* s, uint64_t j, uint64_t* n, const uint64_t** 
         if (kmer) *kmer = s->hist[j].kmer.data();
         if (score) *score = s->hist[j].score.data();
         if (row) *row = s->hist[j].row.data();
+    });
+}
+
+int kgwas_scan_history_above(kgwas_scan* s, const double* thr, uint64_t* counts, const uint64_t** kmer,
+                             const double** score, const uint64_t** row) {
+    return guarded([&] {
+        if (!s || !thr || !counts) throw Error(KGWAS_ERR_ARG, "kgwas_scan_history_above: null argument");
+        if (!s->record_history) throw Error(KGWAS_ERR_STATE, "scan was created without record_history");
+        const uint64_t P = s->n_pheno;
+        // entries add_association could still accept after heaps whose minimum is thr[j]: score > thr[j]
+        // (NaN scores never pass; thr = -inf keeps everything, NaN included, as the heap may not be full)
+        auto keep = [&](uint64_t j, double sc) { return thr[j] == -std::numeric_limits<double>::infinity() || sc > thr[j]; };
+        s->pool->parallel_for(P, [&](size_t j) {
+            uint64_t c = 0;
+            for (double sc : s->hist[j].score) c += keep(j, sc) ? 1 : 0;
+            counts[j] = c;
+        });
+        std::vector<uint64_t> off(P + 1, 0);
+        for (uint64_t j = 0; j < P; j++) off[j + 1] = off[j] + counts[j];
+        s->exp_kmer.resize(off[P]);
+        s->exp_score.resize(off[P]);
+        s->exp_row.resize(off[P]);
+        s->pool->parallel_for(P, [&](size_t j) {
+            const History& h = s->hist[j];
+            uint64_t o = off[j];
+            for (size_t i = 0; i < h.score.size(); i++)
+                if (keep(j, h.score[i])) {
+                    s->exp_kmer[o] = h.kmer[i];
+                    s->exp_score[o] = h.score[i];
+                    s->exp_row[o] = h.row[i];
+                    o++;
+                }
+        });
+        if (kmer) *kmer = s->exp_kmer.data();
+        if (score) *score = s->exp_score.data();
+        if (row) *row = s->exp_row.data();
+    });
+}
+
+int kgwas_scan_heaps_export(kgwas_scan* s, uint64_t n_cols, const uint64_t* cols, uint64_t* sizes, const uint64_t** kmer,
+                            const double** score, const uint64_t** row) {
+    return guarded([&] {
+        if (!s || (n_cols && (!cols || !sizes))) throw Error(KGWAS_ERR_ARG, "kgwas_scan_heaps_export: null argument");
+        std::vector<uint64_t> off(n_cols + 1, 0);
+        for (uint64_t c = 0; c < n_cols; c++) {
+            if (cols[c] >= s->n_pheno) throw Error(KGWAS_ERR_ARG, "kgwas_scan_heaps_export: column out of range");
+            sizes[c] = s->heaps[cols[c]].size();
+            off[c + 1] = off[c] + sizes[c];
+        }
+        s->exp_kmer.resize(off[n_cols]);
+        s->exp_score.resize(off[n_cols]);
+        s->exp_row.resize(off[n_cols]);
+        s->pool->parallel_for(n_cols, [&](size_t c) {
+            s->heaps[cols[c]].export_state(s->exp_kmer.data() + off[c], s->exp_score.data() + off[c], s->exp_row.data() + off[c]);
+        });
+        if (kmer) *kmer = s->exp_kmer.data();
+        if (score) *score = s->exp_score.data();
+        if (row) *row = s->exp_row.data();
+    });
+}
+
+int kgwas_scan_heaps_import(kgwas_scan* s, uint64_t n_cols, const uint64_t* cols, const uint64_t* sizes, const uint64_t* kmer,
+                            const double* score, const uint64_t* row) {
+    return guarded([&] {
+        if (!s || (n_cols && (!cols || !sizes))) throw Error(KGWAS_ERR_ARG, "kgwas_scan_heaps_import: null argument");
+        for (uint64_t c = 0; c < n_cols; c++) {
+            if (cols[c] >= s->n_pheno) throw Error(KGWAS_ERR_ARG, "kgwas_scan_heaps_import: column out of range");
+            if (sizes[c] && (!kmer || !score || !row)) throw Error(KGWAS_ERR_ARG, "kgwas_scan_heaps_import: null data");
+        }
+        std::vector<uint64_t> off(n_cols + 1, 0);
+        for (uint64_t c = 0; c < n_cols; c++) off[c + 1] = off[c] + sizes[c];
+        s->pool->parallel_for(n_cols, [&](size_t c) {
+            s->heaps[cols[c]].import_state((size_t)sizes[c], kmer + off[c], score + off[c], row + off[c]);
+        });
+        s->finished = false;
+        refresh_full(s);
     });
 }
 

@@ -5,12 +5,14 @@ for the tests). The k-mer table is row-sharded into contiguous ranges, every ran
 shard with no data-path collective, and one small exchange closes the job:
 
   association : rank 0's heaps after its own shard ARE the global heaps after those rows. Every later
-                rank g sends its heap-push history (the effective add_association calls, row order)
+                rank g contributes its heap-push history (the effective add_association calls, row order)
                 filtered by  score > max(final heap minima of the full heaps of shards < g)  — anything
                 else is rejected by add_association whenever it arrives, since the global minimum at
-                that point is at least that large. Rank 0 replays shard 1, 2, ... in order into its own
-                heaps (kgwas_scan_absorb). Volume per rank is about top-N entries per column instead of
-                N*(1+ln(rows/N)).
+                that point is at least that large: about top-N entries per column instead of
+                N*(1+ln(rows/N)). merge_by_column finishes column j on rank j mod G (rank 0's heap state for
+                it travels there, layout included; shards 1, 2, ... are replayed in order; the final states
+                return to rank 0): one all_to_all each way, work per rank P/G columns x G shards.
+                merge_on_root is the simple variant (everything replayed on rank 0).
   kinship     : integer Hamming partials + used-row counts are all-reduced (sum).
 """
 from __future__ import annotations
@@ -109,6 +111,121 @@ def exchange_minima(low: np.ndarray, full: np.ndarray):
     a = torch.stack(bufs).cpu().numpy()
     P = len(low)
     return a[:, :P], a[:, P:] > 0.5
+
+
+def _all_to_all_i64(send_parts):
+    """send_parts[d] = 1-D int64 numpy array for rank d. Returns the list of arrays received from every rank."""
+    world = dist.get_world_size()
+    dev = _dev()
+    ins = [int(len(a)) for a in send_parts]
+    t_in = torch.tensor(ins, dtype=torch.int64, device=dev)
+    all_ins = [torch.zeros(world, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(all_ins, t_in)
+    rank = dist.get_rank()
+    outs = [int(all_ins[src][rank]) for src in range(world)]
+    flat = np.concatenate(send_parts) if sum(ins) else np.zeros(0, np.int64)
+    inp = torch.from_numpy(np.ascontiguousarray(flat, np.int64)).to(dev)
+    out = torch.zeros(sum(outs), dtype=torch.int64, device=dev)
+    dist.all_to_all_single(out, inp, outs, ins)
+    out = out.cpu().numpy()
+    off = np.concatenate([[0], np.cumsum(outs)]).astype(np.int64)
+    return [out[off[i]:off[i + 1]] for i in range(world)]
+
+
+def _pack(counts, kmer, score, row):
+    """One int64 message: [counts..., kmer..., score bits..., row...]."""
+    return np.concatenate([np.asarray(counts, np.uint64).view(np.int64), np.asarray(kmer, np.uint64).view(np.int64),
+                           np.asarray(score, np.float64).view(np.int64), np.asarray(row, np.uint64).view(np.int64)])
+
+
+def _unpack(msg, n_counts):
+    counts = msg[:n_counts].view(np.uint64)
+    n = int(counts.sum())
+    body = msg[n_counts:]
+    assert len(body) == 3 * n, (len(body), n)
+    return counts, body[:n].view(np.uint64), body[n:2 * n].view(np.float64), body[2 * n:].view(np.uint64)
+
+
+def merge_by_column(scan, dst: int = 0):
+    """Column-distributed merge of the shard scans (every rank scanned its contiguous row range; ranks >= 1 with
+    record_history=True). Column j is finished on rank j mod G: rank 0 ships that heap's state there (layout
+    included), every later rank ships the part of its history that can still matter (score above the larger of
+    the earlier shards' final minima), the owner replays shards 1, 2, ... in order - exactly what a single heap
+    would have seen - and the final heap states return to rank 0, whose session then holds the global result
+    (scan.result(j) after this call). One all_to_all each way; per rank the work is P/G columns x G shards, so
+    the merge shrinks with G instead of piling up on rank 0. Returns the total tested-k-mers count.
+    `scan` needs: n_pheno, stats(), lowest(), history_above(), heaps_export(), heaps_import(), absorb_flat(),
+    finish()."""
+    assert dst == 0, "rank 0 holds the heaps of the first shard"
+    import os, time
+    trace = bool(os.environ.get("KGWAS_TRACE"))
+    marks = [("start", time.perf_counter())]
+    mark = (lambda name: marks.append((name, time.perf_counter()))) if trace else (lambda name: None)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    P = scan.n_pheno
+    tested = torch.tensor([scan.stats()["rows_tested"]], dtype=torch.int64, device=_dev())
+    dist.all_reduce(tested, op=dist.ReduceOp.SUM)
+    low, full = scan.lowest()
+    lows, fulls = exchange_minima(low, full)
+    thr = prefix_thresholds(lows, fulls)
+    owned = [np.arange(d, P, world, dtype=np.uint64) for d in range(world)]
+    mark("minima")
+
+    # way out: heap states (from rank 0) / filtered histories (from ranks >= 1), split by owner
+    parts = []
+    if rank == 0:
+        for d in range(world):
+            if d == 0 or len(owned[d]) == 0:
+                parts.append(np.zeros(0, np.int64))
+            else:
+                parts.append(_pack(*scan.heaps_export(owned[d])))
+    else:
+        counts, k, s, r = scan.history_above(thr[rank])
+        off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        for d in range(world):
+            cols = owned[d].astype(np.int64)
+            if len(cols) == 0:
+                parts.append(np.zeros(0, np.int64))
+                continue
+            cat = lambda a: np.concatenate([a[off[j]:off[j + 1]] for j in cols])
+            parts.append(_pack(counts[cols], cat(k), cat(s), cat(r)))
+    mark("export")
+    recv = _all_to_all_i64(parts)
+    mark("all_to_all")
+
+    mine = owned[rank]
+    if len(mine):
+        if rank != 0:
+            sizes, k, s, r = _unpack(recv[0], len(mine))
+            scan.heaps_import(mine, sizes, k, s, r)
+        if world > 1:
+            counts = np.zeros((world - 1, P), np.uint64)
+            ks, ss, rs = [], [], []
+            for g in range(1, world):
+                c, k, s, r = _unpack(recv[g], len(mine))
+                counts[g - 1, mine.astype(np.int64)] = c
+                ks.append(k); ss.append(s); rs.append(r)
+            scan.absorb_flat(counts, ks, ss, rs)  # entries are ordered by column, as counts says
+    mark("absorb")
+
+    # way back: final heap states of the owned columns to rank 0
+    back = [np.zeros(0, np.int64) for _ in range(world)]
+    if rank != 0 and len(mine):
+        back[0] = _pack(*scan.heaps_export(mine))
+    recv = _all_to_all_i64(back)
+    if rank == 0:
+        for g in range(1, world):
+            if len(owned[g]):
+                sizes, k, s, r = _unpack(recv[g], len(owned[g]))
+                scan.heaps_import(owned[g], sizes, k, s, r)
+        mark("collect")
+        scan.finish()
+        mark("finish")
+    if trace:
+        import sys
+        sys.stderr.write("[kgwas] merge_by_column rank %d: %s\n" % (rank, "  ".join(
+            "%s %.1f ms" % (b[0], (b[1] - a[1]) * 1e3) for a, b in zip(marks, marks[1:]))))
+    return int(tested.item())
 
 
 def merge_on_root(scan: "engine.AssociationScan", dst: int = 0):

@@ -209,6 +209,54 @@ class AssociationScan:
         rp = (C.c_void_p * G)(*[a.ctypes.data for a in rs])
         check(lib.kgwas_scan_absorb(self._h, G, ptr(counts), kp, sp, rp))
 
+    def absorb_flat(self, counts: np.ndarray, kmer: Sequence[np.ndarray], score: Sequence[np.ndarray], row: Sequence[np.ndarray]):
+        """absorb() on flat arrays: counts[g][j] entries of column j in shard g, shard g's entries concatenated by
+        column in kmer[g] / score[g] / row[g]."""
+        counts = np.ascontiguousarray(counts, np.uint64)
+        G = counts.shape[0]
+        if G == 0:
+            return
+        ks = [np.ascontiguousarray(a, np.uint64) for a in kmer]
+        ss = [np.ascontiguousarray(a, np.float64) for a in score]
+        rs = [np.ascontiguousarray(a, np.uint64) for a in row]
+        kp = (C.c_void_p * G)(*[a.ctypes.data for a in ks])
+        sp = (C.c_void_p * G)(*[a.ctypes.data for a in ss])
+        rp = (C.c_void_p * G)(*[a.ctypes.data for a in rs])
+        check(lib.kgwas_scan_absorb(self._h, G, ptr(counts), kp, sp, rp))
+
+    def _flat3(self, total, k, s, r):
+        """Views of the library's export scratch: valid until the next history_above / heaps_export call."""
+        if total == 0:
+            return np.zeros(0, np.uint64), np.zeros(0, np.float64), np.zeros(0, np.uint64)
+        return (np.ctypeslib.as_array(k, (total,)), np.ctypeslib.as_array(s, (total,)), np.ctypeslib.as_array(r, (total,)))
+
+    def history_above(self, thr: np.ndarray):
+        """Recorded history entries with score > thr[j] (thr = -inf keeps all), flat by column:
+        (counts[P], kmer, score, row)."""
+        thr = np.ascontiguousarray(thr, np.float64)
+        counts = np.zeros(self.n_pheno, np.uint64)
+        k, s, r = C.POINTER(C.c_uint64)(), C.POINTER(C.c_double)(), C.POINTER(C.c_uint64)()
+        check(lib.kgwas_scan_history_above(self._h, ptr(thr), ptr(counts), C.byref(k), C.byref(s), C.byref(r)))
+        return (counts,) + self._flat3(int(counts.sum()), k, s, r)
+
+    def heaps_export(self, cols):
+        """State of the heaps `cols` in heap-array order, flat: (sizes[len(cols)], kmer, score, row)."""
+        cols = np.ascontiguousarray(cols, np.uint64)
+        sizes = np.zeros(len(cols), np.uint64)
+        k, s, r = C.POINTER(C.c_uint64)(), C.POINTER(C.c_double)(), C.POINTER(C.c_uint64)()
+        check(lib.kgwas_scan_heaps_export(self._h, len(cols), ptr(cols), ptr(sizes), C.byref(k), C.byref(s), C.byref(r)))
+        return (sizes,) + self._flat3(int(sizes.sum()), k, s, r)
+
+    def heaps_import(self, cols, sizes, kmer, score, row):
+        """Re-create exported heap states (layout included) in this session. Call finish() again afterwards."""
+        cols = np.ascontiguousarray(cols, np.uint64)
+        sizes = np.ascontiguousarray(sizes, np.uint64)
+        kmer = np.ascontiguousarray(kmer, np.uint64)
+        score = np.ascontiguousarray(score, np.float64)
+        row = np.ascontiguousarray(row, np.uint64)
+        assert len(kmer) == len(score) == len(row) == int(sizes.sum())
+        check(lib.kgwas_scan_heaps_import(self._h, len(cols), ptr(cols), ptr(sizes), ptr(kmer), ptr(score), ptr(row)))
+
     def _lists(self, fn, j):
         n = C.c_uint64()
         k, s, r = C.POINTER(C.c_uint64)(), C.POINTER(C.c_double)(), C.POINTER(C.c_uint64)()

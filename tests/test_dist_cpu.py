@@ -70,6 +70,57 @@ WORKER = textwrap.dedent("""
             k, s, r = heaps2[j].pop_all()
             o = exp["per_pheno"][j]
             assert (k == o["kmer"]).all() and (r == o["file_row"]).all() and s.tobytes() == o["score"].tobytes()
+    # The column-distributed merge bench.py uses (kdist.merge_by_column): heap states travel to the column's owner
+    # rank in heap-array order, filtered histories follow, final states return to rank 0. The scan session is
+    # stood in for by the pure-Python heap restatement (layout-exact: its array IS libstdc++'s).
+    class PyScan:
+        def __init__(self, hist_):
+            self.n_pheno = P
+            self.hist = hist_
+            self.heaps = [onp.BestHeap(N) for _ in range(P)]
+            for j in range(P):
+                for kk_, ss_, rr_ in zip(*hist_[j]):
+                    self.heaps[j].add(int(kk_), float(ss_), int(rr_))
+        def stats(self):
+            return {"rows_tested": int(kept.sum())}
+        def lowest(self):
+            return (np.asarray([h.lowest for h in self.heaps]), np.asarray([len(h.q) >= N for h in self.heaps]))
+        def history_above(self, t):
+            f = kdist.filter_history(self.hist, t)
+            cnt = np.asarray([len(x[0]) for x in f], np.uint64)
+            cat = lambda i, dt: np.concatenate([np.asarray(x[i], dt) for x in f]) if cnt.sum() else np.zeros(0, dt)
+            return cnt, cat(0, np.uint64), cat(1, np.float64), cat(2, np.uint64)
+        def heaps_export(self, cols):
+            v = [self.heaps[int(j)].q.v for j in cols]
+            flat = [e for x in v for e in x]
+            return (np.asarray([len(x) for x in v], np.uint64), np.asarray([e[0] for e in flat], np.uint64),
+                    np.asarray([e[1] for e in flat], np.float64), np.asarray([e[2] for e in flat], np.uint64))
+        def heaps_import(self, cols, sizes, k, s, r):
+            o = 0
+            for j, n in zip(cols, sizes):
+                h = self.heaps[int(j)]
+                h.q.v = [(int(k[o + i]), float(s[o + i]), int(r[o + i])) for i in range(int(n))]
+                h.lowest = h.q.top()[1] if int(n) else 0.0
+                o += int(n)
+        def absorb_flat(self, counts, ks, ss, rs):
+            for g in range(counts.shape[0]):
+                o = 0
+                for j in range(P):
+                    for i in range(int(counts[g, j])):
+                        self.heaps[j].add(int(ks[g][o + i]), float(ss[g][o + i]), int(rs[g][o + i]))
+                    o += int(counts[g, j])
+        def finish(self):
+            pass
+    ps = PyScan(hist)
+    tested = kdist.merge_by_column(ps)
+    if rank == 0:
+        assert tested == exp["tested"], (tested, exp["tested"])
+        for j in range(P):
+            pops = ps.heaps[j].pop_all()
+            o = exp["per_pheno"][j]
+            assert [e[0] for e in pops] == [int(x) for x in o["kmer"]], "column %%d" %% j
+            assert [e[2] for e in pops] == [int(x) for x in o["file_row"]]
+            assert np.asarray([e[1] for e in pops]).tobytes() == o["score"].tobytes()
     # kinship partials: integer Hamming sums + used-row counts all-reduce to the single-process answer
     mc = int(np.ceil(S_f * 0.05))
     g = onp.unpack_bits(rows[lo:hi], np.arange(S_f, dtype=np.uint64)).astype(np.int64)

@@ -206,6 +206,53 @@ def test_shard_merge_by_absorbing_filtered_histories(topn):
         sc.close()
 
 
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_column_distributed_merge_protocol(world):
+    """What kmersgwas_amd.dist.merge_by_column does over torch.distributed, played by hand in one process: shard
+    scans on `world` sessions, column j finished on session j % world from rank 0's exported heap state (layout
+    included) plus the later shards' filtered histories, final states imported back into session 0. Heavy ties."""
+    from kmersgwas_amd import dist as kdist
+    S_f, S, P, topn = 130, 130, 7, 300
+    rows = random_table(30_000, S_f, seed=world, dup_frac=0.5)
+    col = np.arange(S, dtype=np.uint64)
+    Y = phenotypes(S, P - 1, seed=9, binary=True)
+    mac = onp.min_count(S, 0.05, 5)
+    exp = ob.associate(rows, S_f, col, Y, topn, mac)
+    scans = []
+    for g in range(world):
+        lo, hi = kdist.shard_range(len(rows), g, world)
+        sc = kg.AssociationScan(S_f, col, Y, topn, mac, chunk_rows=4096, record_history=(g > 0))
+        sc.feed_host(rows[lo:hi], lo)
+        sc.finish()
+        scans.append(sc)
+    lows = np.stack([sc.lowest()[0] for sc in scans])
+    fulls = np.stack([sc.lowest()[1] for sc in scans])
+    thr = kdist.prefix_thresholds(lows, fulls)
+    # (copies: the arrays are views of the session's export scratch, reused by heaps_export below)
+    hists = [None] + [tuple(np.array(x) for x in scans[g].history_above(thr[g])) for g in range(1, world)]
+    for d in range(world):
+        mine = np.arange(d, P, world, dtype=np.uint64)
+        if len(mine) == 0:
+            continue
+        if d != 0:
+            scans[d].heaps_import(mine, *scans[0].heaps_export(mine))
+        counts = np.zeros((world - 1, P), np.uint64)
+        ks, ss, rs = [], [], []
+        for g in range(1, world):
+            c, k, s, r = hists[g]
+            off = np.concatenate([[0], np.cumsum(c)]).astype(np.int64)
+            idx = np.concatenate([np.arange(off[int(j)], off[int(j) + 1]) for j in mine])
+            counts[g - 1, mine.astype(np.int64)] = c[mine.astype(np.int64)]
+            ks.append(k[idx]); ss.append(s[idx]); rs.append(r[idx])
+        scans[d].absorb_flat(counts, ks, ss, rs)
+        if d != 0:
+            scans[0].heaps_import(mine, *scans[d].heaps_export(mine))
+    scans[0].finish()
+    _check_topn(scans[0], exp, P, check_pushes=False)
+    for sc in scans:
+        sc.close()
+
+
 @pytest.mark.parametrize("kernel", KERNELS)
 def test_adversarial_order_overflows_candidate_lists(kernel):
     """Rows sorted by ascending score of column 0: every row beats every threshold, so the sparse chunks'
