@@ -117,19 +117,23 @@ def _all_to_all_i64(send_parts):
     """send_parts[d] = 1-D int64 numpy array for rank d. Returns the list of arrays received from every rank."""
     world = dist.get_world_size()
     dev = _dev()
+    # every message carries its length in front: no zero-sized sends or receives reach the backend
+    send_parts = [np.concatenate([np.asarray([len(a)], np.int64), np.asarray(a, np.int64)]) for a in send_parts]
     ins = [int(len(a)) for a in send_parts]
     t_in = torch.tensor(ins, dtype=torch.int64, device=dev)
     all_ins = [torch.zeros(world, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(all_ins, t_in)
     rank = dist.get_rank()
     outs = [int(all_ins[src][rank]) for src in range(world)]
-    flat = np.concatenate(send_parts) if sum(ins) else np.zeros(0, np.int64)
+    flat = np.concatenate(send_parts)
     inp = torch.from_numpy(np.ascontiguousarray(flat, np.int64)).to(dev)
     out = torch.zeros(sum(outs), dtype=torch.int64, device=dev)
     dist.all_to_all_single(out, inp, outs, ins)
     out = out.cpu().numpy()
     off = np.concatenate([[0], np.cumsum(outs)]).astype(np.int64)
-    return [out[off[i]:off[i + 1]] for i in range(world)]
+    msgs = [out[off[i]:off[i + 1]] for i in range(world)]
+    assert all(int(m[0]) == len(m) - 1 for m in msgs)
+    return [m[1:] for m in msgs]
 
 
 def _pack(counts, kmer, score, row):
