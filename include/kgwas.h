@@ -235,6 +235,18 @@ int kgwas_write_plink(const char* out_base, kgwas_table* t, const uint64_t* col,
                       const uint64_t* row_pop);
 
 /* ------------------------------------------------------------------------------------
+ * kmers_table_to_bed (src/kmers_table_to_bed.cpp:93-129): the whole table, MAC-filtered on the phenotyped
+ * accessions col[0..n_acc), as PLINK files <out_base>.<i>.bed/.bim/.fam, a new file set after every batch_size KEPT
+ * k-mers (load_kmers, src/kmers_multiple_databases.cpp:110-113); with unique_patterns only the first k-mer of each
+ * presence/absence hash (hash_presence_absence_pattern, :367-375) over all batches
+ * (output_plink_bed_file_unique_presence_absence_patterns, :254-264). Per-row work (squeeze, popcount, hash, PLINK
+ * bytes) runs on `device`. n_batches / n_written (k-mers written) may be NULL.
+ * ---------------------------------------------------------------------------------- */
+int kgwas_table_to_bed(kgwas_table* t, const uint64_t* col, uint64_t n_acc, const char* const* acc_names, const float* y,
+                       uint64_t min_count, uint64_t batch_size, int unique_patterns, const char* out_base, int device,
+                       uint64_t* n_batches, uint64_t* n_written);
+
+/* ------------------------------------------------------------------------------------
  * Seeded synthetic table rows: kmer = row + 1, per-row frequency q/256 with
  * q in [5, 250], bits from a counter-based generator, so any shard can be produced on its GPU.
  * The host variant is the bit-identical twin used to write small .table files for the CLIs.

@@ -121,6 +121,12 @@ hipError_t launch_pattern_hash(const RowSrc& src, const uint32_t* dmask, uint64_
                                uint32_t min_count, uint64_t* out, unsigned long long* out_count, hipStream_t st);
 hipError_t count_distinct_u64(uint64_t* keys, uint64_t n, uint64_t* result, hipStream_t st);
 
+// kmers_table_to_bed (bed_kernels.hip): per squeezed row its popcount and pattern hash; the PLINK bytes.
+hipError_t launch_bed_rowinfo(const uint32_t* sq, uint64_t n_rows, uint32_t W_m, uint32_t* n1_out, uint64_t* hash_out,
+                              hipStream_t st);
+hipError_t launch_bed_bytes(const uint32_t* sq, uint64_t n_rows, uint32_t W_m, uint32_t bytes_per_row, uint8_t* out,
+                            hipStream_t st);
+
 // Squeeze: out[r][2*W_m dwords] bit i = file bit colmap[i] (colmap[i] == 0xFFFFFFFF -> 0).
 hipError_t launch_squeeze(const uint64_t* file_rows, uint64_t file_stride_w, uint64_t n_rows, const uint32_t* colmap,
                           uint32_t W_m, uint32_t W_f, uint32_t* out, hipStream_t st);

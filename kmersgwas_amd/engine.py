@@ -394,3 +394,17 @@ def synth_rows_host(first_row: int, n_rows: int, n_acc: int, seed: int) -> np.nd
 
 def synth_rows_device(d_ptr: int, first_row: int, n_rows: int, n_acc: int, seed: int, stream: int = 0):
     check(lib.kgwas_synth_rows_device(C.c_void_p(d_ptr), first_row, n_rows, n_acc, seed, C.c_void_p(stream)))
+
+
+def table_to_bed(out_base: str, table: KmersTable, col, acc_names: Sequence[str], y, min_count: int, batch_size: int,
+                 unique_patterns: bool = False, device: int = 0):
+    """kmers_table_to_bed: the MAC-filtered table as PLINK files <out_base>.<i>.{bed,bim,fam}, a new set after every
+    batch_size kept k-mers; unique_patterns keeps the first k-mer of each presence/absence pattern.
+    Returns (batches, k-mers written)."""
+    col = np.ascontiguousarray(col, np.uint64)
+    y = np.ascontiguousarray(y, np.float32)
+    arr = (C.c_char_p * len(acc_names))(*[a.encode() for a in acc_names])
+    nb, nw = C.c_uint64(0), C.c_uint64(0)
+    check(lib.kgwas_table_to_bed(table._h, ptr(col), len(col), arr, ptr(y), min_count, batch_size, 1 if unique_patterns else 0,
+                                 out_base.encode(), device, C.byref(nb), C.byref(nw)))
+    return nb.value, nw.value

@@ -147,6 +147,23 @@ def write_plink(base, rows, S_f, col, acc_names, y, kmer_len, kmer_pop, filerow_
         raise RuntimeError("orc_write_plink failed: %d" % rc)
 
 
+def table_to_bed(base, rows, S_f, col, acc_names, y, kmer_len, min_count, batch_size, unique):
+    """kmers_table_to_bed on in-memory rows; writes <base>.<batch>.{bed,bim,fam}; returns (batches, k-mers written)."""
+    rows = _rows(rows)
+    col = np.ascontiguousarray(col, dtype=np.uint64)
+    arr = (C.c_char_p * len(acc_names))(*[a.encode() for a in acc_names])
+    nw = C.c_uint64(0)
+    L = lib()
+    L.orc_table_to_bed.restype = C.c_uint64
+    L.orc_table_to_bed.argtypes = [C.c_char_p, np.ctypeslib.ndpointer(np.uint64, flags="C"), C.c_uint64, C.c_uint64,
+                                   np.ctypeslib.ndpointer(np.uint64, flags="C"), C.c_uint64, C.c_void_p,
+                                   np.ctypeslib.ndpointer(np.float32, flags="C"), C.c_uint64, C.c_uint64, C.c_uint64, C.c_int,
+                                   C.POINTER(C.c_uint64)]
+    nb = L.orc_table_to_bed(base.encode(), rows.reshape(-1), rows.shape[0], S_f, col, len(col), arr,
+                            np.ascontiguousarray(y, np.float32), kmer_len, min_count, batch_size, 1 if unique else 0, C.byref(nw))
+    return int(nb), int(nw.value)
+
+
 class Heap:
     def __init__(self, n):
         self.h = lib().orc_heap_new(n)

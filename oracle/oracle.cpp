@@ -35,6 +35,7 @@
 #include <string>
 #include <thread>
 #include <tuple>
+#include <unordered_set>
 #include <vector>
 
 #include <nmmintrin.h>
@@ -528,6 +529,50 @@ int orc_write_plink(const char* base_path, const uint64_t* rows, uint64_t n_rows
     std::ofstream fam(base + ".fam");
     for (size_t i = 0; i < S; i++) fam << acc_names[i] << " " << acc_names[i] << " 0 0 0 " << y[i] << std::endl;
     return 0;
+}
+
+// ---- kmers_table_to_bed (f-4) -------------------------------------------------
+// src/kmers_table_to_bed.cpp:93-129: batches of up to `batch_size` KEPT k-mers (load_kmers counts m_kmers.size(),
+// src/kmers_multiple_databases.cpp:103-147: a batch exists iff rows were left when it started), every batch written
+// to <base>.<batch>.{bed,bim,fam}: all kept k-mers (output_plink_bed_file, :204-216) or, with unique, only those
+// whose presence/absence hash was not seen before in ANY batch (:254-264). Returns the number of batches.
+uint64_t orc_table_to_bed(const char* base_path, const uint64_t* rows, uint64_t n_rows, uint64_t S_f, const uint64_t* col,
+                          uint64_t S, const char* const* acc_names, const float* y, uint64_t kmer_len, uint64_t min_count,
+                          uint64_t batch_size, int unique, uint64_t* n_written) {
+    ColMap m = make_map(col, S, S_f);
+    std::unordered_set<uint64_t> seen;
+    uint64_t r = 0, batch = 0, written = 0;
+    while (r < n_rows) {  // m_left_in_file > 0
+        const std::string base = std::string(base_path) + "." + std::to_string(batch);
+        std::ofstream bed(base + ".bed", std::ios::binary), bim(base + ".bim");
+        bed << (char)0x6C << (char)0x1B << (char)0x01;  // src/kmer_general.h:138
+        uint64_t kept = 0;
+        while (kept < batch_size && r < n_rows) {
+            const uint64_t* row = rows + r * (1 + m.W_f);
+            r++;
+            uint64_t pc_orig = 0;
+            for (size_t w = 0; w < m.W_f; w++) pc_orig += popcnt64(row[1 + w] & m.mask[w]);
+            if (!(pc_orig >= min_count && pc_orig <= (S - min_count))) continue;
+            kept++;
+            std::vector<uint64_t> sq(m.W_m, 0);
+            for (size_t c = 0; c < S; c++) sq[c >> 6] |= ((row[1 + m.word_idx[c]] >> m.bit_idx[c]) & 1ull) << (c & 63);
+            if (unique) {
+                const uint64_t seed = pattern_hash(sq.data(), m.W_m);
+                if (seen.count(seed)) continue;
+                seen.insert(seed);
+            }
+            bim << "0\t" << bits_to_kmer(row[0], kmer_len) << "\t0\t0\t0\t1\n";
+            std::string bytes;
+            pa_bytes(sq.data(), m.W_m, S, bytes);
+            bed.write(bytes.data(), bytes.size());
+            written++;
+        }
+        std::ofstream fam(base + ".fam");
+        for (size_t i = 0; i < S; i++) fam << acc_names[i] << " " << acc_names[i] << " 0 0 0 " << y[i] << std::endl;
+        batch++;
+    }
+    if (n_written) *n_written = written;
+    return batch;
 }
 
 // ---- kinship (a-9) ----------------------------------------------------------

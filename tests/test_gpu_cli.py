@@ -119,3 +119,47 @@ def test_emma_kinship_kmers_stdout(tmp_path):
     assert r.stdout == ob.kinship_text(K, n)
     err = r.stderr.decode()
     assert "Min count = %d" % mc in err and "#%d" % n in err
+
+
+@pytest.mark.parametrize("unique", [False, True])
+@pytest.mark.parametrize("S_f,n_pick,batch", [(241, 241, 1000), (300, 257, 777), (70, 33, 100000)])
+def test_kmers_table_to_bed(tmp_path, unique, S_f, n_pick, batch):
+    """the table -> PLINK export tool. Batches count KEPT k-mers, a batch exists iff rows
+    were left when it started, -u keeps the first k-mer of each presence/absence hash over all batches: every file
+    byte-identical to the oracle's, through the CLI and through the library."""
+    k = 31
+    rows = random_table(12_345, S_f, seed=S_f + batch, dup_frac=0.4)
+    rows[-40:, 1:] = 0  # trailing rows that fail the MAC filter (a last batch with nothing kept can exist)
+    table_names = ["acc%d" % i for i in range(S_f)]
+    base = str(tmp_path / "tab")
+    onp.write_table(base, table_names, k, rows[:, 0], rows[:, 1:])
+    pick = np.random.default_rng(5).permutation(S_f)[:n_pick]
+    acc = [table_names[i] for i in pick]
+    y = phenotypes(n_pick, 0, seed=2)[0]
+    ph = tmp_path / "ph.tsv"
+    with open(ph, "w") as f:
+        f.write("accession_id\tphenotype_value\n")
+        for a, v in zip(acc, y):
+            f.write("%s\t%r\n" % (a, float(v)))
+    names2, acc2, Y2 = onp.load_phenotypes(str(ph))
+    col = onp.column_map(table_names, acc2)
+    mc = max(int(np.ceil(n_pick * 0.05)), 5)
+    out_o, out_p, out_l = tmp_path / "orc", tmp_path / "cli", tmp_path / "lib"
+    for d in (out_o, out_p, out_l):
+        d.mkdir()
+    nb, nw = ob.table_to_bed(str(out_o / "x"), rows, S_f, col, acc2, Y2[0], k, mc, batch, unique)
+    assert nb >= 1 and nw > 0
+    cmd = [os.path.join(BIN, "kmers_table_to_bed"), "-t", base, "-k", str(k), "-p", str(ph), "--maf", "0.05", "--mac", "5",
+           "-b", str(batch), "-o", str(out_p / "x")] + (["-u"] if unique else [])
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "using phenotype_value" in r.stderr and r.stderr.count("Batch:") == nb
+    files = _compare_dirs(str(out_p), str(out_o))
+    assert len(files) == 3 * nb
+    tbl = kg.KmersTable(base, k)
+    assert kg.table_to_bed(str(out_l / "x"), tbl, col, acc2, Y2[0], mc, batch, unique) == (nb, nw)
+    tbl.close()
+    _compare_dirs(str(out_l), str(out_o))
+    # option errors behave like the reference's
+    r = subprocess.run(cmd[:-2] if not unique else cmd[:-3], capture_output=True, text=True)  # no -o
+    assert r.returncode == 1 and "is a required parameter" in r.stderr
