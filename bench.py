@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--topn", type=int, default=10001)
     ap.add_argument("--kernel", type=int, default=0)
     ap.add_argument("--chunk-rows", type=int, default=0)
-    ap.add_argument("--cpu-sample-rows", type=int, default=2_000_000)
+    ap.add_argument("--cpu-sample-rows", type=int, default=6_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
