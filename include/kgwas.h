@@ -247,6 +247,24 @@ int kgwas_table_to_bed(kgwas_table* t, const uint64_t* col, uint64_t n_acc, cons
                        uint64_t* n_batches, uint64_t* n_written);
 
 /* ------------------------------------------------------------------------------------
+ * SNP twin of the scorer: MultipleSNPsDataBases (src/snps_multiple_databases.h:25-63) for associate_snps
+ * (src/associate_snps.cpp). open: <base>.fam/.bed with the phenotyped samples in phenotype order (ctor, :66-146,
+ * error texts included); scores: calculate_grammmar_approx_association (:155-172) of every SNP for every column of
+ * Y[n_pheno][n_samples], scores[j*n_snps + i], on `device`; best: get_most_associated_snps (:229-241) per column -
+ * counts[j] sorted SNP indices at indices[j*topn ...]; write: output_plink_bed_file (:252-286) - list l
+ * (counts[l] sorted indices at indices[l*stride ...]) to out_bases[l].bed/.bim.
+ * ---------------------------------------------------------------------------------- */
+typedef struct kgwas_snps kgwas_snps;
+int kgwas_snps_open(const char* base_bedbim, const char* const* samples, uint64_t n_samples, kgwas_snps** out);
+int kgwas_snps_info(const kgwas_snps* s, uint64_t* n_snps, uint64_t* n_samples_file, uint64_t* bytes_per_snp);
+int kgwas_snps_scores(kgwas_snps* s, const float* Y, uint64_t n_pheno, double mac, int device, double* scores);
+int kgwas_snps_best(kgwas_snps* s, const float* Y, uint64_t n_pheno, uint64_t topn, double mac, int device, uint64_t* counts,
+                    uint64_t* indices);
+int kgwas_snps_write(kgwas_snps* s, uint64_t n_lists, const char* const* out_bases, const uint64_t* counts,
+                     const uint64_t* indices, uint64_t stride);
+void kgwas_snps_close(kgwas_snps* s);
+
+/* ------------------------------------------------------------------------------------
  * Seeded synthetic table rows: kmer = row + 1, per-row frequency q/256 with
  * q in [5, 250], bits from a counter-based generator, so any shard can be produced on its GPU.
  * The host variant is the bit-identical twin used to write small .table files for the CLIs.

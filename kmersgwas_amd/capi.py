@@ -34,6 +34,7 @@ SYMBOLS = [
     "kgwas_kinship_create", "kgwas_kinship_feed_device", "kgwas_kinship_feed_host", "kgwas_kinship_partials",
     "kgwas_kinship_from_partials", "kgwas_kinship_get_stats", "kgwas_kinship_destroy", "kgwas_kinship_format",
     "kgwas_write_plink", "kgwas_table_to_bed",
+    "kgwas_snps_open", "kgwas_snps_info", "kgwas_snps_scores", "kgwas_snps_best", "kgwas_snps_write", "kgwas_snps_close",
     "kgwas_synth_rows_device", "kgwas_synth_rows_host",
 ]
 
@@ -175,6 +176,13 @@ lib.kgwas_kinship_destroy.restype = None
 lib.kgwas_kinship_format.argtypes = [_u64, _vp, _u64, C.c_char_p, _u64]
 lib.kgwas_kinship_format.restype = _u64
 lib.kgwas_write_plink.argtypes = [C.c_char_p, _vp, _vp, _u64, _pstr, _vp, _u64, _vp, _vp]
+lib.kgwas_snps_open.argtypes = [C.c_char_p, _pstr, _u64, _vp]
+lib.kgwas_snps_info.argtypes = [_vp, _vp, _vp, _vp]
+lib.kgwas_snps_scores.argtypes = [_vp, _vp, _u64, C.c_double, C.c_int, _vp]
+lib.kgwas_snps_best.argtypes = [_vp, _vp, _u64, _u64, C.c_double, C.c_int, _vp, _vp]
+lib.kgwas_snps_write.argtypes = [_vp, _u64, _pstr, _vp, _vp, _u64]
+lib.kgwas_snps_close.argtypes = [_vp]
+lib.kgwas_snps_close.restype = None
 lib.kgwas_table_to_bed.argtypes = [_vp, _vp, _u64, _pstr, _vp, _u64, _u64, C.c_int, C.c_char_p, C.c_int, _vp, _vp]
 lib.kgwas_synth_rows_device.argtypes = [_vp, _u64, _u64, _u64, _u64, _vp]
 lib.kgwas_synth_rows_host.argtypes = [_vp, _u64, _u64, _u64, _u64]

@@ -127,6 +127,12 @@ hipError_t launch_bed_rowinfo(const uint32_t* sq, uint64_t n_rows, uint32_t W_m,
 hipError_t launch_bed_bytes(const uint32_t* sq, uint64_t n_rows, uint32_t W_m, uint32_t bytes_per_row, uint8_t* out,
                             hipStream_t st);
 
+// SNP scorer (snp_kernels.hip): .bed bytes -> three bit planes per SNP ([snp][3][ndw]); planes -> scores[p][snp].
+hipError_t launch_snp_planes(const uint8_t* bed, uint64_t n_snps, uint32_t bytes_per_snp, const uint32_t* byte_idx,
+                             const uint32_t* shift, uint32_t S, uint32_t ndw, uint32_t* planes, hipStream_t st);
+hipError_t launch_snp_score(const uint32_t* planes, uint64_t n_snps, uint32_t ndw, const float* Yperm, uint32_t L, uint32_t n_pheno,
+                            double mac, double* scores, hipStream_t st);
+
 // Squeeze: out[r][2*W_m dwords] bit i = file bit colmap[i] (colmap[i] == 0xFFFFFFFF -> 0).
 hipError_t launch_squeeze(const uint64_t* file_rows, uint64_t file_stride_w, uint64_t n_rows, const uint32_t* colmap,
                           uint32_t W_m, uint32_t W_f, uint32_t* out, hipStream_t st);

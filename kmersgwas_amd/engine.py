@@ -408,3 +408,55 @@ def table_to_bed(out_base: str, table: KmersTable, col, acc_names: Sequence[str]
     check(lib.kgwas_table_to_bed(table._h, ptr(col), len(col), arr, ptr(y), min_count, batch_size, 1 if unique_patterns else 0,
                                  out_base.encode(), device, C.byref(nb), C.byref(nw)))
     return nb.value, nw.value
+
+
+class SnpsDataBase:
+    """MultipleSNPsDataBases (src/snps_multiple_databases.h:25-63): a PLINK bed/bim/fam trio restricted to the
+    phenotyped samples (phenotype order); scoring runs on the GPU."""
+
+    def __init__(self, base_bedbim: str, samples: Sequence[str]):
+        self._h = C.c_void_p()
+        self.samples = list(samples)
+        arr = (C.c_char_p * len(self.samples))(*[a.encode() for a in self.samples])
+        check(lib.kgwas_snps_open(base_bedbim.encode(), arr, len(self.samples), C.byref(self._h)))
+        n, f, b = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        check(lib.kgwas_snps_info(self._h, C.byref(n), C.byref(f), C.byref(b)))
+        self.n_snps, self.n_samples_file, self.bytes_per_snp = n.value, f.value, b.value
+
+    def scores(self, Y: np.ndarray, mac: float, device: int = 0) -> np.ndarray:
+        """calculate_grammmar_approx_association of every SNP for every row of Y[n_pheno][n_samples]."""
+        Y = np.ascontiguousarray(np.atleast_2d(Y), np.float32)
+        out = np.zeros((Y.shape[0], self.n_snps), np.float64)
+        check(lib.kgwas_snps_scores(self._h, ptr(Y), Y.shape[0], float(mac), device, ptr(out)))
+        return out
+
+    def best(self, Y: np.ndarray, topn: int, mac: float, device: int = 0):
+        """get_most_associated_snps per phenotype column: list of sorted SNP index arrays."""
+        Y = np.ascontiguousarray(np.atleast_2d(Y), np.float32)
+        P = Y.shape[0]
+        counts = np.zeros(P, np.uint64)
+        idx = np.zeros((P, max(topn, 1)), np.uint64)
+        check(lib.kgwas_snps_best(self._h, ptr(Y), P, topn, float(mac), device, ptr(counts), ptr(idx)))
+        return [idx[j, : int(counts[j])].copy() for j in range(P)]
+
+    def write(self, out_bases: Sequence[str], index_lists):
+        """output_plink_bed_file: list l (sorted SNP indices) -> out_bases[l].bed/.bim."""
+        n = len(out_bases)
+        stride = max([len(x) for x in index_lists] + [1])
+        counts = np.asarray([len(x) for x in index_lists], np.uint64)
+        idx = np.zeros((n, stride), np.uint64)
+        for l, x in enumerate(index_lists):
+            idx[l, : len(x)] = x
+        arr = (C.c_char_p * n)(*[b.encode() for b in out_bases])
+        check(lib.kgwas_snps_write(self._h, n, arr, ptr(counts), ptr(idx), stride))
+
+    def close(self):
+        if self._h:
+            lib.kgwas_snps_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -164,6 +164,26 @@ def table_to_bed(base, rows, S_f, col, acc_names, y, kmer_len, min_count, batch_
     return int(nb), int(nw.value)
 
 
+def snps_scores(bed_body, n_samples_file, sample_index, y, mac):
+    """calculate_grammmar_approx_association of every SNP of a .bed body (bytes after the magic) for the samples
+    whose positions in the .fam are sample_index (phenotype order) and their phenotype y."""
+    bed_body = np.ascontiguousarray(np.frombuffer(bed_body, np.uint8))
+    bps = (n_samples_file + 3) // 4
+    n_snps = len(bed_body) // bps
+    idx = np.asarray(sample_index, np.uint64)
+    byte_idx = np.ascontiguousarray(idx // 4, np.uint64)
+    shift = np.ascontiguousarray((idx % 4) * 2, np.uint64)
+    out = np.zeros(n_snps, np.float64)
+    L = lib()
+    L.orc_snps_scores.restype = None
+    L.orc_snps_scores.argtypes = [np.ctypeslib.ndpointer(np.uint8, flags="C"), C.c_uint64, C.c_uint64,
+                                  np.ctypeslib.ndpointer(np.uint64, flags="C"), np.ctypeslib.ndpointer(np.uint64, flags="C"),
+                                  C.c_uint64, np.ctypeslib.ndpointer(np.float32, flags="C"), C.c_double,
+                                  np.ctypeslib.ndpointer(np.float64, flags="C")]
+    L.orc_snps_scores(bed_body, n_snps, bps, byte_idx, shift, len(idx), np.ascontiguousarray(y, np.float32), float(mac), out)
+    return out
+
+
 class Heap:
     def __init__(self, n):
         self.h = lib().orc_heap_new(n)

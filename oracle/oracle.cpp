@@ -575,6 +575,69 @@ uint64_t orc_table_to_bed(const char* base_path, const uint64_t* rows, uint64_t 
     return batch;
 }
 
+// ---- SNP twin of the scorer (f-4) ----------------------------------------------
+// dot_product_SSE4 (src/snps_multiple_databases.cpp:38-63), scalar statement: the same four-lane order as the k-mer
+// scorer; the four lane sums are added left to right in float and returned as double.
+static double snp_dot(const float* R, const uint64_t* bv, size_t n_words) {
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (size_t b = 0; b < n_words / 2; b++) {
+        uint32_t sub[4] = {(uint32_t)(bv[2 * b] & 0xFFFFFFFFu), (uint32_t)(bv[2 * b] >> 32),
+                           (uint32_t)(bv[2 * b + 1] & 0xFFFFFFFFu), (uint32_t)(bv[2 * b + 1] >> 32)};
+        const float* Rb = R + 128 * b;
+        for (size_t s = 0; s < 32; s++)
+            for (size_t l = 0; l < 4; l++) acc[l] = acc[l] + (((sub[l] >> (31 - s)) & 1u) ? Rb[4 * s + l] : 0.0f);
+    }
+    float f = acc[0] + acc[1];
+    f = f + acc[2];
+    f = f + acc[3];
+    return (double)f;
+}
+
+// MultipleSNPsDataBases: the three bit planes and per-SNP sums as the constructor builds them (:112-146), then
+// calculate_grammmar_approx_association (:155-172) for one phenotype column over all SNPs. bed = the .bed body
+// (after the 3 magic bytes), byte_idx/shift = create_map_from_all_samples (:204-219). scores[n_snps].
+void orc_snps_scores(const uint8_t* bed, uint64_t n_snps, uint64_t bytes_per_snp, const uint64_t* byte_idx, const uint64_t* shift,
+                     uint64_t S, const float* y, double mac, double* scores) {
+    const size_t W = 2 * ((S + 127) / 128);  // m_uint64_words (:71)
+    std::vector<float> R;
+    prepare_scores(y, S, W, R);  // resize to W*64 with zeros + permute_scores (:231-232); the sum is not used here
+    const double dubit_to_popcnt[] = {0, 0, 0.5, 1};
+    const uint64_t dubit_to_bit[] = {0, 0, 0, 1}, dubit_to_total[] = {1, 0, 1, 1}, dubit_to_het[] = {0, 0, 1, 0};
+    std::vector<uint64_t> pres(W), tot(W), het(W);
+    for (uint64_t i = 0; i < n_snps; i++) {
+        std::fill(pres.begin(), pres.end(), 0);
+        std::fill(tot.begin(), tot.end(), 0);
+        std::fill(het.begin(), het.end(), 0);
+        const uint8_t* buf = bed + i * bytes_per_snp;
+        double cur_popcnt = 0, cur_S_gi_2 = 0;
+        uint64_t cur_total = 0;
+        for (uint64_t si = 0; si < S; si++) {
+            const uint64_t dubit = (buf[byte_idx[si]] >> shift[si]) & 0x03;
+            cur_popcnt += dubit_to_popcnt[dubit];
+            cur_S_gi_2 += dubit_to_popcnt[dubit] * dubit_to_popcnt[dubit];
+            cur_total += dubit_to_total[dubit];
+            pres[si >> 6] ^= dubit_to_bit[dubit] << (si & 0x3f);
+            tot[si >> 6] ^= dubit_to_total[dubit] << (si & 0x3f);
+            het[si >> 6] ^= dubit_to_het[dubit] << (si & 0x3f);
+        }
+        const double N = (double)cur_total, S_gi = cur_popcnt, S_gi_2 = cur_S_gi_2;
+        if ((mac > S_gi) || (mac > (N - S_gi))) {
+            scores[i] = 0;
+            continue;
+        }
+        double yigi = snp_dot(R.data(), pres.data(), W) + snp_dot(R.data(), het.data(), W) * 0.5;
+        double score_sum = snp_dot(R.data(), tot.data(), W);
+        double p1 = N * yigi;  // no FMA in the reference build (Makefile:4)
+        double p2 = S_gi * score_sum;
+        double r = p1 - p2;
+        r = r * r;
+        double q1 = N * S_gi_2;
+        double q2 = S_gi * S_gi;
+        double den = N * (q1 - q2);
+        scores[i] = r / den;
+    }
+}
+
 // ---- kinship (a-9) ----------------------------------------------------------
 // update_emma_kinshhip_calculation (src/kmers_multiple_databases.cpp:418-438) over rows
 // passing ceil(S_f*maf) <= popcount <= S_f - that, all S_f columns in file order

@@ -163,3 +163,85 @@ def test_kmers_table_to_bed(tmp_path, unique, S_f, n_pick, batch):
     # option errors behave like the reference's
     r = subprocess.run(cmd[:-2] if not unique else cmd[:-3], capture_output=True, text=True)  # no -o
     assert r.returncode == 1 and "is a required parameter" in r.stderr
+
+
+def _write_bedbimfam(base, n_samples, n_snps, seed):
+    """A random PLINK trio: every dubit value occurs (hom. minor 00, missing 01, het 10, hom. major 11)."""
+    rng = np.random.default_rng(seed)
+    dub = rng.choice(4, size=(n_snps, n_samples), p=[0.45, 0.05, 0.2, 0.3]).astype(np.uint8)
+    dub[:5] = 0            # monomorphic SNPs (fail the MAC test -> score 0, but still offered to the heap)
+    dub[5:8] = 1           # all missing: N = 0
+    dub[8, : n_samples // 2] = 3  # a duplicate pair of SNPs: equal scores
+    dub[9] = dub[8]
+    bps = (n_samples + 3) // 4
+    body = np.zeros((n_snps, bps), np.uint8)
+    for s_ in range(n_samples):
+        body[:, s_ // 4] |= (dub[:, s_] << ((s_ % 4) * 2)).astype(np.uint8)
+    names = ["smp%d" % i for i in range(n_samples)]
+    with open(base + ".bed", "wb") as f:
+        f.write(bytes([0x6C, 0x1B, 0x01]) + body.tobytes())
+    with open(base + ".bim", "w") as f:
+        for i in range(n_snps):
+            f.write("1\tsnp%d\t0\t%d\tA\tG\n" % (i, 100 + i))
+    with open(base + ".fam", "w") as f:
+        for n in names:
+            f.write("%s %s 0 0 0 -9\n" % (n, n))
+    return names, body
+
+
+@pytest.mark.parametrize("n_file,n_use,n_snps", [(53, 53, 400), (300, 257, 3000), (1030, 900, 1500)])
+def test_associate_snps(tmp_path, n_file, n_use, n_snps):
+    """the SNP twin of the scorer. Scores bit-identical to the oracle's restatement of
+    calculate_grammmar_approx_association (missing and heterozygous calls, MAC failures = 0, 0/0 = NaN at mac 0), the
+    per-phenotype top-N index lists equal a literal std::priority_queue's, and the tool's output files equal the
+    lines / bytes those lists select."""
+    base = str(tmp_path / "snps")
+    names, body = _write_bedbimfam(base, n_file, n_snps, seed=n_file)
+    pick = np.random.default_rng(1).permutation(n_file)[:n_use]
+    use = [names[i] for i in pick]
+    P, topn = 3, 57
+    Y = phenotypes(n_use, P - 1, seed=4)
+    pnames = ["trait%d" % j for j in range(P)]
+    ph = tmp_path / "ph.tsv"
+    with open(ph, "w") as f:
+        f.write("accession_id\t" + "\t".join(pnames) + "\n")
+        for i, a in enumerate(use):
+            f.write(a + "\t" + "\t".join(repr(float(Y[j, i])) for j in range(P)) + "\n")
+    mac = float(max(np.ceil(0.05 * n_use), 5.0))
+    exp = np.stack([ob.snps_scores(body.tobytes(), n_file, pick, Y[j], mac) for j in range(P)])
+    db = kg.SnpsDataBase(base, use)
+    assert (db.n_snps, db.n_samples_file) == (n_snps, n_file)
+    got = db.scores(Y, mac)
+    assert got.tobytes() == exp.tobytes()
+    assert (exp[:, :8] == 0).all() and (exp[:, 8] == exp[:, 9]).all() and (exp[:, 10:] > 0).any()
+    got0 = db.scores(Y[:1], 0.0)  # mac = 0: nothing is filtered, all-missing SNPs divide 0 by 0
+    exp0 = ob.snps_scores(body.tobytes(), n_file, pick, Y[0], 0.0)
+    assert got0[0].tobytes() == exp0.tobytes() and np.isnan(exp0[5:8]).all()
+    best = db.best(Y, topn, mac)
+    lists = []
+    for j in range(P):
+        h = ob.Heap(topn)
+        h.add_many(np.zeros(n_snps, np.uint64), exp[j], np.arange(n_snps, dtype=np.uint64))
+        rows = np.sort(h.pop_all()[2])
+        lists.append(rows)
+        assert (best[j] == rows).all()
+    out_p, out_o = tmp_path / "prod", tmp_path / "orc"
+    out_p.mkdir(); out_o.mkdir()
+    bim_lines = open(base + ".bim").read().split("\n")
+    for j in range(P):  # output_plink_bed_file, restated: the selected .bim lines and .bed rows
+        with open(out_o / ("o.%s.bed" % pnames[j]), "wb") as f:
+            f.write(bytes([0x6C, 0x1B, 0x01]) + body[lists[j].astype(np.int64)].tobytes())
+        with open(out_o / ("o.%s.bim" % pnames[j]), "w") as f:
+            f.write("".join(bim_lines[int(i)] + "\n" for i in lists[j]))
+    r = subprocess.run([os.path.join(BIN, "associate_snps"), str(ph), base, str(out_p / "o"), str(topn), "0.05", "5"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "(snps,samples) = %d, %d" % (n_snps, n_file) in r.stderr and "Minor allele count  = %g" % mac in r.stderr
+    _compare_dirs(str(out_p), str(out_o))
+    db.close()
+    # a phenotyped sample that is not in the .fam: the reference's uncaught logic_error
+    with pytest.raises(kg.KgwasError) as e:
+        kg.SnpsDataBase(base, use + ["nobody"])
+    assert "All accessions should be in fam file: nobody" in str(e.value)
+    r = subprocess.run([os.path.join(BIN, "associate_snps"), str(ph)], capture_output=True, text=True)
+    assert r.returncode == 1 and "usage:" in r.stderr
