@@ -197,6 +197,7 @@ def main():
         kernel_name = {1: "score_valu_kernel", 2: "score_mfma_kernel", 3: "coarse_kernel"}[ku]
         peak, peak_unit, dtype = F32_MFMA_PEAK_TFLOPS, "TFLOP/s", "f32"
         executed = None
+        hbm_bound = False
         if ku == 3:
             # dominant kernel = the int8 coarse filter; its own launches are timed separately from the exact
             # re-scoring of the survivors. `achieved` stays ALGORITHMIC (2*S flop per k-mer x column); the
@@ -217,6 +218,11 @@ def main():
             rows_scored = sum(sum(st_["coarse_mode_rows"]) for st_ in stats)
             achieved_tflops = flop_per_row * rows_scored / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
             executed = ex_ops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+            # roofline side: 2*S*P op per 8*W bytes against the balance point of the int8 pipe and HBM
+            if flop_per_row / (8.0 * W) < I8_MFMA_PEAK_TOPS * 1e12 / (HBM_PEAK_GBPS * 1e9):
+                hbm_bound = True
+                peak, peak_unit = HBM_PEAK_GBPS, "GB/s (HBM3E)"
+                achieved_tflops = rows_scored * 8.0 * W / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0  # algorithmic bytes / s
         # sanity on the final result of the last step: ascending pops, full heaps
         k, sc, r = last.result(0)
         assert (np.diff(sc) >= 0).all() and len(k) == min(args.topn, tested)
@@ -246,7 +252,7 @@ def main():
             "rows_per_s": total_rows / (ms_per_step / 1e3),
             "hbm_read_GBps_algorithmic": total_rows * 8.0 * W / (ms_per_step / 1e3) / 1e9,
             "rows_tested": int(tested),
-            "roofline": {"bound": "mfma" if ku in (2, 3) else "valu", "kernel": kernel_name,
+            "roofline": {"bound": "hbm" if hbm_bound else ("mfma" if ku in (2, 3) else "valu"), "kernel": kernel_name,
                          "achieved": achieved_tflops, "peak": peak, "unit": peak_unit,
                          "frac": achieved_tflops / peak, "executed_TOPs": executed,
                          "coarse_sets": ([{"int8_slices": mi + 1, "tiles_per_lds_group": stats[-1]["coarse_mode_tiles"][mi],

@@ -23,6 +23,11 @@ struct RowSrc {
     uint32_t avail_dw;  // dwords of bit data present in a row
 };
 
+// The MAC-passing rows of a launch are counted in TESTED_SHARDS counters (block b adds to counter b % TESTED_SHARDS, the
+// host sums them): a single counter takes one device-scope atomic per block or wave, and those serialise at the memory
+// side (1.3e5 of them made an 8 M-row launch of the bit-sliced filter ten times slower than its arithmetic).
+constexpr uint32_t TESTED_SHARDS = 256;
+
 struct ScoreArgs {
     RowSrc src;
     const uint32_t* dmask;      // [2*W_m] AND mask per squeezed dword (0 where no data exists)
@@ -46,7 +51,7 @@ struct ScoreArgs {
     Cand* cand;           // [n_pheno][cap]
     uint32_t* cand_cnt;   // [n_pheno]
     uint32_t cap;
-    unsigned long long* tested;  // MAC-passing rows, accumulated
+    unsigned long long* tested;  // MAC-passing rows, accumulated ([TESTED_SHARDS]; the exact scorers use [0])
     // Device-side threshold tracking (sparse mode, optional): every shipped candidate is counted in a
     // per-column histogram over the top bits of its score; thr_update_kernel raises thr[p] between
     // chunks to the largest bin boundary with >= topn[p] candidates at or above it.

@@ -27,6 +27,8 @@
 // The four kg-lanes of a row thus fetch 64 contiguous bytes per instruction and every byte is used by the
 // lane that loaded it. Bits become int8 0/1 with (nibble * 0x00204081) & 0x01010101 (4 bytes per 3 VALU ops);
 // each expanded operand feeds T column tiles, each B operand (ds_read_b128) four row tiles.
+#include <algorithm>
+
 #include "score_common.h"
 
 #ifndef KGWAS_COARSE_PF
@@ -329,7 +331,7 @@ __global__ void __launch_bounds__(512) coarse_kernel(CoarseArgs a, uint32_t rows
         uint32_t v = tested_local;
         v += __shfl_xor(v, 16);
         v += __shfl_xor(v, 32);
-        if (lane == 15u && v) atomicAdd(a.tested, (unsigned long long)v);
+        if (lane == 15u && v) atomicAdd(&a.tested[blockIdx.x % TESTED_SHARDS], (unsigned long long)v);
     }
 }
 
