@@ -620,7 +620,7 @@ void run_dense(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, uint64_t 
     a.n1_out = s->d_n1.p;
     a.kmer_out = s->d_kmer.p;
     a.tested = s->d_tested_dense.p;
-    KGWAS_HIP(hipMemsetAsync(s->d_tested_dense.p, 0, sizeof(unsigned long long), s->stream));
+    KGWAS_HIP(hipMemsetAsync(s->d_tested_dense.p, 0, TESTED_SHARDS * sizeof(unsigned long long), s->stream));
     KGWAS_HIP(hipEventRecord(es, s->stream));
     maybe_squeeze(s, d_rows, n_rows);
     KGWAS_HIP(hipEventRecord(e0, s->stream));
@@ -1475,7 +1475,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         s->h_n1.alloc(s->dense_rows);
         s->d_kmer.alloc(s->dense_rows);
         s->h_kmer.alloc(s->dense_rows);
-        s->d_tested_dense.alloc(1);
+        s->d_tested_dense.alloc(TESTED_SHARDS);
 
         for (uint64_t j = 0; j < P; j++) s->heaps.emplace_back((size_t)s->topn[j]);
         s->hist.resize(P);

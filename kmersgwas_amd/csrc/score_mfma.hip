@@ -273,7 +273,7 @@ __device__ __forceinline__ void score_rows(const ScoreArgs& a, const float* ylds
         v += __shfl_xor(v, 2);
         v += __shfl_xor(v, 4);
         v += __shfl_xor(v, 8);
-        if (lane == 0 && v) atomicAdd(a.tested, (unsigned long long)v);
+        if (lane == 0 && v) atomicAdd(&a.tested[blockIdx.x % TESTED_SHARDS], (unsigned long long)v);
     }
 }
 

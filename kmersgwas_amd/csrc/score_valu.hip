@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(256) score_valu_kernel(ScoreArgs a) {
     if (blockIdx.y == 0 && in_range) {
         if (a.n1_out) a.n1_out[r] = n1;
         if (a.kmer_out) a.kmer_out[r] = a.file_rows[r * a.file_stride_w];
-        if (pass && a.tested) atomicAdd(a.tested, 1ull);  // hipcc folds this into one atomic per wave
+        if (pass && a.tested) atomicAdd(&a.tested[blockIdx.x % TESTED_SHARDS], 1ull);  // hipcc folds this into one atomic per wave
     }
     if (!in_range) return;
 #pragma unroll
