@@ -70,120 +70,6 @@ __global__ void __launch_bounds__(256) synth_kernel(uint64_t* rows, uint64_t fir
 }
 
 // ------------------------------------------------------------------------------------------
-// Kinship, step 1: MAC filter over all S_f columns + bit transpose.
-// T[c][rw] (u32) holds sample c's presence bits for rows 32*rw .. 32*rw+31 of the launch;
-// rows failing the filter contribute all-zero bits, i.e. nothing to any Hamming distance.
-// A block covers 512 rows (two 256-row halves) so that each sample's output is one 64-byte line.
-// ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) kin_transpose_kernel(const uint64_t* file_rows, uint64_t file_stride_w,
-                                                            uint64_t n_rows, uint32_t S_f, uint32_t S_pad,
-                                                            uint32_t min_count, uint32_t* T, uint64_t n_rw,
-                                                            unsigned long long* n_used) {
-    extern __shared__ uint32_t lds_u32[];
-    const uint32_t W_f = (S_f + 63u) / 64u;
-    const uint32_t in_dw = 2u * W_f, in_ld = in_dw + 1u;
-    uint32_t* lin = lds_u32;                     // [256][in_ld]
-    uint32_t* lout = lds_u32 + 256u * in_ld;     // [S_pad][16]
-    const uint64_t blk_row0 = (uint64_t)blockIdx.x * 512u;
-    const uint32_t* fr = reinterpret_cast<const uint32_t*>(file_rows);
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-
-    for (uint32_t half = 0; half < 2u; half++) {
-        const uint64_t row0 = blk_row0 + half * 256u;
-        __syncthreads();
-        for (uint32_t e = threadIdx.x; e < 256u * in_dw; e += 256u) {
-            const uint32_t rr = e / in_dw, dw = e - rr * in_dw;
-            const uint64_t gr = row0 + rr;
-            lin[rr * in_ld + dw] = (gr < n_rows) ? fr[gr * file_stride_w * 2u + 2u + dw] : 0u;
-        }
-        __syncthreads();
-        const uint32_t rr = threadIdx.x;
-        const uint64_t r = row0 + rr;
-        uint32_t n1 = 0;
-        for (uint32_t dw = 0; dw < in_dw; dw++) n1 += __popc(lin[rr * in_ld + dw]);
-        // src/emma_kinship_kmers.cpp:83,89 -> load_kmers' predicate with all S_f columns
-        const bool pass = (r < n_rows) && (S_f >= min_count) && (n1 >= min_count) && (n1 <= S_f - min_count);
-        if (pass) atomicAdd(n_used, 1ull);
-        for (uint32_t c = 0; c < S_pad; c++) {
-            const bool bit = pass && (c < S_f) && ((lin[rr * in_ld + (c >> 5)] >> (c & 31u)) & 1u);
-            const unsigned long long bal = __ballot(bit);
-            if (lane == 0) {
-                lout[c * 16u + half * 8u + wave * 2u + 0u] = (uint32_t)bal;
-                lout[c * 16u + half * 8u + wave * 2u + 1u] = (uint32_t)(bal >> 32);
-            }
-        }
-    }
-    __syncthreads();
-    const uint64_t rw0 = (uint64_t)blockIdx.x * 16u;
-    for (uint32_t e = threadIdx.x; e < S_pad * 16u; e += 256u) {
-        const uint32_t c = e >> 4, k = e & 15u;
-        if (rw0 + k < n_rw) T[(uint64_t)c * n_rw + rw0 + k] = lout[e];
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Kinship, step 2: H[i][j] += sum_rw popcount(T[i][rw] ^ T[j][rw]) — a "GEMM" whose
-// multiply-add is xor + v_bcnt_u32_b32. 64x64 tile per block, 4x4 per thread, split over rw.
-// 1 ^ g_i ^ g_j summed over the used rows is n_used - H[i][j].
-// ------------------------------------------------------------------------------------------
-#define KIN_KC 32u
-__global__ void __launch_bounds__(256) kin_gram_kernel(const uint32_t* T, uint64_t n_rw, uint32_t S_pad,
-                                                       unsigned long long* H, uint32_t n_t1d, uint64_t rw_per_split) {
-    __shared__ uint32_t A[64][KIN_KC + 1];
-    __shared__ uint32_t B[64][KIN_KC + 1];
-    // decode lower-triangular tile index
-    uint32_t tix = blockIdx.x, ib = 0;
-    while (tix >= ib + 1u) {
-        tix -= ib + 1u;
-        ib++;
-    }
-    const uint32_t jb = tix;
-    (void)n_t1d;
-    const uint64_t k_begin = (uint64_t)blockIdx.y * rw_per_split;
-    uint64_t k_end = k_begin + rw_per_split;
-    if (k_end > n_rw) k_end = n_rw;
-    const uint32_t ti = threadIdx.x >> 4, tj = threadIdx.x & 15u;
-    uint32_t acc[4][4];
-#pragma unroll
-    for (int x = 0; x < 4; x++)
-#pragma unroll
-        for (int y = 0; y < 4; y++) acc[x][y] = 0u;
-
-    for (uint64_t k0 = k_begin; k0 < k_end; k0 += KIN_KC) {
-        __syncthreads();
-        for (uint32_t e = threadIdx.x; e < 64u * KIN_KC; e += 256u) {
-            const uint32_t row = e / KIN_KC, kw = e % KIN_KC;
-            const bool ok = (k0 + kw) < k_end;
-            A[row][kw] = ok ? T[(uint64_t)(ib * 64u + row) * n_rw + k0 + kw] : 0u;
-            B[row][kw] = ok ? T[(uint64_t)(jb * 64u + row) * n_rw + k0 + kw] : 0u;
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (uint32_t kw = 0; kw < KIN_KC; kw++) {
-            uint32_t av[4], bv[4];
-#pragma unroll
-            for (int x = 0; x < 4; x++) av[x] = A[ti * 4 + x][kw];
-#pragma unroll
-            for (int y = 0; y < 4; y++) bv[y] = B[tj * 4 + y][kw];
-#pragma unroll
-            for (int x = 0; x < 4; x++)
-#pragma unroll
-                for (int y = 0; y < 4; y++) acc[x][y] += __popc(av[x] ^ bv[y]);
-        }
-    }
-#pragma unroll
-    for (int x = 0; x < 4; x++)
-#pragma unroll
-        for (int y = 0; y < 4; y++) {
-            const uint32_t i = ib * 64u + ti * 4u + x, j = jb * 64u + tj * 4u + y;
-            if (acc[x][y]) {
-                atomicAdd(&H[(uint64_t)i * S_pad + j], (unsigned long long)acc[x][y]);
-                if (ib != jb) atomicAdd(&H[(uint64_t)j * S_pad + i], (unsigned long long)acc[x][y]);
-            }
-        }
-}
-
-// ------------------------------------------------------------------------------------------
 // Device-side threshold tracking. BestAssociationsHeap::add_association only changes a full heap
 // when score > lowest_score (src/best_associations_heap.cpp:49-58); lowest_score after some rows is
 // the N-th largest score seen, so ANY value v with at least N seen scores >= v is a lower bound of it.
@@ -264,34 +150,6 @@ hipError_t launch_synth(uint64_t* rows, uint64_t first_row, uint64_t n_rows, uin
     uint64_t blocks = (total + 255) / 256;
     if (blocks > 256ull * 32ull) blocks = 256ull * 32ull;
     hipLaunchKernelGGL(synth_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, rows, first_row, n_rows, n_acc, seed);
-    return hipGetLastError();
-}
-
-hipError_t launch_kin_transpose(const uint64_t* file_rows, uint64_t file_stride_w, uint64_t n_rows, uint32_t S_f,
-                                uint32_t S_pad, uint32_t min_count, uint32_t* T, uint64_t n_rw,
-                                unsigned long long* n_used, hipStream_t st) {
-    if (n_rows == 0) return hipSuccess;
-    const uint32_t W_f = (S_f + 63u) / 64u;
-    const size_t lds = ((size_t)256u * (2u * W_f + 1u) + (size_t)S_pad * 16u) * 4u;
-    if (lds > 160u * 1024u) return hipErrorInvalidValue;
-    hipError_t e = ensure_dyn_lds((const void*)kin_transpose_kernel, lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kin_transpose_kernel, dim3((uint32_t)((n_rows + 511) / 512)), dim3(256), lds, st, file_rows,
-                       file_stride_w, n_rows, S_f, S_pad, min_count, T, n_rw, n_used);
-    return hipGetLastError();
-}
-
-hipError_t launch_kin_gram(const uint32_t* T, uint64_t n_rw, uint32_t S_pad, unsigned long long* H, hipStream_t st) {
-    if (n_rw == 0) return hipSuccess;
-    const uint32_t nt = S_pad / 64u;
-    const uint32_t tiles = nt * (nt + 1u) / 2u;
-    // enough k-splits to fill 256 CUs several times over, each split a multiple of KIN_KC words
-    uint64_t want = (256ull * 8ull + tiles - 1) / tiles;
-    uint64_t per = (n_rw + want - 1) / want;
-    per = ((per + KIN_KC - 1) / KIN_KC) * KIN_KC;
-    if (per < KIN_KC * 4) per = KIN_KC * 4;
-    const uint32_t splits = (uint32_t)((n_rw + per - 1) / per);
-    hipLaunchKernelGGL(kin_gram_kernel, dim3(tiles, splits), dim3(256), 0, st, T, n_rw, S_pad, H, nt, per);
     return hipGetLastError();
 }
 

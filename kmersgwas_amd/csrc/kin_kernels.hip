@@ -1,0 +1,219 @@
+// kin_kernels.hip — emma_kinship_kmers on the GPU (src/emma_kinship_kmers.cpp:77-102,
+// update_emma_kinshhip_calculation, src/kmers_multiple_databases.cpp:418-438).
+//
+// K[i][j] += 1 ^ g_i ^ g_j over the rows that pass ceil(S_f*maf) <= popcount <= S_f - that equals
+// n_used - Hamming(i, j), and Hamming(i, j) = c_ii + c_jj - 2 c_ij with c_ij = sum_rows g_i g_j: the accumulation is
+// ONE symmetric integer Gram matrix of the bit table, exact in int32 per chunk and u64 across chunks. Two kernels per
+// chunk of rows:
+//   kin_transpose_kernel : MAC filter over all S_f columns (failing rows contribute zero bits) + bit transpose into
+//                          sample-major planes T[sample][row/32], 32x32 bit tiles transposed across 32 lanes in five
+//                          butterfly stages (the previous version took one ballot per sample: 1152 per 64 rows,
+//                          half of the whole accumulation's time);
+//   kin_gram_kernel      : C = T T^t on v_mfma_i32_16x16x64_i8. A wave owns a 64 x 128 tile of C (32 accumulators) and
+//                          expands its own operands from the planes (16 row bits -> 16 bytes: 12 VALU ops) - 144 VALU ops
+//                          per 32 MFMAs, the two waves of a SIMD overlapping one's expansion with the other's MFMAs.
+//                          The xor-popcount formulation this replaces does S^2/64 lane-ops per row (VALU-bound,
+//                          146 T pair-updates/s at 1135 samples).
+#include "kernels.h"
+
+namespace kgwas {
+
+typedef int kin_i32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ kin_i32x4 kin_expand16(uint32_t x) {  // 16 bits -> 16 int8 0/1 (k-element e in byte e)
+    kin_i32x4 r;
+    r[0] = (int)(((x & 0xFu) * 0x00204081u) & 0x01010101u);
+    r[1] = (int)((((x >> 4) & 0xFu) * 0x00204081u) & 0x01010101u);
+    r[2] = (int)((((x >> 8) & 0xFu) * 0x00204081u) & 0x01010101u);
+    r[3] = (int)((((x >> 12) & 0xFu) * 0x00204081u) & 0x01010101u);
+    return r;
+}
+
+// 32 x 32 bit-matrix transpose across the 32 lanes of a half wave: in: lane r holds row r (bit s = sample s);
+// out: lane s holds sample s (bit r = row r).
+__device__ __forceinline__ uint32_t transpose32(uint32_t x, uint32_t lane) {
+    uint32_t m = 0x0000FFFFu;
+#pragma unroll
+    for (int j = 16; j != 0; j >>= 1) {
+        const uint32_t y = __shfl_xor(x, j);
+        const bool lo = (lane & (uint32_t)j) == 0u;
+        const uint32_t a = lo ? x : y, b = lo ? y : x;
+        const uint32_t t = ((a >> j) ^ b) & m;
+        x = lo ? (a ^ (t << j)) : (b ^ t);
+        m ^= m << (j >> 1);
+    }
+    return x;
+}
+
+}  // namespace
+
+// T[c][rw] (u32) = sample c's presence bits for rows 32*rw .. 32*rw+31 of the launch; rows failing the filter are
+// all-zero. A block covers 512 rows (two 256-row halves) so that each sample's output is one 64-byte line.
+__global__ void __launch_bounds__(256) kin_transpose_kernel(const uint64_t* file_rows, uint64_t file_stride_w, uint64_t n_rows,
+                                                            uint32_t S_f, uint32_t S_pad, uint32_t min_count, uint32_t* T,
+                                                            uint64_t n_rw, unsigned long long* n_used) {
+    extern __shared__ uint32_t kin_lds[];
+    const uint32_t stride_dw = (uint32_t)(2u * file_stride_w);
+    uint32_t* lin = kin_lds;                        // [256][stride_dw] verbatim rows (k-mer word included)
+    uint32_t* lout = kin_lds + 256u * stride_dw;    // [S_pad][16]
+    const uint32_t in_dw = 2u * ((S_f + 63u) / 64u);
+    const uint64_t blk_row0 = (uint64_t)blockIdx.x * 512u;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    unsigned long long kept = 0;
+    for (uint32_t half = 0; half < 2u; half++) {
+        const uint64_t row0 = blk_row0 + half * 256u;
+        __syncthreads();
+        if (row0 < n_rows) {  // coalesced verbatim copy of up to 256 contiguous rows
+            const uint64_t left = n_rows - row0;
+            const uint32_t n2 = (uint32_t)((left < 256u ? left : 256u) * file_stride_w);
+            const uint2* src = reinterpret_cast<const uint2*>(file_rows + row0 * file_stride_w);
+            uint2* dst = reinterpret_cast<uint2*>(lin);
+            for (uint32_t i = threadIdx.x; i < n2; i += 256u) dst[i] = src[i];
+        }
+        __syncthreads();
+        const uint64_t r = row0 + threadIdx.x;
+        const uint32_t* my = lin + (size_t)threadIdx.x * stride_dw + 2u;
+        uint32_t n1 = 0;
+        if (r < n_rows)
+            for (uint32_t d = 0; d < in_dw; d++) n1 += __popc(my[d]);
+        // src/emma_kinship_kmers.cpp:83,89 -> load_kmers' predicate with all S_f columns
+        const bool pass = (r < n_rows) && (S_f >= min_count) && (n1 >= min_count) && (n1 <= S_f - min_count);
+        kept += __popcll(__ballot(pass));
+        for (uint32_t d = 0; d < S_pad / 32u; d++) {
+            uint32_t x = (pass && d < in_dw) ? my[d] : 0u;
+            if (32u * d + 32u > S_f) x &= (32u * d < S_f) ? ((1u << (S_f - 32u * d)) - 1u) : 0u;  // file padding bits
+            x = transpose32(x, lane);
+            // lane s of 32-lane group g now holds sample 32d + s over the group's 32 rows
+            lout[(32u * d + (lane & 31u)) * 16u + half * 8u + wave * 2u + (lane >> 5)] = x;
+        }
+    }
+    if (lane == 0 && kept) atomicAdd(&n_used[blockIdx.x % TESTED_SHARDS], kept);  // each wave adds the rows it counted
+    __syncthreads();
+    const uint64_t rw0 = (uint64_t)blockIdx.x * 16u;
+    for (uint32_t e = threadIdx.x; e < S_pad * 16u; e += 256u) {
+        const uint32_t c = e >> 4, k = e & 15u;
+        if (rw0 + k < n_rw) T[(uint64_t)c * n_rw + rw0 + k] = lout[e];
+    }
+}
+
+// C[i][j] += sum over the launch's rows of g_i g_j for the 128 x 128 sample tile (ib, jb), jb >= ib, and a slice of
+// the rows (blockIdx.y). Block = 2 waves; wave w owns samples ib*128 + 64w .. +63 against all 128 of jb.
+// MFMA k index <-> rows: lane (m, kg) supplies rows 64s + 16kg .. +15 of sample m for step s, i.e. the low or high
+// half of dword 2s + kg/2 of that sample's plane.
+constexpr uint32_t KIN_KC = 16;  // plane dwords (512 rows) staged per round
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) kin_gram_kernel(const uint32_t* T, uint64_t n_rw, uint32_t S_pad, unsigned long long* C,
+                                                       uint64_t rw_per_split) {
+    __shared__ uint32_t LA[128][KIN_KC + 1];
+    __shared__ uint32_t LB[128][KIN_KC + 1];
+    uint32_t tix = blockIdx.x, ib = 0;  // upper-triangular tile index -> (ib, jb), jb >= ib
+    const uint32_t nt = S_pad / 128u;
+    while (tix >= nt - ib) {
+        tix -= nt - ib;
+        ib++;
+    }
+    const uint32_t jb = ib + tix;
+    const uint64_t k_begin = (uint64_t)blockIdx.y * rw_per_split;
+    uint64_t k_end = k_begin + rw_per_split;
+    if (k_end > n_rw) k_end = n_rw;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t m = lane & 15u, kg = lane >> 4;
+    kin_i32x4 acc[4][8];
+#pragma unroll
+    for (int x = 0; x < 4; x++)
+#pragma unroll
+        for (int y = 0; y < 8; y++) acc[x][y] = (kin_i32x4){0, 0, 0, 0};
+
+    // A round stages KIN_KC plane dwords (512 rows) of the 128 + 128 samples: 16-byte loads, 4 lanes per sample, and the
+    // NEXT round's loads are already in flight (registers) while this round's 8 MFMA steps run.
+    constexpr int NLD = (2 * 128 * KIN_KC / 4) / 128;  // uint4 loads per lane and round
+    uint4 nxt[NLD];
+    auto issue = [&](uint64_t k0) {
+#pragma unroll
+        for (int q = 0; q < NLD; q++) {
+            const uint32_t e = q * 128u + threadIdx.x;            // 0 .. 2*128*KIN_KC/4 - 1
+            const uint32_t row = e / (KIN_KC / 4u), part = e % (KIN_KC / 4u);  // row 0..255 (A then B), 4-dword part
+            const uint32_t srow = (row < 128u ? ib * 128u + row : jb * 128u + (row - 128u));
+            uint64_t kw = k0 + 4u * part;
+            if (kw + 4u > n_rw) kw = n_rw - 4u;  // n_rw is a multiple of 16: clamp instead of branching (tail is masked below)
+            nxt[q] = *reinterpret_cast<const uint4*>(T + (uint64_t)srow * n_rw + kw);
+        }
+    };
+    auto land = [&](uint64_t k0) {
+#pragma unroll
+        for (int q = 0; q < NLD; q++) {
+            const uint32_t e = q * 128u + threadIdx.x;
+            const uint32_t row = e / (KIN_KC / 4u), part = e % (KIN_KC / 4u);
+            uint32_t* dst = (row < 128u ? &LA[row][4u * part] : &LB[row - 128u][4u * part]);
+            const uint64_t kw = k0 + 4u * part;
+            const uint32_t v[4] = {nxt[q].x, nxt[q].y, nxt[q].z, nxt[q].w};
+#pragma unroll
+            for (int c = 0; c < 4; c++) dst[c] = (kw + c < k_end) ? v[c] : 0u;  // beyond this block's slice: zero bits
+        }
+    };
+    if (k_begin < k_end) issue(k_begin);
+    for (uint64_t k0 = k_begin; k0 < k_end; k0 += KIN_KC) {
+        __syncthreads();
+        land(k0);
+        __syncthreads();
+        if (k0 + KIN_KC < k_end) issue(k0 + KIN_KC);
+#pragma unroll 2
+        for (uint32_t s = 0; s < KIN_KC / 2u; s++) {
+            const uint32_t dw = 2u * s + (kg >> 1), sh = (kg & 1u) * 16u;
+            kin_i32x4 A[4], B[8];
+#pragma unroll
+            for (int x = 0; x < 4; x++) A[x] = kin_expand16((LA[wave * 64u + x * 16u + m][dw] >> sh) & 0xFFFFu);
+#pragma unroll
+            for (int y = 0; y < 8; y++) B[y] = kin_expand16((LB[y * 16u + m][dw] >> sh) & 0xFFFFu);
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+#pragma unroll
+                for (int y = 0; y < 8; y++) acc[x][y] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[x], B[y], acc[x][y], 0, 0, 0);
+        }
+    }
+    // D[row = 4kg + jj][col = m] of tile (x, y)
+#pragma unroll
+    for (int x = 0; x < 4; x++)
+#pragma unroll
+        for (int y = 0; y < 8; y++)
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+                const int v = acc[x][y][jj];
+                if (v) {
+                    const uint32_t i = ib * 128u + wave * 64u + x * 16u + kg * 4u + jj, j = jb * 128u + y * 16u + m;
+                    atomicAdd(&C[(uint64_t)i * S_pad + j], (unsigned long long)v);
+                }
+            }
+}
+
+hipError_t launch_kin_transpose(const uint64_t* file_rows, uint64_t file_stride_w, uint64_t n_rows, uint32_t S_f,
+                                uint32_t S_pad, uint32_t min_count, uint32_t* T, uint64_t n_rw, unsigned long long* n_used,
+                                hipStream_t st) {
+    if (n_rows == 0) return hipSuccess;
+    const size_t lds = (size_t)(256u * 2u * file_stride_w + (size_t)S_pad * 16u) * 4u;
+    if (lds > 160u * 1024u) return hipErrorInvalidValue;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kin_transpose_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kin_transpose_kernel, dim3((uint32_t)((n_rows + 511) / 512)), dim3(256), lds, st, file_rows, file_stride_w,
+                       n_rows, S_f, S_pad, min_count, T, n_rw, n_used);
+    return hipGetLastError();
+}
+
+hipError_t launch_kin_gram(const uint32_t* T, uint64_t n_rw, uint32_t S_pad, unsigned long long* C, hipStream_t st) {
+    if (n_rw == 0) return hipSuccess;
+    const uint32_t nt = S_pad / 128u;
+    const uint32_t tiles = nt * (nt + 1u) / 2u;
+    // enough row slices to fill 256 CUs several times over, each a multiple of KIN_KC plane words
+    uint64_t want = (256ull * 12ull + tiles - 1) / tiles;
+    uint64_t per = (n_rw + want - 1) / want;
+    per = ((per + KIN_KC - 1) / KIN_KC) * KIN_KC;
+    if (per < KIN_KC * 4) per = KIN_KC * 4;
+    const uint32_t splits = (uint32_t)((n_rw + per - 1) / per);
+    hipLaunchKernelGGL(kin_gram_kernel, dim3(tiles, splits), dim3(128), 0, st, T, n_rw, S_pad, C, per);
+    return hipGetLastError();
+}
+
+}  // namespace kgwas

@@ -78,7 +78,7 @@ int kgwas_kinship_create(int32_t device, uint64_t n_acc_file, uint64_t min_count
         k->S_f = n_acc_file;
         k->W_f = (n_acc_file + 63) / 64;
         k->min_count = min_count;
-        k->S_pad = (uint32_t)((n_acc_file + 63) / 64 * 64);
+        k->S_pad = (uint32_t)((n_acc_file + 127) / 128 * 128);  // whole 128 x 128 Gram tiles
         k->chunk_rows = 1ull << 20;  // the reference's own batch size (src/emma_kinship_kmers.cpp:89)
         k->n_rw_cap = (k->chunk_rows + 511) / 512 * 16;
         KGWAS_HIP(hipStreamCreateWithFlags(&k->stream, hipStreamNonBlocking));
@@ -87,9 +87,9 @@ int kgwas_kinship_create(int32_t device, uint64_t n_acc_file, uint64_t min_count
         KGWAS_HIP(hipEventCreate(&k->ev1));
         KGWAS_HIP(hipMalloc((void**)&k->d_T, (size_t)k->S_pad * k->n_rw_cap * 4));
         KGWAS_HIP(hipMalloc((void**)&k->d_H, (size_t)k->S_pad * k->S_pad * 8));
-        KGWAS_HIP(hipMalloc((void**)&k->d_n, 8));
+        KGWAS_HIP(hipMalloc((void**)&k->d_n, TESTED_SHARDS * 8));
         KGWAS_HIP(hipMemset(k->d_H, 0, (size_t)k->S_pad * k->S_pad * 8));
-        KGWAS_HIP(hipMemset(k->d_n, 0, 8));
+        KGWAS_HIP(hipMemset(k->d_n, 0, TESTED_SHARDS * 8));
         *out = k.release();
     });
 }
@@ -131,10 +131,14 @@ int kgwas_kinship_partials(kgwas_kinship* k, uint64_t* hamming, uint64_t* n_used
         KGWAS_HIP(hipStreamSynchronize(k->stream));
         std::vector<unsigned long long> H((size_t)k->S_pad * k->S_pad);
         KGWAS_HIP(hipMemcpy(H.data(), k->d_H, H.size() * 8, hipMemcpyDeviceToHost));
-        unsigned long long n = 0;
-        KGWAS_HIP(hipMemcpy(&n, k->d_n, 8, hipMemcpyDeviceToHost));
+        unsigned long long n = 0, shards[TESTED_SHARDS];
+        KGWAS_HIP(hipMemcpy(shards, k->d_n, sizeof(shards), hipMemcpyDeviceToHost));
+        for (unsigned long long v : shards) n += v;
+        // d_H holds the Gram counts c_ij = sum_rows g_i g_j (tiles on or above the diagonal of the 128-sample tiling);
+        // Hamming(i, j) = c_ii + c_jj - 2 c_ij
+        auto c = [&](uint64_t i, uint64_t j) { return (i / 128 <= j / 128) ? H[i * k->S_pad + j] : H[j * k->S_pad + i]; };
         for (uint64_t i = 0; i < k->S_f; i++)
-            for (uint64_t j = 0; j < k->S_f; j++) hamming[i * k->S_f + j] = H[i * k->S_pad + j];
+            for (uint64_t j = 0; j < k->S_f; j++) hamming[i * k->S_f + j] = (i == j) ? 0 : c(i, i) + c(j, j) - 2 * c(i, j);
         *n_used = n;
     });
 }
