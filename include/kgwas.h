@@ -214,6 +214,9 @@ typedef struct kgwas_kinship kgwas_kinship;
 int kgwas_kinship_create(int32_t device, uint64_t n_acc_file, uint64_t min_count, kgwas_kinship** out);
 int kgwas_kinship_feed_device(kgwas_kinship* k, const void* d_rows, uint64_t n_rows, void* hip_stream);
 int kgwas_kinship_feed_host(kgwas_kinship* k, const uint64_t* rows, uint64_t n_rows);
+/* Rows [row0, row0 + n_rows) of an open .table through the double-buffered ingest (file read, copy and kernels
+ * overlap); replaces the reference's load-a-batch-then-accumulate loop (src/emma_kinship_kmers.cpp:86-99). */
+int kgwas_kinship_feed_table(kgwas_kinship* k, kgwas_table* t, uint64_t row0, uint64_t n_rows);
 /* Hamming-distance partials (S_f x S_f u64, full symmetric) and rows used so far: integer, so
  * partials of different shards simply add (all-reduce) before kgwas_kinship_from_partials. */
 int kgwas_kinship_partials(kgwas_kinship* k, uint64_t* hamming, uint64_t* n_used);

@@ -31,7 +31,7 @@ SYMBOLS = [
     "kgwas_scan_create", "kgwas_scan_feed_device", "kgwas_scan_feed_host", "kgwas_scan_feed_table", "kgwas_scan_finish", "kgwas_scan_result",
     "kgwas_scan_history", "kgwas_scan_get_stats", "kgwas_scan_reset", "kgwas_scan_lowest", "kgwas_scan_absorb", "kgwas_scan_history_above", "kgwas_scan_heaps_export", "kgwas_scan_heaps_import", "kgwas_scan_destroy", "kgwas_scan_scores_dense",
     "kgwas_merge_shards",
-    "kgwas_kinship_create", "kgwas_kinship_feed_device", "kgwas_kinship_feed_host", "kgwas_kinship_partials",
+    "kgwas_kinship_create", "kgwas_kinship_feed_device", "kgwas_kinship_feed_host", "kgwas_kinship_feed_table", "kgwas_kinship_partials",
     "kgwas_kinship_from_partials", "kgwas_kinship_get_stats", "kgwas_kinship_destroy", "kgwas_kinship_format",
     "kgwas_write_plink", "kgwas_table_to_bed",
     "kgwas_snps_open", "kgwas_snps_info", "kgwas_snps_scores", "kgwas_snps_best", "kgwas_snps_write", "kgwas_snps_close",
@@ -168,6 +168,7 @@ lib.kgwas_merge_shards.argtypes = [_u64, _vp, _u64, _vp, _pp, _pp, _pp, _u32, _p
 lib.kgwas_kinship_create.argtypes = [_i32, _u64, _u64, _pp]
 lib.kgwas_kinship_feed_device.argtypes = [_vp, _vp, _u64, _vp]
 lib.kgwas_kinship_feed_host.argtypes = [_vp, _vp, _u64]
+lib.kgwas_kinship_feed_table.argtypes = [_vp, _vp, _u64, _u64]
 lib.kgwas_kinship_partials.argtypes = [_vp, _vp, _pu64]
 lib.kgwas_kinship_from_partials.argtypes = [_u64, _vp, _u64, _vp]
 lib.kgwas_kinship_get_stats.argtypes = [_vp, _pdbl, _pu64, _pu64]

@@ -72,15 +72,13 @@ int main(int argc, char* argv[]) {
         kgwas_kinship* kin = nullptr;
         ck(kgwas_kinship_create((int32_t)result.u64("device", 0), n_acc, min_count, &kin));
         cerr << "loading..." << endl;
-        const uint64_t batch = 1ull << 20;  // :89
-        vector<uint64_t> buf;
+        // the reference loads 2^20 rows, then accumulates them (:89-99); here the file read, the copy and the
+        // kernels of consecutive pieces overlap (kgwas_kinship_feed_table)
+        const uint64_t batch = 1ull << 24;
         for (uint64_t row0 = 0; row0 < n_rows; row0 += batch) {
-            const uint64_t n = std::min<uint64_t>(batch, n_rows - row0);
-            buf.resize(n * (1 + W_f));
-            ck(kgwas_table_read_rows(tbl, row0, n, buf.data()));
+            ck(kgwas_kinship_feed_table(kin, tbl, row0, std::min<uint64_t>(batch, n_rows - row0)));
             cerr << ".";
             cerr.flush();
-            ck(kgwas_kinship_feed_host(kin, buf.data(), n));
         }
         vector<uint64_t> H(n_acc * n_acc), K(n_acc * n_acc);
         uint64_t n_snps = 0;

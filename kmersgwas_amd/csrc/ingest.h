@@ -1,0 +1,173 @@
+// ingest.h — chunked, double-buffered host / file ingest shared by the scan and the kinship accumulation
+// (replaces the reference's load-a-batch-then-compute loops,
+// src/associate_kmers.cpp:104-148 and src/emma_kinship_kmers.cpp:86-99).
+//
+// Three pinned pieces are filled by producer threads, two device pieces receive them on a copy stream, and the
+// consumer works on piece k while piece k+1 is copied and piece k+2 is produced. The consumer sees the rows in
+// order, so results do not depend on the piece size.
+#pragma once
+#include <condition_variable>
+#include <cstdlib>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "common.h"
+
+namespace kgwas {
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    void alloc(size_t count) {
+        release();
+        if (count) KGWAS_HIP(hipMalloc((void**)&p, count * sizeof(T)));
+        n = count;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    ~DevBuf() { release(); }
+};
+template <class T>
+struct PinBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    void alloc(size_t count) {
+        release();
+        if (count) KGWAS_HIP(hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocMapped));
+        n = count;
+    }
+    T* dev() const {
+        T* d = nullptr;
+        if (p) KGWAS_HIP(hipHostGetDevicePointer((void**)&d, p, 0));
+        return d;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    ~PinBuf() { release(); }
+};
+
+class Ingest {
+public:
+    // fill(dst, row_off, cnt): produce rows [row_off, row_off + cnt) of this feed, in file layout, into pinned memory
+    // (runs on a producer thread, up to two pieces ahead of the consumer).
+    using Fill = std::function<void(uint64_t*, uint64_t, uint64_t)>;
+    // consume(d_rows, row_off, cnt): work on a device piece; `stream` already waits for its copy. Must return with
+    // the work on the piece complete (the device buffer is reused two pieces later).
+    using Consume = std::function<void(const uint64_t*, uint64_t, uint64_t)>;
+
+    ~Ingest() {
+        for (auto& e : ev_)
+            if (e) (void)hipEventDestroy(e);
+        if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
+    }
+
+    // stride = 64-bit words per row; max_piece_rows bounds a piece (the consumer's own chunk limit).
+    void run(uint64_t stride, uint64_t n_rows, uint64_t max_piece_rows, hipStream_t stream, const Fill& fill,
+             const Consume& consume) {
+        if (n_rows == 0) return;
+        if (!piece_rows_) {
+            uint64_t pr = (128ull << 20) / (8 * stride);  // 128 MiB pieces (64 MiB: 30 % slower, 256 MiB: no faster)
+            if (const char* e = getenv("KGWAS_INGEST_PIECE_ROWS"))
+                if (atoll(e) > 0) pr = (uint64_t)atoll(e);
+            pr = std::max<uint64_t>(128, std::min<uint64_t>(pr, max_piece_rows) / 128 * 128);
+            piece_rows_ = pr;
+            for (auto& h : h_) h.alloc(pr * stride);
+            for (auto& d : d_) d.alloc(pr * stride);
+            KGWAS_HIP(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+            for (auto& e : ev_) KGWAS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        const uint64_t piece = piece_rows_;
+        const uint64_t n_pieces = (n_rows + piece - 1) / piece;
+        auto count_of = [&](uint64_t k) { return std::min<uint64_t>(piece, n_rows - k * piece); };
+
+        std::mutex mu;
+        std::condition_variable cv;
+        uint64_t next_piece = 0, consumed = 0;  // next piece to produce / pieces whose buffers may be overwritten
+        std::vector<char> done(n_pieces, 0);
+        bool stop = false;
+        std::string producer_error;
+        // One producer per pinned buffer: a single thread tops out near 15 GB/s (pread from the page cache) or
+        // 28 GB/s (memcpy), well under the PCIe link.
+        auto producer_main = [&] {
+            try {
+                for (;;) {
+                    uint64_t k;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return stop || next_piece >= n_pieces || next_piece < consumed + 3; });
+                        if (stop || next_piece >= n_pieces) return;
+                        k = next_piece++;
+                    }
+                    fill(h_[k % 3].p, k * piece, count_of(k));
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        done[k] = 1;
+                    }
+                    cv.notify_all();
+                }
+            } catch (const std::exception& e) {
+                std::unique_lock<std::mutex> lk(mu);
+                producer_error = e.what();
+                stop = true;
+                cv.notify_all();
+            }
+        };
+        std::vector<std::thread> producers;
+        struct Joiner {  // whatever happens below, the producers are stopped and joined before the buffers go away
+            std::vector<std::thread>& t;
+            std::mutex& mu;
+            std::condition_variable& cv;
+            bool& stop;
+            ~Joiner() {
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    stop = true;
+                }
+                cv.notify_all();
+                for (auto& x : t)
+                    if (x.joinable()) x.join();
+            }
+        } joiner{producers, mu, cv, stop};
+        for (uint64_t i = 0; i < std::min<uint64_t>(3, n_pieces); i++) producers.emplace_back(producer_main);
+
+        auto compute = [&](uint64_t k) {
+            KGWAS_HIP(hipStreamWaitEvent(stream, ev_[k % 2], 0));
+            consume(d_[k % 2].p, k * piece, count_of(k));
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                consumed = k + 1;
+            }
+            cv.notify_all();
+        };
+        for (uint64_t k = 0; k < n_pieces; k++) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || done[k]; });
+                if (!done[k]) throw Error(KGWAS_ERR_IO, producer_error.empty() ? "ingest stopped" : producer_error);
+            }
+            KGWAS_HIP(hipMemcpyAsync(d_[k % 2].p, h_[k % 3].p, count_of(k) * stride * 8, hipMemcpyHostToDevice, copy_stream_));
+            KGWAS_HIP(hipEventRecord(ev_[k % 2], copy_stream_));
+            if (k >= 1) compute(k - 1);
+        }
+        compute(n_pieces - 1);
+    }
+
+private:
+    PinBuf<uint64_t> h_[3];
+    DevBuf<uint64_t> d_[2];
+    hipStream_t copy_stream_ = nullptr;
+    hipEvent_t ev_[2] = {nullptr, nullptr};
+    uint64_t piece_rows_ = 0;
+};
+
+}  // namespace kgwas

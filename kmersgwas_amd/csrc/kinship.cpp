@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "common.h"
+#include "ingest.h"
 #include "kernels.h"
 #include "synth.h"
 
@@ -25,8 +26,7 @@ struct kgwas_kinship {
     uint32_t* d_T = nullptr;
     unsigned long long* d_H = nullptr;
     unsigned long long* d_n = nullptr;
-    uint64_t* d_stage = nullptr;
-    size_t stage_words = 0;
+    Ingest ingest;  // host / file feeds: three pinned pieces, two device pieces, a copy stream
     double kernel_ms = 0;
     uint64_t launches = 0, rows_fed = 0;
     ~kgwas_kinship() {
@@ -34,7 +34,6 @@ struct kgwas_kinship {
         if (d_T) (void)hipFree(d_T);
         if (d_H) (void)hipFree(d_H);
         if (d_n) (void)hipFree(d_n);
-        if (d_stage) (void)hipFree(d_stage);
         if (ev_user) (void)hipEventDestroy(ev_user);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
@@ -109,18 +108,28 @@ int kgwas_kinship_feed_host(kgwas_kinship* k, const uint64_t* rows, uint64_t n_r
         if (!k || (!rows && n_rows)) throw Error(KGWAS_ERR_ARG, "kgwas_kinship_feed_host: null argument");
         KGWAS_HIP(hipSetDevice(k->device));
         const uint64_t stride = 1 + k->W_f;
-        const size_t need = (size_t)k->chunk_rows * stride;
-        if (k->stage_words < need) {
-            if (k->d_stage) (void)hipFree(k->d_stage);
-            k->d_stage = nullptr;
-            KGWAS_HIP(hipMalloc((void**)&k->d_stage, need * 8));
-            k->stage_words = need;
-        }
-        for (uint64_t pos = 0; pos < n_rows; pos += k->chunk_rows) {
-            const uint64_t c = std::min<uint64_t>(k->chunk_rows, n_rows - pos);
-            KGWAS_HIP(hipMemcpy(k->d_stage, rows + pos * stride, c * stride * 8, hipMemcpyHostToDevice));
-            kin_feed(k, k->d_stage, c);
-        }
+        k->ingest.run(
+            stride, n_rows, k->chunk_rows, k->stream,
+            [&](uint64_t* dst, uint64_t row_off, uint64_t cnt) { memcpy(dst, rows + row_off * stride, cnt * stride * 8); },
+            [&](const uint64_t* d_rows, uint64_t, uint64_t cnt) { kin_feed(k, d_rows, cnt); });
+    });
+}
+
+int kgwas_kinship_feed_table(kgwas_kinship* k, kgwas_table* t, uint64_t row0, uint64_t n_rows) {
+    return guarded([&] {
+        if (!k || !t) throw Error(KGWAS_ERR_ARG, "kgwas_kinship_feed_table: null argument");
+        uint64_t n_acc = 0, t_rows = 0, wpr = 0;
+        uint32_t klen = 0;
+        if (kgwas_table_info(t, &n_acc, &t_rows, &wpr, &klen) != KGWAS_OK) throw Error(KGWAS_ERR_ARG, kgwas_last_error());
+        if (n_acc != k->S_f) throw Error(KGWAS_ERR_ARG, "kgwas_kinship_feed_table: table and session disagree on the accession count");
+        if (row0 > t_rows || n_rows > t_rows - row0) throw Error(KGWAS_ERR_ARG, "kgwas_kinship_feed_table: out of range");
+        KGWAS_HIP(hipSetDevice(k->device));
+        k->ingest.run(
+            1 + k->W_f, n_rows, k->chunk_rows, k->stream,
+            [&](uint64_t* dst, uint64_t row_off, uint64_t cnt) {
+                if (kgwas_table_read_rows(t, row0 + row_off, cnt, dst) != KGWAS_OK) throw Error(KGWAS_ERR_IO, kgwas_last_error());
+            },
+            [&](const uint64_t* d_rows, uint64_t, uint64_t cnt) { kin_feed(k, d_rows, cnt); });
     });
 }
 

@@ -38,6 +38,7 @@
 
 #include "common.h"
 #include "heap.h"
+#include "ingest.h"
 #include "kernels.h"
 
 using namespace kgwas;
@@ -319,44 +320,6 @@ struct History {
     std::vector<double> score;
 };
 
-template <class T>
-struct DevBuf {
-    T* p = nullptr;
-    size_t n = 0;
-    void alloc(size_t count) {
-        release();
-        if (count) KGWAS_HIP(hipMalloc((void**)&p, count * sizeof(T)));
-        n = count;
-    }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        n = 0;
-    }
-    ~DevBuf() { release(); }
-};
-template <class T>
-struct PinBuf {
-    T* p = nullptr;
-    size_t n = 0;
-    void alloc(size_t count) {
-        release();
-        if (count) KGWAS_HIP(hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocMapped));
-        n = count;
-    }
-    T* dev() const {
-        T* d = nullptr;
-        if (p) KGWAS_HIP(hipHostGetDevicePointer((void**)&d, p, 0));
-        return d;
-    }
-    void release() {
-        if (p) (void)hipHostFree(p);
-        p = nullptr;
-        n = 0;
-    }
-    ~PinBuf() { release(); }
-};
-
 constexpr int MAX_SLOTS = 16;  // upper bound on sparse chunks the GPU may run ahead of the host replay
 
 struct Slot {
@@ -449,11 +412,7 @@ struct kgwas_scan {
     // host / file ingest (kgwas_scan_feed_host, kgwas_scan_feed_table): three pinned pieces filled by a producer
     // thread, two device pieces, a copy stream; piece k+1 is read and copied while piece k is scored and replayed
     DevBuf<uint64_t> d_stage;  // kgwas_scan_scores_dense staging
-    PinBuf<uint64_t> h_ing[3];
-    DevBuf<uint64_t> d_ing[2];
-    hipStream_t copy_stream = nullptr;
-    hipEvent_t ev_ing[2] = {nullptr, nullptr};
-    uint64_t ing_piece_rows = 0;
+    Ingest ingest;
 
     std::vector<BestHeap> heaps;
     std::vector<History> hist;
@@ -485,9 +444,6 @@ struct kgwas_scan {
         if (ev_ds) (void)hipEventDestroy(ev_ds);
         if (ev_d0) (void)hipEventDestroy(ev_d0);
         if (ev_d1) (void)hipEventDestroy(ev_d1);
-        for (auto& e : ev_ing)
-            if (e) (void)hipEventDestroy(e);
-        if (copy_stream) (void)hipStreamDestroy(copy_stream);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -1507,104 +1463,17 @@ int kgwas_scan_feed_device(kgwas_scan* s, const void* d_rows, uint64_t n_rows, u
 
 namespace {
 
-// Chunked, double-buffered ingest (replaces the reference's load-everything-then-compute
-// batches, src/associate_kmers.cpp:104-148). `fill(dst, row_off, cnt)` produces rows [row_off, row_off + cnt) of
-// this feed in file layout into pinned memory; it runs on a producer thread up to two pieces ahead. Piece k+1 is
-// produced and copied (own stream) while piece k is scored and replayed; results do not depend on the piece size
-// (rows are scored in order, thresholds only ever lag).
-void ingest_run(kgwas_scan* s, uint64_t n_rows, uint64_t first_row,
-                const std::function<void(uint64_t*, uint64_t, uint64_t)>& fill) {
+// Chunked, double-buffered ingest (ingest.h): piece k+1 is produced and copied while piece k is scored and
+// replayed; results do not depend on the piece size (rows are scored in order, thresholds only ever lag).
+void ingest_run(kgwas_scan* s, uint64_t n_rows, uint64_t first_row, const Ingest::Fill& fill) {
     if (n_rows == 0) {
         feed_device_impl(s, nullptr, 0, first_row);
         return;
     }
-    const uint64_t stride = 1 + s->W_f;
-    if (!s->ing_piece_rows) {
-        uint64_t pr = (128ull << 20) / (8 * stride);  // 128 MiB pieces (64 MiB: 30 % slower, 256 MiB: no faster)
-        if (const char* e = getenv("KGWAS_INGEST_PIECE_ROWS"))
-            if (atoll(e) > 0) pr = (uint64_t)atoll(e);
-        pr = std::max<uint64_t>(128, std::min<uint64_t>(pr, s->chunk_max) / 128 * 128);
-        s->ing_piece_rows = pr;
-        for (auto& h : s->h_ing) h.alloc(pr * stride);
-        for (auto& d : s->d_ing) d.alloc(pr * stride);
-        KGWAS_HIP(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
-        for (auto& e : s->ev_ing) KGWAS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
-    const uint64_t piece = s->ing_piece_rows;
-    const uint64_t n_pieces = (n_rows + piece - 1) / piece;
-    auto count_of = [&](uint64_t k) { return std::min<uint64_t>(piece, n_rows - k * piece); };
-
-    std::mutex mu;
-    std::condition_variable cv;
-    uint64_t next_piece = 0, copied = 0;  // next piece to produce / pieces whose pinned buffer may be overwritten
-    std::vector<char> done(n_pieces, 0);
-    bool stop = false;
-    std::string producer_error;
-    // One producer per pinned buffer: a single thread tops out near 15 GB/s (pread from the page cache) or
-    // 28 GB/s (memcpy), well under the PCIe link.
-    auto producer_main = [&] {
-        try {
-            for (;;) {
-                uint64_t k;
-                {
-                    std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return stop || next_piece >= n_pieces || next_piece < copied + 3; });
-                    if (stop || next_piece >= n_pieces) return;
-                    k = next_piece++;
-                }
-                fill(s->h_ing[k % 3].p, k * piece, count_of(k));
-                {
-                    std::unique_lock<std::mutex> lk(mu);
-                    done[k] = 1;
-                }
-                cv.notify_all();
-            }
-        } catch (const std::exception& e) {
-            std::unique_lock<std::mutex> lk(mu);
-            producer_error = e.what();
-            stop = true;
-            cv.notify_all();
-        }
-    };
-    std::vector<std::thread> producers;
-    struct Joiner {  // whatever happens below, the producers are stopped and joined before the buffers go away
-        std::vector<std::thread>& t;
-        std::mutex& mu;
-        std::condition_variable& cv;
-        bool& stop;
-        ~Joiner() {
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                stop = true;
-            }
-            cv.notify_all();
-            for (auto& x : t)
-                if (x.joinable()) x.join();
-        }
-    } joiner{producers, mu, cv, stop};
-    for (uint64_t i = 0; i < std::min<uint64_t>(3, n_pieces); i++) producers.emplace_back(producer_main);
-
-    auto compute = [&](uint64_t k) {
-        KGWAS_HIP(hipStreamWaitEvent(s->stream, s->ev_ing[k % 2], 0));
-        feed_device_impl(s, s->d_ing[k % 2].p, count_of(k), first_row + k * piece);  // returns with the stream idle
-        {
-            std::unique_lock<std::mutex> lk(mu);
-            copied = k + 1;
-        }
-        cv.notify_all();
-    };
-    for (uint64_t k = 0; k < n_pieces; k++) {
-        {
-            std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return stop || done[k]; });
-            if (!done[k]) throw Error(KGWAS_ERR_IO, producer_error.empty() ? "ingest stopped" : producer_error);
-        }
-        KGWAS_HIP(hipMemcpyAsync(s->d_ing[k % 2].p, s->h_ing[k % 3].p, count_of(k) * stride * 8, hipMemcpyHostToDevice,
-                                 s->copy_stream));
-        KGWAS_HIP(hipEventRecord(s->ev_ing[k % 2], s->copy_stream));
-        if (k >= 1) compute(k - 1);
-    }
-    compute(n_pieces - 1);
+    s->ingest.run(1 + s->W_f, n_rows, s->chunk_max, s->stream, fill,
+                  [&](const uint64_t* d_rows, uint64_t row_off, uint64_t cnt) {
+                      feed_device_impl(s, d_rows, cnt, first_row + row_off);  // returns with the stream idle
+                  });
 }
 
 }  // namespace

@@ -334,6 +334,10 @@ class Kinship:
         rows = np.ascontiguousarray(rows, np.uint64)
         check(lib.kgwas_kinship_feed_host(self._h, ptr(rows), rows.size // (1 + self.words_per_row)))
 
+    def feed_table(self, table: "KmersTable", row0: int, n_rows: int):
+        """Rows [row0, row0 + n_rows) of an open table; file read, copy and kernels of consecutive pieces overlap."""
+        check(lib.kgwas_kinship_feed_table(self._h, table._h, row0, n_rows))
+
     def feed_device(self, d_ptr: int, n_rows: int, stream: int = 0):
         check(lib.kgwas_kinship_feed_device(self._h, C.c_void_p(d_ptr), n_rows, C.c_void_p(stream)))
 

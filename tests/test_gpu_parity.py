@@ -426,6 +426,31 @@ def test_device_resident_feed_equals_host_feed():
         assert (k == o["kmer"]).all() and (r == o["file_row"]).all() and s.tobytes() == o["score"].tobytes()
 
 
+@pytest.mark.parametrize("piece", [0, 640])
+def test_kinship_double_buffered_ingest(monkeypatch, tmp_path, piece):
+    """kgwas_kinship_feed_table / feed_host run the rows through the pinned-piece pipeline: many small pieces with
+    a ragged tail, several feeds and the default piece size all give the oracle's matrix."""
+    if piece:
+        monkeypatch.setenv("KGWAS_INGEST_PIECE_ROWS", str(piece))
+    S_f, k, n_rows = 173, 31, 9_001
+    rows = random_table(n_rows, S_f, seed=piece + 17)
+    base = str(tmp_path / "t")
+    onp.write_table(base, ["a%d" % i for i in range(S_f)], k, rows[:, 0], rows[:, 1:])
+    mc = int(np.ceil(S_f * 0.05))
+    K, n = ob.kinship(rows, S_f, mc)
+    tbl = kg.KmersTable(base, k)
+    kin = kg.Kinship(S_f, mc)
+    kin.feed_table(tbl, 0, 4_000)
+    kin.feed_table(tbl, 4_000, 0)
+    kin.feed_table(tbl, 4_000, 5_001)
+    with pytest.raises(kg.KgwasError):
+        kin.feed_table(tbl, 9_000, 2)  # beyond the table
+    Kg, ng = kin.matrix()
+    assert ng == n and (Kg == K).all()
+    kin.close()
+    tbl.close()
+
+
 @pytest.mark.parametrize("S_f,n_rows", [(5, 100), (64, 700), (77, 2000), (241, 5000), (1135, 3000)])
 def test_kinship_exact(S_f, n_rows):
     rows = random_table(n_rows, S_f, seed=S_f)
