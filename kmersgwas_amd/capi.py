@@ -13,7 +13,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libkgwas.so")
+# KGWAS_LIB: load another build of the same library (kernel experiments, tools/coarse_variants.sh)
+LIB_PATH = os.environ.get("KGWAS_LIB") or os.path.join(_HERE, "lib", "libkgwas.so")
 
 KGWAS_OK = 0
 KGWAS_ERR_ARG, KGWAS_ERR_IO, KGWAS_ERR_FORMAT, KGWAS_ERR_DEVICE, KGWAS_ERR_STATE, KGWAS_ERR_NOMEM = -1, -2, -3, -4, -5, -6

@@ -104,8 +104,8 @@ struct CoarseArgs {
     uint32_t key_cap;
     uint32_t row_bits;
     unsigned long long* tested;
-    // E(N1) = eg_max + min(rall_max, N1 * rmax_max) bounds |yigi_ref - yc| for every column (phenotype units, each
-    // the maximum over the columns, rounded up): float32 summation error of the reference chains, the larger
+    // E(N1) = eg_max + min(rall_max, N1 * rmax_max) bounds |yigi_ref - yc| / u_p for every column (units of Dc,
+    // each the maximum over the columns, rounded up): float32 summation error of the reference chains, the larger
     // one-sign sum of the quantisation residuals, the largest residual.
     float eg_max, rall_max, rmax_max;
 };

@@ -705,7 +705,10 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
         c.tested = a.tested;
         KGWAS_HIP(hipMemsetAsync(s->d_key_count.p, 0, sizeof(uint32_t), s->stream));
         KGWAS_HIP(hipMemsetAsync(s->d_surv.p, 0xFF, (size_t)s->key_slots * sizeof(uint32_t), s->stream));  // sorts last
-        KGWAS_HIP(launch_coarse(c, M.T, n_rows >= (1u << 20) ? 2048u : 512u, s->stream));
+        static const uint32_t rpb_env = getenv("KGWAS_COARSE_RPB") ? (uint32_t)atoi(getenv("KGWAS_COARSE_RPB")) : 0u;  // experiments
+        // rows per block: the operand tiles (up to 128 KB) are loaded into LDS once per block, so blocks are long
+        // where the launch still fills the chip four times over
+        KGWAS_HIP(launch_coarse(c, M.T, rpb_env ? rpb_env : (n_rows >= (1u << 22) ? 4096u : n_rows >= (1u << 20) ? 2048u : 512u), s->stream));
         KGWAS_HIP(hipEventRecord(sl.ev_mid, s->stream));
         a.tested = nullptr;  // counted by the coarse pass
         KGWAS_HIP(launch_surv_sort(s->d_surv.p, s->d_surv_sorted.p, s->key_slots, s->d_key_count.p, s->key_slots,
@@ -1255,7 +1258,8 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
             std::vector<int> q0(S), q1(S);
             auto up = [](double x) { return std::nextafter((float)x, std::numeric_limits<float>::infinity()); };
             struct ErrBound {
-                float eg, rall, rmax;  // phenotype units, rounded up
+                float eg, rall, rmax;     // phenotype units, rounded up
+                float egD, rallD, rmaxD;  // the same in units of Dc (divided by u), rounded up: what the kernel uses
             };
             auto quantise = [&](uint64_t j, int ns, CoarseCol& cc, ErrBound& eb) {
                 const double Nd = (double)S, sum = (double)sums[j];
@@ -1293,6 +1297,10 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                 eb.eg = up((Eg + rho / Nd) * (1.0 + 1e-6) + 1e-30);
                 eb.rall = up(std::max(rpos, rneg) * (1.0 + 1e-6));
                 eb.rmax = up(rmax * (1.0 + 1e-6));
+                const double iu = 1.0 / u * (1.0 + 1e-6);
+                eb.egD = up((double)eb.eg * iu);
+                eb.rallD = up((double)eb.rall * iu);
+                eb.rmaxD = up((double)eb.rmax * iu);
             };
             // One slice halves the matrix work but widens the bound; it is offered when, for every column, the bound
             // at N1 = S/2 stays below 15 % of the deviation of yigi a z = 4 association needs (2*sigma*sqrt(S)), so the
@@ -1348,7 +1356,8 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                         for (uint64_t jj = 0; jj < 8; jj++)
                             for (uint64_t kg = 0; kg < 4; kg++)
                                 for (uint64_t e = 0; e < 16; e++) {
-                                    const uint64_t smp = 512 * g + 128 * kg + 16 * jj + e;
+                                    // k-element e of step jj <-> sample (score_coarse.hip: expand_step)
+                                    const uint64_t smp = 512 * g + 128 * kg + 32 * (e / 4) + 8 * (e % 4) + jj;
                                     if (smp >= S) continue;
                                     const uint64_t lane = kg * 16 + n;
                                     const uint64_t base = (((lg * n_kgroups + g) * 8 + jj) * T);
@@ -1365,9 +1374,9 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                     CoarseCol& cc = cols[lg * slots + slot];
                     ErrBound eb;
                     quantise(j, ns, cc, eb);
-                    M.eg_max = std::max(M.eg_max, eb.eg);
-                    M.rall_max = std::max(M.rall_max, eb.rall);
-                    M.rmax_max = std::max(M.rmax_max, eb.rmax);
+                    M.eg_max = std::max(M.eg_max, eb.egD);
+                    M.rall_max = std::max(M.rall_max, eb.rallD);
+                    M.rmax_max = std::max(M.rmax_max, eb.rmaxD);
                     cc.pheno = (int32_t)j;
                     put(lg, slot, q0, q1);
                 }

@@ -21,19 +21,19 @@
 //     exact path; the coarse pass only decides what is worth looking at.
 //
 // Coarse mode does not care about accumulation order, so the k-index of the MFMA is mapped to samples in
-// the way that needs no data exchange: in a 512-sample group g, lane (m = lane&15, kg = lane>>4) loads ITS
-// OWN 16 bytes of row m (samples 512g+128kg .. +127) and MFMA j = 0..7 uses bits 16j..16j+15 of them, i.e.
-//        k = 16*kg + e   <->   sample 512g + 128kg + 16j + e.
-// The four kg-lanes of a row thus fetch 64 contiguous bytes per instruction and every byte is used by the
-// lane that loaded it. Bits become int8 0/1 with (nibble * 0x00204081) & 0x01010101 (4 bytes per 3 VALU ops);
-// each expanded operand feeds T column tiles, each B operand (ds_read_b128) four row tiles.
+// the way that needs no data exchange and the fewest lane-ops: in a 512-sample group g, lane (m = lane&15,
+// kg = lane>>4) loads ITS OWN 16 bytes (dwords q = 0..3) of row m (samples 512g+128kg .. +127), and MFMA step
+// j = 0..7 takes bit 8e + j of dword q as k-element 4q + e of that lane, i.e.
+//        k = 16*kg + 4q + e   <->   sample 512g + 128kg + 32q + 8e + j.
+// The four kg-lanes of a row thus fetch 64 contiguous bytes per instruction, every byte is used by the lane that
+// loaded it, and an operand dword is (dword >> j) & 0x01010101: two lane-ops per 4 operand bytes (the earlier
+// nibble * 0x00204081 & 0x01010101 needed three, and the vector instructions beside the MFMAs are what bounds this
+// kernel); each expanded operand feeds T column tiles, each B operand (ds_read_b128) four row tiles.
 #include <algorithm>
+#include <type_traits>
 
 #include "score_common.h"
 
-#ifndef KGWAS_COARSE_PF
-#define KGWAS_COARSE_PF 0  // 0: load each unit when it starts, 1: prefetch the next sample group, 2: also across passes
-#endif                     // (measured: 12.3 / 12.5 / 13.4 ms per pass of one-slice launches; 1 and 2 cost registers)
 #define COARSE_SBUF 2048u  // survivor keys a block buffers in LDS
 #ifndef KGWAS_COARSE_PHASES
 #define KGWAS_COARSE_PHASES 1  // pin the per-step order: LDS reads, operand expansion, MFMAs
@@ -46,13 +46,12 @@ namespace kgwas {
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-// 16 presence bits -> 16 int8 0/1 (k-element e in byte e).
-__device__ __forceinline__ i32x4 expand16(uint32_t x) {
+// A operand of step j from the lane's four row dwords: byte e of operand dword q = bit 8e + j of row dword q,
+// i.e. k-element 4q + e <-> sample 32q + 8e + j of the lane's 128 (two lane-ops per dword, one for j = 0).
+__device__ __forceinline__ i32x4 expand_step(const uint32_t (&w)[4], int j) {
     i32x4 r;
-    r[0] = (int)(((x & 0xFu) * 0x00204081u) & 0x01010101u);
-    r[1] = (int)((((x >> 4) & 0xFu) * 0x00204081u) & 0x01010101u);
-    r[2] = (int)((((x >> 8) & 0xFu) * 0x00204081u) & 0x01010101u);
-    r[3] = (int)((((x >> 12) & 0xFu) * 0x00204081u) & 0x01010101u);
+#pragma unroll
+    for (int q = 0; q < 4; q++) r[q] = (int)((w[q] >> j) & 0x01010101u);
     return r;
 }
 
@@ -62,12 +61,14 @@ __device__ __forceinline__ i32x4 expand16(uint32_t x) {
 // The conservative test. The host centres the quantisation at c = sum/N (sum = the reference's float32 sum), so
 //   r_c = N*yc - N1*sum = N*u*Dc            Dc = D0 (one slice) or 254*D0 + D1 (two slices, s0 = 254*s1), u = s0 or s1,
 // an exact integer times a column constant. A pair can only have score_ref > thr if
-//   |Dc| >= alpha_p * sqrt(d(N1)) - E(N1)/u_p,    alpha_p = sqrt(thr_p)/(N*u_p),  E(N1) = Eg + min(Rall, N1*rmax)
-// with Eg, Rall, rmax (header) taken as their maxima over all columns, so E is a per-ROW term (permutation columns
-// share them anyway). The right-hand side is evaluated in float32 from constants the host rounded in the safe
-// direction (alpha down by 2^-19 relative, sqrt(d) down by 2^-20, E and 1/u up by 1e-6), which dominates the
-// float32 rounding of the three operations: the computed limit never exceeds the true one, so no possible
-// candidate is dropped. 5 cheap lane-ops per pair instead of 14 double-precision ones.
+//   |Dc| >= alpha_p * sqrt(d(N1)) - E_p(N1)/u_p,    alpha_p = sqrt(thr_p)/(N*u_p),  E_p(N1) = Eg_p + min(Rall_p, N1*rmax_p).
+// The error terms are taken in units of Dc (Eg_p/u_p, ... : the quantisation residual is at most half a unit per
+// sample whatever the column's scale) and as their maxima over all columns, so E/u is a per-ROW term and the test is
+//   margin = |Dc| - alpha_p * sqrt(d)   (float(Dc), then one float32 fma),    survivor iff margin + E >= 0
+// evaluated from constants the host rounded in the safe direction (alpha down by 2^-19 relative, sqrt(d) down by
+// 2^-20, the error terms up by 1e-6): the slack 2.8e-6 * alpha * sqrt(d) dominates the roundings of float(Dc) and of
+// the fma (6e-8 relative each), and the final addition cannot change the sign of an exact non-negative sum - so no
+// possible candidate is dropped. The maximum of the margins of a lane's pairs of one row is tested once.
 //
 // N1 comes out of the matrix pipe as well: the last operand column of every LDS group holds 1 for each phenotyped
 // sample (0 elsewhere), so its dot product IS the masked popcount - no masks, no popcounts, no mask loads in the
@@ -91,6 +92,7 @@ __global__ void __launch_bounds__(512) coarse_kernel(CoarseArgs a, uint32_t rows
     // atomics per launch on ~100 addresses: they serialise at the memory side and cost more than the MFMAs).
     uint32_t* sctl = reinterpret_cast<uint32_t*>(colc + 3 * SLOTS);  // [0] reserved, [1] start of the first reservation that did not fit, [2] global base, [3] n
     uint32_t* sbuf = sctl + 4;
+    float* wscr = reinterpret_cast<float*>(sbuf + COARSE_SBUF) + wave * 192u;  // wave-private: 64 x N1, 64 x (sqrt(d), E)
     if (threadIdx.x == 0) {
         sctl[0] = 0u;
         sctl[1] = 0xFFFFFFFFu;
@@ -119,10 +121,11 @@ __global__ void __launch_bounds__(512) coarse_kernel(CoarseArgs a, uint32_t rows
         __syncthreads();
 
         // piece[rt][q] = dword q of this lane's 16 bytes of row tile rt for the current (pass, sample group) unit
-        // (bytes 64g + 16kg .. +15 of the row's bits; zero beyond its data). The pieces of the NEXT unit - the next
-        // sample group, or group 0 of the wave's next 64 rows - are fetched into the same registers as soon as the
-        // current unit has expanded them (first half after step 3, second half after step 7): ~4 steps (2000 cycles)
-        // ahead of their use, and across the epilogue, which two waves per SIMD could not hide otherwise.
+        // (bytes 64g + 16kg .. +15 of the row's bits; beyond the row's data the load is clamped onto its last 8 bytes:
+        // whatever bits arrive there meet zero operands, sample slots >= S are zero in every column). The pieces of
+        // the NEXT unit - the next sample group, or group 0 of the wave's next 64 rows - are fetched into the same
+        // registers as soon as the current unit has expanded them: 4-5 steps (2000+ cycles) ahead of their use, and
+        // across the epilogue.
         uint32_t piece[RT][4];
         uint32_t ro[RT];  // 32-bit byte offsets (launch_coarse guarantees the chunk spans < 4 GiB) of the rows to fetch next
         auto set_rows = [&](uint64_t rb0) {
@@ -130,66 +133,49 @@ __global__ void __launch_bounds__(512) coarse_kernel(CoarseArgs a, uint32_t rows
             for (int rt = 0; rt < RT; rt++) {
                 uint64_t r = rb0 + rt * 16u + m;
                 if (r >= a.n_rows) r = a.n_rows - 1;
-                ro[rt] = ((uint32_t)r * (uint32_t)a.src.stride_dw + a.src.off_dw + 4u * kg) * 4u;
+                ro[rt] = ((uint32_t)r * (uint32_t)a.src.stride_dw + a.src.off_dw) * 4u;
             }
         };
         auto load_half = [&](uint32_t g, int h) {
-            const uint32_t b0 = 64u * g + 8u * h;  // + 16*kg is part of ro
+            uint32_t b0 = 64u * g + 8u * h + 16u * kg;
+            b0 = b0 + 8u <= avail_b ? b0 : avail_b - 8u;  // unconditional load (a branch here splits the scheduling region)
 #pragma unroll
             for (int rt = 0; rt < RT; rt++) {
-                uint2 v = make_uint2(0u, 0u);
-                if ((KGWAS_COARSE_ABLATE & 8) == 0 && b0 + 16u * kg + 8u <= avail_b)
+                uint2 v;
+                if (KGWAS_COARSE_ABLATE & 8)
+                    v = make_uint2(ro[rt] + b0, lane * 2654435761u);
+                else
                     v = *reinterpret_cast<const uint2*>(rows_base + (ro[rt] + b0));
-                if (KGWAS_COARSE_ABLATE & 8) v = make_uint2(ro[rt] + b0, lane * 2654435761u);
                 piece[rt][2 * h] = v.x;
                 piece[rt][2 * h + 1] = v.y;
             }
         };
         const uint64_t wave_row0 = blk_row0 + wave * (RT * 16u);
-        if (KGWAS_COARSE_PF == 2 && wave_row0 < a.n_rows) {
-            set_rows(wave_row0);
-            load_half(0, 0);
-            load_half(0, 1);
-        }
 
         for (uint32_t ps = 0; ps * rows_per_pass < rows_per_block; ps++) {
             const uint64_t rbase = wave_row0 + (uint64_t)ps * rows_per_pass;
             if (rbase >= a.n_rows) break;  // wave-uniform
-            const uint64_t rnext = rbase + rows_per_pass;
-            const bool next_pass = (KGWAS_COARSE_PF == 2) && ((ps + 1) * rows_per_pass < rows_per_block) && (rnext < a.n_rows);  // wave-uniform
-            if (KGWAS_COARSE_PF < 2) {
-                set_rows(rbase);
-                load_half(0, 0);
-                load_half(0, 1);
-            }
             i32x4 acc[RT][T];
-#pragma unroll
-            for (int rt = 0; rt < RT; rt++)
-#pragma unroll
-                for (int t = 0; t < T; t++) acc[rt][t] = (i32x4){0, 0, 0, 0};
 
-            for (uint32_t g = 0; g < n_kgroups; g++) {
-                const bool last_g = g + 1 == n_kgroups;
-                const bool fetch = (KGWAS_COARSE_PF >= 1) && (!last_g || next_pass);  // is there a next unit (wave-uniform)
-                const uint32_t gn = last_g ? 0u : g + 1u;
+            // One step = one bit position of every byte of the lane's 16 row bytes = 64 MFMA k-elements, T x RT MFMAs.
+            // Per step the B operands are requested from LDS first, the A operands are expanded while those reads are in
+            // flight, then the MFMAs issue back to back. What was measured on gfx950 about this loop (tools/issue_model.hip,
+            // tools/coarse_variants.sh): beside each 16-cycle MFMA a SIMD issues two other vector instructions for free
+            // and pays ~4 cycles for every further one; a long run of vector instructions in one wave (the epilogue) is
+            // NOT hidden behind its partner's MFMAs, with or without s_setprio or a start offset between the two waves;
+            // software-pipelined variants (A operands double-buffered and interleaved with the MFMAs, B operands reloaded
+            // in place behind their tile, next row dwords prefetched) all measured 5-25 % slower than this plain order.
+            auto run_group = [&](uint32_t g, auto first_tag) {
+                constexpr bool FIRST = decltype(first_tag)::value;  // first sample group: the accumulators start at zero
                 const i32x4* bg = blds + (size_t)g * 8u * T * 64u + lane;
+                if (FIRST) set_rows(rbase);
+                load_half(g, 0);
+                load_half(g, 1);
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    if (KGWAS_COARSE_PF == 0 && j == 0 && g > 0) {
-                        load_half(g, 0);
-                        load_half(g, 1);
-                    }
-                    // Phase order per step: all B operands of the step are requested from LDS first, the A operands are
-                    // expanded while those reads are in flight, then the T x 4 MFMAs issue back to back (the wave's
-                    // partner on the SIMD runs its own load/expand phase underneath them).
                     i32x4 B[T];
 #pragma unroll
-                    for (int t = 0; t < T; t++) {
-                        if (KGWAS_COARSE_ABLATE & 4)
-                            B[t] = (i32x4){(int)lane, t, j, (int)g};
-                        else
-                            B[t] = bg[(j * T + t) * 64];
-                    }
+                    for (int t = 0; t < T; t++) B[t] = (KGWAS_COARSE_ABLATE & 4) ? (i32x4){(int)(lane & 1u), 0, 1, 0} : bg[(j * T + t) * 64];
 #if KGWAS_COARSE_PHASES
                     __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -197,83 +183,131 @@ __global__ void __launch_bounds__(512) coarse_kernel(CoarseArgs a, uint32_t rows
 #pragma unroll
                     for (int rt = 0; rt < RT; rt++) {
                         if (KGWAS_COARSE_ABLATE & 2)
-                            A[rt] = (i32x4){(int)piece[rt][0], (int)piece[rt][1], (int)piece[rt][2], (int)piece[rt][3] + j};
+                            A[rt] = (i32x4){(int)(piece[rt][0] & 0x01010101u), (int)(piece[rt][1] & 0x01010101u),
+                                            (int)(piece[rt][2] & 0x01010101u), (int)(piece[rt][3] & 0x01010101u)};
                         else
-                            A[rt] = expand16((piece[rt][j >> 1] >> ((j & 1) * 16)) & 0xFFFFu);
+                            A[rt] = expand_step(piece[rt], j);
                     }
-                    if (j == 3 && fetch) {  // dwords 0,1 served j = 0..3
-                        if (last_g) set_rows(rnext);
-                        load_half(gn, 0);
-                    }
-                    if (j == 7 && fetch) load_half(gn, 1);  // dwords 2,3 served j = 4..7
 #if KGWAS_COARSE_PHASES
                     __builtin_amdgcn_sched_barrier(0);
 #endif
 #pragma unroll
                     for (int t = 0; t < T; t++) {
 #pragma unroll
-                        for (int rt = 0; rt < RT; rt++)
-                            acc[rt][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[rt], B[t], acc[rt][t], 0, 0, 0);
+                        for (int rt = 0; rt < RT; rt++) {
+                            if (FIRST && j == 0)
+                                acc[rt][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[rt], B[t], (i32x4){0, 0, 0, 0}, 0, 0, 0);
+                            else
+                                acc[rt][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[rt], B[t], acc[rt][t], 0, 0, 0);
+                        }
                     }
 #if KGWAS_COARSE_PHASES
                     __builtin_amdgcn_sched_barrier(0);
 #endif
                 }
-            }
+            };
+            run_group(0u, std::true_type{});
+            for (uint32_t g = 1; g < n_kgroups; g++) run_group(g, std::false_type{});
 
-            // Per-row terms of the 16 rows whose accumulator registers this lane holds (row kg*4+jj of tile rt):
-            // N1 from the ones column (slot 15 of the last column group: lane kg*16+15 holds it for these rows),
-            // sqrt(d) rounded down (+inf for a row that does not exist or fails the MAC filter: nothing survives),
-            // and the row's error term E(N1) rounded up.
+            // Per-row terms. Lane (kg, m) holds accumulator registers of the 16 rows kg*4 + jj of the four row tiles
+            // ("row slot" i = rt*4 + jj); the 16 m-lanes of a kg share them. N1 comes from the ones column (slot 15
+            // of the last column group: lane (kg, 15) holds it for all 16 slots); through a wave-private LDS
+            // exchange every lane computes the terms of ONE row (slot i = m) - sqrt(d) rounded down, +inf for a row
+            // that does not exist or fails the MAC filter (nothing survives), and the row's error term E(N1) in
+            // units of Dc, rounded up - and reads back the 16 it needs (the same terms computed 16 times per lane
+            // were a quarter of the kernel's vector work).
             float sqd[RT * 4], er[RT * 4];
             {
+                int* n1s = reinterpret_cast<int*>(wscr);
+                float2* trm = reinterpret_cast<float2*>(wscr + 64);
+                if (m == 15u) {
+#pragma unroll
+                    for (int rt = 0; rt < RT; rt++) *reinterpret_cast<i32x4*>(n1s + kg * 16u + rt * 4) = acc[rt][T - 1];
+                }
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t n1r = (uint32_t)n1s[lane];  // row slot m of this kg
                 const uint64_t left = a.n_rows - rbase;
                 const uint32_t rows_here = left < 64u ? (uint32_t)left : 64u;
                 const bool mac_any = a.S >= 2u * a.min_count;  // else no N1 can satisfy mc <= N1 <= S - mc
                 const uint32_t span = a.S - 2u * a.min_count;
-                uint32_t n_ok = 0;
+                const bool ok = mac_any & ((m >> 2) * 16u + kg * 4u + (m & 3u) < rows_here) & ((n1r - a.min_count) <= span);
+                if (lg == 0) tested_local += ok ? 1u : 0u;
+                const float f = (float)n1r;
+                const float sq = __builtin_amdgcn_sqrtf(f * (Nf - f)) * 0.99999905f;  // d < 2^24 is exact; 1 ulp sqrt; (1 - 2^-20)
+                float2 tm;
+                tm.x = ok ? sq : __builtin_huge_valf();
+                tm.y = (a.eg_max + fminf(a.rall_max, f * a.rmax_max)) * 1.000001f;
+                if (KGWAS_COARSE_ABLATE & 16) tm = make_float2(1000.0f + m, 1.0f);
+                trm[lane] = tm;
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < RT * 4; i += 2) {
+                    const float4 v = *reinterpret_cast<const float4*>(trm + kg * 16u + i);
+                    sqd[i] = v.x;
+                    er[i] = v.y;
+                    sqd[i + 1] = v.z;
+                    er[i + 1] = v.w;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            // The test, ~2.5 lane-ops per pair: margin = |Dc| - alpha_p * sqrt(d) (float(Dc), one fma with |.| and
+            // negation as operand modifiers), a running maximum per row slot (max3), and ONE compare per row slot:
+            // the slot has a survivor iff max margin + E >= 0. Which pairs passed is only worked out for row slots
+            // with a hit (steady state: ~2 of the 1024 (lane, slot) units of a pass).
+            auto pair_margin = [&](int i, int g, float al) {
+                int dc = acc[i >> 2][NS * g][i & 3];
+                if (NS == 2) dc = __mul24(dc, 254) + acc[i >> 2][NS * g + NS - 1][i & 3];  // |D0| <= 127 * S < 2^23
+                return fmaf(-al, sqd[i], fabsf((float)dc));  // NaN (frozen column) never wins a maximum
+            };
+            float alc[PG];
+#pragma unroll
+            for (int g = 0; g < PG; g++) alc[g] = colc[g * 16 + m];
+            uint64_t hit[RT * 4];
+            if (!(KGWAS_COARSE_ABLATE & 1)) {
+                float mx[RT * 4];
+#pragma unroll
+                for (int i = 0; i < RT * 4; i++) mx[i] = -__builtin_huge_valf();
+#pragma unroll
+                for (int g = 0; g < PG; g++)
+#pragma unroll
+                    for (int i = 0; i < RT * 4; i++) mx[i] = fmaxf(mx[i], pair_margin(i, g, alc[g]));
+#pragma unroll
+                for (int i = 0; i < RT * 4; i++) hit[i] = __ballot(mx[i] + er[i] >= 0.0f);
+            } else {
+#pragma unroll
+                for (int i = 0; i < RT * 4; i++) hit[i] = 0;
+                int x = 0;  // keeps every accumulator (and its MFMAs) alive at one lane-op each
+#pragma unroll
+                for (int i = 0; i < RT * 4; i++)
+#pragma unroll
+                    for (int t = 0; t < T; t++) x ^= acc[i >> 2][t][i & 3];
+                hit[0] = __ballot(x == 0x7fffffff);
+            }
+            uint64_t hit_any = 0;
+#pragma unroll
+            for (int i = 0; i < RT * 4; i++) hit_any |= hit[i];
+            if ((KGWAS_COARSE_ABLATE & 32) && hit_any) {  // tests only: a token side effect instead of the emission
+                if (lane == 0) atomicAdd(&sctl[0], 0u);
+                hit_any = 0;
+            }
+            // mb[g] bit i = pair (row slot i, column g*16 + m) survives; rebuilt for the row slots that had a hit.
+            uint32_t mb[PG];
+#pragma unroll
+            for (int g = 0; g < PG; g++) mb[g] = 0;
+            if (hit_any) {
 #pragma unroll
                 for (int i = 0; i < RT * 4; i++) {
-                    const int rt = i >> 2, jj = i & 3;
-                    const uint32_t n1r = (uint32_t)__shfl(acc[rt][T - 1][jj], (int)(kg * 16u + 15u));
-                    const bool ok = mac_any & ((uint32_t)(rt * 16 + jj) + kg * 4u < rows_here) & ((n1r - a.min_count) <= span);
-                    n_ok += ok ? 1u : 0u;
-                    const float f = (float)n1r;
-                    const float sq = __builtin_amdgcn_sqrtf(f * (Nf - f)) * 0.99999905f;  // d < 2^24 is exact; 1 ulp sqrt; (1 - 2^-20)
-                    sqd[i] = ok ? sq : __builtin_huge_valf();
-                    er[i] = (a.eg_max + fminf(a.rall_max, f * a.rmax_max)) * 1.000001f;
-                    if (KGWAS_COARSE_ABLATE & 16) {
-                        sqd[i] = 1000.0f + i;
-                        er[i] = 1.0f;
+                    if (hit[i]) {  // wave-uniform
+#pragma unroll
+                        for (int g = 0; g < PG; g++) {
+                            float al = alc[g];
+                            asm volatile("" : "+v"(al));  // recompute here: keeping all 16 * PG compare masks alive costs more
+                            mb[g] |= (pair_margin(i, g, al) + er[i] >= 0.0f) ? (1u << i) : 0u;
+                        }
                     }
                 }
-                if (lg == 0 && m == 15u) tested_local += n_ok;  // the four m = 15 lanes cover the wave's 64 rows
             }
-            // A lane holds 16 (row, column) pairs per column group; the four kg lanes of one m share the column.
-            // All groups are tested first; then, if the wave has survivors at all, each column's list counter is bumped
-            // ONCE for the 64 pairs the wave holds for it, all the (returning) atomics are issued back to back, and
-            // only then are the rows written: one L2 round trip per wave pass instead of one per group (that was 55 %
-            // of the kernel), and no atomic per survivor (which serialised the early chunks in the L2).
-            uint32_t mb[PG];
-            uint32_t any_bits = 0;
-#pragma unroll
-            for (int g = 0; g < PG; g++) {
-                const float al = colc[g * 16 + m], iu = colc[SLOTS + g * 16 + m];
-                uint32_t mbits = 0;
-#pragma unroll
-                for (int i = RT * 4 - 1; i >= 0; i--) {
-                    int dc = acc[i >> 2][NS * g][i & 3];
-                    if (NS == 2) dc = dc * 254 + acc[i >> 2][NS * g + NS - 1][i & 3];
-                    const float lim = fmaf(al, sqd[i], -(iu * er[i]));
-                    mbits = (mbits << 1) | ((fabsf((float)dc) >= lim) ? 1u : 0u);
-                }
-                if (KGWAS_COARSE_ABLATE & 1) mbits = (acc[0][NS * g][0] == 0x7fffffff) ? 1u : 0u;  // keeps the accumulators alive
-                mb[g] = mbits;
-                any_bits |= mbits;
-            }
-            if (KGWAS_COARSE_ABLATE & 32) any_bits = (any_bits == 0x12345678u) ? 1u : 0u;
-            if ((KGWAS_COARSE_ABLATE & 128) && lane == 0 && any_bits) atomicAdd(&sctl[0], 0u);
-            if (!(KGWAS_COARSE_ABLATE & 128) && __any(any_bits != 0u)) {  // wave-uniform
+            if (hit_any) {  // wave-uniform
                 uint32_t lane_cnt = 0;
 #pragma unroll
                 for (int g = 0; g < PG; g++) lane_cnt += __popc(mb[g]);
@@ -299,7 +333,7 @@ __global__ void __launch_bounds__(512) coarse_kernel(CoarseArgs a, uint32_t rows
                 uint32_t k = (fits ? wbase : gb) + (incl - lane_cnt);
 #pragma unroll
                 for (int g = 0; g < PG; g++) {
-                    uint32_t mbits = (KGWAS_COARSE_ABLATE & 64) ? 0u : mb[g];
+                    uint32_t mbits = mb[g];
                     const uint32_t pk = (uint32_t)colp[g * 16 + m] << a.row_bits;  // column >= 0 wherever a bit is set
                     while (mbits) {
                         const uint32_t b = __ffs(mbits) - 1u;
@@ -328,10 +362,10 @@ __global__ void __launch_bounds__(512) coarse_kernel(CoarseArgs a, uint32_t rows
             if (gb + i < a.key_cap) a.keys[gb + i] = sbuf[i];
     }
     if (a.tested) {
-        uint32_t v = tested_local;
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        if (lane == 15u && v) atomicAdd(&a.tested[blockIdx.x % TESTED_SHARDS], (unsigned long long)v);
+        uint32_t v = tested_local;  // every lane counted one row per pass
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d);
+        if (lane == 0u && v) atomicAdd(&a.tested[blockIdx.x % TESTED_SHARDS], (unsigned long long)v);
     }
 }
 
@@ -387,7 +421,8 @@ __global__ void __launch_bounds__(256) rescore_kernel(ScoreArgs a, const uint32_
 }
 
 // B operands of one LDS group + the group's per-column constants (3 x up to 128 words) + the block's survivor buffer
-size_t coarse_lds_bytes(uint32_t n_kgroups, uint32_t T) { return (size_t)n_kgroups * 8u * T * 1024u + 1536u + 16u + 4u * COARSE_SBUF; }
+// + the eight waves' row-term exchange areas
+size_t coarse_lds_bytes(uint32_t n_kgroups, uint32_t T) { return (size_t)n_kgroups * 8u * T * 1024u + 1536u + 16u + 4u * COARSE_SBUF + 8u * 768u; }
 
 template <int T, int NS>
 static hipError_t launch_coarse_t(const CoarseArgs& a, uint32_t rows_per_block, uint32_t n_rowblocks, size_t lds,
