@@ -129,7 +129,12 @@ template <int FLAGS>
 __global__ void __launch_bounds__(512) k2(int* out, const uint2* rows, int reps, uint32_t seed) {
     extern __shared__ i32x4 big[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    for (uint32_t i = threadIdx.x; i < 2u * 8u * 7u * 64u; i += blockDim.x) big[i] = (i32x4){(int)(i & 1u), 1, 0, 1};
+    for (uint32_t i = threadIdx.x; i < 2u * 8u * 7u * 64u; i += blockDim.x) {
+        if (FLAGS & 128)  // realistic operand bytes (data-dependent power)
+            big[i] = (i32x4){(int)(i * 2654435761u), (int)(i * 40503u + 77u) * 0x01000193, (int)((i ^ 0x5bd1e995u) * 2246822519u), (int)(i * 3266489917u + 1u)};
+        else
+            big[i] = (i32x4){(int)(i & 1u), 1, 0, 1};
+    }
     __syncthreads();
     i32x4 acc[28];
 #pragma unroll
@@ -270,6 +275,8 @@ int main() {
     run2<3>("k2: + global row loads, 2-op expansion", d, rows);
     run2<11>("k2: + loads, 2-op expansion, v_mov zeroing", d, rows);
     run2<7>("k2: loads, 2-op expansion, no epilogue", d, rows);
+    run2<7 + 128>("k2: loads, 2-op expansion, no epilogue, RANDOM operand bytes", d, rows);
+    run2<3 + 128>("k2: loads, 2-op expansion, epilogue, RANDOM operand bytes", d, rows);
     run2<3 + 16>("k2: loads, 2-op, epilogue, waves 4-7 start late", d, rows);
     run2<3 + 32>("k2: loads, 2-op, epilogue, waves 4-7 s_setprio 1", d, rows);
     run2<3 + 16 + 32>("k2: loads, 2-op, epilogue, late + prio", d, rows);

@@ -44,7 +44,7 @@ def assoc(rows, S, P, kernel, topn=10001, reps=2):
     st = scan.stats()
     kms = st["score_kernel_ms"]
     print("assoc rows=%d S=%d P=%d kernel=%s: %.1f ms/pass (kernel %.1f ms)  %.2f G rows/s  table %.0f GB/s (kernel-only %.0f GB/s = %.1f%% of 8 TB/s)  %.1f TFLOP/s useful"
-          % (rows, S, P, {1: "valu", 2: "mfma"}[st["kernel_used"]], best * 1e3, kms, rows / best / 1e9, rows * 8 * W / best / 1e9,
+          % (rows, S, P, {1: "valu", 2: "mfma", 3: "coarse"}.get(st["kernel_used"], "?"), best * 1e3, kms, rows / best / 1e9, rows * 8 * W / best / 1e9,
              rows * 8 * W / (kms * 1e-3) / 1e9, rows * 8 * W / (kms * 1e-3) / 8e12 * 100, 2.0 * rows * S * P / (kms * 1e-3) / 1e12))
     scan.close()
     del t
@@ -70,7 +70,9 @@ if __name__ == "__main__":
     rk = int(sys.argv[2]) if len(sys.argv) > 2 else 8_000_000
     assoc(ra, 1024, 1, kg.KERNEL_VALU)
     assoc(ra, 1024, 1, kg.KERNEL_MFMA)
+    assoc(2 * ra, 1024, 1, kg.KERNEL_AUTO)
     assoc(ra // 5, 2048, 201, kg.KERNEL_AUTO)
+    assoc(ra, 2048, 201, kg.KERNEL_AUTO)
     assoc(ra // 2, 1135, 101, kg.KERNEL_AUTO)
     kinship(rk, 1135)
     kinship(rk // 2, 241)
