@@ -10,7 +10,8 @@
 //     pop : std::pop_heap(c.begin(), c.end(), comp); c.pop_back();
 //     top : c.front()
 // and the algorithms only ever look at the elements through `comp`. We issue the same calls on a
-// vector of 16-byte (score, slot) entries — k-mer and row live in side arrays indexed by slot — so
+// vector of 16-byte (score, slot) entries — k-mer and row live in a side array of 16-byte pairs indexed by slot
+// (one cache line written per push, not two) — so
 // every comparison, and therefore every move, is the one the reference's 24-byte tuples would
 // make, at 2/3 of the memory traffic of the replay (the hot loop of the host side).
 #pragma once
@@ -29,6 +30,9 @@ class alignas(128) BestHeap {
         double score;
         uint32_t slot;
     };
+    struct Pay {  // what an entry carries besides its score
+        uint64_t kmer, row;
+    };
     struct Greater {
         inline bool operator()(const Ent& l, const Ent& r) const { return l.score > r.score; }
     };
@@ -41,8 +45,7 @@ class alignas(128) BestHeap {
         inserted_++;
         if (v_.size() < n_res_) {
             const uint32_t slot = (uint32_t)v_.size();
-            kmer_.push_back(kmer);
-            row_.push_back(row);
+            pay_.push_back(Pay{kmer, (uint64_t)row});
             v_.push_back(Ent{score, slot});
             std::push_heap(v_.begin(), v_.end(), Greater());
             pushes_++;
@@ -51,8 +54,7 @@ class alignas(128) BestHeap {
         }
         if (score > lowest_) {
             const uint32_t slot = v_.front().slot;  // the evicted minimum's slot is reused
-            kmer_[slot] = kmer;
-            row_[slot] = row;
+            pay_[slot] = Pay{kmer, (uint64_t)row};
             replace_top(v_.data(), (ptrdiff_t)v_.size(), Ent{score, slot});
             pushes_++;
             lowest_ = v_.front().score;
@@ -124,8 +126,7 @@ class alignas(128) BestHeap {
             BestHeap& H = *hp[k];
             a[k] = H.v_.data();
             const uint32_t slot = a[k][0].slot;
-            H.kmer_[slot] = kmer[k];
-            H.row_[slot] = row[k];
+            H.pay_[slot] = Pay{kmer[k], row[k]};
             x[k] = Ent{score[k], slot};
             v[k] = a[k][n - 1];
             h[k] = 0;
@@ -193,18 +194,20 @@ class alignas(128) BestHeap {
     void export_state(uint64_t* kmer, double* score, uint64_t* row) const {  // size() entries each
         size_t i = 0;
         for (const Ent& e : v_) {
-            kmer[i] = kmer_[e.slot];
+            kmer[i] = pay_[e.slot].kmer;
             score[i] = e.score;
-            row[i] = row_[e.slot];
+            row[i] = pay_[e.slot].row;
             i++;
         }
     }
     void import_state(size_t n, const uint64_t* kmer, const double* score, const uint64_t* row) {
         if (n > n_res_) n = n_res_;
         v_.clear();
-        kmer_.assign(kmer, kmer + n);
-        row_.assign(row, row + n);
-        for (size_t i = 0; i < n; i++) v_.push_back(Ent{score[i], (uint32_t)i});
+        pay_.clear();
+        for (size_t i = 0; i < n; i++) {
+            pay_.push_back(Pay{kmer[i], row[i]});
+            v_.push_back(Ent{score[i], (uint32_t)i});
+        }
         lowest_ = n ? v_.front().score : 0;
     }
 
@@ -220,9 +223,9 @@ class alignas(128) BestHeap {
         row.resize(n);
         Ent* a = tmp.data();
         for (size_t i = 0; i < n; i++) {
-            kmer[i] = kmer_[a[0].slot];
+            kmer[i] = pay_[a[0].slot].kmer;
             score[i] = a[0].score;
-            row[i] = row_[a[0].slot];
+            row[i] = pay_[a[0].slot].row;
             pop_top(a, (ptrdiff_t)(n - i));
         }
     }
@@ -275,9 +278,9 @@ class alignas(128) BestHeap {
             ptrdiff_t h[K], c[K];
 #pragma unroll
             for (int k = 0; k < K; k++) {
-                (*kmer[k])[i] = hp[k]->kmer_[a[k][0].slot];
+                (*kmer[k])[i] = hp[k]->pay_[a[k][0].slot].kmer;
                 (*score[k])[i] = a[k][0].score;
-                (*row[k])[i] = hp[k]->row_[a[k][0].slot];
+                (*row[k])[i] = hp[k]->pay_[a[k][0].slot].row;
                 v[k] = a[k][m - 1];
                 h[k] = 0;
                 c[k] = 0;
@@ -320,7 +323,7 @@ class alignas(128) BestHeap {
    private:
     size_t n_res_;
     std::vector<Ent> v_;
-    std::vector<uint64_t> kmer_, row_;
+    std::vector<Pay> pay_;
     uint64_t inserted_, pushes_;
     double lowest_;
 };
