@@ -173,7 +173,7 @@ static inline void replace_pair(Ent* a, Ent* b, ptrdiff_t n, Ent xa, Ent xb) {
     b[hb] = xb;
 }
 
-// variants 6,7,8: K = 3, 4, 6 equal-size heaps in lockstep (generic form of replace_pair).
+// variants 6,7,8: K = 3, 4, 6 equal-size heaps in lockstep (generic form of replace_pair); 9,10,11,12: K = 5, 7, 8, 2.
 template <int K>
 static inline void replace_multi(Ent* const* a, ptrdiff_t n, Ent* x) {
     Ent v[K];
@@ -265,7 +265,7 @@ int main(int argc, char** argv) {
     const int H = argc > 2 ? atoi(argv[2]) : 7;
     const int N = argc > 3 ? atoi(argv[3]) : 10001;
     const int pushes = argc > 4 ? atoi(argv[4]) : 400000;
-    for (int variant = 0; variant < 9; variant++) {
+    for (int variant = 0; variant < 13; variant++) {
         std::vector<double> ns(T);
         std::vector<uint64_t> chk(T);
         std::vector<std::thread> th;
@@ -314,6 +314,14 @@ int main(int argc, char** argv) {
                     run_multi<4>(heaps, km, rw, u, H, N, pushes);
                 } else if (variant == 8) {
                     run_multi<6>(heaps, km, rw, u, H, N, pushes);
+                } else if (variant == 9) {
+                    run_multi<5>(heaps, km, rw, u, H, N, pushes);
+                } else if (variant == 10) {
+                    run_multi<7>(heaps, km, rw, u, H, N, pushes);
+                } else if (variant == 11) {
+                    run_multi<8>(heaps, km, rw, u, H, N, pushes);
+                } else if (variant == 12) {
+                    run_multi<2>(heaps, km, rw, u, H, N, pushes);
                 } else if (variant == 5) {
                     int h = 0;
                     for (; h + 1 < H; h += 2)
