@@ -38,8 +38,11 @@
 #ifndef KGWAS_COARSE_PHASES
 #define KGWAS_COARSE_PHASES 1  // pin the per-step order: LDS reads, operand expansion, MFMAs
 #endif
+// Timing experiments only (wrong results; tools/coarse_variants.sh builds the variants). Bits: 1 the tests are replaced by
+// an XOR over all accumulators (every MFMA stays alive), 2 no operand expansion, 4 no LDS operand reads, 8 no row loads,
+// 16 constant row terms, 32 a token side effect instead of the survivor emission.
 #ifndef KGWAS_COARSE_ABLATE
-#define KGWAS_COARSE_ABLATE 0  // timing experiments only (wrong results): 1 no test, 2 no expansion, 4 no LDS reads, 8 no row loads
+#define KGWAS_COARSE_ABLATE 0
 #endif
 
 namespace kgwas {
