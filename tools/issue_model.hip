@@ -156,7 +156,18 @@ __global__ void __launch_bounds__(512) k2(int* out, const uint2* rows, int reps,
 #pragma unroll
         for (int i = 0; i < 175; i++) { VDEP(x0); VDEP(x1); VDEP(x2); VDEP(x3); }
     }
-    for (int r = 0; r < reps; r += 16) {
+    __shared__ int pass_counter;
+    if (threadIdx.x == 0) pass_counter = 0;
+    __syncthreads();
+    const int total_passes = (reps / 16) * (int)(blockDim.x >> 6);
+    for (int r = 0; r < reps || (FLAGS & 256); r += 16) {
+        if (FLAGS & 256) {  // the block's passes are handed out dynamically: a wave that runs ahead simply takes more
+            int t = 0;
+            if (lane == 0) t = atomicAdd(&pass_counter, 1);
+            t = __builtin_amdgcn_readfirstlane(t);
+            if (t >= total_passes) break;
+            r = (t >> 3) * 16;  // which rows: only the address pattern matters here
+        }
         if (FLAGS & 8) {
 #pragma unroll
             for (int i = 0; i < 28; i++) asm volatile("v_mov_b32 %0, 0\n v_mov_b32 %1, 0\n v_mov_b32 %2, 0\n v_mov_b32 %3, 0" : "=v"(acc[i][0]), "=v"(acc[i][1]), "=v"(acc[i][2]), "=v"(acc[i][3]));
@@ -277,6 +288,10 @@ int main() {
     run2<7>("k2: loads, 2-op expansion, no epilogue", d, rows);
     run2<7 + 128>("k2: loads, 2-op expansion, no epilogue, RANDOM operand bytes", d, rows);
     run2<3 + 128>("k2: loads, 2-op expansion, epilogue, RANDOM operand bytes", d, rows);
+    run2<3 + 256>("k2: loads, 2-op, epilogue, dynamic passes", d, rows);
+    run2<3 + 256 + 32>("k2: loads, 2-op, epilogue, dynamic passes + waves 4-7 s_setprio 1", d, rows);
+    run2<7 + 256>("k2: loads, 2-op, no epilogue, dynamic passes", d, rows);
+    run2<7 + 256 + 32>("k2: loads, 2-op, no epilogue, dynamic passes + waves 4-7 s_setprio 1", d, rows);
     run2<3 + 16>("k2: loads, 2-op, epilogue, waves 4-7 start late", d, rows);
     run2<3 + 32>("k2: loads, 2-op, epilogue, waves 4-7 s_setprio 1", d, rows);
     run2<3 + 16 + 32>("k2: loads, 2-op, epilogue, late + prio", d, rows);
