@@ -116,9 +116,9 @@ def test_topn_identities_with_ties(kernel, binary, dup):
 
 @pytest.mark.parametrize("slices", [1, 2])
 @pytest.mark.parametrize("S,P,shift", [(241, 1, 0.0), (241, 5, 0.0), (241, 40, 100.0), (1024, 101, 0.0), (1024, 130, -7.5),
-                                       (1500, 23, 3.0), (300, 333, 1.0)])
+                                       (1500, 23, 3.0), (300, 333, 1.0), (2048, 40, 0.5), (2600, 9, 0.0)])
 def test_coarse_filter_shapes(monkeypatch, slices, S, P, shift):
-    """The int8 filter in every operand-tile shape (1..8 tiles per LDS group, one or two LDS groups, 1..3
+    """The int8 filter in every operand-tile shape (1..8 tiles per LDS group, one or more LDS groups, 1..6
     512-sample groups), with one and with two int8 slices per column, on shifted phenotypes (the quantisation is
     centred) and duplicated patterns: survivors, pop order, scores and push counts equal the oracle's."""
     monkeypatch.setenv("KGWAS_COARSE_SLICES", str(slices))
