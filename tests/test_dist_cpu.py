@@ -1,4 +1,4 @@
-"""world_size-2 `gloo` test of the multi-GPU plumbing on CPU (kmersgwas_amd/dist.py).
+"""world_size-2 and -5 `gloo` tests of the multi-GPU plumbing on CPU (kmersgwas_amd/dist.py).
 
 The product's scoring needs a GPU, so each rank's shard-local heap-push history and kinship partials
 are produced here by the oracle (as the checker / stand-in data source); what is under test is the
@@ -137,15 +137,19 @@ WORKER = textwrap.dedent("""
 """)
 
 
-def test_two_rank_gloo_merge_and_kinship_allreduce(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 5])  # 5 ranks > 3 columns: ranks that own no column take part with empty messages
+def test_gloo_merge_and_kinship_allreduce(tmp_path, world):
     script = tmp_path / "worker.py"
     script.write_text(WORKER % {"root": ROOT})
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(script)]
     env = dict(os.environ, OMP_NUM_THREADS="1")
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert r.stdout.count("-ok") == 2, r.stdout
+    assert r.stdout.count("-ok") == world, r.stdout
