@@ -160,6 +160,7 @@ __global__ void __launch_bounds__(512) k2(int* out, const uint2* rows, int reps,
     if (threadIdx.x == 0) pass_counter = 0;
     __syncthreads();
     const int total_passes = (reps / 16) * (int)(blockDim.x >> 6);
+    if ((FLAGS & 512) && __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_barrier();  // waves 4-7 one phase behind
     for (int r = 0; r < reps || (FLAGS & 256); r += 16) {
         if (FLAGS & 256) {  // the block's passes are handed out dynamically: a wave that runs ahead simply takes more
             int t = 0;
@@ -203,10 +204,12 @@ __global__ void __launch_bounds__(512) k2(int* out, const uint2* rows, int reps,
                         }
                     }
                 WAITL();
+                if (FLAGS & 512) __builtin_amdgcn_s_barrier();  // explicit hand-off: one half of the waves multiplies
 #pragma unroll
                 for (int t = 0; t < 7; t++)
 #pragma unroll
                     for (int rt = 0; rt < 4; rt++) MFMA(acc[t * 4 + rt], A[rt], B[t]);
+                if (FLAGS & 512) __builtin_amdgcn_s_barrier();  // while the other half loads and expands
             }
         }
         if (!(FLAGS & 4)) {
@@ -214,6 +217,7 @@ __global__ void __launch_bounds__(512) k2(int* out, const uint2* rows, int reps,
             for (int i = 0; i < 175; i++) { VDEP(x0); VDEP(x1); VDEP(x2); VDEP(x3); }
         }
     }
+    if ((FLAGS & 512) && __builtin_amdgcn_readfirstlane(threadIdx.x) < 256) __builtin_amdgcn_s_barrier();  // barrier counts match
     i32x4 s = (i32x4){(int)(x0 ^ x1 ^ x2 ^ x3), 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < 28; i++) s += acc[i];
@@ -286,8 +290,12 @@ int main() {
     run2<3>("k2: + global row loads, 2-op expansion", d, rows);
     run2<11>("k2: + loads, 2-op expansion, v_mov zeroing", d, rows);
     run2<7>("k2: loads, 2-op expansion, no epilogue", d, rows);
+    run2<6>("k2: 2-op expansion, no loads, no epilogue", d, rows);
     run2<7 + 128>("k2: loads, 2-op expansion, no epilogue, RANDOM operand bytes", d, rows);
     run2<3 + 128>("k2: loads, 2-op expansion, epilogue, RANDOM operand bytes", d, rows);
+    run2<6 + 512>("k2: 2-op, no loads, no epilogue, barrier hand-off between wave halves", d, rows);
+    run2<7 + 512>("k2: loads, 2-op, no epilogue, barrier hand-off", d, rows);
+    run2<3 + 512>("k2: loads, 2-op, epilogue, barrier hand-off", d, rows);
     run2<3 + 256>("k2: loads, 2-op, epilogue, dynamic passes", d, rows);
     run2<3 + 256 + 32>("k2: loads, 2-op, epilogue, dynamic passes + waves 4-7 s_setprio 1", d, rows);
     run2<7 + 256>("k2: loads, 2-op, no epilogue, dynamic passes", d, rows);
