@@ -49,6 +49,19 @@ namespace kgwas {
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef KGWAS_COARSE_TIMELINE  // diagnostics build (tools/coarse_timeline.py): cycle stamps of waves 0 and 4 of one block
+__device__ unsigned long long g_coarse_tl[2 * 16 * 64];
+#define TL_STAMP(idx)                                                                       \
+    do {                                                                                    \
+        if (tl_on) {                                                                        \
+            const unsigned long long t_ = clock64();                                        \
+            if (lane == 0) g_coarse_tl[tl_base + (idx)] = t_;                               \
+        }                                                                                   \
+    } while (0)
+#else
+#define TL_STAMP(idx) do { } while (0)
+#endif
+
 // A operand of step j from the lane's four row dwords: byte e of operand dword q = bit 8e + j of row dword q,
 // i.e. k-element 4q + e <-> sample 32q + 8e + j of the lane's 128 (two lane-ops per dword, one for j = 0).
 __device__ __forceinline__ i32x4 expand_step(const uint32_t (&w)[4], int j) {
@@ -159,6 +172,11 @@ __global__ void __launch_bounds__(512) coarse_kernel(CoarseArgs a, uint32_t rows
             const uint64_t rbase = wave_row0 + (uint64_t)ps * rows_per_pass;
             if (rbase >= a.n_rows) break;  // wave-uniform
             i32x4 acc[RT][T];
+#ifdef KGWAS_COARSE_TIMELINE
+            const bool tl_on = blockIdx.x == KGWAS_COARSE_TIMELINE && (wave & 3u) == 0u && ps < 16u && lg == 0;
+            const uint32_t tl_base = ((wave >> 2) * 16u + ps) * 64u;
+#endif
+            TL_STAMP(0);
 
             // One step = one bit position of every byte of the lane's 16 row bytes = 64 MFMA k-elements, T x RT MFMAs.
             // Per step the B operands are requested from LDS first, the A operands are expanded while those reads are in
@@ -176,6 +194,7 @@ __global__ void __launch_bounds__(512) coarse_kernel(CoarseArgs a, uint32_t rows
                 load_half(g, 1);
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
+                    if (g < 2) TL_STAMP(1 + (g * 8 + j) * 3);  // step start
                     i32x4 B[T];
 #pragma unroll
                     for (int t = 0; t < T; t++) B[t] = (KGWAS_COARSE_ABLATE & 4) ? (i32x4){(int)(lane & 1u), 0, 1, 0} : bg[(j * T + t) * 64];
@@ -194,6 +213,11 @@ __global__ void __launch_bounds__(512) coarse_kernel(CoarseArgs a, uint32_t rows
 #if KGWAS_COARSE_PHASES
                     __builtin_amdgcn_sched_barrier(0);
 #endif
+#ifdef KGWAS_COARSE_TIMELINE
+                    __builtin_amdgcn_s_waitcnt(0);  // operands arrived (vmcnt 0, lgkmcnt 0)
+                    if (g < 2) TL_STAMP(2 + (g * 8 + j) * 3);  // operands ready, MFMAs start
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
                     for (int t = 0; t < T; t++) {
 #pragma unroll
@@ -207,11 +231,13 @@ __global__ void __launch_bounds__(512) coarse_kernel(CoarseArgs a, uint32_t rows
 #if KGWAS_COARSE_PHASES
                     __builtin_amdgcn_sched_barrier(0);
 #endif
+                    if (g < 2) TL_STAMP(3 + (g * 8 + j) * 3);  // MFMAs issued
                 }
             };
             run_group(0u, std::true_type{});
             for (uint32_t g = 1; g < n_kgroups; g++) run_group(g, std::false_type{});
 
+            TL_STAMP(50);  // main loop done
             // Per-row terms. Lane (kg, m) holds accumulator registers of the 16 rows kg*4 + jj of the four row tiles
             // ("row slot" i = rt*4 + jj); the 16 m-lanes of a kg share them. N1 comes from the ones column (slot 15
             // of the last column group: lane (kg, 15) holds it for all 16 slots); through a wave-private LDS
@@ -253,6 +279,7 @@ __global__ void __launch_bounds__(512) coarse_kernel(CoarseArgs a, uint32_t rows
                 }
                 __builtin_amdgcn_wave_barrier();
             }
+            TL_STAMP(51);  // row terms exchanged
             // The test, ~2.5 lane-ops per pair: margin = |Dc| - alpha_p * sqrt(d) (float(Dc), one fma with |.| and
             // negation as operand modifiers), a running maximum per row slot (max3), and ONE compare per row slot:
             // the slot has a survivor iff max margin + E >= 0. Which pairs passed is only worked out for row slots
@@ -286,6 +313,7 @@ __global__ void __launch_bounds__(512) coarse_kernel(CoarseArgs a, uint32_t rows
                     for (int t = 0; t < T; t++) x ^= acc[i >> 2][t][i & 3];
                 hit[0] = __ballot(x == 0x7fffffff);
             }
+            TL_STAMP(52);  // tests done
             uint64_t hit_any = 0;
 #pragma unroll
             for (int i = 0; i < RT * 4; i++) hit_any |= hit[i];
@@ -314,42 +342,62 @@ __global__ void __launch_bounds__(512) coarse_kernel(CoarseArgs a, uint32_t rows
                 uint32_t lane_cnt = 0;
 #pragma unroll
                 for (int g = 0; g < PG; g++) lane_cnt += __popc(mb[g]);
-                uint32_t incl = lane_cnt;  // inclusive scan over the wave
+                // keys of this lane's survivors go to slots k, k + 1, ... of the block buffer (fits) or of the global list
+                auto write_keys = [&](uint32_t k, bool fits) {
 #pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const uint32_t t = __shfl_up(incl, d);
-                    if ((int)lane >= d) incl += t;
-                }
-                const uint32_t total = __shfl(incl, 63);
-                uint32_t wbase = 0;
-                if (lane == 0) wbase = atomicAdd(&sctl[0], total);  // LDS
-                wbase = __shfl(wbase, 0);
-                const bool fits = wbase + total <= COARSE_SBUF;  // wave-uniform
-                uint32_t gb = 0;
-                if (!fits) {  // dense survivors (ramp chunks): this wave appends to the global list itself
-                    if (lane == 0) {
-                        atomicMin(&sctl[1], wbase);
-                        gb = atomicAdd(a.key_count, total);
+                    for (int g = 0; g < PG; g++) {
+                        uint32_t mbits = mb[g];
+                        const uint32_t pk = (uint32_t)colp[g * 16 + m] << a.row_bits;  // column >= 0 wherever a bit is set
+                        while (mbits) {
+                            const uint32_t b = __ffs(mbits) - 1u;
+                            mbits &= mbits - 1u;
+                            const uint32_t key = pk | (uint32_t)(rbase + (b >> 2) * 16u + kg * 4u + (b & 3u));
+                            if (fits)
+                                sbuf[k] = key;
+                            else if (k < a.key_cap)
+                                a.keys[k] = key;
+                            k++;
+                        }
                     }
-                    gb = __shfl(gb, 0);
-                }
-                uint32_t k = (fits ? wbase : gb) + (incl - lane_cnt);
+                };
+                if (__popcll(__ballot(lane_cnt != 0u)) <= 8) {
+                    // Steady state: a couple of lanes hold a survivor or two. Each reserves its own slots with one LDS
+                    // atomic (a wave-wide scan plus a leader's reservation is a chain of nine dependent LDS-pipe
+                    // round trips, ~1500 cycles per pass that nothing overlaps).
+                    if (lane_cnt) {
+                        const uint32_t base = atomicAdd(&sctl[0], lane_cnt);  // LDS
+                        const bool fits = base + lane_cnt <= COARSE_SBUF;
+                        uint32_t gb = 0;
+                        if (!fits) {
+                            atomicMin(&sctl[1], base);
+                            gb = atomicAdd(a.key_count, lane_cnt);
+                        }
+                        write_keys(fits ? base : gb, fits);
+                    }
+                } else {
+                    uint32_t incl = lane_cnt;  // inclusive scan over the wave
 #pragma unroll
-                for (int g = 0; g < PG; g++) {
-                    uint32_t mbits = mb[g];
-                    const uint32_t pk = (uint32_t)colp[g * 16 + m] << a.row_bits;  // column >= 0 wherever a bit is set
-                    while (mbits) {
-                        const uint32_t b = __ffs(mbits) - 1u;
-                        mbits &= mbits - 1u;
-                        const uint32_t key = pk | (uint32_t)(rbase + (b >> 2) * 16u + kg * 4u + (b & 3u));
-                        if (fits)
-                            sbuf[k] = key;
-                        else if (k < a.key_cap)
-                            a.keys[k] = key;
-                        k++;
+                    for (int d = 1; d < 64; d <<= 1) {
+                        const uint32_t t = __shfl_up(incl, d);
+                        if ((int)lane >= d) incl += t;
                     }
+                    const uint32_t total = __shfl(incl, 63);
+                    uint32_t wbase = 0;
+                    if (lane == 0) wbase = atomicAdd(&sctl[0], total);  // LDS
+                    wbase = __shfl(wbase, 0);
+                    const bool fits = wbase + total <= COARSE_SBUF;  // wave-uniform
+                    uint32_t gb = 0;
+                    if (!fits) {  // dense survivors (ramp chunks): this wave appends to the global list itself
+                        if (lane == 0) {
+                            atomicMin(&sctl[1], wbase);
+                            gb = atomicAdd(a.key_count, total);
+                        }
+                        gb = __shfl(gb, 0);
+                    }
+                    write_keys((fits ? wbase : gb) + (incl - lane_cnt), fits);
                 }
             }
+            TL_STAMP(53);  // hits resolved, survivors emitted
         }
     }
     __syncthreads();
@@ -475,6 +523,13 @@ hipError_t launch_coarse(const CoarseArgs& a, uint32_t T, uint32_t rows_per_bloc
     return hipErrorInvalidValue;
 #endif
 }
+
+#ifdef KGWAS_COARSE_TIMELINE
+extern "C" int kgwas_debug_coarse_timeline(unsigned long long* out, unsigned long long n) {
+    if (n > 2 * 16 * 64) n = 2 * 16 * 64;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_coarse_tl), n * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 hipError_t launch_rescore(const ScoreArgs& a, const uint32_t* keys, const uint32_t* surv_off, const uint32_t* surv_cnt,
                           uint32_t surv_cap, uint32_t row_bits, hipStream_t st) {
