@@ -41,4 +41,6 @@ for w in range(2):
               "row terms %4d tests %4d hits+emit %5d"
               % (ps, t[53] - t[0], "-" if prev_end is None else str(t[0] - prev_end), st[0][0] - t[0], sum(p_phase), max(p_phase),
                  " ".join(str(x) for x in p_phase), sum(m_phase), sum(m_phase) // 16, " ".join(str(x) for x in m_phase), t[51] - t[50], t[52] - t[51], t[53] - t[52]))
+        if t[54] or t[55] or t[56]:
+            print("         barrier waits: before the MFMA phases %d, after them %d; MFMA issue time %d (sum over the 16 steps)" % (t[54], t[55], t[56]))
         prev_end = t[53]
