@@ -150,7 +150,8 @@ def main():
             if os.environ.get("KGWAS_BENCH_MERGE_DIAG"):  # diagnostics: separate "waiting for the slowest rank" from the merge
                 dist.barrier()
             tm = time.perf_counter()
-            tested = kdist.merge_by_column(scan)  # rank 0's session now holds the global heaps
+            merge = {"root": kdist.merge_to_root, "column": kdist.merge_by_column}.get(os.environ.get("KGWAS_BENCH_MERGE", ""), kdist.merge_shards)
+            tested = merge(scan)  # rank 0's session now holds the global heaps
             merge_ms.append((time.perf_counter() - tm) * 1e3)
         else:
             tested = st["rows_tested"]

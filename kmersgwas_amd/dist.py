@@ -12,7 +12,8 @@ shard with no data-path collective, and one small exchange closes the job:
                 N*(1+ln(rows/N)). merge_by_column finishes column j on rank j mod G (rank 0's heap state for
                 it travels there, layout included; shards 1, 2, ... are replayed in order; the final states
                 return to rank 0): one all_to_all each way, work per rank P/G columns x G shards.
-                merge_on_root is the simple variant (everything replayed on rank 0).
+                merge_to_root replays everything on rank 0 (one exchange, no heap state travels: cheaper for
+                few ranks); merge_shards picks between the two. merge_on_root is the first, simple variant.
   kinship     : integer Hamming partials + used-row counts are all-reduced (sum).
 """
 from __future__ import annotations
@@ -230,6 +231,44 @@ def merge_by_column(scan, dst: int = 0):
         sys.stderr.write("[kgwas] merge_by_column rank %d: %s\n" % (rank, "  ".join(
             "%s %.1f ms" % (b[0], (b[1] - a[1]) * 1e3) for a, b in zip(marks, marks[1:]))))
     return int(tested.item())
+
+
+def merge_to_root(scan, dst: int = 0):
+    """The same result as merge_by_column with every column finished on rank 0: ranks >= 1 send the part of their
+    history that can still matter (score above the larger of the earlier shards' final minima; filtered and laid out
+    flat by the library), rank 0 replays shards 1, 2, ... in order into its own heaps. One exchange, no heap state
+    travels; rank 0 does P x N x ln(G) pushes (about a fifth of its own scan's at G = 8), so this is the cheaper
+    variant for few ranks, merge_by_column (work per rank P/G columns, but two exchanges of the heap states) for
+    many. Returns the total tested-k-mers count. `scan` needs: n_pheno, stats(), lowest(), history_above(),
+    absorb_flat(), finish()."""
+    assert dst == 0, "rank 0 holds the heaps of the first shard"
+    rank, world = dist.get_rank(), dist.get_world_size()
+    P = scan.n_pheno
+    tested = torch.tensor([scan.stats()["rows_tested"]], dtype=torch.int64, device=_dev())
+    dist.all_reduce(tested, op=dist.ReduceOp.SUM)
+    low, full = scan.lowest()
+    lows, fulls = exchange_minima(low, full)
+    thr = prefix_thresholds(lows, fulls)
+    parts = [np.zeros(0, np.int64) for _ in range(world)]
+    if rank != 0:
+        parts[0] = _pack(*scan.history_above(thr[rank]))
+    recv = _all_to_all_i64(parts)
+    if rank == 0:
+        if world > 1:
+            counts = np.zeros((world - 1, P), np.uint64)
+            ks, ss, rs = [], [], []
+            for g in range(1, world):
+                c, k, s, r = _unpack(recv[g], P)
+                counts[g - 1] = c
+                ks.append(k); ss.append(s); rs.append(r)
+            scan.absorb_flat(counts, ks, ss, rs)
+        scan.finish()
+    return int(tested.item())
+
+
+def merge_shards(scan, dst: int = 0):
+    """merge_to_root for up to four ranks, merge_by_column beyond (see there)."""
+    return merge_to_root(scan, dst) if dist.get_world_size() <= 4 else merge_by_column(scan, dst)
 
 
 def merge_on_root(scan: "engine.AssociationScan", dst: int = 0):

@@ -111,16 +111,17 @@ WORKER = textwrap.dedent("""
                     o += int(counts[g, j])
         def finish(self):
             pass
-    ps = PyScan(hist)
-    tested = kdist.merge_by_column(ps)
-    if rank == 0:
-        assert tested == exp["tested"], (tested, exp["tested"])
-        for j in range(P):
-            pops = ps.heaps[j].pop_all()
-            o = exp["per_pheno"][j]
-            assert [e[0] for e in pops] == [int(x) for x in o["kmer"]], "column %%d" %% j
-            assert [e[2] for e in pops] == [int(x) for x in o["file_row"]]
-            assert np.asarray([e[1] for e in pops]).tobytes() == o["score"].tobytes()
+    for merge in (kdist.merge_by_column, kdist.merge_to_root, kdist.merge_shards):
+        ps = PyScan(hist)
+        tested = merge(ps)
+        if rank == 0:
+            assert tested == exp["tested"], (tested, exp["tested"])
+            for j in range(P):
+                pops = ps.heaps[j].pop_all()
+                o = exp["per_pheno"][j]
+                assert [e[0] for e in pops] == [int(x) for x in o["kmer"]], "column %%d" %% j
+                assert [e[2] for e in pops] == [int(x) for x in o["file_row"]]
+                assert np.asarray([e[1] for e in pops]).tobytes() == o["score"].tobytes()
     # kinship partials: integer Hamming sums + used-row counts all-reduce to the single-process answer
     mc = int(np.ceil(S_f * 0.05))
     g = onp.unpack_bits(rows[lo:hi], np.arange(S_f, dtype=np.uint64)).astype(np.int64)
