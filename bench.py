@@ -134,7 +134,7 @@ def main():
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     host_threads = max(1, usable_cpus() // max(local_world, 1))
     session = kg.AssociationScan(S, col, Y, args.topn, mac, device=dev, kernel=args.kernel,
-                                 chunk_rows=args.chunk_rows, record_history=(world > 1 and rank > 0), host_threads=host_threads)
+                                 chunk_rows=args.chunk_rows, record_history=(2 if (world > 1 and rank > 0) else 0), host_threads=host_threads)
 
     merge_ms = []
 

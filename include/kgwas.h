@@ -116,7 +116,9 @@ typedef struct kgwas_scan_params {
     uint64_t chunk_rows;     /* max rows per device chunk; 0 = default */
     uint32_t host_threads;   /* replay threads; 0 = hardware concurrency */
     uint32_t kernel;         /* KGWAS_KERNEL_* */
-    uint32_t record_history; /* keep every effective heap push (for cross-shard merges) */
+    uint32_t record_history; /* what a later shard must keep for a cross-shard merge: 1 = every effective heap push
+                                (kgwas_scan_history, kgwas_scan_history_above); 2 = only each heap's last evictions
+                                (kgwas_scan_history_above alone; it fails loudly if the ring was too short) */
     uint32_t count_patterns; /* --pattern_counter: count distinct presence/absence patterns of tested rows */
 } kgwas_scan_params;
 

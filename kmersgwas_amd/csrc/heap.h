@@ -54,6 +54,7 @@ class alignas(128) BestHeap {
         }
         if (score > lowest_) {
             const uint32_t slot = v_.front().slot;  // the evicted minimum's slot is reused
+            note_eviction(slot, v_.front().score);
             pay_[slot] = Pay{kmer, (uint64_t)row};
             replace_top(v_.data(), (ptrdiff_t)v_.size(), Ent{score, slot});
             pushes_++;
@@ -126,6 +127,7 @@ class alignas(128) BestHeap {
             BestHeap& H = *hp[k];
             a[k] = H.v_.data();
             const uint32_t slot = a[k][0].slot;
+            H.note_eviction(slot, a[k][0].score);
             H.pay_[slot] = Pay{kmer[k], row[k]};
             x[k] = Ent{score[k], slot};
             v[k] = a[k][n - 1];
@@ -204,6 +206,7 @@ class alignas(128) BestHeap {
         if (n > n_res_) n = n_res_;
         v_.clear();
         pay_.clear();
+        evicted_ = 0;
         for (size_t i = 0; i < n; i++) {
             pay_.push_back(Pay{kmer[i], row[i]});
             v_.push_back(Ent{score[i], (uint32_t)i});
@@ -320,10 +323,53 @@ class alignas(128) BestHeap {
         }
     }
 
+    // ---- eviction ring (record_history = 2) --------------------------------------------------------------------
+    // What a later shard has to contribute to a cross-shard merge is its effective pushes with a score above the
+    // earlier shards' final minimum T. Every effective push is either still in the heap or was evicted as the
+    // minimum of its time, and evicted scores only rise: the pushes above T are the heap's entries above T plus
+    // the LAST few evictions (T and this heap's own final minimum are N-th order statistics of equally large
+    // shards: they differ by O(sqrt N) ranks). So instead of logging all N(1 + ln(M/N)) pushes, the last R
+    // evictions are kept in a small cache-resident ring.
+    struct Rec {
+        uint64_t kmer;
+        double score;
+        uint64_t row;
+    };
+    void enable_ring(size_t r) {
+        ring_.assign(r, Rec{0, 0, 0});
+        evicted_ = 0;
+    }
+    inline bool ring_enabled() const { return !ring_.empty(); }
+    // The effective pushes with score > thr (thr = -inf: all of them) in row order, appended to `out`. Returns false
+    // if evictions that may have qualified have already left the ring.
+    bool pushes_above(double thr, std::vector<Rec>& out) const {
+        const bool all = thr == -__builtin_huge_val();
+        const size_t R = ring_.size(), kept = evicted_ < R ? (size_t)evicted_ : R;
+        if (evicted_ > R) {  // the oldest surviving eviction bounds everything that was dropped from below it
+            const Rec& oldest = ring_[evicted_ % R];
+            if (all || oldest.score > thr) return false;
+        }
+        const size_t first = out.size();
+        for (const Ent& e : v_)
+            if (all || e.score > thr) out.push_back(Rec{pay_[e.slot].kmer, e.score, pay_[e.slot].row});
+        for (size_t i = 0; i < kept; i++)
+            if (all || ring_[i].score > thr) out.push_back(ring_[i]);
+        std::sort(out.begin() + (ptrdiff_t)first, out.end(), [](const Rec& a, const Rec& b) { return a.row < b.row; });
+        return true;
+    }
+
    private:
+    inline void note_eviction(uint32_t slot, double score) {
+        if (!ring_.empty()) {
+            ring_[evicted_ % ring_.size()] = Rec{pay_[slot].kmer, score, pay_[slot].row};
+            evicted_++;
+        }
+    }
     size_t n_res_;
     std::vector<Ent> v_;
     std::vector<Pay> pay_;
+    std::vector<Rec> ring_;
+    uint64_t evicted_ = 0;
     uint64_t inserted_, pushes_;
     double lowest_;
 };

@@ -33,6 +33,7 @@
 #include <vector>
 
 #include <dirent.h>
+#include <immintrin.h>
 #include <pthread.h>
 #include <sched.h>
 
@@ -315,9 +316,42 @@ unsigned usable_cpus() {
     return n;
 }
 
+// Effective pushes of one phenotype column in row order (record_history: what a later shard contributes to the
+// cross-shard merge). An append-only log of 24-byte records written with streaming stores: 10 M records per pass go
+// straight to memory instead of through the worker's L2, where they would evict the heaps the same thread is
+// updating (recording through three std::vectors cost 12 ms per 36 ms pass). The separate arrays that
+// kgwas_scan_history hands out are made on demand.
 struct History {
-    std::vector<uint64_t> kmer, row;
-    std::vector<double> score;
+    struct Rec {
+        uint64_t kmer;
+        double score;
+        uint64_t row;
+    };
+    Rec* p = nullptr;
+    size_t n = 0, cap = 0;
+    std::vector<uint64_t> v_kmer, v_row;  // kgwas_scan_history's views
+    std::vector<double> v_score;
+    History() = default;
+    History(const History&) = delete;
+    History& operator=(const History&) = delete;
+    History(History&& o) noexcept : p(o.p), n(o.n), cap(o.cap) { o.p = nullptr; o.n = o.cap = 0; }
+    ~History() { free(p); }
+    inline void push(uint64_t kmer, double score, uint64_t row) {
+        if (n == cap) grow();
+        p[n] = Rec{kmer, score, row};
+        n++;
+    }
+    void grow() {
+        const size_t nc = cap ? cap * 2 : (1u << 14);
+        void* q = nullptr;
+        if (posix_memalign(&q, 64, nc * sizeof(Rec)) != 0) throw std::bad_alloc();
+        _mm_sfence();  // our own streaming stores must have landed before they are copied
+        if (n) memcpy(q, p, n * sizeof(Rec));
+        free(p);
+        p = static_cast<Rec*>(q);
+        cap = nc;
+    }
+    void clear() { n = 0; }
 };
 
 constexpr int MAX_SLOTS = 16;  // upper bound on sparse chunks the GPU may run ahead of the host replay
@@ -354,7 +388,8 @@ struct kgwas_scan {
     std::vector<float> Y;
     bool direct = false;
     uint32_t kernel_used = 0;
-    bool record_history = false;
+    bool record_history = false;  // mode 1: every effective push is logged (hist)
+    size_t history_ring = 0;      // mode 2: each heap keeps its last history_ring evictions instead (heap.h)
     uint64_t chunk_max = 0, dense_rows = 0, dense_chunk = 0;
     uint32_t cap = 0;
     uint64_t max_topn = 0;
@@ -618,13 +653,10 @@ void run_dense(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, uint64_t 
             if (!(S >= mc && n1 >= mc && n1 <= S - mc)) continue;
             if (h.add(s->h_kmer.p[r], sc[r], (size_t)(first_row + r))) {
                 local++;
-                if (s->record_history) {
-                    s->hist[j].kmer.push_back(s->h_kmer.p[r]);
-                    s->hist[j].score.push_back(sc[r]);
-                    s->hist[j].row.push_back(first_row + r);
-                }
+                if (s->record_history) s->hist[j].push(s->h_kmer.p[r], sc[r], first_row + r);
             }
         }
+        if (s->record_history) _mm_sfence();  // streaming stores of the history log
         pushes += local;
     });
     s->st.heap_pushes += pushes.load();
@@ -888,12 +920,7 @@ bool reap_sparse(kgwas_scan* s, Slot& sl) {
                         BestHeap::replace_top_n(K, hp, km, sc, rw);
                     }
                     for (int k = 0; k < K; k++) {
-                        if (s->record_history) {
-                            History& hi = s->hist[who[k]->j];
-                            hi.kmer.push_back(km[k]);
-                            hi.score.push_back(sc[k]);
-                            hi.row.push_back(rw[k]);
-                        }
+                        if (s->record_history) s->hist[who[k]->j].push(km[k], sc[k], rw[k]);
                         who[k]->i++;
                     }
                     local += (uint64_t)K;
@@ -910,6 +937,7 @@ bool reap_sparse(kgwas_scan* s, Slot& sl) {
             if (s->trace && w == 0)
                 fprintf(stderr, "[kgwas]   worker 0: %llu rounds, %llu pushes, scan %.0f heap %.0f kcycles (tsc)\n",
                         (unsigned long long)rounds, (unsigned long long)local, tsc_scan / 1e3, tsc_heap / 1e3);
+            if (s->record_history) _mm_sfence();  // streaming stores of the history log
             pushes += local;
             cands += nc;
             if (s->trace)
@@ -937,13 +965,10 @@ bool reap_sparse(kgwas_scan* s, Slot& sl) {
             const Cand& e = c[(uint32_t)key];
             if (h.add(e.kmer, e.score, (size_t)e.row)) {
                 local++;
-                if (s->record_history) {
-                    s->hist[j].kmer.push_back(e.kmer);
-                    s->hist[j].score.push_back(e.score);
-                    s->hist[j].row.push_back(e.row);
-                }
+                if (s->record_history) s->hist[j].push(e.kmer, e.score, e.row);
             }
         }
+        if (s->record_history) _mm_sfence();  // streaming stores of the history log
         pushes += local;
         cands += n;
     });
@@ -1089,7 +1114,13 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         s->col.assign(p->col, p->col + s->S);
         s->topn.assign(p->topn, p->topn + s->n_pheno);
         s->Y.assign(p->Y, p->Y + s->n_pheno * s->S);
-        s->record_history = p->record_history != 0;
+        if (p->record_history > 2) throw Error(KGWAS_ERR_ARG, "record_history: 0 (off), 1 (full log) or 2 (eviction ring)");
+        s->record_history = p->record_history == 1;
+        if (p->record_history == 2) {
+            s->history_ring = 4096;
+            if (const char* e = getenv("KGWAS_HISTORY_RING"))
+                if (atoll(e) > 0) s->history_ring = (size_t)atoll(e);
+        }
         s->count_patterns = p->count_patterns != 0;
         std::vector<bool> seen(s->S_f, false);
         for (uint64_t i = 0; i < s->S; i++) {
@@ -1442,7 +1473,10 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         s->h_kmer.alloc(s->dense_rows);
         s->d_tested_dense.alloc(TESTED_SHARDS);
 
-        for (uint64_t j = 0; j < P; j++) s->heaps.emplace_back((size_t)s->topn[j]);
+        for (uint64_t j = 0; j < P; j++) {
+            s->heaps.emplace_back((size_t)s->topn[j]);
+            if (s->history_ring) s->heaps.back().enable_ring(s->history_ring);
+        }
         s->hist.resize(P);
         s->keys.resize(P);
         s->col_ms.assign(P, 0.0);
@@ -1578,10 +1612,20 @@ int kgwas_scan_history(kgwas_scan* s, uint64_t j, uint64_t* n, const uint64_t** 
     return guarded([&] {
         if (!s || j >= s->n_pheno) throw Error(KGWAS_ERR_ARG, "kgwas_scan_history: bad argument");
         if (!s->record_history) throw Error(KGWAS_ERR_STATE, "scan was created without record_history");
-        if (n) *n = s->hist[j].kmer.size();
-        if (kmer) *kmer = s->hist[j].kmer.data();
-        if (score) *score = s->hist[j].score.data();
-        if (row) *row = s->hist[j].row.data();
+        History& h = s->hist[j];
+        _mm_sfence();
+        h.v_kmer.resize(h.n);
+        h.v_score.resize(h.n);
+        h.v_row.resize(h.n);
+        for (size_t i = 0; i < h.n; i++) {
+            h.v_kmer[i] = h.p[i].kmer;
+            h.v_score[i] = h.p[i].score;
+            h.v_row[i] = h.p[i].row;
+        }
+        if (n) *n = h.n;
+        if (kmer) *kmer = h.v_kmer.data();
+        if (score) *score = h.v_score.data();
+        if (row) *row = h.v_row.data();
     });
 }
 
@@ -1589,14 +1633,46 @@ int kgwas_scan_history_above(kgwas_scan* s, const double* thr, uint64_t* counts,
                              const double** score, const uint64_t** row) {
     return guarded([&] {
         if (!s || !thr || !counts) throw Error(KGWAS_ERR_ARG, "kgwas_scan_history_above: null argument");
-        if (!s->record_history) throw Error(KGWAS_ERR_STATE, "scan was created without record_history");
+        if (!s->record_history && !s->history_ring) throw Error(KGWAS_ERR_STATE, "scan was created without record_history");
         const uint64_t P = s->n_pheno;
+        if (s->history_ring) {  // mode 2: the heap's entries and its last evictions above thr, put in row order
+            std::vector<std::vector<BestHeap::Rec>> recs(P);
+            std::vector<char> ok(P, 1);
+            s->pool->parallel_for(P, [&](size_t j) { ok[j] = s->heaps[j].pushes_above(thr[j], recs[j]) ? 1 : 0; });
+            for (uint64_t j = 0; j < P; j++)
+                if (!ok[j])
+                    throw Error(KGWAS_ERR_STATE, "record_history = 2: column " + std::to_string(j) + " needs evictions that left its ring of " +
+                                                     std::to_string(s->history_ring) + " (raise KGWAS_HISTORY_RING, or use record_history = 1)");
+            std::vector<uint64_t> off(P + 1, 0);
+            for (uint64_t j = 0; j < P; j++) {
+                counts[j] = recs[j].size();
+                off[j + 1] = off[j] + counts[j];
+            }
+            s->exp_kmer.resize(off[P]);
+            s->exp_score.resize(off[P]);
+            s->exp_row.resize(off[P]);
+            s->pool->parallel_for(P, [&](size_t j) {
+                uint64_t o = off[j];
+                for (const BestHeap::Rec& r : recs[j]) {
+                    s->exp_kmer[o] = r.kmer;
+                    s->exp_score[o] = r.score;
+                    s->exp_row[o] = r.row;
+                    o++;
+                }
+            });
+            if (kmer) *kmer = s->exp_kmer.data();
+            if (score) *score = s->exp_score.data();
+            if (row) *row = s->exp_row.data();
+            return;
+        }
         // entries add_association could still accept after heaps whose minimum is thr[j]: score > thr[j]
         // (NaN scores never pass; thr = -inf keeps everything, NaN included, as the heap may not be full)
         auto keep = [&](uint64_t j, double sc) { return thr[j] == -std::numeric_limits<double>::infinity() || sc > thr[j]; };
+        _mm_sfence();
         s->pool->parallel_for(P, [&](size_t j) {
+            const History& h = s->hist[j];
             uint64_t c = 0;
-            for (double sc : s->hist[j].score) c += keep(j, sc) ? 1 : 0;
+            for (size_t i = 0; i < h.n; i++) c += keep(j, h.p[i].score) ? 1 : 0;
             counts[j] = c;
         });
         std::vector<uint64_t> off(P + 1, 0);
@@ -1607,11 +1683,11 @@ int kgwas_scan_history_above(kgwas_scan* s, const double* thr, uint64_t* counts,
         s->pool->parallel_for(P, [&](size_t j) {
             const History& h = s->hist[j];
             uint64_t o = off[j];
-            for (size_t i = 0; i < h.score.size(); i++)
-                if (keep(j, h.score[i])) {
-                    s->exp_kmer[o] = h.kmer[i];
-                    s->exp_score[o] = h.score[i];
-                    s->exp_row[o] = h.row[i];
+            for (size_t i = 0; i < h.n; i++)
+                if (keep(j, h.p[i].score)) {
+                    s->exp_kmer[o] = h.p[i].kmer;
+                    s->exp_score[o] = h.p[i].score;
+                    s->exp_row[o] = h.p[i].row;
                     o++;
                 }
         });
@@ -1688,14 +1764,11 @@ int kgwas_scan_absorb(kgwas_scan* s, uint64_t n_shards, const uint64_t* counts, 
                 for (uint64_t i = 0; i < n; i++)
                     if (h.add(kmer[g][o + i], score[g][o + i], (size_t)row[g][o + i])) {
                         local++;
-                        if (s->record_history) {
-                            s->hist[j].kmer.push_back(kmer[g][o + i]);
-                            s->hist[j].score.push_back(score[g][o + i]);
-                            s->hist[j].row.push_back(row[g][o + i]);
-                        }
+                        if (s->record_history) s->hist[j].push(kmer[g][o + i], score[g][o + i], row[g][o + i]);
                     }
             }
-            pushes += local;
+            if (s->record_history) _mm_sfence();  // streaming stores of the history log
+        pushes += local;
         });
         s->st.heap_pushes += pushes.load();
         s->finished = false;
@@ -1708,12 +1781,11 @@ int kgwas_scan_reset(kgwas_scan* s) {
         KGWAS_HIP(hipSetDevice(s->device));
         KGWAS_HIP(hipStreamSynchronize(s->stream));
         s->heaps.clear();
-        for (uint64_t j = 0; j < s->n_pheno; j++) s->heaps.emplace_back((size_t)s->topn[j]);
-        for (auto& h : s->hist) {
-            h.kmer.clear();
-            h.score.clear();
-            h.row.clear();
+        for (uint64_t j = 0; j < s->n_pheno; j++) {
+            s->heaps.emplace_back((size_t)s->topn[j]);
+            if (s->history_ring) s->heaps.back().enable_ring(s->history_ring);
         }
+        for (auto& h : s->hist) h.clear();
         s->all_full = false;
         s->hist_ready = false;
         s->rows_submitted = 0;

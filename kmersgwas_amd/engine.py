@@ -130,10 +130,13 @@ class BestAssociationsHeap:
 
 
 class AssociationScan:
-    """Pass 1 of associate_kmers for all phenotype columns at once."""
+    """Pass 1 of associate_kmers for all phenotype columns at once.
+    record_history: what a shard other than the first keeps for a cross-shard merge (kmersgwas_amd.dist): 1 / True =
+    every effective heap push (history(), history_above()); 2 = each heap's last evictions only (history_above()
+    alone, 6 % of a pass instead of 14 %; raises if the ring - KGWAS_HISTORY_RING, default 4096 - was too short)."""
 
     def __init__(self, n_acc_file: int, col, Y, topn, min_count: int, device: int = 0, kernel: int = capi.KERNEL_AUTO,
-                 chunk_rows: int = 0, host_threads: int = 0, record_history: bool = False,
+                 chunk_rows: int = 0, host_threads: int = 0, record_history: int = 0,
                  count_patterns: bool = False):
         self.col = np.ascontiguousarray(col, np.uint64)
         self.Y = np.ascontiguousarray(Y, np.float32)
@@ -156,7 +159,7 @@ class AssociationScan:
         p.chunk_rows = chunk_rows
         p.host_threads = host_threads
         p.kernel = kernel
-        p.record_history = 1 if record_history else 0
+        p.record_history = int(record_history)  # False/0 off, True/1 full log, 2 eviction ring
         p.count_patterns = 1 if count_patterns else 0
         self._h = C.c_void_p()
         check(lib.kgwas_scan_create(C.byref(p), C.byref(self._h)))

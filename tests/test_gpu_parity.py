@@ -207,8 +207,63 @@ def test_shard_merge_by_absorbing_filtered_histories(topn):
         sc.close()
 
 
+def test_eviction_ring_history_equals_full_log(monkeypatch):
+    """record_history = 2 (each heap keeps only its last evictions) must hand kgwas_scan_history_above exactly what the
+    full log (record_history = 1) hands out, for thresholds around the heaps' own final minima (what another shard of
+    the same size produces), with heavy ties; and must fail loudly when the ring is too short for the threshold."""
+    S_f, S, P, topn = 130, 130, 6, 400
+    rows = random_table(40_000, S_f, seed=3, dup_frac=0.5)
+    col = np.arange(S, dtype=np.uint64)
+    Y = phenotypes(S, P - 1, seed=2, binary=True)
+    mac = onp.min_count(S, 0.05, 5)
+    full = kg.AssociationScan(S_f, col, Y, topn, mac, chunk_rows=4096, record_history=1)
+    ring = kg.AssociationScan(S_f, col, Y, topn, mac, chunk_rows=4096, record_history=2)
+    for sc in (full, ring):
+        sc.feed_host(rows[:25_000], 0)
+        sc.feed_host(rows[25_000:], 25_000)
+    low = full.lowest()[0]
+    hist = [full.history(j) for j in range(P)]
+    for name, thr in (("own minima", low), ("a little below", low * 0.97), ("a little above", low * 1.03),
+                      ("other shard", kg_other_minima(rows, S_f, col, Y, topn, mac))):
+        a = [np.array(x) for x in full.history_above(thr)]
+        b = [np.array(x) for x in ring.history_above(thr)]
+        for x, y in zip(a, b):
+            assert x.tobytes() == y.tobytes(), name
+        # and both equal the plain filter of the full history
+        exp_counts = [int((hist[j][1] > thr[j]).sum()) for j in range(P)]
+        assert [int(c) for c in a[0]] == exp_counts, name
+    # everything ever pushed (thr = -inf): here the default ring of 4096 still holds every eviction
+    a = [np.array(x) for x in full.history_above(np.full(P, -np.inf))]
+    b = [np.array(x) for x in ring.history_above(np.full(P, -np.inf))]
+    assert all(x.tobytes() == y.tobytes() for x, y in zip(a, b)) and int(a[0].sum()) == sum(len(h[0]) for h in hist)
+    full.close()
+    ring.close()
+    monkeypatch.setenv("KGWAS_HISTORY_RING", "8")
+    tiny = kg.AssociationScan(S_f, col, Y, topn, mac, chunk_rows=4096, record_history=2)
+    tiny.feed_host(rows, 0)
+    with pytest.raises(kg.KgwasError):
+        tiny.history_above(low * 0.5)
+    with pytest.raises(kg.KgwasError):
+        tiny.history_above(np.full(P, -np.inf))
+    with pytest.raises(kg.KgwasError):
+        tiny.history(0)  # the full log does not exist in this mode
+    tiny.close()
+
+
+def kg_other_minima(rows, S_f, col, Y, topn, mac):
+    """Final heap minima of a scan over the same rows in reverse k-mer order (a stand-in for another shard)."""
+    sc = kg.AssociationScan(S_f, col, Y, topn, mac, chunk_rows=4096)
+    r2 = rows[::-1].copy()
+    r2[:, 0] = rows[:, 0]
+    sc.feed_host(r2, 0)
+    low = sc.lowest()[0].copy()
+    sc.close()
+    return low
+
+
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("world", [2, 3, 5])
-def test_column_distributed_merge_protocol(world):
+def test_column_distributed_merge_protocol(world, mode):
     """What kmersgwas_amd.dist.merge_by_column does over torch.distributed, played by hand in one process: shard
     scans on `world` sessions, column j finished on session j % world from rank 0's exported heap state (layout
     included) plus the later shards' filtered histories, final states imported back into session 0. Heavy ties."""
@@ -222,7 +277,7 @@ def test_column_distributed_merge_protocol(world):
     scans = []
     for g in range(world):
         lo, hi = kdist.shard_range(len(rows), g, world)
-        sc = kg.AssociationScan(S_f, col, Y, topn, mac, chunk_rows=4096, record_history=(g > 0))
+        sc = kg.AssociationScan(S_f, col, Y, topn, mac, chunk_rows=4096, record_history=(mode if g > 0 else 0))
         sc.feed_host(rows[lo:hi], lo)
         sc.finish()
         scans.append(sc)
