@@ -354,6 +354,15 @@ struct History {
     void clear() { n = 0; }
 };
 
+// Evictions a heap of N entries keeps for the cross-shard merge (record_history = 2): the entries of a shard above
+// another equally large shard's N-th score number N +- sqrt(2N); 16 of those deviations, unless KGWAS_HISTORY_RING
+// says otherwise (`forced` > 1).
+inline size_t ring_size(size_t forced, uint64_t topn) {
+    if (forced > 1) return forced;
+    const double r = 16.0 * std::sqrt(2.0 * (double)topn);
+    return (size_t)std::min<double>(std::max<double>(r, 256.0), 1048576.0);
+}
+
 constexpr int MAX_SLOTS = 16;  // upper bound on sparse chunks the GPU may run ahead of the host replay
 
 struct Slot {
@@ -1117,7 +1126,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         if (p->record_history > 2) throw Error(KGWAS_ERR_ARG, "record_history: 0 (off), 1 (full log) or 2 (eviction ring)");
         s->record_history = p->record_history == 1;
         if (p->record_history == 2) {
-            s->history_ring = 4096;
+            s->history_ring = 1;  // per heap: 16 standard deviations of the rank distance between two shards' N-th scores
             if (const char* e = getenv("KGWAS_HISTORY_RING"))
                 if (atoll(e) > 0) s->history_ring = (size_t)atoll(e);
         }
@@ -1475,7 +1484,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
 
         for (uint64_t j = 0; j < P; j++) {
             s->heaps.emplace_back((size_t)s->topn[j]);
-            if (s->history_ring) s->heaps.back().enable_ring(s->history_ring);
+            if (s->history_ring) s->heaps.back().enable_ring(ring_size(s->history_ring, s->topn[j]));
         }
         s->hist.resize(P);
         s->keys.resize(P);
@@ -1642,7 +1651,7 @@ int kgwas_scan_history_above(kgwas_scan* s, const double* thr, uint64_t* counts,
             for (uint64_t j = 0; j < P; j++)
                 if (!ok[j])
                     throw Error(KGWAS_ERR_STATE, "record_history = 2: column " + std::to_string(j) + " needs evictions that left its ring of " +
-                                                     std::to_string(s->history_ring) + " (raise KGWAS_HISTORY_RING, or use record_history = 1)");
+                                                     std::to_string(ring_size(s->history_ring, s->topn[j])) + " (raise KGWAS_HISTORY_RING, or use record_history = 1)");
             std::vector<uint64_t> off(P + 1, 0);
             for (uint64_t j = 0; j < P; j++) {
                 counts[j] = recs[j].size();
@@ -1783,7 +1792,7 @@ int kgwas_scan_reset(kgwas_scan* s) {
         s->heaps.clear();
         for (uint64_t j = 0; j < s->n_pheno; j++) {
             s->heaps.emplace_back((size_t)s->topn[j]);
-            if (s->history_ring) s->heaps.back().enable_ring(s->history_ring);
+            if (s->history_ring) s->heaps.back().enable_ring(ring_size(s->history_ring, s->topn[j]));
         }
         for (auto& h : s->hist) h.clear();
         s->all_full = false;

@@ -217,8 +217,11 @@ def test_eviction_ring_history_equals_full_log(monkeypatch):
     Y = phenotypes(S, P - 1, seed=2, binary=True)
     mac = onp.min_count(S, 0.05, 5)
     full = kg.AssociationScan(S_f, col, Y, topn, mac, chunk_rows=4096, record_history=1)
+    monkeypatch.setenv("KGWAS_HISTORY_RING", "100000")  # (the default, 16 sqrt(2 topn) = 452 here, is exercised below)
     ring = kg.AssociationScan(S_f, col, Y, topn, mac, chunk_rows=4096, record_history=2)
-    for sc in (full, ring):
+    monkeypatch.delenv("KGWAS_HISTORY_RING")
+    dflt = kg.AssociationScan(S_f, col, Y, topn, mac, chunk_rows=4096, record_history=2)
+    for sc in (full, ring, dflt):
         sc.feed_host(rows[:25_000], 0)
         sc.feed_host(rows[25_000:], 25_000)
     low = full.lowest()[0]
@@ -232,10 +235,18 @@ def test_eviction_ring_history_equals_full_log(monkeypatch):
         # and both equal the plain filter of the full history
         exp_counts = [int((hist[j][1] > thr[j]).sum()) for j in range(P)]
         assert [int(c) for c in a[0]] == exp_counts, name
-    # everything ever pushed (thr = -inf): here the default ring of 4096 still holds every eviction
+    # everything ever pushed (thr = -inf): the large ring still holds every eviction, the default one does not
     a = [np.array(x) for x in full.history_above(np.full(P, -np.inf))]
     b = [np.array(x) for x in ring.history_above(np.full(P, -np.inf))]
     assert all(x.tobytes() == y.tobytes() for x, y in zip(a, b)) and int(a[0].sum()) == sum(len(h[0]) for h in hist)
+    with pytest.raises(kg.KgwasError):
+        dflt.history_above(np.full(P, -np.inf))
+    # the default ring: bounds from a shard of the same size are served, and equal the full log's answer
+    for thr in (low, kg_other_minima(rows, S_f, col, Y, topn, mac)):
+        a = [np.array(x) for x in full.history_above(thr)]
+        b = [np.array(x) for x in dflt.history_above(thr)]
+        assert all(x.tobytes() == y.tobytes() for x, y in zip(a, b))
+    dflt.close()
     full.close()
     ring.close()
     monkeypatch.setenv("KGWAS_HISTORY_RING", "8")

@@ -1,3 +1,4 @@
+"""Cost of keeping the cross-shard history during a pass: record_history 0 (off), 1 (full log), 2 (eviction ring)."""
 import sys, os, time
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
@@ -11,7 +12,7 @@ table = torch.empty(M * W, dtype=torch.int64, device="cuda")
 stream = torch.cuda.current_stream().cuda_stream
 kg.synth_rows_device(table.data_ptr(), 0, M, S, 20240601, stream)
 torch.cuda.synchronize()
-for rh in (False, True, False, True):
+for rh in (0, 1, 2, 0, 1, 2):
     scan = kg.AssociationScan(S, np.arange(S, dtype=np.uint64), Y, 10001, mac, device=0, record_history=rh)
     ts = []
     for it in range(5):
