@@ -76,8 +76,8 @@ def cgroup_throttle():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--rows", type=int, default=100_000_000, help="k-mer rows per GPU")
     ap.add_argument("--samples", type=int, default=1024)
     ap.add_argument("--perms", type=int, default=100)
