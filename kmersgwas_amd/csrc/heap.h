@@ -354,8 +354,41 @@ class alignas(128) BestHeap {
             if (all || e.score > thr) out.push_back(Rec{pay_[e.slot].kmer, e.score, pay_[e.slot].row});
         for (size_t i = 0; i < kept; i++)
             if (all || ring_[i].score > thr) out.push_back(ring_[i]);
-        std::sort(out.begin() + (ptrdiff_t)first, out.end(), [](const Rec& a, const Rec& b) { return a.row < b.row; });
+        sort_by_row(out.data() + first, out.size() - first);
         return true;
+    }
+    // Row order (rows are unique within a column) by LSD radix sort on the row's offset from the smallest one, 16 bits
+    // per pass: a shard spans < 2^32 rows, so two passes over ~N records instead of a comparison sort (this runs once
+    // per column on the merge's critical path).
+    static void sort_by_row(Rec* a, size_t n) {
+        if (n < 2) return;
+        uint64_t lo = a[0].row, hi = a[0].row;
+        for (size_t i = 1; i < n; i++) {
+            lo = a[i].row < lo ? a[i].row : lo;
+            hi = a[i].row > hi ? a[i].row : hi;
+        }
+        const uint64_t span = hi - lo;
+        if (n < 64 || span >= (1ull << 48)) {
+            std::sort(a, a + n, [](const Rec& x, const Rec& y) { return x.row < y.row; });
+            return;
+        }
+        std::vector<Rec> tmp(n);
+        std::vector<uint32_t> cnt(65536);
+        Rec* src = a;
+        Rec* dst = tmp.data();
+        for (int shift = 0; shift < 48 && (span >> shift) != 0; shift += 16) {
+            std::fill(cnt.begin(), cnt.end(), 0u);
+            for (size_t i = 0; i < n; i++) cnt[((src[i].row - lo) >> shift) & 0xFFFFu]++;
+            uint32_t run = 0;
+            for (uint32_t& c : cnt) {
+                const uint32_t t = c;
+                c = run;
+                run += t;
+            }
+            for (size_t i = 0; i < n; i++) dst[cnt[((src[i].row - lo) >> shift) & 0xFFFFu]++] = src[i];
+            std::swap(src, dst);
+        }
+        if (src != a) std::copy(src, src + n, a);
     }
 
    private:
