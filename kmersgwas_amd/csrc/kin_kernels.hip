@@ -10,8 +10,8 @@
 //                          butterfly stages (the previous version took one ballot per sample: 1152 per 64 rows,
 //                          half of the whole accumulation's time);
 //   kin_gram_kernel      : C = T T^t on v_mfma_i32_16x16x64_i8. A wave owns a 64 x 128 tile of C (32 accumulators) and
-//                          expands its own operands from the planes (16 row bits -> 16 bytes: 12 VALU ops) - 144 VALU ops
-//                          per 32 MFMAs, the two waves of a SIMD overlapping one's expansion with the other's MFMAs.
+//                          expands its own operands from the planes ((dword >> j) & 0x01010101: 8 VALU ops per 16
+//                          bytes) - 96 VALU ops per 32 MFMAs, the plane dwords read from LDS once per 8 steps.
 //                          The xor-popcount formulation this replaces does S^2/64 lane-ops per row (VALU-bound,
 //                          146 T pair-updates/s at 1135 samples).
 #include "kernels.h"
@@ -22,12 +22,15 @@ typedef int kin_i32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-__device__ __forceinline__ kin_i32x4 kin_expand16(uint32_t x) {  // 16 bits -> 16 int8 0/1 (k-element e in byte e)
+// Operand of MFMA step j from four plane dwords (128 rows of one sample): byte e of operand dword q = bit 8e + j of
+// plane dword q, i.e. k-element 4q + e <-> row 32q + 8e + j of the lane's 128. A and B operands use the same map, so
+// the k index pairs a row with itself; two lane-ops per 4 operand bytes.
+__device__ __forceinline__ kin_i32x4 kin_expand_step(const uint4& w, int j) {
     kin_i32x4 r;
-    r[0] = (int)(((x & 0xFu) * 0x00204081u) & 0x01010101u);
-    r[1] = (int)((((x >> 4) & 0xFu) * 0x00204081u) & 0x01010101u);
-    r[2] = (int)((((x >> 8) & 0xFu) * 0x00204081u) & 0x01010101u);
-    r[3] = (int)((((x >> 12) & 0xFu) * 0x00204081u) & 0x01010101u);
+    r[0] = (int)((w.x >> j) & 0x01010101u);
+    r[1] = (int)((w.y >> j) & 0x01010101u);
+    r[2] = (int)((w.z >> j) & 0x01010101u);
+    r[3] = (int)((w.w >> j) & 0x01010101u);
     return r;
 }
 
@@ -100,13 +103,14 @@ __global__ void __launch_bounds__(256) kin_transpose_kernel(const uint64_t* file
 
 // C[i][j] += sum over the launch's rows of g_i g_j for the 128 x 128 sample tile (ib, jb), jb >= ib, and a slice of
 // the rows (blockIdx.y). Block = 2 waves; wave w owns samples ib*128 + 64w .. +63 against all 128 of jb.
-// MFMA k index <-> rows: lane (m, kg) supplies rows 64s + 16kg .. +15 of sample m for step s, i.e. the low or high
-// half of dword 2s + kg/2 of that sample's plane.
+// MFMA k index <-> rows: per round of 512 rows lane (m, kg) holds plane dwords 4kg .. 4kg+3 (rows 128kg .. +127) of
+// its samples and step j = 0..7 takes bit j of each of their bytes (kin_expand_step).
 constexpr uint32_t KIN_KC = 16;  // plane dwords (512 rows) staged per round
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) kin_gram_kernel(const uint32_t* T, uint64_t n_rw, uint32_t S_pad, unsigned long long* C,
                                                        uint64_t rw_per_split) {
-    __shared__ uint32_t LA[128][KIN_KC + 1];
-    __shared__ uint32_t LB[128][KIN_KC + 1];
+    constexpr uint32_t LROW = KIN_KC + 4;  // 80-byte rows: 16-byte aligned for ds_read_b128 / ds_write_b128
+    __shared__ __attribute__((aligned(16))) uint32_t LA[128][LROW];
+    __shared__ __attribute__((aligned(16))) uint32_t LB[128][LROW];
     uint32_t tix = blockIdx.x, ib = 0;  // upper-triangular tile index -> (ib, jb), jb >= ib
     const uint32_t nt = S_pad / 128u;
     while (tix >= nt - ib) {
@@ -158,18 +162,22 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
         land(k0);
         __syncthreads();
         if (k0 + KIN_KC < k_end) issue(k0 + KIN_KC);
-#pragma unroll 2
-        for (uint32_t s = 0; s < KIN_KC / 2u; s++) {
-            const uint32_t dw = 2u * s + (kg >> 1), sh = (kg & 1u) * 16u;
-            kin_i32x4 A[4], B[8];
+        uint4 wA[4], wB[8];
 #pragma unroll
-            for (int x = 0; x < 4; x++) A[x] = kin_expand16((LA[wave * 64u + x * 16u + m][dw] >> sh) & 0xFFFFu);
+        for (int x = 0; x < 4; x++) wA[x] = *reinterpret_cast<const uint4*>(&LA[wave * 64u + x * 16u + m][4u * kg]);
 #pragma unroll
-            for (int y = 0; y < 8; y++) B[y] = kin_expand16((LB[y * 16u + m][dw] >> sh) & 0xFFFFu);
+        for (int y = 0; y < 8; y++) wB[y] = *reinterpret_cast<const uint4*>(&LB[y * 16u + m][4u * kg]);
+#pragma unroll 1
+        for (int j = 0; j < 8; j++) {
+            kin_i32x4 A[4];
 #pragma unroll
-            for (int x = 0; x < 4; x++)
+            for (int x = 0; x < 4; x++) A[x] = kin_expand_step(wA[x], j);
 #pragma unroll
-                for (int y = 0; y < 8; y++) acc[x][y] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[x], B[y], acc[x][y], 0, 0, 0);
+            for (int y = 0; y < 8; y++) {
+                const kin_i32x4 B = kin_expand_step(wB[y], j);
+#pragma unroll
+                for (int x = 0; x < 4; x++) acc[x][y] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[x], B, acc[x][y], 0, 0, 0);
+            }
         }
     }
     // D[row = 4kg + jj][col = m] of tile (x, y)
