@@ -34,26 +34,54 @@ __device__ __forceinline__ kin_i32x4 kin_expand_step(const uint4& w, int j) {
     return r;
 }
 
+// x of lane (lane ^ J) for J = 1, 2, 4, 8 as DPP moves (vector-ALU operand modifiers: no trip through the LDS
+// crossbar that __shfl_xor's ds_bpermute takes): quad permutes for 1 and 2; for 4 and 8 a row shift left into the
+// lanes whose bit J is clear and a row shift right into the others, selected by the DPP bank mask (banks = groups
+// of four lanes of a 16-lane row).
+template <int J>
+__device__ __forceinline__ uint32_t lane_xor_dpp(uint32_t x) {
+    int r = (int)x;
+    if (J == 1) {
+        r = __builtin_amdgcn_update_dpp(r, (int)x, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+    } else if (J == 2) {
+        r = __builtin_amdgcn_update_dpp(r, (int)x, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+    } else if (J == 4) {
+        r = __builtin_amdgcn_update_dpp(r, (int)x, 0x104, 0xF, 0x5, false);  // row_shl:4 into banks 0, 2
+        r = __builtin_amdgcn_update_dpp(r, (int)x, 0x114, 0xF, 0xA, false);  // row_shr:4 into banks 1, 3
+    } else {
+        r = __builtin_amdgcn_update_dpp(r, (int)x, 0x108, 0xF, 0x3, false);  // row_shl:8 into banks 0, 1
+        r = __builtin_amdgcn_update_dpp(r, (int)x, 0x118, 0xF, 0xC, false);  // row_shr:8 into banks 2, 3
+    }
+    return (uint32_t)r;
+}
+
 // 32 x 32 bit-matrix transpose across the 32 lanes of a half wave: in: lane r holds row r (bit s = sample s);
-// out: lane s holds sample s (bit r = row r).
+// out: lane s holds sample s (bit r = row r). Five butterfly stages; only the first (lanes 16 apart) crosses a
+// 16-lane row and goes through the LDS crossbar.
+template <int J>
+__device__ __forceinline__ void transpose_stage(uint32_t& x, uint32_t& m, uint32_t lane) {
+    const uint32_t y = J == 16 ? (uint32_t)__shfl_xor((int)x, 16) : lane_xor_dpp<J>(x);
+    const bool lo = (lane & (uint32_t)J) == 0u;
+    const uint32_t a = lo ? x : y, b = lo ? y : x;
+    const uint32_t t = ((a >> J) ^ b) & m;
+    x = lo ? (a ^ (t << J)) : (b ^ t);
+    m ^= m << (J >> 1);
+}
 __device__ __forceinline__ uint32_t transpose32(uint32_t x, uint32_t lane) {
     uint32_t m = 0x0000FFFFu;
-#pragma unroll
-    for (int j = 16; j != 0; j >>= 1) {
-        const uint32_t y = __shfl_xor(x, j);
-        const bool lo = (lane & (uint32_t)j) == 0u;
-        const uint32_t a = lo ? x : y, b = lo ? y : x;
-        const uint32_t t = ((a >> j) ^ b) & m;
-        x = lo ? (a ^ (t << j)) : (b ^ t);
-        m ^= m << (j >> 1);
-    }
+    transpose_stage<16>(x, m, lane);
+    transpose_stage<8>(x, m, lane);
+    transpose_stage<4>(x, m, lane);
+    transpose_stage<2>(x, m, lane);
+    transpose_stage<1>(x, m, lane);
     return x;
 }
 
 }  // namespace
 
-// T[c][rw] (u32) = sample c's presence bits for rows 32*rw .. 32*rw+31 of the launch; rows failing the filter are
-// all-zero. A block covers 512 rows (two 256-row halves) so that each sample's output is one 64-byte line.
+// Plane word rw (u32) of sample c = its presence bits for rows 32*rw .. 32*rw+31 of the launch, stored tile-major as
+// T[rw / 16][c][rw % 16]; rows failing the filter are all-zero. A block covers 512 rows (two 256-row halves) = one
+// block of 16 plane words.
 __global__ void __launch_bounds__(256) kin_transpose_kernel(const uint64_t* file_rows, uint64_t file_stride_w, uint64_t n_rows,
                                                             uint32_t S_f, uint32_t S_pad, uint32_t min_count, uint32_t* T,
                                                             uint64_t n_rw, unsigned long long* n_used) {
@@ -94,11 +122,12 @@ __global__ void __launch_bounds__(256) kin_transpose_kernel(const uint64_t* file
     }
     if (lane == 0 && kept) atomicAdd(&n_used[blockIdx.x % TESTED_SHARDS], kept);  // each wave adds the rows it counted
     __syncthreads();
-    const uint64_t rw0 = (uint64_t)blockIdx.x * 16u;
-    for (uint32_t e = threadIdx.x; e < S_pad * 16u; e += 256u) {
-        const uint32_t c = e >> 4, k = e & 15u;
-        if (rw0 + k < n_rw) T[(uint64_t)c * n_rw + rw0 + k] = lout[e];
-    }
+    // Tile-major planes: T[block of 16 plane words (512 rows)][sample][16] - this block's 512 rows of all samples are
+    // one contiguous 64*S_pad-byte piece, and the Gram kernel's round (16 plane words of 128 samples) is one 8 KB piece.
+    uint4* dst = reinterpret_cast<uint4*>(T + (uint64_t)blockIdx.x * S_pad * 16u);
+    const uint4* src = reinterpret_cast<const uint4*>(lout);
+    if ((uint64_t)blockIdx.x * 16u < n_rw)
+        for (uint32_t e = threadIdx.x; e < S_pad * 4u; e += 256u) dst[e] = src[e];
 }
 
 // C[i][j] += sum over the launch's rows of g_i g_j for the 128 x 128 sample tile (ib, jb), jb >= ib, and a slice of
@@ -141,7 +170,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
             const uint32_t srow = (row < 128u ? ib * 128u + row : jb * 128u + (row - 128u));
             uint64_t kw = k0 + 4u * part;
             if (kw + 4u > n_rw) kw = n_rw - 4u;  // n_rw is a multiple of 16: clamp instead of branching (tail is masked below)
-            nxt[q] = *reinterpret_cast<const uint4*>(T + (uint64_t)srow * n_rw + kw);
+            nxt[q] = *reinterpret_cast<const uint4*>(T + ((kw >> 4) * S_pad + srow) * 16u + (kw & 15u));
         }
     };
     auto land = [&](uint64_t k0) {
