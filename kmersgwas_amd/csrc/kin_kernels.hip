@@ -80,54 +80,48 @@ __device__ __forceinline__ uint32_t transpose32(uint32_t x, uint32_t lane) {
 }  // namespace
 
 // Plane word rw (u32) of sample c = its presence bits for rows 32*rw .. 32*rw+31 of the launch, stored tile-major as
-// T[rw / 16][c][rw % 16]; rows failing the filter are all-zero. A block covers 512 rows (two 256-row halves) = one
-// block of 16 plane words.
+// T[rw / 8][c][rw % 8]; rows failing the filter are all-zero. A block covers 256 rows = one tile of 8 plane words
+// (76 KB of LDS at 1135 samples: two blocks per CU, so one's loads overlap the other's transposes).
 __global__ void __launch_bounds__(256) kin_transpose_kernel(const uint64_t* file_rows, uint64_t file_stride_w, uint64_t n_rows,
                                                             uint32_t S_f, uint32_t S_pad, uint32_t min_count, uint32_t* T,
                                                             uint64_t n_rw, unsigned long long* n_used) {
     extern __shared__ uint32_t kin_lds[];
     const uint32_t stride_dw = (uint32_t)(2u * file_stride_w);
     uint32_t* lin = kin_lds;                        // [256][stride_dw] verbatim rows (k-mer word included)
-    uint32_t* lout = kin_lds + 256u * stride_dw;    // [S_pad][16]
+    uint32_t* lout = kin_lds + 256u * stride_dw;    // [S_pad][8]
     const uint32_t in_dw = 2u * ((S_f + 63u) / 64u);
-    const uint64_t blk_row0 = (uint64_t)blockIdx.x * 512u;
+    const uint64_t row0 = (uint64_t)blockIdx.x * 256u;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    unsigned long long kept = 0;
-    for (uint32_t half = 0; half < 2u; half++) {
-        const uint64_t row0 = blk_row0 + half * 256u;
-        __syncthreads();
-        if (row0 < n_rows) {  // coalesced verbatim copy of up to 256 contiguous rows
-            const uint64_t left = n_rows - row0;
-            const uint32_t n2 = (uint32_t)((left < 256u ? left : 256u) * file_stride_w);
-            const uint2* src = reinterpret_cast<const uint2*>(file_rows + row0 * file_stride_w);
-            uint2* dst = reinterpret_cast<uint2*>(lin);
-            for (uint32_t i = threadIdx.x; i < n2; i += 256u) dst[i] = src[i];
-        }
-        __syncthreads();
-        const uint64_t r = row0 + threadIdx.x;
-        const uint32_t* my = lin + (size_t)threadIdx.x * stride_dw + 2u;
-        uint32_t n1 = 0;
-        if (r < n_rows)
-            for (uint32_t d = 0; d < in_dw; d++) n1 += __popc(my[d]);
-        // src/emma_kinship_kmers.cpp:83,89 -> load_kmers' predicate with all S_f columns
-        const bool pass = (r < n_rows) && (S_f >= min_count) && (n1 >= min_count) && (n1 <= S_f - min_count);
-        kept += __popcll(__ballot(pass));
-        for (uint32_t d = 0; d < S_pad / 32u; d++) {
-            uint32_t x = (pass && d < in_dw) ? my[d] : 0u;
-            if (32u * d + 32u > S_f) x &= (32u * d < S_f) ? ((1u << (S_f - 32u * d)) - 1u) : 0u;  // file padding bits
-            x = transpose32(x, lane);
-            // lane s of 32-lane group g now holds sample 32d + s over the group's 32 rows
-            lout[(32u * d + (lane & 31u)) * 16u + half * 8u + wave * 2u + (lane >> 5)] = x;
-        }
+    if (row0 < n_rows) {  // coalesced verbatim copy of up to 256 contiguous rows
+        const uint64_t left = n_rows - row0;
+        const uint32_t n2 = (uint32_t)((left < 256u ? left : 256u) * file_stride_w);
+        const uint2* src = reinterpret_cast<const uint2*>(file_rows + row0 * file_stride_w);
+        uint2* dst = reinterpret_cast<uint2*>(lin);
+        for (uint32_t i = threadIdx.x; i < n2; i += 256u) dst[i] = src[i];
+    }
+    __syncthreads();
+    const uint64_t r = row0 + threadIdx.x;
+    const uint32_t* my = lin + (size_t)threadIdx.x * stride_dw + 2u;
+    uint32_t n1 = 0;
+    if (r < n_rows)
+        for (uint32_t d = 0; d < in_dw; d++) n1 += __popc(my[d]);
+    // src/emma_kinship_kmers.cpp:83,89 -> load_kmers' predicate with all S_f columns
+    const bool pass = (r < n_rows) && (S_f >= min_count) && (n1 >= min_count) && (n1 <= S_f - min_count);
+    const unsigned long long kept = __popcll(__ballot(pass));
+    for (uint32_t d = 0; d < S_pad / 32u; d++) {
+        uint32_t x = (pass && d < in_dw) ? my[d] : 0u;
+        if (32u * d + 32u > S_f) x &= (32u * d < S_f) ? ((1u << (S_f - 32u * d)) - 1u) : 0u;  // file padding bits
+        x = transpose32(x, lane);
+        // lane s of 32-lane group g now holds sample 32d + s over the group's 32 rows
+        lout[(32u * d + (lane & 31u)) * 8u + wave * 2u + (lane >> 5)] = x;
     }
     if (lane == 0 && kept) atomicAdd(&n_used[blockIdx.x % TESTED_SHARDS], kept);  // each wave adds the rows it counted
     __syncthreads();
-    // Tile-major planes: T[block of 16 plane words (512 rows)][sample][16] - this block's 512 rows of all samples are
-    // one contiguous 64*S_pad-byte piece, and the Gram kernel's round (16 plane words of 128 samples) is one 8 KB piece.
-    uint4* dst = reinterpret_cast<uint4*>(T + (uint64_t)blockIdx.x * S_pad * 16u);
+    // this block's 256 rows of all samples are one contiguous 32*S_pad-byte piece; the Gram kernel's round (16 plane
+    // words of 128 samples) is two 4 KB pieces
+    uint4* dst = reinterpret_cast<uint4*>(T + (uint64_t)blockIdx.x * S_pad * 8u);
     const uint4* src = reinterpret_cast<const uint4*>(lout);
-    if ((uint64_t)blockIdx.x * 16u < n_rw)
-        for (uint32_t e = threadIdx.x; e < S_pad * 4u; e += 256u) dst[e] = src[e];
+    for (uint32_t e = threadIdx.x; e < S_pad * 2u; e += 256u) dst[e] = src[e];
 }
 
 // C[i][j] += sum over the launch's rows of g_i g_j for the 128 x 128 sample tile (ib, jb), jb >= ib, and a slice of
@@ -170,7 +164,7 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
             const uint32_t srow = (row < 128u ? ib * 128u + row : jb * 128u + (row - 128u));
             uint64_t kw = k0 + 4u * part;
             if (kw + 4u > n_rw) kw = n_rw - 4u;  // n_rw is a multiple of 16: clamp instead of branching (tail is masked below)
-            nxt[q] = *reinterpret_cast<const uint4*>(T + ((kw >> 4) * S_pad + srow) * 16u + (kw & 15u));
+            nxt[q] = *reinterpret_cast<const uint4*>(T + ((kw >> 3) * S_pad + srow) * 8u + (kw & 7u));
         }
     };
     auto land = [&](uint64_t k0) {
@@ -228,13 +222,14 @@ hipError_t launch_kin_transpose(const uint64_t* file_rows, uint64_t file_stride_
                                 uint32_t S_pad, uint32_t min_count, uint32_t* T, uint64_t n_rw, unsigned long long* n_used,
                                 hipStream_t st) {
     if (n_rows == 0) return hipSuccess;
-    const size_t lds = (size_t)(256u * 2u * file_stride_w + (size_t)S_pad * 16u) * 4u;
+    const size_t lds = (size_t)(256u * 2u * file_stride_w + (size_t)S_pad * 8u) * 4u;
     if (lds > 160u * 1024u) return hipErrorInvalidValue;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kin_transpose_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kin_transpose_kernel, dim3((uint32_t)((n_rows + 511) / 512)), dim3(256), lds, st, file_rows, file_stride_w,
+    // one block per tile of 8 plane words: every word of T up to n_rw is written (tiles beyond the rows hold zeros)
+    hipLaunchKernelGGL(kin_transpose_kernel, dim3((uint32_t)(n_rw / 8u)), dim3(256), lds, st, file_rows, file_stride_w,
                        n_rows, S_f, S_pad, min_count, T, n_rw, n_used);
     return hipGetLastError();
 }
