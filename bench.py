@@ -4,9 +4,17 @@
 Metric (BASELINE.json): k-mers x permutations scored per second. A "step" is one full pass of the
 hot path (associate_kmers pass 1: MAC filter, score every k-mer against every phenotype column,
 top-N heaps with best_associations_heap semantics) over a synthetic table that is already resident
-in HBM when the timed region starts. At N=1 the workload is BASELINE.json configs[1]: 100M k-mers x
-1024 samples, 1 phenotype + 100 permutations, top 10001 per column. With N>1 every rank scans its
-own 100M-row shard (weak scaling) and rank 0 merges the ranks' heap histories over RCCL.
+in HBM when the timed region starts.
+
+  N = 1 : BASELINE.json configs[1]: 100M k-mers x 1024 samples, 1 phenotype + 100 permutations, top 10001
+          per column. The same JSON line carries the sub-records "p1_scan" (the one-column scan of the same
+          table: the HBM-roofline configuration, BASELINE.md row 2'), "kinship" (configs[4] in shape: 8M rows x
+          1135 samples through the kinship kernels, with the single-threaded CPU accumulation beside it),
+          "parity_check" (the GPU's heaps over the CPU baseline's rows equal the oracle's) and "cpu_baseline".
+  N > 1 : BASELINE.json configs[3] per GPU: every rank scans its own shard of 2048 samples x 201 columns
+          (2.5e8 rows = 66 GB per GPU unless --rows says otherwise; weak scaling, contiguous row shards) and the
+          ranks' heap histories are merged over RCCL inside the timed region. "single_gpu_same_shard" is
+          rank 0's shard scanned alone (no merge), so that the N-GPU value has its own N = 1 reference.
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -51,17 +59,125 @@ def usable_cpus():
 
 def cpu_baseline(S, Y, mac, topn, seed, sample_rows, threads):
     """Oracle (CPU restatement of the reference algorithm: per-bit squeeze loader + SSE-order
-    scorer + std::priority_queue, one thread per phenotype column) on a bounded sample."""
+    scorer + std::priority_queue, one thread per phenotype column) on a bounded sample.
+    Returns (record, oracle result) - the result is what parity_check compares the GPU with."""
     import kmersgwas_amd as kg
     from oracle import binding as ob
     rows = kg.synth_rows_host(0, sample_rows, S, seed)
     t0 = time.perf_counter()
     res = ob.associate(rows, S, np.arange(S, dtype=np.uint64), Y, topn, mac, batch_size=10_000_000, threads=threads)
     dt = time.perf_counter() - t0
-    return dict(value=sample_rows * Y.shape[0] / dt, unit="kmer*phenotype/s", cores=threads, kind="port",
-                sample="%d rows x %d samples x %d columns of the same synthetic table; oracle/oracle.cpp "
-                       "(load %.2fs + score %.2fs)" % (sample_rows, S, Y.shape[0], res["t_load"], res["t_score"]),
-                seconds=dt)
+    rec = dict(value=sample_rows * Y.shape[0] / dt, unit="kmer*phenotype/s", cores=threads, kind="port",
+               sample="%d rows x %d samples x %d columns of the same synthetic table; oracle/oracle.cpp "
+                      "(load %.2fs + score %.2fs)" % (sample_rows, S, Y.shape[0], res["t_load"], res["t_score"]),
+               seconds=dt)
+    return rec, res
+
+
+def parity_check(kg, table_ptr, stream, S, col, Y, topn, mac, sample_rows, oracle_res, dev, host_threads):
+    """The GPU path over the CPU baseline's rows (the first sample_rows rows of the resident table) against the
+    oracle's result: identities, row ids, scores (bytes), effective pushes, tested rows. True / False."""
+    scan = kg.AssociationScan(S, col, Y, topn, mac, device=dev, host_threads=host_threads)
+    try:
+        scan.feed_device(table_ptr, sample_rows, 0, stream)
+        scan.finish()
+        st = scan.stats()
+        ok = st["heap_pushes"] == oracle_res["pushes"] and st["rows_tested"] == oracle_res["tested"]
+        for j in range(Y.shape[0]):
+            k, s, r = scan.result(j)
+            o = oracle_res["per_pheno"][j]
+            ok = ok and len(k) == len(o["kmer"]) and bool((k == o["kmer"]).all()) and bool((r == o["file_row"]).all()) \
+                and s.tobytes() == o["score"].tobytes()
+        return bool(ok)
+    finally:
+        scan.close()
+
+
+def p1_scan_record(kg, torch, table, stream, M, S, Y, topn, mac, dev, host_threads, passes=5):
+    """One phenotype column over the resident table: 8*(1+W_f) bytes per row against 2*S flop - the HBM-bound
+    configuration of the scan (BASELINE.md row 2')."""
+    W = 1 + (S + 63) // 64
+    scan = kg.AssociationScan(S, np.arange(S, dtype=np.uint64), Y[:1], topn, mac, device=dev, host_threads=host_threads)
+    try:
+        def one():
+            scan.reset()
+            scan.feed_device(table.data_ptr(), M, 0, stream)
+            scan.finish()
+            return scan.stats()
+        one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sts = [one() for _ in range(passes)]
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / passes
+        k_ms = sum(s["score_kernel_ms"] for s in sts) / passes
+        c_ms = sum(s["coarse_kernel_ms"] for s in sts) / passes
+        f_ms = sum(s["p1_kernel_ms"] for s in sts) / passes if "p1_kernel_ms" in sts[0] else 0.0
+        filt_ms = f_ms if f_ms > 0 else c_ms
+        name = {1: "score_valu_kernel", 2: "score_mfma_kernel", 3: "coarse_kernel", 4: "p1_filter_kernel"}.get(sts[-1]["kernel_used"], "?")
+        gb = M * 8.0 * W / 1e9
+        return {"workload": "%dM k-mers x %d samples, 1 phenotype column, top-%d" % (M // 1_000_000, S, topn),
+                "kernel": name, "ms_per_pass": dt * 1e3, "rows_per_s": M / dt,
+                "hbm_GBps": gb / dt, "frac_of_8TBps": gb / dt / HBM_PEAK_GBPS,
+                "all_kernels_ms_per_pass": k_ms, "kernels_hbm_GBps": gb / (k_ms * 1e-3) if k_ms > 0 else None,
+                "kernels_frac_of_8TBps": gb / (k_ms * 1e-3) / HBM_PEAK_GBPS if k_ms > 0 else None,
+                "filter_kernel_ms_per_pass": filt_ms,
+                "filter_kernel_hbm_GBps": gb / (filt_ms * 1e-3) if filt_ms > 0 else None,
+                "filter_kernel_frac_of_8TBps": gb / (filt_ms * 1e-3) / HBM_PEAK_GBPS if filt_ms > 0 else None,
+                "heap_pushes_per_pass": sum(s["heap_pushes"] for s in sts) // passes,
+                "replay_cpu_ms_per_pass": sum(s["replay_cpu_ms"] for s in sts) / passes}
+    finally:
+        scan.close()
+
+
+def kinship_record(kg, torch, stream, dev, rows=8_000_000, S_f=1135, seed=20240601, cpu_rows=20_000, passes=3):
+    """BASELINE.json configs[4] in shape: emma_kinship_kmers' accumulation over `rows` rows x 1135 accessions
+    resident in HBM, and the reference's single-threaded loop (oracle) on a slice of the same rows."""
+    from oracle import binding as ob
+    W = 1 + (S_f + 63) // 64
+    mc = int(np.ceil(S_f * 0.05))
+    t = torch.empty(rows * W, dtype=torch.int64, device="cuda")
+    kg.synth_rows_device(t.data_ptr(), 0, rows, S_f, seed, stream)
+    torch.cuda.synchronize()
+    wall, kern = [], []
+    n_used = 0
+    for i in range(passes + 1):
+        kin = kg.Kinship(S_f, mc, device=dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        kin.feed_device(t.data_ptr(), rows, stream)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if i:  # the first pass warms up
+            wall.append(dt * 1e3)
+            kern.append(kin.stats()["kernel_ms"])
+        if i == passes:
+            Hg, n_used = kin.partials()
+        kin.close()
+    host_rows = kg.synth_rows_host(0, cpu_rows, S_f, seed)
+    t0 = time.perf_counter()
+    K, n = ob.kinship(host_rows, S_f, mc)
+    cpu_dt = time.perf_counter() - t0
+    # parity on the slice: a second, short accumulation over the same rows
+    kin = kg.Kinship(S_f, mc, device=dev)
+    kin.feed_device(t.data_ptr(), cpu_rows, stream)
+    Kg, ng = kin.matrix()
+    kin.close()
+    del t
+    k_ms = float(np.mean(kern))
+    ops = float(S_f) * S_f * rows  # SURVEY.md 8d: S_f^2 integer MACs per row using the symmetry
+    return {"workload": "%dM k-mers x %d accessions, maf 0.05 (BASELINE.json configs[4] in shape)" % (rows // 1_000_000, S_f),
+            "kernels": "kin_transpose_kernel + kin_gram_kernel", "kernels_ms": k_ms, "wall_ms": float(np.mean(wall)),
+            "rows_per_s": rows / (k_ms * 1e-3), "rows_used": int(n_used),
+            "algorithmic_TOPs": 2.0 * ops / (k_ms * 1e-3) / 1e12, "peak_TOPs": I8_MFMA_PEAK_TOPS,
+            "frac": 2.0 * ops / (k_ms * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS,
+            "pair_updates_per_s": rows * (S_f * (S_f - 1) / 2.0) / (k_ms * 1e-3),
+            "parity_check": bool(ng == n and (Kg == K).all()),
+            "cpu_baseline": {"value": cpu_rows / cpu_dt, "unit": "rows/s", "cores": 1, "kind": "port",
+                             "sample": "%d rows of the same table; oracle/oracle.cpp kinship loop "
+                                       "(src/kmers_multiple_databases.cpp:418-438 is single-threaded)" % cpu_rows,
+                             "seconds": cpu_dt,
+                             "pair_updates_per_s": cpu_rows * (S_f * (S_f - 1) / 2.0) / cpu_dt}}
 
 
 def cgroup_throttle():
@@ -76,16 +192,17 @@ def cgroup_throttle():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--rows", type=int, default=100_000_000, help="k-mer rows per GPU")
-    ap.add_argument("--samples", type=int, default=1024)
-    ap.add_argument("--perms", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (default: about 5 s of them)")
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=0, help="k-mer rows per GPU (default: 1e8 at --gpus 1, 2.5e8 beyond)")
+    ap.add_argument("--samples", type=int, default=0, help="default: 1024 at --gpus 1, 2048 beyond")
+    ap.add_argument("--perms", type=int, default=-1, help="default: 100 at --gpus 1, 200 beyond")
     ap.add_argument("--topn", type=int, default=10001)
     ap.add_argument("--kernel", type=int, default=0)
     ap.add_argument("--chunk-rows", type=int, default=0)
     ap.add_argument("--cpu-sample-rows", type=int, default=6_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-subrecords", action="store_true", help="skip p1_scan / kinship / parity_check")
     args = ap.parse_args()
 
     import torch
@@ -96,6 +213,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    multi = world > 1 or args.gpus > 1
+    if args.samples == 0:
+        args.samples = 2048 if multi else 1024
+    if args.perms < 0:
+        args.perms = 200 if multi else 100
+    if args.rows == 0:
+        args.rows = 250_000_000 if multi else 100_000_000
+    config_name = ("BASELINE.json configs[3] per GPU" if (args.samples, args.perms) == (2048, 200) else
+                   "BASELINE.json configs[1]" if (args.samples, args.perms, args.rows) == (1024, 100, 100_000_000) else "custom")
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         ndev = torch.cuda.device_count()
@@ -138,24 +264,23 @@ def main():
 
     merge_ms = []
 
-    def one_step():
+    def one_step(merge=True):
         scan = session
         scan.reset()
         scan.feed_device(table.data_ptr(), M, first_row, stream)
-        if world == 1:
+        if world == 1 or not merge:
             scan.finish()  # with several ranks the merge finishes rank 0's session once, at its end
         st = scan.stats()
-        heaps = None
-        if world > 1:
+        if world > 1 and merge:
             if os.environ.get("KGWAS_BENCH_MERGE_DIAG"):  # diagnostics: separate "waiting for the slowest rank" from the merge
                 dist.barrier()
             tm = time.perf_counter()
-            merge = {"root": kdist.merge_to_root, "column": kdist.merge_by_column}.get(os.environ.get("KGWAS_BENCH_MERGE", ""), kdist.merge_shards)
-            tested = merge(scan)  # rank 0's session now holds the global heaps
+            fn = {"root": kdist.merge_to_root, "column": kdist.merge_by_column}.get(os.environ.get("KGWAS_BENCH_MERGE", ""), kdist.merge_shards)
+            tested = fn(scan)  # rank 0's session now holds the global heaps
             merge_ms.append((time.perf_counter() - tm) * 1e3)
         else:
             tested = st["rows_tested"]
-        return scan, st, heaps, tested
+        return scan, st, tested
 
     def sync():
         torch.cuda.synchronize()
@@ -163,8 +288,19 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        scan, st, heaps, tested = one_step()
+    t_w = time.perf_counter()
+    for _ in range(max(args.warmup, 1)):
+        scan, st, tested = one_step()
+    sync()
+    if args.steps <= 0:  # about 5 s of timed steps, the same count on every rank
+        est = (time.perf_counter() - t_w) / max(args.warmup, 1)
+        n = int(min(400, max(10, round(5.0 / max(est, 1e-3)))))
+        if world > 1:
+            tn = torch.tensor([n], dtype=torch.int64, device=kdist._dev())
+            dist.broadcast(tn, 0)
+            n = int(tn.item())
+        args.steps = n
+    n_merge_warm = len(merge_ms)
     sync()
     thr0 = cgroup_throttle()
     t0 = time.perf_counter()
@@ -173,7 +309,7 @@ def main():
     last = None
     for _ in range(args.steps):
         ts = time.perf_counter()
-        last, st, heaps, tested = one_step()
+        last, st, tested = one_step()
         stats.append(st)
         step_ms.append((time.perf_counter() - ts) * 1e3)
     sync()
@@ -183,6 +319,22 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=kdist._dev())
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+
+    # the N = 1 reference of a multi-GPU run: rank 0's shard alone, no merge (other ranks wait)
+    single = None
+    if world > 1:
+        if rank == 0:
+            k1 = max(2, min(5, args.steps))
+            one_step(merge=False)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(k1):
+                one_step(merge=False)
+            torch.cuda.synchronize()
+            d1 = (time.perf_counter() - t1) / k1
+            single = {"ms_per_step": d1 * 1e3, "value": M * P / d1, "steps": k1,
+                      "note": "rank 0's shard scanned alone while the other ranks idle: the N = 1 point for this curve"}
+        dist.barrier()
 
     if rank == 0:
         ms_per_step = dt * 1e3 / args.steps
@@ -202,12 +354,10 @@ def main():
         if ku == 3:
             # dominant kernel = the int8 coarse filter; its own launches are timed separately from the exact
             # re-scoring of the survivors. `achieved` stays ALGORITHMIC (2*S flop per k-mer x column); the
-            # kernel executes 2 int8 slices per column and pads columns/samples to its tiles (`executed`).
+            # kernel executes 1-2 int8 slices per column and pads columns/samples to its tiles (`executed`).
             k_ms = sum(s["coarse_kernel_ms"] for s in stats)
             k_launch = sum(s["coarse_launches"] for s in stats)
-            rows_scored = sum(s["rows_fed"] for s in stats) - 16384 * args.steps  # the dense chunk uses the exact kernel
             avg_ms = k_ms / max(k_launch, 1)
-            achieved_tflops = flop_per_row * rows_scored / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
             peak, peak_unit, dtype = I8_MFMA_PEAK_TOPS, "TOP/s (int8 MFMA dense)", "i8 filter + f32/f64 exact re-score"
             Wm = 2 * ((S + 127) // 128)
             kgroups = (Wm + 7) // 8
@@ -227,27 +377,32 @@ def main():
         # sanity on the final result of the last step: ascending pops, full heaps
         k, sc, r = last.result(0)
         assert (np.diff(sc) >= 0).all() and len(k) == min(args.topn, tested)
-        # HBM traffic per launch cannot be read from inside the process; it comes from the committed
-        # rocprofv3 PMC passes of this same workload (FETCH_SIZE x2 on gfx950 + WRITE_SIZE).
+        # HBM traffic per launch cannot be read from inside the process (PMC counters need rocprofv3 around it):
+        # it is taken from the committed PMC passes of this workload and only when that profile was taken of the
+        # kernel that ran here (FETCH_SIZE x2 on gfx950 + WRITE_SIZE); otherwise null.
         traffic, traffic_src = None, None
         pmc_name = "r01b_coarse_pmc_hbm_traffic.json" if ku == 3 else "r01a_exactmfma_pmc_hbm_traffic.json"
-        pmc = os.path.join(ROOT, "profiles", pmc_name)
-        if S == 1024 and P == 101 and ku in (2, 3) and os.path.exists(pmc):
-            try:
-                j = json.load(open(pmc))
-                # PMC bytes per row of the steady launches -> GB per average launch of this run
-                traffic = j["traffic_bytes_per_row"] * (rows_scored / max(k_launch, 1)) / 1e9
-                traffic_src = "profiles/" + pmc_name
-            except Exception:
-                pass
+        for cand in ("r02_coarse_pmc_hbm_traffic.json", pmc_name):
+            pmc = os.path.join(ROOT, "profiles", cand)
+            if S == 1024 and P == 101 and ku in (2, 3) and os.path.exists(pmc):
+                try:
+                    j = json.load(open(pmc))
+                    if kernel_name not in str(j.get("kernel", kernel_name)):
+                        raise RuntimeError("profile %s is of kernel %r, this run used %r" % (cand, j.get("kernel"), kernel_name))
+                    # PMC bytes per row of the steady launches -> GB per average launch of this run
+                    traffic = j["traffic_bytes_per_row"] * (rows_scored / max(k_launch, 1)) / 1e9
+                    traffic_src = "profiles/" + cand
+                    break
+                except (KeyError, ValueError):
+                    pass
         out = {
             "metric": "k-mers x permutations scored/sec", "value": value, "unit": "kmer*phenotype/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
             "data": "synthetic",
             "config": {"workload": "synthetic %dM k-mers x %d samples per GPU, 1 phenotype + %d permutations, "
-                                   "top-%d per column, maf 0.05 / mac 5 (BASELINE.json configs[1])"
-                                   % (M // 1_000_000, S, args.perms, args.topn),
+                                   "top-%d per column, maf 0.05 / mac 5 (%s)"
+                                   % (M // 1_000_000, S, args.perms, args.topn, config_name),
                        "rows_per_gpu": M, "samples": S, "phenotype_columns": P, "topn": args.topn,
                        "min_count": int(mac), "sharding": "rows, contiguous per rank" if world > 1 else "none"},
             "rows_per_s": total_rows / (ms_per_step / 1e3),
@@ -263,6 +418,7 @@ def main():
                                             "ms_per_step": sum(st_["coarse_mode_ms"][mi] for st_ in stats) / args.steps}
                                            for mi in range(2) if stats[-1]["coarse_mode_tiles"][mi]] if ku == 3 else None),
                          "executed_frac": (executed / peak) if executed else None, "traffic": traffic,
+                         "traffic_from_profile": traffic is not None,
                          "traffic_unit": "GB per average launch (HBM-side, PMC)", "traffic_source": traffic_src,
                          "algorithmic_GB_per_launch": rows_scored / max(k_launch, 1) * 8.0 * W / 1e9,
                          "launches": k_launch, "avg_launch_ms": avg_ms,
@@ -271,21 +427,48 @@ def main():
                          "hbm_frac_of_8TBps": (rows_scored * 8.0 * W / (k_ms * 1e-3) / 1e9) / HBM_PEAK_GBPS
                          if k_ms > 0 else 0.0},
             "host": {"replay_ms_per_step": sum(s["replay_ms"] for s in stats) / args.steps,
+                     "replay_cpu_ms_per_step": sum(s["replay_cpu_ms"] for s in stats) / args.steps,
+                     "replay_tail_ms_per_step": sum(s["replay_tail_ms"] for s in stats) / args.steps,
                      "candidates_per_step": sum(s["candidates"] for s in stats) // args.steps,
                      "heap_pushes_per_step": sum(s["heap_pushes"] for s in stats) // args.steps,
                      "chunks_per_step": sum(s["chunks"] for s in stats) // args.steps,
                      "gpu_wait_ms_per_step": sum(s["gpu_wait_ms"] for s in stats) / args.steps,
                      "dense_phase_ms_per_step": sum(s["dense_ms"] for s in stats) / args.steps,
                      "cores": usable_cpus(), "replay_threads_per_rank": host_threads, "logical_cpus": os.cpu_count(),
-                     "step_ms": [round(x, 2) for x in step_ms],
+                     "step_ms": [round(x, 2) for x in (step_ms if len(step_ms) <= 40 else step_ms[:20] + step_ms[-20:])],
+                     "step_ms_median": float(np.median(step_ms)), "step_ms_max": float(np.max(step_ms)),
                      # cross-shard merge on rank 0's clock (includes waiting for the slowest rank's scan)
-                     "merge_ms": [round(x, 2) for x in merge_ms[args.warmup:]],
+                     "merge_ms": [round(x, 2) for x in merge_ms[n_merge_warm:][:40]],
+                     "merge_ms_mean": float(np.mean(merge_ms[n_merge_warm:])) if merge_ms[n_merge_warm:] else None,
                      # CFS bandwidth throttling of this container during the timed region (cpu.stat deltas)
                      "cgroup_nr_throttled": thr1[0] - thr0[0], "cgroup_throttled_ms": (thr1[1] - thr0[1]) / 1e3},
         }
+        if single is not None:
+            out["single_gpu_same_shard"] = single
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(S, Y, mac, args.topn, seed_table, args.cpu_sample_rows,
-                                               threads=min(usable_cpus(), P))
+            rec, ores = cpu_baseline(S, Y, mac, args.topn, seed_table, min(args.cpu_sample_rows, M),
+                                     threads=min(usable_cpus(), P))
+            out["cpu_baseline"] = rec
+            try:
+                out["parity_check"] = parity_check(kg, table.data_ptr(), stream, S, col, Y, args.topn, mac,
+                                                   min(args.cpu_sample_rows, M), ores, dev, host_threads)
+            except Exception as e:  # a failed comparison must show up in the line, not kill it
+                out["parity_check"] = False
+                out["parity_check_error"] = repr(e)
+        if world == 1 and not args.no_subrecords and config_name == "BASELINE.json configs[1]":
+            try:
+                out["p1_scan"] = p1_scan_record(kg, torch, table, stream, M, S, Y, args.topn, mac, dev, host_threads)
+            except Exception as e:
+                out["p1_scan"] = {"error": repr(e)}
+            last.close()
+            last = None
+            session.close()
+            del table
+            torch.cuda.empty_cache()
+            try:
+                out["kinship"] = kinship_record(kg, torch, stream, dev)
+            except Exception as e:
+                out["kinship"] = {"error": repr(e)}
         print(json.dumps(out))
     if last is not None:
         last.close()

@@ -131,7 +131,8 @@ typedef struct kgwas_scan_stats {
     uint64_t score_launches;    /* launches of the scoring kernel */
     double score_kernel_ms;     /* sum of hipEvent durations of the scoring kernel */
     double squeeze_kernel_ms;   /* sum of hipEvent durations of the squeeze kernel (0 in direct mode) */
-    double replay_ms;           /* host wall time spent replaying candidates (control thread view) */
+    double replay_ms;           /* host time spent replaying candidates: the busiest replay worker's busy time (the workers
+                                   run beside the GPU and beside each other) + the synchronous dense / overflow replays */
     double gpu_wait_ms;         /* host wall time blocked waiting for sparse chunks to finish */
     double dense_ms;            /* host wall time of the dense (heap-filling) phase, GPU + replay */
     double coarse_kernel_ms;    /* sum of hipEvent durations of coarse_kernel alone (KGWAS_KERNEL_COARSE) */
@@ -145,6 +146,8 @@ typedef struct kgwas_scan_stats {
     uint64_t coarse_mode_launches[2];
     uint64_t coarse_mode_rows[2];      /* rows filtered with this set */
     double coarse_mode_ms[2];          /* hipEvent time of its coarse_kernel launches */
+    double replay_cpu_ms;       /* CPU time of the replay summed over the workers (replay_ms: the busiest worker's share) */
+    double replay_tail_ms;      /* wall time the replay still needed after the GPU had finished the feed's last chunk */
 } kgwas_scan_stats;
 
 int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out);

@@ -69,6 +69,7 @@ class ScanStats(C.Structure):
         ("coarse_mode_tiles", C.c_uint32 * 2), ("coarse_mode_lgroups", C.c_uint32 * 2),
         ("coarse_mode_launches", C.c_uint64 * 2), ("coarse_mode_rows", C.c_uint64 * 2),
         ("coarse_mode_ms", C.c_double * 2),
+        ("replay_cpu_ms", C.c_double), ("replay_tail_ms", C.c_double),
     ]
 
     def as_dict(self):

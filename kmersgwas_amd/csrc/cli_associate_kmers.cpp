@@ -176,7 +176,8 @@ int main(int argc, char* argv[]) {
             ofstream fout(fn_base + ".tested_kmers");
             fout << st.rows_tested << endl;
         }
-        cerr << "[kgwas] kernel=" << (st.kernel_used == KGWAS_KERNEL_MFMA ? "mfma_f32" : "valu")
+        cerr << "[kgwas] kernel="
+             << (st.kernel_used == KGWAS_KERNEL_COARSE ? "coarse_i8+exact" : st.kernel_used == KGWAS_KERNEL_MFMA ? "mfma_f32" : "valu")
              << " direct=" << st.direct_mode << " chunks=" << st.chunks << " score_kernel_ms=" << st.score_kernel_ms
              << " candidates=" << st.candidates << " heap_pushes=" << st.heap_pushes << endl;
         kgwas_scan_destroy(scan);

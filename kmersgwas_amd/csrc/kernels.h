@@ -151,6 +151,8 @@ hipError_t launch_synth(uint64_t* rows, uint64_t first_row, uint64_t n_rows, uin
 hipError_t launch_kin_transpose(const uint64_t* file_rows, uint64_t file_stride_w, uint64_t n_rows, uint32_t S_f,
                                 uint32_t S_pad, uint32_t min_count, uint32_t* T, uint64_t n_rw,
                                 unsigned long long* n_used, hipStream_t st);
+// rows per transpose block the LDS allows for this table shape (256, 128, 64; 0 = too many accessions)
+uint32_t kin_transpose_rows_per_block(uint64_t file_stride_w, uint32_t S_pad);
 hipError_t launch_kin_gram(const uint32_t* T, uint64_t n_rw, uint32_t S_pad, unsigned long long* H, hipStream_t st);
 
 }  // namespace kgwas

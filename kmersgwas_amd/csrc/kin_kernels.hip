@@ -80,48 +80,68 @@ __device__ __forceinline__ uint32_t transpose32(uint32_t x, uint32_t lane) {
 }  // namespace
 
 // Plane word rw (u32) of sample c = its presence bits for rows 32*rw .. 32*rw+31 of the launch, stored tile-major as
-// T[rw / 8][c][rw % 8]; rows failing the filter are all-zero. A block covers 256 rows = one tile of 8 plane words
-// (76 KB of LDS at 1135 samples: two blocks per CU, so one's loads overlap the other's transposes).
+// T[rw / 8][c][rw % 8]; rows failing the filter are all-zero. A block covers blockDim.x = 256 rows = one tile of 8
+// plane words (76 KB of LDS at 1135 samples: two blocks per CU, so one's loads overlap the other's transposes); where
+// 256 verbatim rows plus their planes do not fit the LDS (more than ~2500 accessions) a block takes 128 or 64 rows,
+// i.e. 4 or 2 of a tile's 8 plane words (launch_kin_transpose).
 __global__ void __launch_bounds__(256) kin_transpose_kernel(const uint64_t* file_rows, uint64_t file_stride_w, uint64_t n_rows,
                                                             uint32_t S_f, uint32_t S_pad, uint32_t min_count, uint32_t* T,
                                                             uint64_t n_rw, unsigned long long* n_used) {
     extern __shared__ uint32_t kin_lds[];
+    const uint32_t rpb = blockDim.x;     // rows per block: 256, 128 or 64
+    const uint32_t wpb = rpb / 32u;      // plane words per block and sample
     const uint32_t stride_dw = (uint32_t)(2u * file_stride_w);
-    uint32_t* lin = kin_lds;                        // [256][stride_dw] verbatim rows (k-mer word included)
-    uint32_t* lout = kin_lds + 256u * stride_dw;    // [S_pad][8]
+    uint32_t* lin = kin_lds;                        // [rpb][stride_dw] verbatim rows (k-mer word included)
+    uint32_t* lout = kin_lds + rpb * stride_dw;     // [S_pad][wpb]
     const uint32_t in_dw = 2u * ((S_f + 63u) / 64u);
-    const uint64_t row0 = (uint64_t)blockIdx.x * 256u;
+    const uint64_t row0 = (uint64_t)blockIdx.x * rpb;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    if (row0 < n_rows) {  // coalesced verbatim copy of up to 256 contiguous rows
+    if (row0 < n_rows) {  // coalesced verbatim copy of up to rpb contiguous rows
         const uint64_t left = n_rows - row0;
-        const uint32_t n2 = (uint32_t)((left < 256u ? left : 256u) * file_stride_w);
+        const uint32_t n2 = (uint32_t)((left < rpb ? left : rpb) * file_stride_w);
         const uint2* src = reinterpret_cast<const uint2*>(file_rows + row0 * file_stride_w);
         uint2* dst = reinterpret_cast<uint2*>(lin);
-        for (uint32_t i = threadIdx.x; i < n2; i += 256u) dst[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < n2; i += rpb) dst[i] = src[i];
     }
     __syncthreads();
     const uint64_t r = row0 + threadIdx.x;
     const uint32_t* my = lin + (size_t)threadIdx.x * stride_dw + 2u;
+    // file padding bits (>= S_f) count neither in the predicate nor in the planes: calculate_unsqueezed_popcnt masks
+    // with m_map_mask (src/kmers_multiple_databases.cpp:149-154)
+    auto masked = [&](uint32_t d) {
+        uint32_t x = my[d];
+        if (32u * d + 32u > S_f) x &= (32u * d < S_f) ? ((1u << (S_f - 32u * d)) - 1u) : 0u;
+        return x;
+    };
     uint32_t n1 = 0;
     if (r < n_rows)
-        for (uint32_t d = 0; d < in_dw; d++) n1 += __popc(my[d]);
+        for (uint32_t d = 0; d < in_dw; d++) n1 += __popc(masked(d));
     // src/emma_kinship_kmers.cpp:83,89 -> load_kmers' predicate with all S_f columns
     const bool pass = (r < n_rows) && (S_f >= min_count) && (n1 >= min_count) && (n1 <= S_f - min_count);
     const unsigned long long kept = __popcll(__ballot(pass));
     for (uint32_t d = 0; d < S_pad / 32u; d++) {
-        uint32_t x = (pass && d < in_dw) ? my[d] : 0u;
-        if (32u * d + 32u > S_f) x &= (32u * d < S_f) ? ((1u << (S_f - 32u * d)) - 1u) : 0u;  // file padding bits
+        uint32_t x = (pass && d < in_dw) ? masked(d) : 0u;
         x = transpose32(x, lane);
         // lane s of 32-lane group g now holds sample 32d + s over the group's 32 rows
-        lout[(32u * d + (lane & 31u)) * 8u + wave * 2u + (lane >> 5)] = x;
+        lout[(32u * d + (lane & 31u)) * wpb + wave * 2u + (lane >> 5)] = x;
     }
     if (lane == 0 && kept) atomicAdd(&n_used[blockIdx.x % TESTED_SHARDS], kept);  // each wave adds the rows it counted
     __syncthreads();
-    // this block's 256 rows of all samples are one contiguous 32*S_pad-byte piece; the Gram kernel's round (16 plane
-    // words of 128 samples) is two 4 KB pieces
-    uint4* dst = reinterpret_cast<uint4*>(T + (uint64_t)blockIdx.x * S_pad * 8u);
-    const uint4* src = reinterpret_cast<const uint4*>(lout);
-    for (uint32_t e = threadIdx.x; e < S_pad * 2u; e += 256u) dst[e] = src[e];
+    if (rpb == 256u) {
+        // this block's 256 rows of all samples are one contiguous 32*S_pad-byte piece; the Gram kernel's round (16
+        // plane words of 128 samples) is two 4 KB pieces
+        uint4* dst = reinterpret_cast<uint4*>(T + (uint64_t)blockIdx.x * S_pad * 8u);
+        const uint4* src = reinterpret_cast<const uint4*>(lout);
+        for (uint32_t e = threadIdx.x; e < S_pad * 2u; e += 256u) dst[e] = src[e];
+    } else {
+        const uint32_t per_tile = 256u / rpb;  // blocks per tile of 8 plane words
+        const uint64_t tile = blockIdx.x / per_tile;
+        const uint32_t w0 = (blockIdx.x % per_tile) * wpb;
+        uint2* dst = reinterpret_cast<uint2*>(T + tile * S_pad * 8u + w0);  // sample c: dst[c * 4 + i], i < wpb / 2
+        const uint2* src = reinterpret_cast<const uint2*>(lout);
+        const uint32_t h = wpb / 2u;
+        for (uint32_t e = threadIdx.x; e < S_pad * h; e += rpb) dst[(e / h) * 4u + (e % h)] = src[e];
+    }
 }
 
 // C[i][j] += sum over the launch's rows of g_i g_j for the 128 x 128 sample tile (ib, jb), jb >= ib, and a slice of
@@ -218,19 +238,31 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
             }
 }
 
+size_t kin_transpose_lds_bytes(uint64_t file_stride_w, uint32_t S_pad, uint32_t rpb) {
+    return ((size_t)rpb * 2u * file_stride_w + (size_t)S_pad * (rpb / 32u)) * 4u;
+}
+
+// Rows per transpose block: the most (256, 128, 64) whose verbatim rows + planes fit the 160 KB of LDS; 0 = none does.
+uint32_t kin_transpose_rows_per_block(uint64_t file_stride_w, uint32_t S_pad) {
+    for (uint32_t rpb : {256u, 128u, 64u})
+        if (kin_transpose_lds_bytes(file_stride_w, S_pad, rpb) <= 160u * 1024u) return rpb;
+    return 0u;
+}
+
 hipError_t launch_kin_transpose(const uint64_t* file_rows, uint64_t file_stride_w, uint64_t n_rows, uint32_t S_f,
                                 uint32_t S_pad, uint32_t min_count, uint32_t* T, uint64_t n_rw, unsigned long long* n_used,
                                 hipStream_t st) {
     if (n_rows == 0) return hipSuccess;
-    const size_t lds = (size_t)(256u * 2u * file_stride_w + (size_t)S_pad * 8u) * 4u;
-    if (lds > 160u * 1024u) return hipErrorInvalidValue;
+    const uint32_t rpb = kin_transpose_rows_per_block(file_stride_w, S_pad);
+    if (!rpb) return hipErrorInvalidValue;  // kgwas_kinship_create rejects such sessions with a message
+    const size_t lds = kin_transpose_lds_bytes(file_stride_w, S_pad, rpb);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kin_transpose_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    // one block per tile of 8 plane words: every word of T up to n_rw is written (tiles beyond the rows hold zeros)
-    hipLaunchKernelGGL(kin_transpose_kernel, dim3((uint32_t)(n_rw / 8u)), dim3(256), lds, st, file_rows, file_stride_w,
-                       n_rows, S_f, S_pad, min_count, T, n_rw, n_used);
+    // every word of T up to n_rw is written (blocks beyond the rows write zeros): n_rw / 8 tiles x 256 / rpb blocks
+    hipLaunchKernelGGL(kin_transpose_kernel, dim3((uint32_t)(n_rw / 8u * (256u / rpb))), dim3(rpb), lds, st, file_rows,
+                       file_stride_w, n_rows, S_f, S_pad, min_count, T, n_rw, n_used);
     return hipGetLastError();
 }
 

@@ -78,6 +78,9 @@ int kgwas_kinship_create(int32_t device, uint64_t n_acc_file, uint64_t min_count
         k->W_f = (n_acc_file + 63) / 64;
         k->min_count = min_count;
         k->S_pad = (uint32_t)((n_acc_file + 127) / 128 * 128);  // whole 128 x 128 Gram tiles
+        if (!kin_transpose_rows_per_block(1 + k->W_f, k->S_pad))
+            throw Error(KGWAS_ERR_ARG, "kgwas_kinship_create: " + std::to_string(n_acc_file) +
+                                           " accessions exceed what the bit-transpose kernel can stage in LDS (about 9900)");
         k->chunk_rows = 1ull << 20;  // the reference's own batch size (src/emma_kinship_kmers.cpp:89)
         k->n_rw_cap = (k->chunk_rows + 511) / 512 * 16;
         KGWAS_HIP(hipStreamCreateWithFlags(&k->stream, hipStreamNonBlocking));

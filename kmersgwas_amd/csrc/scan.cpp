@@ -81,18 +81,26 @@ class Pool {
     // (~320 KB at N = 10001) stays in one core's cache from chunk to chunk.
     void parallel_for(size_t n, const std::function<void(size_t)>& fn) {
         if (n == 0) return;
-        {
-            std::unique_lock<std::mutex> lk(mu_);
-            fn_ = &fn;
-            n_items_ = n;
-            if (claimed_.size() < n) claimed_ = std::vector<std::atomic<uint8_t>>(n);
-            for (size_t i = 0; i < n; i++) claimed_[i].store(0, std::memory_order_relaxed);
-            pending_ = th_.size();
-            done_.store(0, std::memory_order_relaxed);
-            gen_.fetch_add(1, std::memory_order_release);
-        }
+        start(n, fn);
+        wait();
+    }
+    // The two halves of parallel_for: start() hands the items out and returns, wait() blocks until every worker is
+    // done. Between the two the workers run on their own (the streaming replay: items are worker loops that end when
+    // told to). fn must stay alive until wait() returns; one start at a time.
+    void start(size_t n, const std::function<void(size_t)>& fn) {
+        std::unique_lock<std::mutex> lk(mu_);
+        fn_ = &fn;
+        n_items_ = n;
+        if (claimed_.size() < n) claimed_ = std::vector<std::atomic<uint8_t>>(n);
+        for (size_t i = 0; i < n; i++) claimed_[i].store(0, std::memory_order_relaxed);
+        pending_ = th_.size();
+        done_.store(0, std::memory_order_relaxed);
+        gen_.fetch_add(1, std::memory_order_release);
+        lk.unlock();
         cv_.notify_all();
-        for (int spin = 0; spin < 20000; spin++) {  // replays take a few ms at most: spin before sleeping
+    }
+    void wait(bool spin = true) {
+        for (int sp = 0; spin && sp < 20000; sp++) {  // replays take a few ms at most: spin before sleeping
             if (done_.load(std::memory_order_acquire)) break;
             __builtin_ia32_pause();
         }
@@ -365,6 +373,11 @@ inline size_t ring_size(size_t forced, uint64_t topn) {
 
 constexpr int MAX_SLOTS = 16;  // upper bound on sparse chunks the GPU may run ahead of the host replay
 
+// What a worker adds up while replaying (chunk, column group) units.
+struct ReplayAcc {
+    uint64_t pushes = 0, cands = 0, busy_ns = 0, units = 0;
+};
+
 struct Slot {
     PinBuf<Cand> cand;  // written by the GPU straight into mapped host memory
     Cand* d_cand = nullptr;
@@ -468,6 +481,22 @@ struct kgwas_scan {
     bool all_full = false;
     uint64_t rows_done = 0;  // rows whose replay is complete
     std::unique_ptr<Pool> pool;
+    // Streaming replay (feed_device_impl): columns in n_groups groups, (chunk, group) work units.
+    struct alignas(64) GroupState {
+        std::atomic<uint64_t> done{0};  // chunks of this feed the group has replayed = the next one it must take
+        std::atomic<uint32_t> busy{0};  // a worker is on it
+    };
+    size_t n_groups = 1;
+    std::unique_ptr<GroupState[]> gstate;
+    std::unique_ptr<std::atomic<uint32_t>[]> slot_left;  // [n_slots] groups that have not replayed the slot's chunk yet
+    std::atomic<uint64_t> seq_submitted{0}, seq_published{0}, seq_replayed{0};
+    std::atomic<bool> rp_quit{false}, rp_failed{false};
+    std::atomic<int> rp_idle{0};
+    std::mutex rp_mu;
+    std::condition_variable rp_cv_work, rp_cv_done;
+    std::function<void(size_t)> rp_fn;
+    ReplayAcc rp_acc;  // sums over the workers of the current streaming replay
+    uint64_t rp_max_busy_ns = 0;
     kgwas_scan_stats st{};
     bool finished = false;
     std::vector<std::vector<uint64_t>> res_kmer, res_row;
@@ -785,19 +814,155 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
 
 void process_range_sync(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_rows, uint64_t first_row);
 
-// Wait for a submitted sparse chunk, replay its candidates in row order, refresh thresholds.
-// Returns false if a candidate list overflowed (nothing was replayed).
-bool reap_sparse(kgwas_scan* s, Slot& sl) {
-    {
-        auto w0 = std::chrono::steady_clock::now();
-        KGWAS_HIP(hipEventSynchronize(sl.ev_done));  // kernel done (mapped candidate writes visible) + counts copied
-        s->st.gpu_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+// ---- replay of a sparse chunk's records -------------------------------------------------------------------
+// The unit of host work is (chunk, column group): group g owns the columns g, g + n_groups, ... and replays a
+// chunk's records of those columns in row order. A group's chunks must be replayed in submission order; different
+// groups are independent (columns never interact). Two drivers use it: the streaming replay below (workers pick
+// (chunk, group) units as the GPU completes chunks, no barrier between chunks) and the synchronous overflow path.
+void replay_group(kgwas_scan* s, Slot& sl, size_t g, ReplayAcc& acc) {
+    const auto tb0 = std::chrono::steady_clock::now();
+    const uint64_t row0 = sl.first_row;
+    const size_t NG = s->n_groups;
+    uint64_t local = 0, nc = 0;
+    if (sl.used_coarse) {
+        // Records arrive in row order (sorted on the device). The group's columns advance together: per round, every
+        // column scans forward to its next record that beats the column's current minimum (everything else is a
+        // no-op for add_association), then the heaps of equal size take their replacements in lockstep (heap.h).
+        // Columns are independent, so interleaving them changes nothing in any column's own sequence of pushes.
+        const double none = -std::numeric_limits<double>::infinity();
+        struct Cur {
+            const double* sc;
+            const uint64_t* km;
+            const uint32_t* rw;
+            uint32_t i, n;
+            BestHeap* h;
+            size_t j;
+        };
+        constexpr int MK = BestHeap::MAX_LOCKSTEP;
+        Cur cols[MK];
+        size_t n_cols = 0;
+        for (size_t j = g; j < s->n_pheno; j += NG) {
+            const uint32_t n = sl.h_surv_cnt.p[j];
+            if (!n) continue;
+            const uint64_t o = j * (uint64_t)s->cap;
+            cols[n_cols++] = Cur{sl.so_score.p + o, sl.so_kmer.p + o, sl.so_row.p + o, 0, n, &s->heaps[j], j};
+        }
+        // The records were just written by the GPU (no CPU cache holds them) and the replay walks several short
+        // streams at once, more than the hardware prefetchers track: pull them in up front, a line at a time.
+        for (size_t c = 0; c < n_cols; c++) {
+            const Cur& cu = cols[c];
+            for (uint32_t i = 0; i < cu.n; i += 8) __builtin_prefetch(cu.sc + i);
+            for (uint32_t i = 0; i < cu.n; i += 8) __builtin_prefetch(cu.km + i);
+            for (uint32_t i = 0; i < cu.n; i += 16) __builtin_prefetch(cu.rw + i);
+        }
+        while (n_cols) {
+            // next effective record of every column still active
+            for (size_t c = 0; c < n_cols;) {
+                Cur& cu = cols[c];
+                bool ready = false;
+                while (cu.i < cu.n) {
+                    const double v = cu.sc[cu.i];
+                    if (v == none) {  // a survivor of the coarse bound that is not a candidate
+                        cu.i++;
+                        continue;
+                    }
+                    if (!cu.h->full() || v > cu.h->lowest()) {
+                        ready = true;
+                        break;
+                    }
+                    nc++;
+                    cu.h->note_rejected();
+                    cu.i++;
+                }
+                if (ready)
+                    c++;
+                else
+                    cols[c] = cols[--n_cols];
+            }
+            // lockstep groups of equal heap size (columns that differ, or are not full, go one at a time)
+            size_t done = 0;
+            while (done < n_cols) {
+                BestHeap* hp[MK];
+                uint64_t km[MK], rw[MK];
+                double sc[MK];
+                Cur* who[MK];
+                int K = 0;
+                const size_t cap0 = cols[done].h->capacity();
+                const bool full0 = cols[done].h->full();
+                size_t c = done;
+                for (; c < n_cols && K < MK; c++) {
+                    Cur& cu = cols[c];
+                    if (cu.h->capacity() != cap0 || !cu.h->full() || !full0) break;
+                    hp[K] = cu.h;
+                    km[K] = cu.km[cu.i];
+                    sc[K] = cu.sc[cu.i];
+                    rw[K] = row0 + cu.rw[cu.i];
+                    who[K] = &cu;
+                    K++;
+                }
+                if (K == 0) {  // not full: plain add_association
+                    Cur& cu = cols[done];
+                    hp[0] = cu.h;
+                    km[0] = cu.km[cu.i];
+                    sc[0] = cu.sc[cu.i];
+                    rw[0] = row0 + cu.rw[cu.i];
+                    who[0] = &cu;
+                    cu.h->add(km[0], sc[0], (size_t)rw[0]);
+                    K = 1;
+                    c = done + 1;
+                } else {
+                    BestHeap::replace_top_n(K, hp, km, sc, rw);
+                }
+                for (int k = 0; k < K; k++) {
+                    if (s->record_history) s->hist[who[k]->j].push(km[k], sc[k], rw[k]);
+                    who[k]->i++;
+                }
+                local += (uint64_t)K;
+                nc += (uint64_t)K;
+                done = c;
+            }
+        }
+    } else {
+        for (size_t j = g; j < s->n_pheno; j += NG) {
+            const uint32_t n = sl.h_cnt.p[j];
+            if (!n) continue;
+            const Cand* c = sl.cand.p + j * (uint64_t)s->cap;
+            BestHeap& h = s->heaps[j];
+            // The device filtered against a minimum that is one chunk old. Anything not above the
+            // CURRENT minimum would be rejected by add_association whenever it arrives (the minimum only
+            // rises), so it is dropped before the sort. The survivors are put in row order through
+            // compact (row-in-chunk, index) keys.
+            std::vector<uint64_t>& keys = s->keys[j];
+            keys.clear();
+            const bool full = h.full();
+            const double low = h.lowest();
+            for (uint32_t i = 0; i < n; i++)
+                if (!full || c[i].score > low) keys.push_back(((c[i].row - row0) << 32) | i);
+            std::sort(keys.begin(), keys.end());
+            for (uint64_t key : keys) {
+                const Cand& e = c[(uint32_t)key];
+                if (h.add(e.kmer, e.score, (size_t)e.row)) {
+                    local++;
+                    if (s->record_history) s->hist[j].push(e.kmer, e.score, e.row);
+                }
+            }
+            nc += n;
+        }
     }
+    if (s->record_history) _mm_sfence();  // streaming stores of the history log
+    acc.pushes += local;
+    acc.cands += nc;
+    acc.units++;
+    acc.busy_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tb0).count();
+}
+
+// The GPU side of a finished chunk: kernel timings into the statistics; returns false if a list overflowed (the
+// chunk must then be redone, nothing of it may be replayed).
+bool chunk_complete(kgwas_scan* s, Slot& sl) {
     sl.busy = false;
     float ms = 0;
     KGWAS_HIP(hipEventElapsedTime(&ms, sl.ev_k0, sl.ev_k1));
     s->st.score_kernel_ms += ms;
-    const float ms_kernel = ms;
     if (sl.used_coarse) {
         float mc = 0;
         KGWAS_HIP(hipEventElapsedTime(&mc, sl.ev_k0, sl.ev_mid));
@@ -808,201 +973,52 @@ bool reap_sparse(kgwas_scan* s, Slot& sl) {
         s->st.coarse_mode_rows[sl.coarse_mode] += sl.n_rows;
     }
     if (!s->direct) {
-        KGWAS_HIP(hipEventElapsedTime(&ms, sl.ev_sq0, sl.ev_k0));
-        s->st.squeeze_kernel_ms += ms;
+        float mq = 0;
+        KGWAS_HIP(hipEventElapsedTime(&mq, sl.ev_sq0, sl.ev_k0));
+        s->st.squeeze_kernel_ms += mq;
     }
-    for (uint64_t j = 0; j < s->n_pheno; j++)
-        if (sl.h_cnt.p[j] > s->cap ||
-            (s->coarse && (sl.h_surv_cnt.p[j] > s->cap || sl.h_surv_cnt.p[s->n_pheno] > s->key_slots))) {
-            if (s->trace) {
-                uint64_t tot = 0, mx = 0;
-                for (uint64_t q = 0; q < s->n_pheno; q++) {
-                    tot += sl.h_surv_cnt.p[q];
-                    mx = std::max<uint64_t>(mx, sl.h_surv_cnt.p[q]);
-                }
-                fprintf(stderr, "[kgwas] chunk rows=%llu first=%llu OVERFLOW: survivors total %llu, max per column %llu, cap %u\n",
-                        (unsigned long long)sl.n_rows, (unsigned long long)sl.first_row, (unsigned long long)tot,
-                        (unsigned long long)mx, s->cap);
-            }
-            return false;
+    bool over = false;
+    for (uint64_t j = 0; j < s->n_pheno && !over; j++)
+        over = sl.h_cnt.p[j] > s->cap ||
+               (s->coarse && (sl.h_surv_cnt.p[j] > s->cap || sl.h_surv_cnt.p[s->n_pheno] > s->key_slots));
+    if (s->trace) {
+        uint64_t tot = 0, mx = 0;
+        for (uint64_t q = 0; q < s->n_pheno; q++) {
+            const uint64_t v = s->coarse && sl.used_coarse ? sl.h_surv_cnt.p[q] : sl.h_cnt.p[q];
+            tot += v;
+            mx = std::max<uint64_t>(mx, v);
         }
-
-    auto t0 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[kgwas] chunk rows=%llu first=%llu kernel=%.3fms records %llu (max per column %llu, cap %u)%s\n",
+                (unsigned long long)sl.n_rows, (unsigned long long)sl.first_row, ms, (unsigned long long)tot,
+                (unsigned long long)mx, s->cap, over ? " OVERFLOW" : "");
+    }
+    if (over) return false;
     for (uint32_t i = 0; i < TESTED_SHARDS; i++) s->st.rows_tested += sl.h_tested.p[i];
-    std::atomic<uint64_t> pushes(0), cands(0);
-    const uint64_t row0 = sl.first_row;
-    if (sl.used_coarse) {
-        // Records arrive in row order (sorted on the device). A worker owns the columns w, w+T, ... and advances
-        // all of them together: per round, every column scans forward to its next record that beats the column's
-        // current minimum (everything else is a no-op for add_association), then the heaps of equal size take
-        // their replacements in lockstep (heap.h). Columns are independent, so interleaving them changes nothing
-        // in any column's own sequence of pushes.
-        const size_t T = s->pool->size();
-        const double none = -std::numeric_limits<double>::infinity();
-        s->pool->parallel_for(std::min<size_t>(T, s->n_pheno), [&](size_t w) {
-            struct Cur {
-                const double* sc;
-                const uint64_t* km;
-                const uint32_t* rw;
-                uint32_t i, n;
-                BestHeap* h;
-                size_t j;
-            };
-            constexpr int MK = BestHeap::MAX_LOCKSTEP;
-            const auto tc0 = std::chrono::steady_clock::now();
-            std::vector<Cur> cols;
-            for (size_t j = w; j < s->n_pheno; j += T) {
-                const uint32_t n = sl.h_surv_cnt.p[j];
-                if (!n) continue;
-                const uint64_t o = j * (uint64_t)s->cap;
-                cols.push_back(Cur{sl.so_score.p + o, sl.so_kmer.p + o, sl.so_row.p + o, 0, n, &s->heaps[j], j});
-            }
-            // The records were just written by the GPU (no CPU cache holds them) and the replay walks ~20 short
-            // streams at once, more than the hardware prefetchers track: pull them in up front, a line at a time.
-            for (const Cur& cu : cols) {
-                for (uint32_t i = 0; i < cu.n; i += 8) __builtin_prefetch(cu.sc + i);
-                for (uint32_t i = 0; i < cu.n; i += 8) __builtin_prefetch(cu.km + i);
-                for (uint32_t i = 0; i < cu.n; i += 16) __builtin_prefetch(cu.rw + i);
-            }
-            uint64_t local = 0, nc = 0;
-            uint64_t tsc_scan = 0, tsc_heap = 0, rounds = 0;
-            while (!cols.empty()) {
-                const uint64_t q0 = s->trace ? __builtin_ia32_rdtsc() : 0;
-                // next effective record of every column still active
-                for (size_t c = 0; c < cols.size();) {
-                    Cur& cu = cols[c];
-                    bool ready = false;
-                    while (cu.i < cu.n) {
-                        const double v = cu.sc[cu.i];
-                        if (v == none) {  // a survivor of the coarse bound that is not a candidate
-                            cu.i++;
-                            continue;
-                        }
-                        if (!cu.h->full() || v > cu.h->lowest()) {
-                            ready = true;
-                            break;
-                        }
-                        nc++;
-                        cu.h->note_rejected();
-                        cu.i++;
-                    }
-                    if (ready) {
-                        c++;
-                    } else {
-                        cols[c] = cols.back();
-                        cols.pop_back();
-                    }
-                }
-                // lockstep groups of equal heap size (columns that differ, or are not full, go one at a time)
-                const uint64_t q1 = s->trace ? __builtin_ia32_rdtsc() : 0;
-                size_t done = 0;
-                while (done < cols.size()) {
-                    BestHeap* hp[MK];
-                    uint64_t km[MK], rw[MK];
-                    double sc[MK];
-                    Cur* who[MK];
-                    int K = 0;
-                    const size_t cap0 = cols[done].h->capacity();
-                    const bool full0 = cols[done].h->full();
-                    size_t c = done;
-                    for (; c < cols.size() && K < MK; c++) {
-                        Cur& cu = cols[c];
-                        if (cu.h->capacity() != cap0 || !cu.h->full() || !full0) break;
-                        hp[K] = cu.h;
-                        km[K] = cu.km[cu.i];
-                        sc[K] = cu.sc[cu.i];
-                        rw[K] = row0 + cu.rw[cu.i];
-                        who[K] = &cu;
-                        K++;
-                    }
-                    if (K == 0) {  // not full: plain add_association
-                        Cur& cu = cols[done];
-                        hp[0] = cu.h;
-                        km[0] = cu.km[cu.i];
-                        sc[0] = cu.sc[cu.i];
-                        rw[0] = row0 + cu.rw[cu.i];
-                        who[0] = &cu;
-                        cu.h->add(km[0], sc[0], (size_t)rw[0]);
-                        K = 1;
-                        c = done + 1;
-                    } else {
-                        BestHeap::replace_top_n(K, hp, km, sc, rw);
-                    }
-                    for (int k = 0; k < K; k++) {
-                        if (s->record_history) s->hist[who[k]->j].push(km[k], sc[k], rw[k]);
-                        who[k]->i++;
-                    }
-                    local += (uint64_t)K;
-                    nc += (uint64_t)K;
-                    done = c;
-                }
-                if (s->trace) {
-                    const uint64_t q2 = __builtin_ia32_rdtsc();
-                    tsc_scan += q1 - q0;
-                    tsc_heap += q2 - q1;
-                    rounds++;
-                }
-            }
-            if (s->trace && w == 0)
-                fprintf(stderr, "[kgwas]   worker 0: %llu rounds, %llu pushes, scan %.0f heap %.0f kcycles (tsc)\n",
-                        (unsigned long long)rounds, (unsigned long long)local, tsc_scan / 1e3, tsc_heap / 1e3);
-            if (s->record_history) _mm_sfence();  // streaming stores of the history log
-            pushes += local;
-            cands += nc;
-            if (s->trace)
-                s->col_ms[w] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count();
-        });
-    } else
-    s->pool->parallel_for(s->n_pheno, [&](size_t j) {
-        const uint32_t n = sl.h_cnt.p[j];
-        if (!n) return;
-        const Cand* c = sl.cand.p + j * (uint64_t)s->cap;
-        BestHeap& h = s->heaps[j];
-        // The device filtered against a minimum that is one chunk old. Anything not above the
-        // CURRENT minimum would be rejected by add_association whenever it arrives (the minimum only
-        // rises), so it is dropped before the sort. The survivors are put in row order through
-        // compact (row-in-chunk, index) keys.
-        std::vector<uint64_t>& keys = s->keys[j];
-        keys.clear();
-        const bool full = h.full();
-        const double low = h.lowest();
-        for (uint32_t i = 0; i < n; i++)
-            if (!full || c[i].score > low) keys.push_back(((c[i].row - row0) << 32) | i);
-        std::sort(keys.begin(), keys.end());
-        uint64_t local = 0;
-        for (uint64_t key : keys) {
-            const Cand& e = c[(uint32_t)key];
-            if (h.add(e.kmer, e.score, (size_t)e.row)) {
-                local++;
-                if (s->record_history) s->hist[j].push(e.kmer, e.score, e.row);
-            }
-        }
-        if (s->record_history) _mm_sfence();  // streaming stores of the history log
-        pushes += local;
-        cands += n;
-    });
-    s->st.heap_pushes += pushes.load();
-    s->st.candidates += cands.load();
-    const double rep_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    s->st.replay_ms += rep_ms;
+    return true;
+}
+
+void add_replay_stats(kgwas_scan* s, const ReplayAcc& a) {
+    s->st.heap_pushes += a.pushes;
+    s->st.candidates += a.cands;
+    s->st.replay_cpu_ms += (double)a.busy_ns * 1e-6;
+}
+
+// Synchronous: wait for a submitted sparse chunk, replay its records (all groups, one barrier), refresh thresholds.
+// Returns false if a candidate list overflowed (nothing was replayed). Overflow recovery only.
+bool reap_sparse(kgwas_scan* s, Slot& sl) {
+    {
+        auto w0 = std::chrono::steady_clock::now();
+        KGWAS_HIP(hipEventSynchronize(sl.ev_done));  // kernel done (mapped candidate writes visible) + counts copied
+        s->st.gpu_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+    }
+    if (!chunk_complete(s, sl)) return false;
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<ReplayAcc> accs(s->n_groups);
+    s->pool->parallel_for(s->n_groups, [&](size_t g) { replay_group(s, sl, g, accs[g]); });
+    for (const ReplayAcc& a : accs) add_replay_stats(s, a);
+    s->st.replay_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     s->rows_done += sl.n_rows;
     upload_thresholds(s);
-    if (s->trace) {
-        const size_t T = s->pool->size();
-        std::vector<double> busy(T, 0.0);
-        double tot = 0, mx = 0;
-        for (uint64_t j = 0; j < s->n_pheno; j++) {
-            busy[j % T] += s->col_ms[j];
-            tot += s->col_ms[j];
-            s->col_ms[j] = 0;
-        }
-        for (double b : busy) mx = std::max(mx, b);
-        fprintf(stderr,
-                "[kgwas] chunk rows=%llu first=%llu kernel=%.3fms cands=%llu pushes=%llu replay=%.3fms (worker busy: max %.3f "
-                "mean %.3f)\n",
-                (unsigned long long)sl.n_rows, (unsigned long long)sl.first_row, ms_kernel,
-                (unsigned long long)cands.load(), (unsigned long long)pushes.load(), rep_ms, mx, tot / (double)T);
-    }
     return true;
 }
 
@@ -1035,6 +1051,82 @@ uint64_t next_sparse_chunk(const kgwas_scan* s) {
     return (ci + 127) / 128 * 128;
 }
 
+// ---- streaming replay ----------------------------------------------------------------------------------------
+// Sparse chunks carry sequence numbers (slot = seq % n_slots). The control thread (the caller of a feed) submits
+// chunks while slots are free, waits for the GPU to finish them in order and PUBLISHES them (seq_published); the
+// pool's workers, running one long item each, pick (chunk, group) units: any group that is not being worked on and
+// whose next chunk is published, the group furthest behind first. There is no barrier between chunks, so a chunk's
+// slowest group does not hold the others up (the per-chunk barrier cost 17 % of the replay at 101 columns on 16
+// workers), and the pool is woken once per feed instead of once per chunk. A slot is reused when all groups have
+// replayed its chunk (seq_replayed counts such chunks; they complete in order).
+void replay_worker(kgwas_scan* s, size_t /*w*/) {
+    ReplayAcc acc;
+    size_t last = (size_t)-1;
+    const size_t NG = s->n_groups;
+    int idle_spins = 0;
+    try {
+        for (;;) {
+            if (s->rp_quit.load(std::memory_order_acquire)) break;
+            const uint64_t pub = s->seq_published.load(std::memory_order_acquire);
+            size_t best = (size_t)-1;
+            uint64_t best_done = ~0ull;
+            for (size_t g = 0; g < NG; g++) {
+                kgwas_scan::GroupState& G = s->gstate[g];
+                if (G.busy.load(std::memory_order_relaxed)) continue;
+                const uint64_t d = G.done.load(std::memory_order_acquire);
+                if (d >= pub) continue;
+                if (d < best_done || (d == best_done && g == last)) {
+                    best = g;
+                    best_done = d;
+                }
+            }
+            if (best != (size_t)-1) {
+                kgwas_scan::GroupState& G = s->gstate[best];
+                uint32_t expect = 0;
+                if (!G.busy.compare_exchange_strong(expect, 1u, std::memory_order_acq_rel)) continue;
+                const uint64_t d = G.done.load(std::memory_order_acquire);
+                if (d >= s->seq_published.load(std::memory_order_acquire)) {  // somebody else did it meanwhile
+                    G.busy.store(0u, std::memory_order_release);
+                    continue;
+                }
+                const size_t si = (size_t)(d % (uint64_t)s->n_slots);
+                replay_group(s, s->slot[si], best, acc);
+                G.done.store(d + 1, std::memory_order_release);
+                G.busy.store(0u, std::memory_order_release);
+                last = best;
+                idle_spins = 0;
+                if (s->slot_left[si].fetch_sub(1u, std::memory_order_acq_rel) == 1u) {  // the chunk's last group
+                    {
+                        std::lock_guard<std::mutex> lk(s->rp_mu);
+                        s->seq_replayed.fetch_add(1, std::memory_order_release);
+                    }
+                    s->rp_cv_done.notify_all();
+                }
+                if (s->rp_idle.load(std::memory_order_relaxed) > 0) s->rp_cv_work.notify_one();  // the group may have more
+                continue;
+            }
+            // nothing to do: the GPU is behind (or other workers hold the groups that have work)
+            if (++idle_spins < 64) {
+                for (int i = 0; i < 32; i++) __builtin_ia32_pause();
+                continue;
+            }
+            std::unique_lock<std::mutex> lk(s->rp_mu);
+            if (s->rp_quit.load(std::memory_order_acquire)) break;
+            s->rp_idle.fetch_add(1, std::memory_order_relaxed);
+            s->rp_cv_work.wait_for(lk, std::chrono::microseconds(200));
+            s->rp_idle.fetch_sub(1, std::memory_order_relaxed);
+        }
+    } catch (...) {
+        s->rp_failed.store(true, std::memory_order_release);
+    }
+    std::lock_guard<std::mutex> lk(s->rp_mu);
+    s->rp_acc.pushes += acc.pushes;
+    s->rp_acc.cands += acc.cands;
+    s->rp_acc.busy_ns += acc.busy_ns;
+    s->rp_acc.units += acc.units;
+    s->rp_max_busy_ns = std::max(s->rp_max_busy_ns, acc.busy_ns);
+}
+
 // The GPU runs up to n_slots chunks ahead of the host replay. Heap pushes are front-loaded (60 % of them
 // belong to the first 10 % of a 100 M-row table) and inherently serial per column, so the host lags during
 // that part; instead of idling, the GPU keeps scoring later chunks against the thresholds it has (staler
@@ -1044,37 +1136,135 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
     const uint64_t stride = 1 + s->W_f;
     uint64_t pos = 0;
     if (s->count_patterns) hash_patterns(s, d_rows, n_rows);
-    std::deque<int> inflight;  // slot indices, oldest first
-    uint64_t n_submitted = 0;
-    auto reap_oldest = [&]() {
-        Slot& sl = s->slot[inflight.front()];
-        inflight.pop_front();
-        if (!reap_sparse(s, sl)) {
-            // A candidate list overflowed. Let the younger chunks finish (their lists stay in their own
-            // slots and are reaped in order afterwards) and redo this range synchronously in halves.
-            KGWAS_HIP(hipStreamSynchronize(s->stream));
-            process_range_sync(s, sl, sl.rows, sl.n_rows, sl.first_row);
+    const uint64_t depth = s->direct ? (uint64_t)s->n_slots : 1;  // squeezed mode has a single squeeze buffer
+    uint64_t sub = 0, pub = 0;  // chunks submitted / published in this feed (the control thread is their only writer)
+    bool running = false;
+    std::chrono::steady_clock::time_point t_start;
+    auto replayed = [&]() { return s->seq_replayed.load(std::memory_order_acquire); };
+    auto start_async = [&]() {
+        if (running) return;
+        s->rp_quit.store(false, std::memory_order_release);
+        s->rp_acc = ReplayAcc();
+        s->rp_max_busy_ns = 0;
+        t_start = std::chrono::steady_clock::now();
+        s->pool->start(s->pool->size(), s->rp_fn);
+        running = true;
+    };
+    auto wait_replayed = [&](uint64_t target) {
+        std::unique_lock<std::mutex> lk(s->rp_mu);
+        while (s->seq_replayed.load(std::memory_order_acquire) < target) {
+            if (s->rp_failed.load(std::memory_order_acquire)) break;
+            s->rp_cv_done.wait_for(lk, std::chrono::milliseconds(1));
         }
     };
-    const size_t depth = s->direct ? (size_t)s->n_slots : 1;  // squeezed mode has a single squeeze buffer
-    while (pos < n_rows) {
-        if (!s->all_full) {
-            while (!inflight.empty()) reap_oldest();
-            const uint64_t c = std::min<uint64_t>(s->dense_chunk, n_rows - pos);
-            run_dense(s, d_rows + pos * stride, c, first_row + pos, nullptr, nullptr, true);
-            pos += c;
-            continue;
+    auto stop_async = [&]() {
+        if (!running) return;
+        {
+            std::lock_guard<std::mutex> lk(s->rp_mu);
+            s->rp_quit.store(true, std::memory_order_release);
         }
-        if (inflight.size() >= depth) reap_oldest();
-        const uint64_t c = std::min<uint64_t>(next_sparse_chunk(s), n_rows - pos);
-        const int idx = (int)(n_submitted % (uint64_t)s->n_slots);  // FIFO: reaped n_slots submissions ago
-        submit_sparse(s, s->slot[idx], d_rows + pos * stride, c, first_row + pos, /*count_hist=*/true);
-        s->rows_submitted += c;
-        inflight.push_back(idx);
-        n_submitted++;
-        pos += c;
+        s->rp_cv_work.notify_all();
+        s->pool->wait(false);
+        running = false;
+        add_replay_stats(s, s->rp_acc);
+        // the replay's share of the wall clock: the busiest worker's time (they run side by side)
+        s->st.replay_ms += (double)s->rp_max_busy_ns * 1e-6;
+        if (s->trace)
+            fprintf(stderr, "[kgwas] streaming replay: %llu units, cpu %.2f ms on %zu workers, busiest worker %.2f ms, wall %.2f ms\n",
+                    (unsigned long long)s->rp_acc.units, (double)s->rp_acc.busy_ns * 1e-6, s->pool->size(),
+                    (double)s->rp_max_busy_ns * 1e-6,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
+        if (s->rp_failed.load(std::memory_order_acquire)) throw Error(KGWAS_ERR_NOMEM, "replay worker failed (out of memory?)");
+    };
+    // (sequence numbers restart with every feed: nothing is in flight between feeds)
+    s->seq_submitted.store(0);
+    s->seq_published.store(0);
+    s->seq_replayed.store(0);
+    for (size_t g = 0; g < s->n_groups; g++) {
+        s->gstate[g].done.store(0);
+        s->gstate[g].busy.store(0);
     }
-    while (!inflight.empty()) reap_oldest();
+    try {
+        for (;;) {
+            if (pos < n_rows && !s->all_full) {  // dense phase: until every heap is full
+                wait_replayed(sub);  // (nothing is in flight here in practice: heaps never un-fill)
+                stop_async();
+                const uint64_t c = std::min<uint64_t>(s->dense_chunk, n_rows - pos);
+                run_dense(s, d_rows + pos * stride, c, first_row + pos, nullptr, nullptr, true);
+                pos += c;
+                continue;
+            }
+            // submit while slots are free
+            while (pos < n_rows && sub - replayed() < depth) {
+                start_async();
+                const uint64_t c = std::min<uint64_t>(next_sparse_chunk(s), n_rows - pos);
+                const size_t si = (size_t)(sub % (uint64_t)s->n_slots);  // its previous chunk was replayed n_slots chunks ago
+                s->slot_left[si].store((uint32_t)s->n_groups, std::memory_order_release);
+                submit_sparse(s, s->slot[si], d_rows + pos * stride, c, first_row + pos, /*count_hist=*/true);
+                s->rows_submitted += c;
+                sub++;
+                s->seq_submitted.store(sub, std::memory_order_release);
+                pos += c;
+            }
+            if (pub < sub) {  // publish the oldest chunk the GPU still owes
+                Slot& sl = s->slot[(size_t)(pub % (uint64_t)s->n_slots)];
+                {
+                    auto w0 = std::chrono::steady_clock::now();
+                    KGWAS_HIP(hipEventSynchronize(sl.ev_done));  // records and counts are in host memory
+                    s->st.gpu_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+                }
+                if (chunk_complete(s, sl)) {
+                    pub++;
+                    {
+                        std::lock_guard<std::mutex> lk(s->rp_mu);
+                        s->seq_published.store(pub, std::memory_order_release);
+                    }
+                    s->rp_cv_work.notify_all();
+                    // The exact minima as far as the workers have come (racy reads of monotone values: any value a
+                    // minimum has had after some prefix of the rows is a valid bound for every later row).
+                    upload_thresholds(s);
+                } else {
+                    // A list overflowed. Everything before the chunk is replayed first, the younger chunks finish on
+                    // the GPU (their records stay in their slots and are published in order afterwards), and this
+                    // range is redone synchronously in halves against the heaps' exact minima.
+                    wait_replayed(pub);
+                    stop_async();
+                    KGWAS_HIP(hipStreamSynchronize(s->stream));
+                    process_range_sync(s, sl, sl.rows, sl.n_rows, sl.first_row);
+                    pub++;
+                    for (size_t g = 0; g < s->n_groups; g++) s->gstate[g].done.store(pub, std::memory_order_release);
+                    s->seq_replayed.store(pub, std::memory_order_release);
+                    s->seq_published.store(pub, std::memory_order_release);
+                    if (pub < sub || pos < n_rows) start_async();
+                }
+                continue;
+            }
+            if (pos < n_rows) {  // every slot holds a chunk that is still being replayed
+                wait_replayed(replayed() + 1);
+                if (s->rp_failed.load(std::memory_order_acquire)) break;
+                continue;
+            }
+            break;
+        }
+        {
+            auto w0 = std::chrono::steady_clock::now();
+            wait_replayed(sub);
+            s->st.replay_tail_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+        }
+        stop_async();
+    } catch (...) {
+        if (running) {
+            {
+                std::lock_guard<std::mutex> lk(s->rp_mu);
+                s->rp_quit.store(true, std::memory_order_release);
+            }
+            s->rp_cv_work.notify_all();
+            s->pool->wait(false);
+        }
+        (void)hipStreamSynchronize(s->stream);
+        throw;
+    }
+    s->rows_done = s->rows_submitted;
     s->st.rows_fed += n_rows;
 }
 
@@ -1265,6 +1455,8 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         s->h_hist_base.alloc(P);
         s->d_pat_cnt.alloc(1);
         KGWAS_HIP(hipMemset(s->d_pat_cnt.p, 0, 8));
+        KGWAS_HIP(hipMemset(s->d_thr.p, 0, P * sizeof(double)));  // 0 = "nothing is filtered" until the heaps say otherwise
+        KGWAS_HIP(hipMemset(s->d_thr_host.p, 0, P * sizeof(double)));
         s->d_topn.alloc(P);
         KGWAS_HIP(hipMemcpy(s->d_topn.p, s->topn.data(), P * 8, hipMemcpyHostToDevice));
         KGWAS_HIP(hipMemcpy(s->d_dmask.p, dmask.data(), dmask.size() * 4, hipMemcpyHostToDevice));
@@ -1471,7 +1663,8 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
             KGWAS_HIP(hipEventCreate(&sl.ev_sq0));
             KGWAS_HIP(hipEventCreate(&sl.ev_k0));
             KGWAS_HIP(hipEventCreate(&sl.ev_k1));
-            KGWAS_HIP(hipEventCreate(&sl.ev_done));
+            // (blocking wait: the control thread sleeps instead of spinning beside the replay workers)
+            KGWAS_HIP(hipEventCreateWithFlags(&sl.ev_done, hipEventBlockingSync));
             KGWAS_HIP(hipEventCreate(&sl.ev_mid));
         }
         s->d_dense.alloc(P * s->dense_rows);
@@ -1495,6 +1688,20 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
             if (atoi(e) > 0) nt = (unsigned)atoi(e);
         nt = (unsigned)std::min<uint64_t>(nt, P);
         s->pool.reset(new Pool(nt, pick_replay_cpus(nt, s->device)));
+        // Column groups of the replay: about two per worker (so that (chunk, group) units balance over the workers),
+        // at most MAX_LOCKSTEP columns each (a group's heaps take their replacements in lockstep).
+        {
+            uint64_t gsize = (P + 2ull * nt - 1) / (2ull * nt);
+            gsize = std::max<uint64_t>(1, std::min<uint64_t>(gsize, (uint64_t)BestHeap::MAX_LOCKSTEP));
+            if (const char* e = getenv("KGWAS_REPLAY_GROUP"))
+                if (atoi(e) > 0) gsize = std::min<uint64_t>((uint64_t)atoi(e), (uint64_t)BestHeap::MAX_LOCKSTEP);
+            s->n_groups = (size_t)((P + gsize - 1) / gsize);
+            s->gstate.reset(new kgwas_scan::GroupState[s->n_groups]);
+            s->slot_left.reset(new std::atomic<uint32_t>[MAX_SLOTS]);
+            for (int i = 0; i < MAX_SLOTS; i++) s->slot_left[i].store(0);
+            kgwas_scan* raw = s.get();
+            s->rp_fn = [raw](size_t w) { replay_worker(raw, w); };
+        }
         s->st.kernel_used = s->coarse ? (uint32_t)KGWAS_KERNEL_COARSE : kern;
         s->st.direct_mode = s->direct ? 1 : 0;
         *out = s.release();
@@ -1743,6 +1950,12 @@ int kgwas_scan_heaps_import(kgwas_scan* s, uint64_t n_cols, const uint64_t* cols
         });
         s->finished = false;
         refresh_full(s);
+        // The device's thresholds and score histograms describe the rows behind the heaps that were just replaced:
+        // start them again from the imported minima before anything else is fed (the next sparse chunk re-bases the
+        // histograms, start_histograms).
+        KGWAS_HIP(hipSetDevice(s->device));
+        s->hist_ready = false;
+        upload_thresholds(s);
     });
 }
 
@@ -1781,6 +1994,11 @@ int kgwas_scan_absorb(kgwas_scan* s, uint64_t n_shards, const uint64_t* counts, 
         });
         s->st.heap_pushes += pushes.load();
         s->finished = false;
+        refresh_full(s);
+        // feeding may go on after an absorb: the device thresholds follow the heaps (see kgwas_scan_heaps_import)
+        KGWAS_HIP(hipSetDevice(s->device));
+        s->hist_ready = false;
+        upload_thresholds(s);
     });
 }
 

@@ -116,7 +116,8 @@ def test_topn_identities_with_ties(kernel, binary, dup):
 
 @pytest.mark.parametrize("slices", [1, 2])
 @pytest.mark.parametrize("S,P,shift", [(241, 1, 0.0), (241, 5, 0.0), (241, 40, 100.0), (1024, 101, 0.0), (1024, 130, -7.5),
-                                       (1500, 23, 3.0), (300, 333, 1.0), (2048, 40, 0.5), (2600, 9, 0.0)])
+                                       (1500, 23, 3.0), (300, 333, 1.0), (2048, 40, 0.5), (2600, 9, 0.0),
+                                       (2048, 201, 0.0)])  # BASELINE configs[3]: 4 sample groups x several LDS groups
 def test_coarse_filter_shapes(monkeypatch, slices, S, P, shift):
     """The int8 filter in every operand-tile shape (1..8 tiles per LDS group, one or more LDS groups, 1..6
     512-sample groups), with one and with two int8 slices per column, on shifted phenotypes (the quantisation is
@@ -136,6 +137,36 @@ def test_coarse_filter_shapes(monkeypatch, slices, S, P, shift):
     mi = slices - 1  # the forced operand set is the only one built, and it covers all columns
     assert st["coarse_mode_tiles"][1 - mi] == 0 and st["coarse_mode_launches"][mi] > 0
     assert st["coarse_mode_tiles"][mi] * st["coarse_mode_lgroups"][mi] >= slices * ((P + 15) // 16)
+    _check_topn(scan, exp, P)
+    assert st["rows_tested"] == exp["tested"]
+    scan.close()
+
+
+@pytest.mark.parametrize("slices", [0, 1, 2])
+def test_config3_shape_ft10_phenotype(monkeypatch, slices):
+    """BASELINE configs[2] in shape: 1135 accessions x 101 columns, column 0 = the reference's flowering-time example
+    (examples/flowering_time_arabidopsis/FT10.pheno, first 1135 accessions, raw values: all large and positive, which
+    stresses the centred quantisation of the int8 filter), columns 1..100 its permutations. slices = 0 leaves the choice
+    of the operand set to the session (both sets resident, chunk by chunk)."""
+    if slices:
+        monkeypatch.setenv("KGWAS_COARSE_SLICES", str(slices))
+    names, acc, Yf = onp.load_phenotypes(os.path.join(GOLD, "FT10.pheno"))
+    S, P = 1135, 101
+    y0 = Yf[0, :S].astype(np.float32)
+    rng = np.random.default_rng(10)
+    Y = np.ascontiguousarray(np.stack([y0] + [rng.permutation(y0) for _ in range(P - 1)]).astype(np.float32))
+    rows = random_table(60_000, S, seed=1135, dup_frac=0.2)
+    col = np.arange(S, dtype=np.uint64)
+    mac = onp.min_count(S, 0.05, 5)
+    topn = 501
+    exp = ob.associate(rows, S, col, Y, topn, mac, batch_size=20_000, threads=4)
+    scan = kg.AssociationScan(S, col, Y, topn, mac, chunk_rows=8192)
+    scan.feed_host(rows[:41_000], 0)
+    scan.feed_host(rows[41_000:], 41_000)
+    scan.finish()
+    st = scan.stats()
+    assert st["kernel_used"] == kg.KERNEL_COARSE and st["direct_mode"] == 1
+    assert sum(st["coarse_mode_launches"]) > 0
     _check_topn(scan, exp, P)
     assert st["rows_tested"] == exp["tested"]
     scan.close()
@@ -318,6 +349,36 @@ def test_column_distributed_merge_protocol(world, mode):
     _check_topn(scans[0], exp, P, check_pushes=False)
     for sc in scans:
         sc.close()
+
+
+@pytest.mark.parametrize("fresh", [True, False])
+def test_heaps_import_then_feed(fresh):
+    """kgwas_scan_heaps_import promises that an imported heap goes on exactly as it would have in the exporting
+    session: a session that imports the state after rows [0, cut) and is then FED rows [cut, n) must end where a
+    single scan ends. The device-side thresholds / histograms have to follow the import (fresh session: they were
+    never written; used session: they describe other rows - here a scan of the table's tail, whose minima are far
+    higher than the imported ones would allow)."""
+    S_f = S = 300
+    P, topn, cut = 11, 400, 30_000
+    rows = random_table(90_000, S_f, seed=41, dup_frac=0.3)
+    col = np.arange(S, dtype=np.uint64)
+    Y = phenotypes(S, P - 1, seed=5)
+    mac = onp.min_count(S, 0.05, 5)
+    exp = ob.associate(rows, S_f, col, Y, topn, mac, threads=4)
+    a = kg.AssociationScan(S_f, col, Y, topn, mac, chunk_rows=4096)
+    a.feed_host(rows[:cut], 0)
+    b = kg.AssociationScan(S_f, col, Y, topn, mac, chunk_rows=4096)
+    if not fresh:  # leave thresholds and histograms of unrelated rows behind
+        b.feed_host(rows[cut:], cut)
+        b.feed_host(rows[cut:], cut)
+    cols = np.arange(P, dtype=np.uint64)
+    b.heaps_import(cols, *a.heaps_export(cols))
+    b.feed_host(rows[cut:50_000], cut)
+    b.feed_host(rows[50_000:], 50_000)
+    b.finish()
+    _check_topn(b, exp, P, check_pushes=False)
+    a.close()
+    b.close()
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
@@ -517,7 +578,8 @@ def test_kinship_double_buffered_ingest(monkeypatch, tmp_path, piece):
     tbl.close()
 
 
-@pytest.mark.parametrize("S_f,n_rows", [(5, 100), (64, 700), (77, 2000), (241, 5000), (1135, 3000)])
+@pytest.mark.parametrize("S_f,n_rows", [(5, 100), (64, 700), (77, 2000), (241, 5000), (1135, 3000), (2048, 1500),
+                                        (2600, 900), (5000, 500)])
 def test_kinship_exact(S_f, n_rows):
     rows = random_table(n_rows, S_f, seed=S_f)
     mc = int(np.ceil(S_f * 0.05))
