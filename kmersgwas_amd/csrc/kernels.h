@@ -58,11 +58,10 @@ struct ScoreArgs {
     uint32_t* hist;             // [n_pheno][hist_bins] or null
     const uint32_t* hist_base;  // [n_pheno] (bits(score) >> HIST_SHIFT) of bin 0
     uint32_t hist_bins;
-    // Ordered output of the re-score kernel (coarse path): entry i of column p describes the i-th survivor in
-    // row order; score is -inf for a survivor that is not a candidate (score <= thr or MAC-filtered).
-    double* so_score;    // [n_pheno][cap] or null
-    uint64_t* so_kmer;   // [n_pheno][cap]
-    uint32_t* so_row;    // [n_pheno][cap] chunk-local row
+    // Output of the coarse path (rescore + compaction): the chunk's candidates in (column, row) order.
+    double* so_score;    // [key_cap] or null
+    uint64_t* so_kmer;   // [key_cap]
+    uint32_t* so_row;    // [key_cap] chunk-local row
 };
 
 constexpr int HIST_SHIFT = 44;          // 8 mantissa bits per bin: 0.4 % score resolution
@@ -111,8 +110,13 @@ struct CoarseArgs {
 };
 size_t coarse_lds_bytes(uint32_t n_kgroups, uint32_t T);
 hipError_t launch_coarse(const CoarseArgs& a, uint32_t T, uint32_t rows_per_block, hipStream_t st);
+// Survivors (sorted keys, per-column ranges) -> exact candidates compacted in (column, row) order into a.so_score /
+// a.so_kmer / a.so_row (HBM); meta[0..P) = candidates per column, meta[P..2P) = their offsets, meta[2P] = total,
+// meta[2P + 1] = survivor keys emitted. tile_pref [P + 1], tile_cnt / tile_off [key_cap / 256 + P + 1], tmp_score [key_cap].
 hipError_t launch_rescore(const ScoreArgs& a, const uint32_t* keys, const uint32_t* surv_off, const uint32_t* surv_cnt,
-                          uint32_t surv_cap, uint32_t row_bits, hipStream_t st);
+                          uint32_t row_bits, uint32_t* tile_pref, uint32_t* tile_cnt, uint32_t* tile_off, double* tmp_score,
+                          const uint32_t* key_count, uint32_t* meta, hipStream_t st);
+hipError_t launch_chunk_prep(uint32_t* cand_cnt, uint32_t n_pheno, unsigned long long* tested, uint32_t* key_count, hipStream_t st);
 
 // Survivor keys -> (column, row) order + each column's range (surv_sort.hip). n_slots = size of the key arrays.
 hipError_t surv_sort_temp_bytes(uint32_t n_slots, size_t* bytes);

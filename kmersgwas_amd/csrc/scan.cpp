@@ -383,14 +383,19 @@ struct Slot {
     Cand* d_cand = nullptr;
     DevBuf<uint32_t> d_cnt;
     PinBuf<uint32_t> h_cnt;
-    PinBuf<uint32_t> h_surv_cnt;  // coarse filter: survivors per column (overflow check), [n_pheno] = all of them
-    // coarse filter: the re-score kernel's row-ordered records, written straight into mapped host memory
+    bool copies_ordered = false;  // coarse chunks: the record copies are on the copy stream (ev_done follows them)
+    // coarse filter: the chunk's candidates compacted in (column, row) order - in HBM (d_so_*), and the host copy the
+    // control thread orders on the copy stream once the counts are known (exactly `total` records per array);
+    // h_meta: [0, P) candidates per column, [P, 2P) their offsets, [2P] total, [2P + 1] survivor keys emitted
     PinBuf<double> so_score;
     PinBuf<uint64_t> so_kmer;
     PinBuf<uint32_t> so_row;
-    double* d_so_score = nullptr;
-    uint64_t* d_so_kmer = nullptr;
-    uint32_t* d_so_row = nullptr;
+    DevBuf<double> d_so_score;
+    DevBuf<uint64_t> d_so_kmer;
+    DevBuf<uint32_t> d_so_row;
+    DevBuf<uint32_t> d_meta;
+    PinBuf<uint32_t> h_meta;
+    hipEvent_t ev_counts = nullptr;  // compute stream: compaction done, h_meta copied
     DevBuf<unsigned long long> d_tested;
     PinBuf<unsigned long long> h_tested;
     hipEvent_t ev_sq0 = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_done = nullptr, ev_mid = nullptr;
@@ -417,7 +422,7 @@ struct kgwas_scan {
     uint64_t max_topn = 0;
     uint32_t nb_full = 0;  // leading 128-sample blocks the MFMA scorer may read unmasked
 
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, copy_stream = nullptr;  // copy_stream: candidate records HBM -> host
     hipEvent_t ev_user = nullptr, ev_ds = nullptr, ev_d0 = nullptr, ev_d1 = nullptr;  // caller sync + dense-chunk timing
     DevBuf<uint32_t> d_dmask, d_colmap, d_sq;
     DevBuf<float> d_Yperm, d_Ymfma, d_sums;
@@ -447,6 +452,8 @@ struct kgwas_scan {
     // survivor keys of the chunk being filtered, their sorted copy, each column's range in it; shared by all chunks
     // (consumed by the re-score kernel in stream order)
     DevBuf<uint32_t> d_surv, d_surv_sorted, d_surv_cnt, d_surv_off, d_key_count;
+    DevBuf<uint32_t> d_tile_pref, d_tile_cnt, d_tile_off;  // tiles of 256 survivors (launch_rescore)
+    DevBuf<double> d_tmp_score;                            // exact score of every survivor (-inf: not a candidate)
     uint32_t key_slots = 0;  // capacity of the key list = n_pheno * cap
     DevBuf<uint8_t> d_sort_tmp;
     uint32_t row_key_bits = 32;
@@ -487,6 +494,8 @@ struct kgwas_scan {
         std::atomic<uint32_t> busy{0};  // a worker is on it
     };
     size_t n_groups = 1;
+    std::vector<std::vector<uint32_t>> grp_cols;  // columns of group g (at most BestHeap::MAX_LOCKSTEP)
+    std::vector<int> grp_home;                    // the worker that owns group g, -1: floating (anybody takes it)
     std::unique_ptr<GroupState[]> gstate;
     std::unique_ptr<std::atomic<uint32_t>[]> slot_left;  // [n_slots] groups that have not replayed the slot's chunk yet
     std::atomic<uint64_t> seq_submitted{0}, seq_published{0}, seq_replayed{0};
@@ -510,6 +519,7 @@ struct kgwas_scan {
             if (s.ev_k1) (void)hipEventDestroy(s.ev_k1);
             if (s.ev_done) (void)hipEventDestroy(s.ev_done);
             if (s.ev_mid) (void)hipEventDestroy(s.ev_mid);
+            if (s.ev_counts) (void)hipEventDestroy(s.ev_counts);
         };
         for (auto& s : slot) drop_events(s);
         drop_events(redo);
@@ -518,6 +528,7 @@ struct kgwas_scan {
         if (ev_d0) (void)hipEventDestroy(ev_d0);
         if (ev_d1) (void)hipEventDestroy(ev_d1);
         if (stream) (void)hipStreamDestroy(stream);
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
     }
 };
 
@@ -741,12 +752,11 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
                                  s->stream));
         a.thr = s->d_thr_redo.p;
     }
-    KGWAS_HIP(hipMemsetAsync(sl.d_cnt.p, 0, s->n_pheno * sizeof(uint32_t), s->stream));
-    KGWAS_HIP(hipMemsetAsync(sl.d_tested.p, 0, TESTED_SHARDS * sizeof(unsigned long long), s->stream));
+    const bool use_coarse = s->coarse && count_hist;
+    KGWAS_HIP(launch_chunk_prep(sl.d_cnt.p, (uint32_t)s->n_pheno, sl.d_tested.p, use_coarse ? s->d_key_count.p : nullptr, s->stream));
     KGWAS_HIP(hipEventRecord(sl.ev_sq0, s->stream));
     maybe_squeeze(s, d_rows, n_rows);
     KGWAS_HIP(hipEventRecord(sl.ev_k0, s->stream));
-    const bool use_coarse = s->coarse && count_hist;
     sl.used_coarse = use_coarse;
     if (use_coarse) {
         CoarseArgs c;
@@ -773,7 +783,6 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
         c.key_cap = s->key_slots;
         c.row_bits = s->row_key_bits;
         c.tested = a.tested;
-        KGWAS_HIP(hipMemsetAsync(s->d_key_count.p, 0, sizeof(uint32_t), s->stream));
         KGWAS_HIP(hipMemsetAsync(s->d_surv.p, 0xFF, (size_t)s->key_slots * sizeof(uint32_t), s->stream));  // sorts last
         static const uint32_t rpb_env = getenv("KGWAS_COARSE_RPB") ? (uint32_t)atoi(getenv("KGWAS_COARSE_RPB")) : 0u;  // experiments
         // rows per block: the operand tiles (up to 128 KB) are loaded into LDS once per block, so blocks are long
@@ -784,27 +793,29 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
         KGWAS_HIP(launch_surv_sort(s->d_surv.p, s->d_surv_sorted.p, s->key_slots, s->d_key_count.p, s->key_slots,
                                    (uint32_t)s->n_pheno, s->row_key_bits, 32, s->d_surv_off.p, s->d_surv_cnt.p,
                                    s->d_sort_tmp.p, s->d_sort_tmp.n, s->stream));
-        a.so_score = sl.d_so_score;
-        a.so_kmer = sl.d_so_kmer;
-        a.so_row = sl.d_so_row;
-        KGWAS_HIP(launch_rescore(a, s->d_surv_sorted.p, s->d_surv_off.p, s->d_surv_cnt.p, s->cap, s->row_key_bits, s->stream));
-        KGWAS_HIP(hipMemcpyAsync(sl.h_surv_cnt.p + s->n_pheno, s->d_key_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost,
-                                 s->stream));
-        KGWAS_HIP(hipMemcpyAsync(sl.h_surv_cnt.p, s->d_surv_cnt.p, s->n_pheno * sizeof(uint32_t), hipMemcpyDeviceToHost,
-                                 s->stream));
+        a.so_score = sl.d_so_score.p;
+        a.so_kmer = sl.d_so_kmer.p;
+        a.so_row = sl.d_so_row.p;
+        KGWAS_HIP(launch_rescore(a, s->d_surv_sorted.p, s->d_surv_off.p, s->d_surv_cnt.p, s->row_key_bits, s->d_tile_pref.p,
+                                 s->d_tile_cnt.p, s->d_tile_off.p, s->d_tmp_score.p, s->d_key_count.p, sl.d_meta.p, s->stream));
         s->st.score_launches++;
     } else {
-        if (s->coarse) memset(sl.h_surv_cnt.p, 0, (s->n_pheno + 1) * sizeof(uint32_t));
         launch_score(s, a);
     }
     KGWAS_HIP(hipEventRecord(sl.ev_k1, s->stream));
     if (s->hist_ready)  // raise the thresholds for whatever is queued next; no host round trip
         KGWAS_HIP(launch_thr_update(s->d_hist.p, s->d_hist_base.p, HIST_BINS, s->d_topn.p, s->d_thr_host.p, s->d_thr.p,
                                     (uint32_t)s->n_pheno, s->stream));
-    KGWAS_HIP(hipMemcpyAsync(sl.h_cnt.p, sl.d_cnt.p, s->n_pheno * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     KGWAS_HIP(hipMemcpyAsync(sl.h_tested.p, sl.d_tested.p, TESTED_SHARDS * sizeof(unsigned long long), hipMemcpyDeviceToHost,
                              s->stream));
-    KGWAS_HIP(hipEventRecord(sl.ev_done, s->stream));
+    if (use_coarse) {
+        // the record copies follow on the copy stream once the control thread has read the counts (fetch_records)
+        KGWAS_HIP(hipMemcpyAsync(sl.h_meta.p, sl.d_meta.p, (2 * s->n_pheno + 2) * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+        KGWAS_HIP(hipEventRecord(sl.ev_counts, s->stream));
+    } else {
+        KGWAS_HIP(hipMemcpyAsync(sl.h_cnt.p, sl.d_cnt.p, s->n_pheno * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+        KGWAS_HIP(hipEventRecord(sl.ev_done, s->stream));
+    }
     sl.rows = d_rows;
     sl.first_row = first_row;
     sl.n_rows = n_rows;
@@ -822,7 +833,7 @@ void process_range_sync(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_
 void replay_group(kgwas_scan* s, Slot& sl, size_t g, ReplayAcc& acc) {
     const auto tb0 = std::chrono::steady_clock::now();
     const uint64_t row0 = sl.first_row;
-    const size_t NG = s->n_groups;
+    const std::vector<uint32_t>& members = s->grp_cols[g];
     uint64_t local = 0, nc = 0;
     if (sl.used_coarse) {
         // Records arrive in row order (sorted on the device). The group's columns advance together: per round, every
@@ -841,10 +852,10 @@ void replay_group(kgwas_scan* s, Slot& sl, size_t g, ReplayAcc& acc) {
         constexpr int MK = BestHeap::MAX_LOCKSTEP;
         Cur cols[MK];
         size_t n_cols = 0;
-        for (size_t j = g; j < s->n_pheno; j += NG) {
-            const uint32_t n = sl.h_surv_cnt.p[j];
+        for (const uint32_t j : members) {
+            const uint32_t n = sl.h_meta.p[j];
             if (!n) continue;
-            const uint64_t o = j * (uint64_t)s->cap;
+            const uint64_t o = sl.h_meta.p[s->n_pheno + j];
             cols[n_cols++] = Cur{sl.so_score.p + o, sl.so_kmer.p + o, sl.so_row.p + o, 0, n, &s->heaps[j], j};
         }
         // The records were just written by the GPU (no CPU cache holds them) and the replay walks several short
@@ -923,7 +934,7 @@ void replay_group(kgwas_scan* s, Slot& sl, size_t g, ReplayAcc& acc) {
             }
         }
     } else {
-        for (size_t j = g; j < s->n_pheno; j += NG) {
+        for (const uint32_t j : members) {
             const uint32_t n = sl.h_cnt.p[j];
             if (!n) continue;
             const Cand* c = sl.cand.p + j * (uint64_t)s->cap;
@@ -978,19 +989,22 @@ bool chunk_complete(kgwas_scan* s, Slot& sl) {
         s->st.squeeze_kernel_ms += mq;
     }
     bool over = false;
-    for (uint64_t j = 0; j < s->n_pheno && !over; j++)
-        over = sl.h_cnt.p[j] > s->cap ||
-               (s->coarse && (sl.h_surv_cnt.p[j] > s->cap || sl.h_surv_cnt.p[s->n_pheno] > s->key_slots));
+    if (sl.used_coarse) {
+        over = sl.h_meta.p[2 * s->n_pheno + 1] > s->key_slots;  // the survivor key list
+    } else {
+        for (uint64_t j = 0; j < s->n_pheno && !over; j++) over = sl.h_cnt.p[j] > s->cap;
+    }
     if (s->trace) {
         uint64_t tot = 0, mx = 0;
         for (uint64_t q = 0; q < s->n_pheno; q++) {
-            const uint64_t v = s->coarse && sl.used_coarse ? sl.h_surv_cnt.p[q] : sl.h_cnt.p[q];
+            const uint64_t v = sl.used_coarse ? sl.h_meta.p[q] : sl.h_cnt.p[q];
             tot += v;
             mx = std::max<uint64_t>(mx, v);
         }
-        fprintf(stderr, "[kgwas] chunk rows=%llu first=%llu kernel=%.3fms records %llu (max per column %llu, cap %u)%s\n",
+        fprintf(stderr, "[kgwas] chunk rows=%llu first=%llu kernel=%.3fms records %llu (max per column %llu)%s%s\n",
                 (unsigned long long)sl.n_rows, (unsigned long long)sl.first_row, ms, (unsigned long long)tot,
-                (unsigned long long)mx, s->cap, over ? " OVERFLOW" : "");
+                (unsigned long long)mx, sl.used_coarse ? (" survivors " + std::to_string(sl.h_meta.p[2 * s->n_pheno + 1])).c_str() : "",
+                over ? " OVERFLOW" : "");
     }
     if (over) return false;
     for (uint32_t i = 0; i < TESTED_SHARDS; i++) s->st.rows_tested += sl.h_tested.p[i];
@@ -1051,6 +1065,24 @@ uint64_t next_sparse_chunk(const kgwas_scan* s) {
     return (ci + 127) / 128 * 128;
 }
 
+// Coarse chunk: wait for its counts, then order the copy of exactly that many candidate records (three arrays) from
+// HBM on the copy stream; ev_done follows the copies. Other chunks recorded ev_done at submission.
+void fetch_records(kgwas_scan* s, Slot& sl) {
+    if (!sl.used_coarse) return;
+    {
+        auto w0 = std::chrono::steady_clock::now();
+        KGWAS_HIP(hipEventSynchronize(sl.ev_counts));
+        s->st.gpu_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+    }
+    const uint32_t n = sl.h_meta.p[2 * s->n_pheno];
+    if (n && sl.h_meta.p[2 * s->n_pheno + 1] <= s->key_slots) {
+        KGWAS_HIP(hipMemcpyAsync(sl.so_score.p, sl.d_so_score.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s->copy_stream));
+        KGWAS_HIP(hipMemcpyAsync(sl.so_row.p, sl.d_so_row.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, s->copy_stream));
+        KGWAS_HIP(hipMemcpyAsync(sl.so_kmer.p, sl.d_so_kmer.p, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost, s->copy_stream));
+    }
+    KGWAS_HIP(hipEventRecord(sl.ev_done, s->copy_stream));
+}
+
 // ---- streaming replay ----------------------------------------------------------------------------------------
 // Sparse chunks carry sequence numbers (slot = seq % n_slots). The control thread (the caller of a feed) submits
 // chunks while slots are free, waits for the GPU to finish them in order and PUBLISHES them (seq_published); the
@@ -1059,27 +1091,33 @@ uint64_t next_sparse_chunk(const kgwas_scan* s) {
 // slowest group does not hold the others up (the per-chunk barrier cost 17 % of the replay at 101 columns on 16
 // workers), and the pool is woken once per feed instead of once per chunk. A slot is reused when all groups have
 // replayed its chunk (seq_replayed counts such chunks; they complete in order).
-void replay_worker(kgwas_scan* s, size_t /*w*/) {
+void replay_worker(kgwas_scan* s, size_t w) {
     ReplayAcc acc;
-    size_t last = (size_t)-1;
     const size_t NG = s->n_groups;
     int idle_spins = 0;
     try {
         for (;;) {
             if (s->rp_quit.load(std::memory_order_acquire)) break;
             const uint64_t pub = s->seq_published.load(std::memory_order_acquire);
+            // The group furthest behind among this worker's own groups and the floating ones; another worker's group
+            // only when that worker has fallen two published chunks behind (a heap that changes cores drags its
+            // 320 KB along, so groups stay at home unless a core is really slow - a co-tenant, a throttled sibling).
             size_t best = (size_t)-1;
             uint64_t best_done = ~0ull;
-            for (size_t g = 0; g < NG; g++) {
-                kgwas_scan::GroupState& G = s->gstate[g];
-                if (G.busy.load(std::memory_order_relaxed)) continue;
-                const uint64_t d = G.done.load(std::memory_order_acquire);
-                if (d >= pub) continue;
-                if (d < best_done || (d == best_done && g == last)) {
-                    best = g;
-                    best_done = d;
+            for (int pass = 0; pass < 2 && best == (size_t)-1; pass++)
+                for (size_t g = 0; g < NG; g++) {
+                    const int home = s->grp_home[g];
+                    const bool mine = home < 0 || (size_t)home == w;
+                    if (mine != (pass == 0)) continue;
+                    kgwas_scan::GroupState& G = s->gstate[g];
+                    if (G.busy.load(std::memory_order_relaxed)) continue;
+                    const uint64_t d = G.done.load(std::memory_order_acquire);
+                    if (d >= pub || (pass == 1 && d + 2 > pub)) continue;
+                    if (d < best_done) {
+                        best = g;
+                        best_done = d;
+                    }
                 }
-            }
             if (best != (size_t)-1) {
                 kgwas_scan::GroupState& G = s->gstate[best];
                 uint32_t expect = 0;
@@ -1093,7 +1131,6 @@ void replay_worker(kgwas_scan* s, size_t /*w*/) {
                 replay_group(s, s->slot[si], best, acc);
                 G.done.store(d + 1, std::memory_order_release);
                 G.busy.store(0u, std::memory_order_release);
-                last = best;
                 idle_spins = 0;
                 if (s->slot_left[si].fetch_sub(1u, std::memory_order_acq_rel) == 1u) {  // the chunk's last group
                     {
@@ -1137,7 +1174,7 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
     uint64_t pos = 0;
     if (s->count_patterns) hash_patterns(s, d_rows, n_rows);
     const uint64_t depth = s->direct ? (uint64_t)s->n_slots : 1;  // squeezed mode has a single squeeze buffer
-    uint64_t sub = 0, pub = 0;  // chunks submitted / published in this feed (the control thread is their only writer)
+    uint64_t sub = 0, cpy = 0, pub = 0;  // chunks submitted / record copies ordered / published in this feed
     bool running = false;
     std::chrono::steady_clock::time_point t_start;
     auto replayed = [&]() { return s->seq_replayed.load(std::memory_order_acquire); };
@@ -1206,7 +1243,16 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
                 s->seq_submitted.store(sub, std::memory_order_release);
                 pos += c;
             }
-            if (pub < sub) {  // publish the oldest chunk the GPU still owes
+            // Coarse chunks hand their records over in two steps: counts first (compute stream), then exactly that many
+            // records on the copy stream, ordered here as soon as the counts are in - before waiting for an older
+            // chunk's copy if this chunk's counts are already there, so the copy engine never waits for this thread.
+            if (cpy < sub && (cpy == pub || hipEventQuery(s->slot[(size_t)(cpy % (uint64_t)s->n_slots)].ev_counts) == hipSuccess ||
+                              !s->slot[(size_t)(cpy % (uint64_t)s->n_slots)].used_coarse)) {
+                fetch_records(s, s->slot[(size_t)(cpy % (uint64_t)s->n_slots)]);
+                cpy++;
+                continue;
+            }
+            if (pub < cpy) {  // publish the oldest chunk the GPU still owes
                 Slot& sl = s->slot[(size_t)(pub % (uint64_t)s->n_slots)];
                 {
                     auto w0 = std::chrono::steady_clock::now();
@@ -1628,6 +1674,11 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
             s->d_surv_cnt.alloc(P);
             s->d_surv_off.alloc(P);
             s->d_key_count.alloc(1);
+            s->d_tile_pref.alloc(P + 1);
+            s->d_tile_cnt.alloc((size_t)s->key_slots / 256 + P + 2);
+            s->d_tile_off.alloc((size_t)s->key_slots / 256 + P + 2);
+            s->d_tmp_score.alloc(s->key_slots);
+            KGWAS_HIP(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
             size_t tb = 0;
             KGWAS_HIP(surv_sort_temp_bytes(s->key_slots, &tb));
             s->d_sort_tmp.alloc(std::max<size_t>(tb, 16));
@@ -1644,20 +1695,22 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
             const bool is_redo = si == s->n_slots;
             Slot& sl = is_redo ? s->redo : s->slot[si];
             if (s->coarse && !is_redo) {
-                sl.so_score.alloc((uint64_t)s->cap * P);
-                sl.so_kmer.alloc((uint64_t)s->cap * P);
-                sl.so_row.alloc((uint64_t)s->cap * P);
-                sl.d_so_score = sl.so_score.dev();
-                sl.d_so_kmer = sl.so_kmer.dev();
-                sl.d_so_row = sl.so_row.dev();
+                sl.so_score.alloc(s->key_slots);
+                sl.so_kmer.alloc(s->key_slots);
+                sl.so_row.alloc(s->key_slots);
+                sl.d_so_score.alloc(s->key_slots);
+                sl.d_so_kmer.alloc(s->key_slots);
+                sl.d_so_row.alloc(s->key_slots);
+                sl.d_meta.alloc(2 * P + 2);
+                sl.h_meta.alloc(2 * P + 2);
+                memset(sl.h_meta.p, 0, (2 * P + 2) * sizeof(uint32_t));
+                KGWAS_HIP(hipEventCreateWithFlags(&sl.ev_counts, hipEventBlockingSync));
             } else {
                 sl.cand.alloc((uint64_t)s->cap * P);
                 sl.d_cand = sl.cand.dev();
             }
             sl.d_cnt.alloc(P);
             sl.h_cnt.alloc(P);
-            sl.h_surv_cnt.alloc(P + 1);
-            memset(sl.h_surv_cnt.p, 0, (P + 1) * sizeof(uint32_t));
             sl.d_tested.alloc(TESTED_SHARDS);
             sl.h_tested.alloc(TESTED_SHARDS);
             KGWAS_HIP(hipEventCreate(&sl.ev_sq0));
@@ -1688,14 +1741,33 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
             if (atoi(e) > 0) nt = (unsigned)atoi(e);
         nt = (unsigned)std::min<uint64_t>(nt, P);
         s->pool.reset(new Pool(nt, pick_replay_cpus(nt, s->device)));
-        // Column groups of the replay: about two per worker (so that (chunk, group) units balance over the workers),
-        // at most MAX_LOCKSTEP columns each (a group's heaps take their replacements in lockstep).
+        // Column groups of the replay. Worker w owns the columns w, w + T, ... of the first floor(P / T) * T columns,
+        // in groups of at most MAX_LOCKSTEP (a group's heaps take their replacements in lockstep, and stay in their
+        // worker's cache from chunk to chunk); the P mod T columns left over float: each is a group of its own that
+        // whichever worker is furthest ahead takes, which evens out what a static map cannot (101 columns on 16
+        // workers is 5 x 7 + 11 x 6: the 7-column workers set the pace, 17 % above the mean).
         {
-            uint64_t gsize = (P + 2ull * nt - 1) / (2ull * nt);
-            gsize = std::max<uint64_t>(1, std::min<uint64_t>(gsize, (uint64_t)BestHeap::MAX_LOCKSTEP));
+            const uint64_t T = nt, base = P / T;
+            const uint64_t MKc = (uint64_t)BestHeap::MAX_LOCKSTEP;
+            uint64_t per = base ? (base + ((base + MKc - 1) / MKc) - 1) / ((base + MKc - 1) / MKc) : 0;  // balanced split
             if (const char* e = getenv("KGWAS_REPLAY_GROUP"))
-                if (atoi(e) > 0) gsize = std::min<uint64_t>((uint64_t)atoi(e), (uint64_t)BestHeap::MAX_LOCKSTEP);
-            s->n_groups = (size_t)((P + gsize - 1) / gsize);
+                if (atoi(e) > 0 && per) per = std::min<uint64_t>((uint64_t)atoi(e), MKc);
+            for (uint64_t w = 0; w < T && base; w++) {
+                std::vector<uint32_t> cur;
+                for (uint64_t i = 0; i < base; i++) {
+                    cur.push_back((uint32_t)(i * T + w));
+                    if (cur.size() == per || i + 1 == base) {
+                        s->grp_cols.push_back(cur);
+                        s->grp_home.push_back((int)w);
+                        cur.clear();
+                    }
+                }
+            }
+            for (uint64_t j = base * T; j < P; j++) {
+                s->grp_cols.push_back(std::vector<uint32_t>(1, (uint32_t)j));
+                s->grp_home.push_back(-1);
+            }
+            s->n_groups = s->grp_cols.size();
             s->gstate.reset(new kgwas_scan::GroupState[s->n_groups]);
             s->slot_left.reset(new std::atomic<uint32_t>[MAX_SLOTS]);
             for (int i = 0; i < MAX_SLOTS; i++) s->slot_left[i].store(0);

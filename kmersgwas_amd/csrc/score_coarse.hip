@@ -420,55 +420,176 @@ __global__ void __launch_bounds__(512) coarse_kernel(CoarseArgs a, uint32_t rows
     }
 }
 
-// Exact re-scoring of the survivors of one phenotype column (blockIdx.y), one lane per survivor.
-// Same arithmetic as score_valu_kernel: the reference's select-and-add chains, then finish_pair.
+// ---- survivors -> exact candidates, compacted in (column, row) order --------------------------------------------
+// The sorted key list is cut into tiles of 256 survivors that never straddle a column (tile_prefix_kernel); the three
+// kernels below walk the tiles with a fixed grid:
+//   rescore_kernel      exact re-scoring of a tile's survivors (one lane each, the column wave-uniform), exact test
+//                       against thr, threshold histogram; score (or -inf: not a candidate) to HBM, candidates per tile
+//   tile_scan_kernel    exclusive scan of the tiles' candidate counts: where each tile's candidates go, each column's
+//                       range in the compacted list, their total
+//   compact_kernel      candidates to their final place: score f64 | kmer u64 | chunk-local row u32, three arrays
+// The compacted arrays live in HBM; the host copies exactly `total` records per array over PCIe on a copy stream
+// (the first version wrote every survivor, candidate or not, from the kernel into mapped host memory: 20 B per
+// survivor over PCIe inside the compute stream, 7 ms of a 22 ms pass).
+__device__ __forceinline__ uint32_t tile_column(const uint32_t* tile_pref, uint32_t n_pheno, uint32_t t) {
+    uint32_t lo = 0, hi = n_pheno;  // last p with tile_pref[p] <= t
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (tile_pref[mid] <= t) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void __launch_bounds__(256) tile_prefix_kernel(const uint32_t* surv_cnt, uint32_t n_pheno, uint32_t* tile_pref) {
+    __shared__ uint32_t carry, part[256];
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t p0 = 0; p0 < n_pheno; p0 += 256u) {
+        const uint32_t p = p0 + threadIdx.x;
+        const uint32_t v = p < n_pheno ? (surv_cnt[p] + 255u) / 256u : 0u;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (uint32_t d = 1; d < 256u; d <<= 1) {  // inclusive scan
+            const uint32_t x = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+            __syncthreads();
+            part[threadIdx.x] += x;
+            __syncthreads();
+        }
+        if (p < n_pheno) tile_pref[p] = carry + part[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 255u) carry += part[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tile_pref[n_pheno] = carry;
+}
+
+// Same arithmetic as score_valu_kernel: the reference's select-and-add chains, then the exact candidate test.
 __global__ void __launch_bounds__(256) rescore_kernel(ScoreArgs a, const uint32_t* keys, const uint32_t* surv_off,
-                                                      const uint32_t* surv_cnt, uint32_t surv_cap, uint32_t row_mask) {
-    const uint32_t p = blockIdx.y;
-    const uint32_t n = surv_cnt[p];
-    if (n > surv_cap) return;  // overflow: the host redoes this chunk
-    if (blockIdx.x * 256u >= n) return;  // block-uniform
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    const bool valid = i < n;
-    const uint64_t r = keys[surv_off[p] + (valid ? i : 0u)] & row_mask;
-    const uint32_t* rp = a.src.base + r * a.src.stride_dw + a.src.off_dw;
+                                                      const uint32_t* surv_cnt, const uint32_t* tile_pref, uint32_t row_mask,
+                                                      double* tmp_score, uint32_t* tile_cnt) {
+    __shared__ uint32_t wcnt[4];
+    const uint32_t n_tiles = tile_pref[a.n_pheno];
     const uint32_t L = 64u * a.W_m;
     const uint32_t nblk = a.W_m / 2u;
-    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    uint32_t n1 = 0;
-    for (uint32_t b = 0; b < nblk; b++) {
-        uint32_t w[4];
+    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const uint32_t p = tile_column(tile_pref, a.n_pheno, t);
+        const uint32_t i = (t - tile_pref[p]) * 256u + threadIdx.x;
+        const bool valid = i < surv_cnt[p];
+        const uint32_t gi = surv_off[p] + (valid ? i : 0u);
+        const uint64_t r = keys[gi] & row_mask;
+        const uint32_t* rp = a.src.base + r * a.src.stride_dw + a.src.off_dw;
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        uint32_t n1 = 0;
+        for (uint32_t b = 0; b < nblk; b++) {
+            uint32_t w[4];
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-            uint2 v = make_uint2(0u, 0u);
-            if (4u * b + 2u * h + 1u < a.src.avail_dw) v = *reinterpret_cast<const uint2*>(rp + 4u * b + 2u * h);
-            w[2 * h] = v.x & a.dmask[4 * b + 2 * h];
-            w[2 * h + 1] = v.y & a.dmask[4 * b + 2 * h + 1];
-        }
-        n1 += __popc(w[0]) + __popc(w[1]) + __popc(w[2]) + __popc(w[3]);
-        const float* yb = a.Yperm + (size_t)p * L + 128u * b;
-#pragma unroll
-        for (int s = 0; s < 32; s++)
-#pragma unroll
-            for (int l = 0; l < 4; l++) {
-                const int mk = ((int)(w[l] << s)) >> 31;
-                acc[l] = acc[l] + __int_as_float(mk & __float_as_int(yb[4 * s + l]));
+            for (int h = 0; h < 2; h++) {
+                uint2 v = make_uint2(0u, 0u);
+                if (4u * b + 2u * h + 1u < a.src.avail_dw) v = *reinterpret_cast<const uint2*>(rp + 4u * b + 2u * h);
+                w[2 * h] = v.x & a.dmask[4 * b + 2 * h];
+                w[2 * h + 1] = v.y & a.dmask[4 * b + 2 * h + 1];
             }
+            n1 += __popc(w[0]) + __popc(w[1]) + __popc(w[2]) + __popc(w[3]);
+            const float* yb = a.Yperm + (size_t)p * L + 128u * b;
+#pragma unroll
+            for (int s = 0; s < 32; s++)
+#pragma unroll
+                for (int l = 0; l < 4; l++) {
+                    const int mk = ((int)(w[l] << s)) >> 31;
+                    acc[l] = acc[l] + __int_as_float(mk & __float_as_int(yb[4 * s + l]));
+                }
+        }
+        const float yf = ((acc[0] + acc[1]) + acc[2]) + acc[3];
+        double q, d, sc, out = -__builtin_huge_val();
+        score_terms(a, yf, n1, a.sums[p], q, d);
+        if (valid && mac_pass(a, n1) && candidate_score(a, p, q, d, a.thr[p], sc)) out = sc;
+        if (valid) tmp_score[gi] = out;
+        const uint32_t c = __popcll(__ballot(out != -__builtin_huge_val()));
+        if ((threadIdx.x & 63u) == 0u) wcnt[threadIdx.x >> 6] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) tile_cnt[t] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        __syncthreads();
     }
-    if (!valid) return;
-    const float yf = ((acc[0] + acc[1]) + acc[2]) + acc[3];
-    if (!a.so_score) {
-        finish_pair(a, r, p, yf, n1, mac_pass(a, n1), a.sums[p], a.thr[p]);
-        return;
+}
+
+// meta: [0 .. P) candidates per column, [P .. 2P) each column's offset in the compacted arrays, [2P] their total,
+// [2P + 1] the survivor keys the coarse kernel emitted (> key_cap: the list overflowed).
+__global__ void __launch_bounds__(1024) tile_scan_kernel(const uint32_t* tile_cnt, const uint32_t* tile_pref, uint32_t n_pheno,
+                                                         const uint32_t* key_count, uint32_t* tile_off, uint32_t* meta) {
+    __shared__ uint32_t part[1024];
+    const uint32_t n_tiles = tile_pref[n_pheno];
+    const uint32_t per = (n_tiles + 1023u) / 1024u;
+    const uint32_t lo = threadIdx.x * per, hi = lo + per < n_tiles ? lo + per : n_tiles;
+    uint32_t s = 0;
+    for (uint32_t i = lo; i < hi; i++) s += tile_cnt[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {
+        const uint32_t x = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += x;
+        __syncthreads();
     }
-    // Ordered mode: the survivor list is sorted by row, entry i goes to position i (coalesced).
-    double q, d, s, out = -__builtin_huge_val();
-    score_terms(a, yf, n1, a.sums[p], q, d);
-    if (mac_pass(a, n1) && candidate_score(a, p, q, d, a.thr[p], s)) out = s;
-    const uint64_t o = (uint64_t)p * surv_cap + i;
-    a.so_score[o] = out;
-    a.so_kmer[o] = a.file_rows[r * a.file_stride_w];
-    a.so_row[o] = (uint32_t)r;
+    uint32_t run = part[threadIdx.x] - s;
+    for (uint32_t i = lo; i < hi; i++) {
+        tile_off[i] = run;
+        run += tile_cnt[i];
+    }
+    if (threadIdx.x == 1023u) tile_off[n_tiles] = part[1023];
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < n_pheno; p += 1024u) {
+        const uint32_t a = tile_off[tile_pref[p]], b = tile_off[tile_pref[p + 1]];
+        meta[p] = b - a;
+        meta[n_pheno + p] = a;
+    }
+    if (threadIdx.x == 0) {
+        meta[2u * n_pheno] = part[1023];
+        meta[2u * n_pheno + 1u] = *key_count;
+    }
+}
+
+__global__ void __launch_bounds__(256) compact_kernel(ScoreArgs a, const uint32_t* keys, const uint32_t* surv_off,
+                                                      const uint32_t* surv_cnt, const uint32_t* tile_pref, uint32_t row_mask,
+                                                      const double* tmp_score, const uint32_t* tile_off) {
+    __shared__ uint32_t wcnt[4];
+    const uint32_t n_tiles = tile_pref[a.n_pheno];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        if (tile_off[t + 1] == tile_off[t]) continue;  // block-uniform: no candidate in this tile
+        const uint32_t p = tile_column(tile_pref, a.n_pheno, t);
+        const uint32_t i = (t - tile_pref[p]) * 256u + threadIdx.x;
+        const bool valid = i < surv_cnt[p];
+        const uint32_t gi = surv_off[p] + (valid ? i : 0u);
+        const double sc = valid ? tmp_score[gi] : -__builtin_huge_val();
+        const bool is_cand = sc != -__builtin_huge_val();
+        const unsigned long long bal = __ballot(is_cand);
+        if (lane == 0) wcnt[wave] = __popcll(bal);
+        __syncthreads();
+        uint32_t before = __popcll(bal & ((1ull << lane) - 1ull));
+        for (uint32_t w = 0; w < wave; w++) before += wcnt[w];
+        if (is_cand) {
+            const uint32_t r = keys[gi] & row_mask;
+            const uint32_t o = tile_off[t] + before;
+            a.so_score[o] = sc;
+            a.so_kmer[o] = a.file_rows[(uint64_t)r * a.file_stride_w];
+            a.so_row[o] = r;
+        }
+        __syncthreads();
+    }
+}
+
+// One launch instead of a handful of small memsets per chunk: counters of the next chunk.
+__global__ void chunk_prep_kernel(uint32_t* cand_cnt, uint32_t n_pheno, unsigned long long* tested, uint32_t* key_count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_pheno) cand_cnt[i] = 0u;
+    if (i < TESTED_SHARDS) tested[i] = 0ull;
+    if (i == 0 && key_count) *key_count = 0u;
+}
+
+hipError_t launch_chunk_prep(uint32_t* cand_cnt, uint32_t n_pheno, unsigned long long* tested, uint32_t* key_count, hipStream_t st) {
+    const uint32_t n = n_pheno > TESTED_SHARDS ? n_pheno : TESTED_SHARDS;
+    hipLaunchKernelGGL(chunk_prep_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, cand_cnt, n_pheno, tested, key_count);
+    return hipGetLastError();
 }
 
 // B operands of one LDS group + the group's per-column constants (3 x up to 128 words) + the block's survivor buffer
@@ -532,11 +653,17 @@ extern "C" int kgwas_debug_coarse_timeline(unsigned long long* out, unsigned lon
 #endif
 
 hipError_t launch_rescore(const ScoreArgs& a, const uint32_t* keys, const uint32_t* surv_off, const uint32_t* surv_cnt,
-                          uint32_t surv_cap, uint32_t row_bits, hipStream_t st) {
-    if (a.n_pheno == 0 || surv_cap == 0) return hipSuccess;
+                          uint32_t row_bits, uint32_t* tile_pref, uint32_t* tile_cnt, uint32_t* tile_off, double* tmp_score,
+                          const uint32_t* key_count, uint32_t* meta, hipStream_t st) {
+    if (a.n_pheno == 0) return hipSuccess;
     const uint32_t row_mask = row_bits >= 32 ? 0xFFFFFFFFu : ((1u << row_bits) - 1u);
-    hipLaunchKernelGGL(rescore_kernel, dim3((surv_cap + 255u) / 256u, a.n_pheno), dim3(256), 0, st, a, keys, surv_off, surv_cnt,
-                       surv_cap, row_mask);
+    hipLaunchKernelGGL(tile_prefix_kernel, dim3(1), dim3(256), 0, st, surv_cnt, a.n_pheno, tile_pref);
+    // fixed grid, tiles handed out round-robin: 8 blocks of 256 per CU (the tile count is only known on the device)
+    hipLaunchKernelGGL(rescore_kernel, dim3(2048), dim3(256), 0, st, a, keys, surv_off, surv_cnt, tile_pref, row_mask, tmp_score,
+                       tile_cnt);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, tile_cnt, tile_pref, a.n_pheno, key_count, tile_off, meta);
+    hipLaunchKernelGGL(compact_kernel, dim3(2048), dim3(256), 0, st, a, keys, surv_off, surv_cnt, tile_pref, row_mask, tmp_score,
+                       tile_off);
     return hipGetLastError();
 }
 
