@@ -196,6 +196,36 @@ int kgwas_scan_heaps_export(kgwas_scan* s, uint64_t n_cols, const uint64_t* cols
 int kgwas_scan_heaps_import(kgwas_scan* s, uint64_t n_cols, const uint64_t* cols, const uint64_t* sizes, const uint64_t* kmer,
                             const double* score, const uint64_t* row);
 
+/* ------------------------------------------------------------------------------------
+ * The same scan over several GPUs of one node, inside one process (the reference's caller, kmers_gwas.py:133-148, runs
+ * ONE associate_kmers binary): the rows are cut into n_devices contiguous shards in file order, shard g is scanned on
+ * devices[g] by its own session and host thread (a device may be listed more than once), no data moves between the
+ * devices during the scan, and the later shards' effective heap pushes that can still matter are then replayed, in
+ * row order, into shard 0's heaps (kgwas_scan_history_above / kgwas_scan_absorb). Results are those of a single scan.
+ * p->device is ignored; p->host_threads is the replay-thread budget of the whole job (divided among the shards);
+ * p->record_history applies to shard 0 (later shards keep what the merge needs; a shard whose eviction ring turns out
+ * too short is scanned again with the full log). kgwas_multiscan_run_* may be called repeatedly with consecutive row
+ * ranges (not with count_patterns); call kgwas_multiscan_finish before reading results.
+ * ---------------------------------------------------------------------------------- */
+typedef struct kgwas_multiscan kgwas_multiscan;
+int kgwas_multiscan_create(const kgwas_scan_params* p, const int32_t* devices, uint32_t n_devices, kgwas_multiscan** out);
+/* Rows [row0, row0 + n_rows) of an open .table: shard g = the g-th of n_devices equal contiguous pieces, streamed
+ * through kgwas_scan_feed_table on its device. */
+int kgwas_multiscan_run_table(kgwas_multiscan* m, kgwas_table* t, uint64_t row0, uint64_t n_rows);
+/* Shards already resident in HBM: d_rows[g] on devices[g] holds n_rows[g] rows starting at file row first_row[g]
+ * (consecutive shards, in row order). */
+int kgwas_multiscan_run_device(kgwas_multiscan* m, const void* const* d_rows, const uint64_t* n_rows, const uint64_t* first_row);
+int kgwas_multiscan_finish(kgwas_multiscan* m);
+/* As kgwas_scan_result, for the whole table. */
+int kgwas_multiscan_result(kgwas_multiscan* m, uint64_t j, uint64_t* n, const uint64_t** kmer, const double** score,
+                           const uint64_t** row);
+/* total: counters summed over the shards (rows_tested = .tested_kmers, patterns over all shards), times of the slowest
+ * shard; per_shard [n_devices] (NULL: skip) = each session's own statistics of the last run; scan_ms / merge_ms: wall
+ * time of the shard scans and of the cross-shard merges so far; rescans: shards scanned twice (ring too short). */
+int kgwas_multiscan_get_stats(const kgwas_multiscan* m, kgwas_scan_stats* total, kgwas_scan_stats* per_shard, double* scan_ms,
+                              double* merge_ms, uint64_t* rescans);
+void kgwas_multiscan_destroy(kgwas_multiscan* m);
+
 /* calculate_kmer_score for every row and phenotype column (src/kmers_multiple_databases.cpp:327-363):
  * scores[j*n_rows + r] (0 for rows the MAC filter drops), popcnt[r] = masked popcount N1,
  * outputs in host memory. rows_on_device selects how `rows` is interpreted. */
@@ -229,6 +259,10 @@ int kgwas_kinship_partials(kgwas_kinship* k, uint64_t* hamming, uint64_t* n_used
 int kgwas_kinship_from_partials(uint64_t n_acc_file, const uint64_t* hamming, uint64_t n_used, uint64_t* K);
 int kgwas_kinship_get_stats(const kgwas_kinship* k, double* kernel_ms, uint64_t* launches, uint64_t* rows_fed);
 void kgwas_kinship_destroy(kgwas_kinship* k);
+/* The whole table over several devices (one process, one thread + session per device, contiguous row shards, integer
+ * partials added): hamming [S_f x S_f] and n_used as kgwas_kinship_partials gives them for a single device. */
+int kgwas_kinship_table_multi(const int32_t* devices, uint32_t n_devices, kgwas_table* t, uint64_t min_count, uint64_t* hamming,
+                              uint64_t* n_used);
 /* The matrix text emma_kinship_kmers prints to stdout (:95-111). Returns needed bytes. */
 uint64_t kgwas_kinship_format(uint64_t n_acc_file, const uint64_t* K, uint64_t n_used, char* out, uint64_t cap);
 

@@ -32,6 +32,8 @@ SYMBOLS = [
     "kgwas_scan_create", "kgwas_scan_feed_device", "kgwas_scan_feed_host", "kgwas_scan_feed_table", "kgwas_scan_finish", "kgwas_scan_result",
     "kgwas_scan_history", "kgwas_scan_get_stats", "kgwas_scan_reset", "kgwas_scan_lowest", "kgwas_scan_absorb", "kgwas_scan_history_above", "kgwas_scan_heaps_export", "kgwas_scan_heaps_import", "kgwas_scan_destroy", "kgwas_scan_scores_dense",
     "kgwas_merge_shards",
+    "kgwas_multiscan_create", "kgwas_multiscan_run_table", "kgwas_multiscan_run_device", "kgwas_multiscan_finish",
+    "kgwas_multiscan_result", "kgwas_multiscan_get_stats", "kgwas_multiscan_destroy", "kgwas_kinship_table_multi",
     "kgwas_kinship_create", "kgwas_kinship_feed_device", "kgwas_kinship_feed_host", "kgwas_kinship_feed_table", "kgwas_kinship_partials",
     "kgwas_kinship_from_partials", "kgwas_kinship_get_stats", "kgwas_kinship_destroy", "kgwas_kinship_format",
     "kgwas_write_plink", "kgwas_table_to_bed",
@@ -167,6 +169,15 @@ lib.kgwas_scan_destroy.argtypes = [_vp]
 lib.kgwas_scan_destroy.restype = None
 lib.kgwas_scan_scores_dense.argtypes = [_vp, _vp, C.c_int, _u64, _vp, _vp]
 lib.kgwas_merge_shards.argtypes = [_u64, _vp, _u64, _vp, _pp, _pp, _pp, _u32, _pp]
+lib.kgwas_multiscan_create.argtypes = [C.POINTER(ScanParams), _vp, _u32, _pp]
+lib.kgwas_multiscan_run_table.argtypes = [_vp, _vp, _u64, _u64]
+lib.kgwas_multiscan_run_device.argtypes = [_vp, _pp, _vp, _vp]
+lib.kgwas_multiscan_finish.argtypes = [_vp]
+lib.kgwas_multiscan_result.argtypes = [_vp, _u64, _pu64, C.POINTER(_pu64), C.POINTER(_pdbl), C.POINTER(_pu64)]
+lib.kgwas_multiscan_get_stats.argtypes = [_vp, C.POINTER(ScanStats), _vp, _pdbl, _pdbl, _pu64]
+lib.kgwas_multiscan_destroy.argtypes = [_vp]
+lib.kgwas_multiscan_destroy.restype = None
+lib.kgwas_kinship_table_multi.argtypes = [_vp, _u32, _vp, _u64, _vp, _pu64]
 lib.kgwas_kinship_create.argtypes = [_i32, _u64, _u64, _pp]
 lib.kgwas_kinship_feed_device.argtypes = [_vp, _vp, _u64, _vp]
 lib.kgwas_kinship_feed_host.argtypes = [_vp, _vp, _u64]

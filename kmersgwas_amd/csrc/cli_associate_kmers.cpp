@@ -10,7 +10,9 @@
 // Differences from the reference, all invisible to the pipeline: the table is read once (the
 // winners' rows are fetched by file row index instead of a second full pass, :167-195);
 // --parallel sizes the host replay pool instead of a per-column scoring pool; extra options
-// --device and --kernel select the GPU and the scoring kernel.
+// --device and --kernel select the GPU and the scoring kernel, --gpus N row-shards the table over N GPUs of the
+// node inside this one process (kgwas_multiscan: contiguous shards in file order, one session and host thread per
+// GPU, later shards' heap histories replayed into the first shard's heaps; output files are the same).
 #include <sys/time.h>
 
 #include <cmath>
@@ -58,7 +60,8 @@ int main(int argc, char* argv[]) {
         {"mac", 0, true, "Minor allele count", "5"},
         {"k_mers_scores", 0, false, "output the best k_mers scores in binary format", ""},
         {"pattern_counter", 0, false, "Count the number of unique presence/absence patterns", ""},
-        {"device", 0, true, "GPU ordinal", "0"},
+        {"device", 0, true, "GPU ordinal (with --gpus: the first of N consecutive ordinals)", "0"},
+        {"gpus", 0, true, "row-shard the table over this many GPUs (ordinals wrap around the GPUs present)", "1"},
         {"kernel", 0, true, "scoring kernel: 0 auto, 1 vector ALU, 2 f32 MFMA, 3 int8 coarse filter + exact re-score", "0"},
         {"help", 0, false, "print help", ""},
     });
@@ -124,14 +127,37 @@ int main(int argc, char* argv[]) {
         sp.kernel = (uint32_t)vm.u64("kernel", 0);
         sp.record_history = 0;
         sp.count_patterns = vm.count("pattern_counter") ? 1 : 0;
+        // --gpus N: N contiguous row shards, shard g on GPU (device + g) modulo the GPUs present
+        const uint64_t n_gpus = vm.u64("gpus", 1);
+        if (n_gpus < 1 || n_gpus > 64) {
+            cerr << "gpus has to be between 1-64" << endl;
+            exit(1);
+        }
         kgwas_scan* scan = nullptr;
-        ck(kgwas_scan_create(&sp, &scan));
+        kgwas_multiscan* mscan = nullptr;
+        if (n_gpus > 1) {
+            int present = 0;
+            ck(kgwas_device_count(&present));
+            if (present < 1) {
+                cerr << "associate_kmers: no HIP device available: libkgwas has no CPU fallback" << endl;
+                exit(3);
+            }
+            vector<int32_t> devs(n_gpus);
+            for (uint64_t g = 0; g < n_gpus; g++) devs[g] = (int32_t)((sp.device + g) % (uint64_t)present);
+            if ((uint64_t)present < n_gpus)
+                cerr << "[kgwas] " << n_gpus << " shards on " << present << " GPU(s)" << endl;
+            ck(kgwas_multiscan_create(&sp, devs.data(), (uint32_t)n_gpus, &mscan));
+        } else {
+            ck(kgwas_scan_create(&sp, &scan));
+        }
 
         // Pass 1: stream the table through the GPU in file order. The reference loads a batch, then associates it
         // (src/associate_kmers.cpp:104-148); here a batch is read, copied and scored in overlapping 128 MiB pieces
         // (kgwas_scan_feed_table), so no batch-sized host buffer exists and "Load" is hidden behind "Associations".
-        // The per-batch progress lines keep the reference's wording; batch_size only sets their granularity.
+        // The per-batch progress lines keep the reference's wording; batch_size only sets their granularity (with
+        // --gpus the whole table is one batch: every GPU streams its own shard).
         if (batch_size == 0) batch_size = 1;
+        if (mscan) batch_size = std::max<uint64_t>(n_rows, 1);
         double t0 = now_s(), t1;
         size_t batch_index = 0;
         for (uint64_t row0 = 0; row0 < n_rows; row0 += batch_size) {
@@ -139,23 +165,36 @@ int main(int argc, char* argv[]) {
             t1 = now_s();
             cerr << "Load [" << batch_index << "]\t" << (t1 - t0) / 60. << "min" << endl;
             t0 = now_s();
-            ck(kgwas_scan_feed_table(scan, tbl, row0, n));
+            if (mscan)
+                ck(kgwas_multiscan_run_table(mscan, tbl, row0, n));
+            else
+                ck(kgwas_scan_feed_table(scan, tbl, row0, n));
             for (uint64_t j = 0; j < phenotypes_n; j++) cerr << ".";
             t1 = now_s();
             cerr << "Associations [" << batch_index << "]\t" << (t1 - t0) / 60. << "min" << endl;
             t0 = now_s();
             batch_index++;
         }
-        ck(kgwas_scan_finish(scan));
         kgwas_scan_stats st;
-        ck(kgwas_scan_get_stats(scan, &st));
+        double scan_ms = 0, merge_ms = 0;
+        uint64_t rescans = 0;
+        if (mscan) {
+            ck(kgwas_multiscan_finish(mscan));
+            ck(kgwas_multiscan_get_stats(mscan, &st, nullptr, &scan_ms, &merge_ms, &rescans));
+        } else {
+            ck(kgwas_scan_finish(scan));
+            ck(kgwas_scan_get_stats(scan, &st));
+        }
 
         // Outputs (:150-205)
         for (uint64_t j = 0; j < phenotypes_n; j++) {
             uint64_t n = 0;
             const uint64_t *kmer = nullptr, *row = nullptr;
             const double* score = nullptr;
-            ck(kgwas_scan_result(scan, j, &n, &kmer, &score, &row));
+            if (mscan)
+                ck(kgwas_multiscan_result(mscan, j, &n, &kmer, &score, &row));
+            else
+                ck(kgwas_scan_result(scan, j, &n, &kmer, &score, &row));
             if (vm.count("k_mers_scores")) {  // output_to_file_with_scores (best_associations_heap.cpp:82-92)
                 ofstream of(fn_base + "." + to_string(j) + ".best_kmers.scores", ios::binary);
                 for (uint64_t i = 0; i < n; i++) {
@@ -180,7 +219,10 @@ int main(int argc, char* argv[]) {
              << (st.kernel_used == KGWAS_KERNEL_COARSE ? "coarse_i8+exact" : st.kernel_used == KGWAS_KERNEL_MFMA ? "mfma_f32" : "valu")
              << " direct=" << st.direct_mode << " chunks=" << st.chunks << " score_kernel_ms=" << st.score_kernel_ms
              << " candidates=" << st.candidates << " heap_pushes=" << st.heap_pushes << endl;
-        kgwas_scan_destroy(scan);
+        if (mscan)
+            cerr << "[kgwas] gpus=" << n_gpus << " scan_ms=" << scan_ms << " merge_ms=" << merge_ms << " rescans=" << rescans << endl;
+        if (mscan) kgwas_multiscan_destroy(mscan);
+        if (scan) kgwas_scan_destroy(scan);
         kgwas_table_close(tbl);
         kgwas_pheno_free(ph);
     } catch (const std::invalid_argument& e) {

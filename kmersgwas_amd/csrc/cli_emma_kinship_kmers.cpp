@@ -33,7 +33,8 @@ int main(int argc, char* argv[]) {
         {"kmers_table", 't', true, "k-mers table path", ""},
         {"kmers_len", 'k', true, "length of k-mers", ""},
         {"maf", 0, true, "minor allele frequency", ""},
-        {"device", 0, true, "GPU ordinal", "0"},
+        {"device", 0, true, "GPU ordinal (with --gpus: the first of N consecutive ordinals)", "0"},
+        {"gpus", 0, true, "row-shard the table over this many GPUs (ordinals wrap around the GPUs present)", "1"},
         {"help", 0, false, "print help", ""},
     });
     const string desc = "Calculate a kinship matrix from the k-mers table (output to stdout)";
@@ -69,27 +70,45 @@ int main(int argc, char* argv[]) {
         ck(kgwas_table_info(tbl, &n_acc, &n_rows, &W_f, nullptr));
         const size_t min_count = (size_t)ceil(static_cast<double>(n_acc) * MAF);  // :83
         cerr << "Min count = " << min_count << endl;
-        kgwas_kinship* kin = nullptr;
-        ck(kgwas_kinship_create((int32_t)result.u64("device", 0), n_acc, min_count, &kin));
-        cerr << "loading..." << endl;
-        // the reference loads 2^20 rows, then accumulates them (:89-99); here the file read, the copy and the
-        // kernels of consecutive pieces overlap (kgwas_kinship_feed_table)
-        const uint64_t batch = 1ull << 24;
-        for (uint64_t row0 = 0; row0 < n_rows; row0 += batch) {
-            ck(kgwas_kinship_feed_table(kin, tbl, row0, std::min<uint64_t>(batch, n_rows - row0)));
-            cerr << ".";
-            cerr.flush();
+        const uint64_t n_gpus = result.u64("gpus", 1);
+        if (n_gpus < 1 || n_gpus > 64) {
+            cerr << "gpus has to be between 1-64" << endl;
+            exit(1);
         }
         vector<uint64_t> H(n_acc * n_acc), K(n_acc * n_acc);
         uint64_t n_snps = 0;
-        ck(kgwas_kinship_partials(kin, H.data(), &n_snps));
+        cerr << "loading..." << endl;
+        if (n_gpus > 1) {
+            // contiguous row shards, one session + thread per GPU, integer partials added (kgwas_kinship_table_multi)
+            int present = 0;
+            ck(kgwas_device_count(&present));
+            if (present < 1) {
+                cerr << "emma_kinship_kmers: no HIP device available: libkgwas has no CPU fallback" << endl;
+                exit(3);
+            }
+            vector<int32_t> devs(n_gpus);
+            for (uint64_t g = 0; g < n_gpus; g++) devs[g] = (int32_t)((result.u64("device", 0) + g) % (uint64_t)present);
+            ck(kgwas_kinship_table_multi(devs.data(), (uint32_t)n_gpus, tbl, min_count, H.data(), &n_snps));
+        } else {
+            kgwas_kinship* kin = nullptr;
+            ck(kgwas_kinship_create((int32_t)result.u64("device", 0), n_acc, min_count, &kin));
+            // the reference loads 2^20 rows, then accumulates them (:89-99); here the file read, the copy and the
+            // kernels of consecutive pieces overlap (kgwas_kinship_feed_table)
+            const uint64_t batch = 1ull << 24;
+            for (uint64_t row0 = 0; row0 < n_rows; row0 += batch) {
+                ck(kgwas_kinship_feed_table(kin, tbl, row0, std::min<uint64_t>(batch, n_rows - row0)));
+                cerr << ".";
+                cerr.flush();
+            }
+            ck(kgwas_kinship_partials(kin, H.data(), &n_snps));
+            kgwas_kinship_destroy(kin);
+        }
         ck(kgwas_kinship_from_partials(n_acc, H.data(), n_snps, K.data()));
         cerr << "#" << n_snps << endl;
         const uint64_t need = kgwas_kinship_format(n_acc, K.data(), n_snps, nullptr, 0);
         string text(need, '\0');
         kgwas_kinship_format(n_acc, K.data(), n_snps, &text[0], need);
         cout << text;
-        kgwas_kinship_destroy(kin);
         kgwas_table_close(tbl);
     } catch (const std::invalid_argument& e) {
         cerr << "error parsing options: " << e.what() << endl;

@@ -1326,6 +1326,20 @@ void check_device(int device) {
 
 }  // namespace
 
+namespace kgwas {
+unsigned usable_cpus_quota() { return usable_cpus(); }
+// multiscan.cpp: the pattern hashes this session has collected so far (for the distinct count over all shards)
+void scan_patterns_peek(kgwas_scan* s, const uint64_t** d_hashes, uint64_t* n, int* device) {
+    KGWAS_HIP(hipSetDevice(s->device));
+    KGWAS_HIP(hipStreamSynchronize(s->stream));
+    unsigned long long c = 0;
+    if (s->count_patterns) KGWAS_HIP(hipMemcpy(&c, s->d_pat_cnt.p, 8, hipMemcpyDeviceToHost));
+    *d_hashes = s->d_pat.p;
+    *n = c;
+    *device = s->device;
+}
+}  // namespace kgwas
+
 extern "C" {
 
 int kgwas_device_count(int* n_devices) {

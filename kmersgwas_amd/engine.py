@@ -304,6 +304,89 @@ class AssociationScan:
         self.close()
 
 
+class MultiDeviceScan:
+    """kgwas_multiscan: pass 1 of associate_kmers with the table row-sharded over `devices` (one entry per shard; a
+    device may appear more than once) inside this process - what `associate_kmers --gpus N` runs."""
+
+    def __init__(self, n_acc_file: int, col, Y, topn, min_count: int, devices: Sequence[int], kernel: int = capi.KERNEL_AUTO,
+                 chunk_rows: int = 0, host_threads: int = 0, count_patterns: bool = False):
+        self.col = np.ascontiguousarray(col, np.uint64)
+        self.Y = np.ascontiguousarray(Y, np.float32)
+        if self.Y.ndim == 1:
+            self.Y = self.Y[None, :]
+        self.n_pheno, self.n_acc = self.Y.shape
+        self.topn = np.ascontiguousarray(np.broadcast_to(np.asarray(topn, np.uint64), (self.n_pheno,)))
+        self.devices = np.ascontiguousarray(devices, np.int32)
+        self.words_per_row = (n_acc_file + 63) // 64
+        p = capi.ScanParams()
+        p.struct_size = C.sizeof(capi.ScanParams)
+        p.device = 0
+        p.n_acc_file = n_acc_file
+        p.n_acc = self.n_acc
+        p.col = self.col.ctypes.data_as(C.POINTER(C.c_uint64))
+        p.n_pheno = self.n_pheno
+        p.Y = self.Y.ctypes.data_as(C.POINTER(C.c_float))
+        p.topn = self.topn.ctypes.data_as(C.POINTER(C.c_uint64))
+        p.min_count = min_count
+        p.chunk_rows = chunk_rows
+        p.host_threads = host_threads
+        p.kernel = kernel
+        p.record_history = 0
+        p.count_patterns = 1 if count_patterns else 0
+        self._h = C.c_void_p()
+        check(lib.kgwas_multiscan_create(C.byref(p), ptr(self.devices), len(self.devices), C.byref(self._h)))
+
+    def run_table(self, table: "KmersTable", row0: int, n_rows: int):
+        check(lib.kgwas_multiscan_run_table(self._h, table._h, row0, n_rows))
+
+    def run_device(self, d_ptrs: Sequence[int], n_rows: Sequence[int], first_rows: Sequence[int]):
+        G = len(self.devices)
+        pp = (C.c_void_p * G)(*[C.c_void_p(int(x)) for x in d_ptrs])
+        nr = np.ascontiguousarray(n_rows, np.uint64)
+        fr = np.ascontiguousarray(first_rows, np.uint64)
+        check(lib.kgwas_multiscan_run_device(self._h, pp, ptr(nr), ptr(fr)))
+
+    def finish(self):
+        check(lib.kgwas_multiscan_finish(self._h))
+
+    def result(self, j: int):
+        n = C.c_uint64()
+        k, s, r = C.POINTER(C.c_uint64)(), C.POINTER(C.c_double)(), C.POINTER(C.c_uint64)()
+        check(lib.kgwas_multiscan_result(self._h, j, C.byref(n), C.byref(k), C.byref(s), C.byref(r)))
+        m = n.value
+        if m == 0:
+            return np.zeros(0, np.uint64), np.zeros(0, np.float64), np.zeros(0, np.uint64)
+        return (np.ctypeslib.as_array(k, shape=(m,)).copy(), np.ctypeslib.as_array(s, shape=(m,)).copy(),
+                np.ctypeslib.as_array(r, shape=(m,)).copy())
+
+    def stats(self) -> dict:
+        G = len(self.devices)
+        tot = capi.ScanStats()
+        per = (capi.ScanStats * G)()
+        sm, mm, rs = C.c_double(), C.c_double(), C.c_uint64()
+        check(lib.kgwas_multiscan_get_stats(self._h, C.byref(tot), per, C.byref(sm), C.byref(mm), C.byref(rs)))
+        d = tot.as_dict()
+        d.update(scan_ms=sm.value, merge_ms=mm.value, rescans=rs.value, per_shard=[x.as_dict() for x in per])
+        return d
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.kgwas_multiscan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+def kinship_table_multi(table: "KmersTable", min_count: int, devices: Sequence[int]):
+    """emma_kinship_kmers' accumulation over the whole table, row-sharded over `devices`: (K, n_used)."""
+    dv = np.ascontiguousarray(devices, np.int32)
+    H = np.zeros((table.n_acc, table.n_acc), np.uint64)
+    n = C.c_uint64()
+    check(lib.kgwas_kinship_table_multi(ptr(dv), len(dv), table._h, min_count, ptr(H), C.byref(n)))
+    return kinship_from_partials(H, n.value), n.value
+
+
 def merge_shards(topn, shard_histories, threads: int = 0):
     """Cross-shard merge. shard_histories[g][j] = (kmer, score, row) arrays of shard g (row order),
     shards listed in row order. Returns one BestAssociationsHeap per phenotype column."""

@@ -106,6 +106,45 @@ def test_associate_kmers_permutations_subset_scores(tmp_path, kernel):
     assert r.returncode != 0 and "Couldn't find path for DB: not_in_table" in r.stderr
 
 
+@pytest.mark.parametrize("gpus", ["2", "3"])
+def test_associate_kmers_gpus_row_sharded(tmp_path, gpus):
+    """--gpus N: the table row-sharded over N scan sessions inside the one process (kgwas_multiscan; with fewer GPUs
+    present the shards share them), later shards merged into the first: every output file byte-identical to the
+    oracle's single scan, --pattern_counter and .tested_kmers included. Heavy ties (binary trait, duplicated rows)."""
+    names, acc, Y = onp.load_phenotypes(os.path.join(GOLD, "resistence.pheno"))
+    S_f, k = 241, 31
+    table_names = list(reversed(acc))
+    rows = random_table(150_001, S_f, seed=606, dup_frac=0.5)
+    base = str(tmp_path / "kmers_table")
+    onp.write_table(base, table_names, k, rows[:, 0], rows[:, 1:])
+    out_p, out_o = tmp_path / "prod", tmp_path / "orc"
+    out_p.mkdir(); out_o.mkdir()
+    cmd = [os.path.join(BIN, "associate_kmers"), "-p", os.path.join(GOLD, "resistence.pheno"), "-b", "pheno", "-o", str(out_p),
+           "-n", "2001", "--parallel", "4", "--kmers_table", base, "--kmer_len", "31", "--maf", "0.050000", "--mac", "5",
+           "--pattern_counter", "--gpus", gpus]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "gpus=%s" % gpus in r.stderr
+    mac = onp.min_count(241, 0.05, 5)
+    _oracle_outputs(str(out_o), "pheno", rows, S_f, table_names, acc, names, Y, 2001, mac, k)
+    pat = ob.associate(rows, S_f, onp.column_map(table_names, acc), Y, 2001, mac, count_patterns=True)["patterns"]
+    open(os.path.join(str(out_o), "pheno.pattern_counter"), "w").write("%d\n" % pat)
+    _compare_dirs(str(out_p), str(out_o))
+
+
+def test_emma_kinship_kmers_gpus(tmp_path):
+    S_f, k = 173, 31
+    rows = random_table(40_001, S_f, seed=78)
+    names = ["s%d" % i for i in range(S_f)]
+    base = str(tmp_path / "tab")
+    onp.write_table(base, names, k, rows[:, 0], rows[:, 1:])
+    r = subprocess.run([os.path.join(BIN, "emma_kinship_kmers"), "-t", base, "-k", "31", "--maf", "0.05", "--gpus", "3"], capture_output=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    mc = int(np.ceil(S_f * 0.05))
+    K, n = ob.kinship(rows, S_f, mc)
+    assert r.stdout == ob.kinship_text(K, n)
+
+
 def test_emma_kinship_kmers_stdout(tmp_path):
     S_f, k = 241, 31
     rows = random_table(50_000, S_f, seed=77)

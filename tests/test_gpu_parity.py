@@ -351,6 +351,42 @@ def test_column_distributed_merge_protocol(world, mode):
         sc.close()
 
 
+@pytest.mark.parametrize("shards", [2, 5])
+def test_multi_device_scan_equals_single_scan(tmp_path, shards):
+    """kgwas_multiscan through the library: contiguous row shards (all on device 0 here), merged in C++; the table is
+    handed over in two run calls (consecutive ranges), heaps larger than a shard's tested rows for column 0
+    (--first_phenotype_best), a shuffled phenotyped subset (squeeze path), duplicated patterns + a binary trait."""
+    S_f, S, k, P = 200, 180, 31, 7
+    rows = random_table(60_000, S_f, seed=shards, dup_frac=0.4)
+    names = ["a%d" % i for i in range(S_f)]
+    base = str(tmp_path / "t")
+    onp.write_table(base, names, k, rows[:, 0], rows[:, 1:])
+    col = np.random.default_rng(2).permutation(S_f)[:S].astype(np.uint64)
+    Y = phenotypes(S, P - 1, seed=8, binary=True)
+    mac = onp.min_count(S, 0.05, 5)
+    topn = np.full(P, 700, np.uint64)
+    topn[0] = 20_000
+    exp = ob.associate(rows, S_f, col, Y, topn, mac, threads=4)
+    tbl = kg.KmersTable(base, k)
+    ms = kg.MultiDeviceScan(S_f, col, Y, topn, mac, devices=[0] * shards, chunk_rows=4096, host_threads=4)
+    ms.run_table(tbl, 0, 35_000)
+    ms.run_table(tbl, 35_000, 25_000)
+    ms.finish()
+    for j in range(P):
+        kk, ss, rr = ms.result(j)
+        o = exp["per_pheno"][j]
+        assert (kk == o["kmer"]).all() and (rr == o["file_row"]).all() and ss.tobytes() == o["score"].tobytes(), j
+    st = ms.stats()
+    assert st["rows_tested"] == exp["tested"] and len(st["per_shard"]) == shards
+    ms.close()
+    # kinship over shards
+    mc = int(np.ceil(S_f * 0.05))
+    K, n = ob.kinship(rows, S_f, mc)
+    Kg, ng = kg.kinship_table_multi(tbl, mc, [0] * shards)
+    assert ng == n and (Kg == K).all()
+    tbl.close()
+
+
 @pytest.mark.parametrize("fresh", [True, False])
 def test_heaps_import_then_feed(fresh):
     """kgwas_scan_heaps_import promises that an imported heap goes on exactly as it would have in the exporting
