@@ -114,7 +114,7 @@ def p1_scan_record(kg, torch, table, stream, M, S, Y, topn, mac, dev, host_threa
         c_ms = sum(s["coarse_kernel_ms"] for s in sts) / passes
         f_ms = sum(s["p1_kernel_ms"] for s in sts) / passes if "p1_kernel_ms" in sts[0] else 0.0
         filt_ms = f_ms if f_ms > 0 else c_ms
-        name = {1: "score_valu_kernel", 2: "score_mfma_kernel", 3: "coarse_kernel", 4: "p1_filter_kernel"}.get(sts[-1]["kernel_used"], "?")
+        name = {1: "score_valu_kernel", 2: "score_mfma_kernel", 3: "coarse_kernel", 4: "narrow_kernel"}.get(sts[-1]["kernel_used"], "?")
         gb = M * 8.0 * W / 1e9
         return {"workload": "%dM k-mers x %d samples, 1 phenotype column, top-%d" % (M // 1_000_000, S, topn),
                 "kernel": name, "ms_per_pass": dt * 1e3, "rows_per_s": M / dt,
@@ -347,7 +347,7 @@ def main():
         avg_ms = k_ms / max(k_launch, 1)
         achieved_tflops = flop_per_row * rows_scored / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         ku = stats[-1]["kernel_used"]
-        kernel_name = {1: "score_valu_kernel", 2: "score_mfma_kernel", 3: "coarse_kernel"}[ku]
+        kernel_name = {1: "score_valu_kernel", 2: "score_mfma_kernel", 3: "coarse_kernel", 4: "narrow_kernel"}[ku]
         peak, peak_unit, dtype = F32_MFMA_PEAK_TFLOPS, "TFLOP/s", "f32"
         executed = None
         hbm_bound = False

@@ -102,6 +102,9 @@ typedef struct kgwas_scan kgwas_scan;
 #define KGWAS_KERNEL_MFMA 2 /* exact-order f32 MFMA (v_mfma_f32_16x16x4_f32) */
 #define KGWAS_KERNEL_COARSE 3 /* int8-MFMA coarse filter with a rigorous bound + exact re-scoring of survivors;
                                 the dense phase and overflow re-runs use an exact kernel. Same results. */
+#define KGWAS_KERNEL_NARROW 4 /* reported in kgwas_scan_stats.kernel_used only: the filter of scans with 1-4 phenotype
+                                columns (FP4 table bits x FP8 phenotype slices on the block-scaled MFMA; requested
+                                through KGWAS_KERNEL_AUTO or _COARSE), exact re-scoring as above. Same results. */
 
 typedef struct kgwas_scan_params {
     uint32_t struct_size;    /* sizeof(kgwas_scan_params) */

@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("KGWAS_LIB") or os.path.join(_HERE, "lib", "libkgwas.s
 
 KGWAS_OK = 0
 KGWAS_ERR_ARG, KGWAS_ERR_IO, KGWAS_ERR_FORMAT, KGWAS_ERR_DEVICE, KGWAS_ERR_STATE, KGWAS_ERR_NOMEM = -1, -2, -3, -4, -5, -6
-KERNEL_AUTO, KERNEL_VALU, KERNEL_MFMA, KERNEL_COARSE = 0, 1, 2, 3
+KERNEL_AUTO, KERNEL_VALU, KERNEL_MFMA, KERNEL_COARSE, KERNEL_NARROW = 0, 1, 2, 3, 4
 
 # Every symbol include/kgwas.h declares (tests check the library exports each one).
 SYMBOLS = [

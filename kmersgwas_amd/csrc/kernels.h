@@ -118,6 +118,37 @@ hipError_t launch_rescore(const ScoreArgs& a, const uint32_t* keys, const uint32
                           const uint32_t* key_count, uint32_t* meta, hipStream_t st);
 hipError_t launch_chunk_prep(uint32_t* cand_cnt, uint32_t n_pheno, unsigned long long* tested, uint32_t* key_count, hipStream_t st);
 
+// Narrow filter (score_narrow.hip): scans with one to four phenotype columns. FP4 table bits x three FP8 slices per
+// column on v_mfma_scale_f32_16x16x128_f8f6f4; operand row 4 p + k = slice k of phenotype column p, row 4 p + 3 = ones
+// (N1), so that lane (table row, p) of the accumulator tile holds everything its pair needs. Survivors go to the same
+// key list as the coarse filter's.
+constexpr int NARROW_SLICES = 3;
+constexpr uint32_t NARROW_MAX_COLS = 4;
+struct NarrowCol {
+    double w[NARROW_SLICES];  // 2 * u_k: the accumulators are in units of 0.5
+    double t1;                // N * c - sum  (c = sum / N rounded to double: tiny)
+    double eg, rall, rmax;    // E(N1) = eg + min(rall, N1 * rmax) >= |yigi_ref - yc|, rounded up (phenotype units)
+    double pad;               // absolute slack for the double-precision evaluation on both sides
+    float wf[3];              // float32 pre-screen: the slice weights ...
+    float slackf;             // ... and everything the pre-screen leaves out, as an upper bound on |r| (rounded up)
+};
+struct NarrowArgs {
+    RowSrc src;
+    uint64_t n_rows;
+    uint32_t S, n_pheno, min_count;
+    uint32_t n_kgroups;        // 512-sample groups
+    const uint8_t* Bn;         // [n_kgroups * 4 steps][64 lanes][32] FP8 E4M3 slice operands, see score_narrow.hip
+    const NarrowCol* cols;     // [n_pheno]
+    const double* thr;         // [n_pheno]
+    uint32_t* keys;
+    uint32_t* key_count;
+    uint32_t key_cap, row_bits;
+    unsigned long long* tested;
+    uint32_t row_off;          // added to the row index in the keys (a launch that starts inside a chunk)
+};
+size_t narrow_lds_bytes(uint32_t n_kgroups);
+hipError_t launch_narrow(const NarrowArgs& a, uint32_t rows_per_block, hipStream_t st);
+
 // Survivor keys -> (column, row) order + each column's range (surv_sort.hip). n_slots = size of the key arrays.
 hipError_t surv_sort_temp_bytes(uint32_t n_slots, size_t* bytes);
 hipError_t launch_surv_sort(const uint32_t* keys, uint32_t* keys_sorted, uint32_t n_slots, const uint32_t* key_count,

@@ -449,6 +449,10 @@ struct kgwas_scan {
         DevBuf<int8_t> d_Bq;
         DevBuf<CoarseCol> d_cols;
     } cmode[2];
+    // narrow filter (1-3 columns, score_narrow.hip): replaces coarse_kernel in the same pipeline
+    bool narrow = false;
+    DevBuf<uint8_t> d_Bn;
+    DevBuf<NarrowCol> d_ncols;
     // survivor keys of the chunk being filtered, their sorted copy, each column's range in it; shared by all chunks
     // (consumed by the re-score kernel in stream order)
     DevBuf<uint32_t> d_surv, d_surv_sorted, d_surv_cnt, d_surv_off, d_key_count;
@@ -767,7 +771,7 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
         c.n_pheno = a.n_pheno;
         c.min_count = a.min_count;
         c.n_kgroups = s->n_kgroups;
-        const int cm = pick_coarse_mode(s, n_rows);
+        const int cm = s->narrow ? 0 : pick_coarse_mode(s, n_rows);
         const kgwas_scan::CoarseMode& M = s->cmode[cm];
         sl.coarse_mode = cm;
         c.n_lgroups = M.n_lgroups;
@@ -787,6 +791,28 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
         static const uint32_t rpb_env = getenv("KGWAS_COARSE_RPB") ? (uint32_t)atoi(getenv("KGWAS_COARSE_RPB")) : 0u;  // experiments
         // rows per block: the operand tiles (up to 128 KB) are loaded into LDS once per block, so blocks are long
         // where the launch still fills the chip four times over
+        if (s->narrow) {
+            NarrowArgs na;
+            memset(&na, 0, sizeof(na));
+            na.src = a.src;
+            na.n_rows = n_rows;
+            na.S = a.S;
+            na.n_pheno = a.n_pheno;
+            na.min_count = a.min_count;
+            na.n_kgroups = s->n_kgroups;
+            na.Bn = s->d_Bn.p;
+            na.cols = s->d_ncols.p;
+            na.thr = a.thr;
+            na.keys = s->d_surv.p;
+            na.key_count = s->d_key_count.p;
+            na.key_cap = s->key_slots;
+            na.row_bits = s->row_key_bits;
+            na.tested = a.tested;
+            // (short blocks: three 4-wave blocks share a CU and a launch's block count is rarely a multiple of the
+            // 768 block slots, so long blocks leave CUs idle at the end of every launch: 4096 rows per block measured
+            // 3.4 ms per 100 M rows, 768 rows 3.0)
+            KGWAS_HIP(launch_narrow(na, rpb_env ? rpb_env : (n_rows >= (1u << 18) ? 768u : 256u), s->stream));
+        } else
         KGWAS_HIP(launch_coarse(c, M.T, rpb_env ? rpb_env : (n_rows >= (1u << 22) ? 4096u : n_rows >= (1u << 20) ? 2048u : 512u), s->stream));
         KGWAS_HIP(hipEventRecord(sl.ev_mid, s->stream));
         a.tested = nullptr;  // counted by the coarse pass
@@ -1057,7 +1083,7 @@ uint64_t next_sparse_chunk(const kgwas_scan* s) {
     // chunk of c rows ships about topn * c / rows_submitted records per column. Keep that under cap / 3.
     const double m = (double)std::max<uint64_t>(s->rows_submitted, 1);
     // (the one-slice coarse filter lists ~2.5 survivors per candidate, the two-slice one ~1)
-    const double infl = (s->coarse && !s->cmode[1].ready) ? 2.5 : 1.0;
+    const double infl = (s->coarse && !s->narrow && !s->cmode[1].ready) ? 2.5 : 1.0;  // (the narrow filter's survivors are its candidates)
     double c = m * (double)s->cap / (3.0 * infl * (double)std::max<uint64_t>(s->max_topn, 1));
     uint64_t ci = (uint64_t)std::min<double>(c, (double)s->chunk_max);
     ci = std::max<uint64_t>(ci, std::min<uint64_t>(s->dense_rows, s->chunk_max));
@@ -1065,15 +1091,29 @@ uint64_t next_sparse_chunk(const kgwas_scan* s) {
     return (ci + 127) / 128 * 128;
 }
 
+// Wait for an event of a sparse chunk: poll for a while (an event that is about to complete is seen within a
+// microsecond or two), then sleep in the driver (hipEventBlockingSync: the control thread must not occupy a CPU beside
+// the replay workers while the GPU works on a long chunk). A sleeping wait alone costs 50-500 us per wake-up, twice per
+// chunk, which is what a scan with few columns and few chunks then consists of.
+void wait_event(kgwas_scan* s, hipEvent_t ev) {
+    auto w0 = std::chrono::steady_clock::now();
+    bool done = false;
+    for (int i = 0; i < 400 && !done; i++) {
+        const hipError_t q = hipEventQuery(ev);
+        if (q == hipSuccess) done = true;
+        else if (q != hipErrorNotReady) KGWAS_HIP(q);
+        else
+            for (int k = 0; k < 20; k++) __builtin_ia32_pause();
+    }
+    if (!done) KGWAS_HIP(hipEventSynchronize(ev));
+    s->st.gpu_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+}
+
 // Coarse chunk: wait for its counts, then order the copy of exactly that many candidate records (three arrays) from
 // HBM on the copy stream; ev_done follows the copies. Other chunks recorded ev_done at submission.
 void fetch_records(kgwas_scan* s, Slot& sl) {
     if (!sl.used_coarse) return;
-    {
-        auto w0 = std::chrono::steady_clock::now();
-        KGWAS_HIP(hipEventSynchronize(sl.ev_counts));
-        s->st.gpu_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
-    }
+    wait_event(s, sl.ev_counts);
     const uint32_t n = sl.h_meta.p[2 * s->n_pheno];
     if (n && sl.h_meta.p[2 * s->n_pheno + 1] <= s->key_slots) {
         KGWAS_HIP(hipMemcpyAsync(sl.so_score.p, sl.d_so_score.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s->copy_stream));
@@ -1254,11 +1294,7 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
             }
             if (pub < cpy) {  // publish the oldest chunk the GPU still owes
                 Slot& sl = s->slot[(size_t)(pub % (uint64_t)s->n_slots)];
-                {
-                    auto w0 = std::chrono::steady_clock::now();
-                    KGWAS_HIP(hipEventSynchronize(sl.ev_done));  // records and counts are in host memory
-                    s->st.gpu_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
-                }
+                wait_event(s, sl.ev_done);  // records and counts are in host memory
                 if (chunk_complete(s, sl)) {
                     pub++;
                     {
@@ -1427,8 +1463,14 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         s->coarse = want_coarse;
         s->coarse_T = coarse_T;
         s->n_kgroups = n_kgroups;
+        // One to four columns under AUTO: the narrow filter (FP4 x FP8 block-scaled MFMA, three slices per column)
+        // instead of the int8 one, whose 16-column tiles would be mostly padding (KGWAS_NARROW=0: keep the int8 filter).
+        s->narrow = want_coarse && p->kernel == KGWAS_KERNEL_AUTO && s->n_pheno <= NARROW_MAX_COLS &&
+                    narrow_lds_bytes(n_kgroups) <= 64u * 1024u && !(getenv("KGWAS_NARROW") && atoi(getenv("KGWAS_NARROW")) == 0);
 
-        s->chunk_max = p->chunk_rows ? p->chunk_rows : (8ull << 20);
+        // (narrow filter on rows read in place: chunks of up to 32 M rows - with one column a chunk's fixed costs, sort,
+        // re-score, threshold update, weigh more than the candidates a staler threshold lets through)
+        s->chunk_max = p->chunk_rows ? p->chunk_rows : ((s->narrow && s->direct) ? (32ull << 20) : (8ull << 20));
         s->chunk_max = std::max<uint64_t>(128, (s->chunk_max + 127) / 128 * 128);
         if (s->coarse) {  // survivor keys are (column << row_bits | row) in 32 bits, the 0xFFFFFFFF fill included
             uint32_t pbits = 1;
@@ -1436,7 +1478,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
             if (pbits > 22) throw Error(KGWAS_ERR_ARG, "coarse filter: too many phenotype columns for 32-bit survivor keys");
             s->chunk_max = std::max<uint64_t>(128, std::min<uint64_t>(s->chunk_max, 1ull << (32 - pbits)));
         }
-        if (s->coarse) {  // the coarse kernel addresses a chunk's rows with 32-bit byte offsets
+        if (s->coarse && !s->narrow) {  // the coarse kernel addresses a chunk's rows with 32-bit byte offsets
             const uint64_t stride_dw = 2 * (1 + std::max<uint64_t>(s->W_f, s->W_m));
             const uint64_t lim = ((1ull << 32) - (1ull << 20)) / (4 * stride_dw) / 128 * 128;
             s->chunk_max = std::max<uint64_t>(128, std::min<uint64_t>(s->chunk_max, lim));
@@ -1446,7 +1488,9 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         // dense chunks follow while a heap is still short); everything after goes through the sparse path.
         s->dense_chunk = std::min<uint64_t>(s->dense_rows, std::max<uint64_t>(1024, (s->max_topn + s->max_topn / 8 + 512 + 127) / 128 * 128));
         const uint64_t budget = 4ull << 20;  // candidate records per slot (x 24 B x n_slots of mapped pinned memory)
-        uint64_t cap = std::min<uint64_t>(2 * s->max_topn + 4096, std::max<uint64_t>(budget / s->n_pheno, 1024));
+        // (few columns: longer lists, so that the ramp takes ~6 chunks instead of ~13 - a chunk's fixed costs, not its
+        // rows, are what a one-column scan pays for)
+        uint64_t cap = std::min<uint64_t>((s->narrow ? 8 : 2) * s->max_topn + 4096, std::max<uint64_t>(budget / s->n_pheno, 1024));
         s->cap = (uint32_t)std::min<uint64_t>(cap, 0x7FFFFFFFull);
 
         KGWAS_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
@@ -1614,6 +1658,86 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
             if (const char* e = getenv("KGWAS_COARSE_SLICES")) {
                 if (atoi(e) == 1) want[0] = true, want[1] = false;
                 if (atoi(e) == 2) want[0] = false, want[1] = true;
+            }
+            if (s->narrow) {
+                want[0] = want[1] = false;  // the int8 operand sets are not needed
+                // FP8 E4M3 operands of the narrow filter (score_narrow.hip): three slices of integers in [-15, 15] per
+                // column, y_i - c ~ sum_k u_k q_ki with u_0 = max|y_i - c| / 15 and u_{k+1} = u_k / 30 (a rounding
+                // residual of at most u_k / 2 fills the next slice's range exactly), and a ones row per column.
+                auto e4m3 = [](int v) -> uint8_t {
+                    if (v == 0) return 0;
+                    const int sg = v < 0 ? 0x80 : 0, av = std::abs(v);
+                    int e = 0;
+                    while ((2 << e) <= av) e++;
+                    return (uint8_t)(sg | ((e + 7) << 3) | ((av * 8) / (1 << e) - 8));
+                };
+                const uint64_t n_steps = 4ull * n_kgroups;
+                std::vector<uint8_t> Bn(n_steps * 64 * 32, 0);
+                std::vector<NarrowCol> ncols(P);
+                std::vector<int> q(S);
+                auto put_slot = [&](uint64_t slot, const std::vector<int>& v) {
+                    for (uint64_t g = 0; g < n_kgroups; g++)
+                        for (uint64_t jj = 0; jj < 4; jj++)
+                            for (uint64_t k = 0; k < 128; k++) {
+                                // FP4 side: k = 32 kb + 8 q + e' <-> bit 4 e' + jj of dword q of the lane's 16 bytes
+                                const uint64_t kbA = k / 32, e = k % 32, smp = 512 * g + 128 * kbA + 32 * (e / 8) + 4 * (e % 8) + jj;
+                                if (smp >= S) continue;
+                                // FP8 side: lane kb = (k % 64) / 16, byte (k / 64) * 16 + k % 16
+                                const uint64_t lane = slot + 16 * ((k % 64) / 16), byte = (k / 64) * 16 + k % 16;
+                                Bn[((g * 4 + jj) * 64 + lane) * 32 + byte] = e4m3(v[smp]);
+                            }
+                };
+                for (uint64_t j = 0; j < P; j++) {
+                    const double Nd = (double)S, sum = (double)sums[j];
+                    const double c = sum / Nd;
+                    double mx = 0, A = 0;
+                    std::vector<double> t(S);
+                    for (uint64_t i = 0; i < S; i++) {
+                        t[i] = (double)s->Y[j * S + i] - c;
+                        mx = std::max(mx, std::fabs(t[i]));
+                        A += std::fabs((double)s->Y[j * S + i]);
+                    }
+                    double u = mx > 0 ? mx / 15.0 : 1.0;
+                    NarrowCol& nc = ncols[j];
+                    for (int k = 0; k < NARROW_SLICES; k++) {
+                        for (uint64_t i = 0; i < S; i++) {
+                            int v = (int)std::lrint(t[i] / u);
+                            v = std::max(-15, std::min(15, v));
+                            q[i] = v;
+                            t[i] -= u * v;
+                        }
+                        put_slot(4 * j + k, q);  // operand row 4 p + k; 4 p + 3 = ones
+                        nc.w[k] = 2.0 * u;
+                        u /= 30.0;
+                    }
+                    double rpos = 0, rneg = 0, rmax = 0;
+                    for (uint64_t i = 0; i < S; i++) {
+                        if (t[i] > 0) rpos += t[i]; else rneg -= t[i];
+                        rmax = std::max(rmax, std::fabs(t[i]));
+                    }
+                    // (the slice products u_k * v and the running residual are evaluated in double: pad by their rounding)
+                    const double fuzz = 64.0 * std::ldexp(1.0, -52) * (mx + std::fabs(c));
+                    nc.t1 = Nd * c - sum;
+                    nc.eg = (gamma * A * (1.0 + 1e-6) + 1e-12 * (1.0 + A)) * (1.0 + 1e-9);
+                    nc.rall = (std::max(rpos, rneg) + Nd * fuzz) * (1.0 + 1e-9);
+                    nc.rmax = (rmax + fuzz) * (1.0 + 1e-9);
+                    // both sides evaluate N * x - N1 * sum and the slice sums in double: absolute slack of a few ulps of
+                    // the largest intermediate (N * N * max|y|)
+                    nc.pad = 256.0 * std::ldexp(1.0, -52) * Nd * Nd * (mx + std::fabs(c) + 1.0) + 1e-300;
+                    // float32 pre-screen (score_narrow.hip): |r| <= N |ycf| (1 + 2^-10) + slackf: N1 |t1|, N E and the pad
+                    // of the exact test, and the float32 roundings of the three products and sums.
+                    {
+                        const double slack = Nd * (nc.eg + std::min(nc.rall, Nd * nc.rmax)) + Nd * std::fabs(nc.t1) + nc.pad +
+                                             Nd * std::ldexp(1.0, -20) * mx * Nd;
+                        for (int k = 0; k < 3; k++) nc.wf[k] = (float)nc.w[k];
+                        nc.slackf = std::nextafter((float)(slack * 1.001), std::numeric_limits<float>::infinity());
+                    }
+                }
+                for (uint64_t j = 0; j < P; j++) put_slot(4 * j + 3, std::vector<int>(S, 1));
+                s->d_Bn.alloc(Bn.size());
+                s->d_ncols.alloc(P);
+                KGWAS_HIP(hipMemcpy(s->d_Bn.p, Bn.data(), Bn.size(), hipMemcpyHostToDevice));
+                KGWAS_HIP(hipMemcpy(s->d_ncols.p, ncols.data(), P * sizeof(NarrowCol), hipMemcpyHostToDevice));
             }
             for (int mi = 0; mi < 2; mi++) {
                 if (!want[mi]) continue;
@@ -1788,7 +1912,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
             kgwas_scan* raw = s.get();
             s->rp_fn = [raw](size_t w) { replay_worker(raw, w); };
         }
-        s->st.kernel_used = s->coarse ? (uint32_t)KGWAS_KERNEL_COARSE : kern;
+        s->st.kernel_used = s->narrow ? (uint32_t)KGWAS_KERNEL_NARROW : s->coarse ? (uint32_t)KGWAS_KERNEL_COARSE : kern;
         s->st.direct_mode = s->direct ? 1 : 0;
         *out = s.release();
     });

@@ -1,0 +1,410 @@
+// score_narrow.hip — the sparse-phase filter for scans with one to four phenotype columns: the HBM-bound
+// configuration of calculate_kmer_score (src/kmers_multiple_databases.cpp:327-363; 8*(1+W_f) bytes per row against
+// 2*S flop per column, BASELINE.md row 2').
+//
+// With so few columns the int8 filter of score_coarse.hip is bound by its operand expansion (two lane-ops per four
+// table bits) and by the exchange its test needs. Here
+//  * the table bits become an FP4 (E2M1) operand of gfx950's block-scaled MFMA: an FP4 nibble with only bit 0, 1 or 2
+//    set is 0.5, 1.0 or 2.0, so `dword & (0x11111111 << j)` IS a valid operand of 8 values for j = 0, 1, 2 (one
+//    lane-op per 8 table bits; the block scale of that operand, 2^0 / 2^-1 / 2^-2, exact, brings them all to 0.5) and
+//    only bit 3, the FP4 sign bit, has to be shifted first: five lane-ops per 32 table bits instead of eight;
+//  * the 16 "columns" of the one MFMA tile a row needs anyway carry, per phenotype column p < 4, THREE FP8 (E4M3)
+//    slices of small integers,   y_i - c ~ sum_k u_k q_ki,  q_ki in [-15, 15],  u_{k+1} = u_k / 30,  c = sum / N
+//    (residual below 4e-5 of the column's range), and a ones row (its dot product is the masked popcount N1):
+//    operand row 4p + k = slice k of column p, row 4p + 3 = ones;
+//  * the phenotype slices are the A operand and the table rows the B operand, so that the accumulator tile is
+//    [slice rows] x [table rows]: lane (r = lane & 15, p = lane >> 4) ends up with exactly the four numbers its pair
+//    (table row r, phenotype column p) needs - D_0, D_1, D_2 and N1 - and tests it on the spot: no exchange through
+//    LDS, no second pass over the accumulators.
+// v_mfma_scale_f32_16x16x128_f8f6f4 multiplies exact small values and accumulates in float32: every partial sum is a
+// multiple of 0.5 below 2^23, i.e. exact, whatever the order. The test, per pair: with
+//        r_c = N * sum_k u_k D_k + N1 * (N c - sum),     d = N1 (N - N1),
+// keep the pair iff (|r_c| + N * E(N1) + pad)^2 >= thr * d * (1 - 2^-30), E(N1) = Eg + min(Rall, N1 * rmax) bounding
+// |yigi_ref - yc| exactly as in score_coarse.hip (float32 summation error of the reference's chains + quantisation
+// residuals); a float32 pre-screen with its own slack goes first, the double-precision form only runs for the waves
+// that have a pair near its threshold. Survivors go to the same key list as the coarse filter's and are re-scored
+// exactly (rescore_kernel), so results are bit-identical to the exact scorers'.
+//
+// Operand maps (measured on the device, tools/probe_mx.hip): the FP4 operand of lane (i = lane & 15, kb = lane >> 4)
+// holds k = 32 kb + e in nibble e; the FP8 operand of lane (i, kb) holds k = 16 kb + e in byte e < 16 and
+// k = 64 + 16 kb + (e - 16) in byte e >= 16; C/D: column lane & 15, rows 4 (lane >> 4) + i. A lane loads ITS OWN 16
+// bytes of a table row (samples 512 g + 128 kb + 0..127 of sample group g) and MFMA step j = 0..3 takes bit 4 e' + j
+// of dword q as k = 32 kb + 8 q + e': no data moves between lanes.
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "score_common.h"
+
+// Timing experiments only (wrong results; tools/variants.sh builds the variants). Bits: 1 no MFMAs (an XOR keeps the
+// operands alive), 2 no operand expansion, 4 no test, 8 no piece reads from LDS, 16 no slice operand reads, 32 no global
+// row loads.
+#ifndef KGWAS_NARROW_ABLATE
+#define KGWAS_NARROW_ABLATE 0
+#endif
+
+namespace kgwas {
+
+typedef int nv8i __attribute__((ext_vector_type(8)));
+typedef float nv4f __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int NRT = 4;  // tiles of 16 table rows per wave pass
+}  // namespace
+
+// One 512-sample group of a wave pass: four MFMA steps over the lanes' 16-byte pieces of the table rows.
+__device__ __forceinline__ void narrow_group(const uint32_t (&piece)[NRT][4], const uint4* sg, nv4f (&acc)[NRT]) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        uint4 s0, s1;
+        if (KGWAS_NARROW_ABLATE & 16) {
+            s0 = make_uint4(j, 1, 2, 3);
+            s1 = make_uint4(4, 5, 6, j);
+        } else {
+            s0 = sg[j * 128];
+            s1 = sg[j * 128 + 1];
+        }
+        const nv8i Y = {(int)s0.x, (int)s0.y, (int)s0.z, (int)s0.w, (int)s1.x, (int)s1.y, (int)s1.z, (int)s1.w};
+#pragma unroll
+        for (int rt = 0; rt < NRT; rt++) {
+            nv8i G = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (KGWAS_NARROW_ABLATE & 2)
+                    G[q] = (int)piece[rt][q];
+                else
+                    G[q] = j < 3 ? (int)(piece[rt][q] & (0x11111111u << j)) : (int)((piece[rt][q] >> 1) & 0x44444444u);
+            }
+            if (KGWAS_NARROW_ABLATE & 1) {
+                acc[rt][j] += __int_as_float((G[0] ^ G[1] ^ G[2] ^ G[3] ^ Y[j] ^ Y[7 - j]) & 0x3fffff);
+                continue;
+            }
+            // A: the slices, FP8 E4M3 (cbsz 0), block scale 2^0; B: the table bits, FP4 (blgp 4), block scale
+            // 2^0 / 2^-1 / 2^-2 / 2^-2 for nibble bit 0 / 1 / 2 / 2 (bit 3 shifted down by one)
+            if (j == 0) acc[rt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(Y, G, acc[rt], 0, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+            if (j == 1) acc[rt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(Y, G, acc[rt], 0, 4, 0, 0x7F7F7F7F, 0, 0x7E7E7E7E);
+            if (j >= 2) acc[rt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(Y, G, acc[rt], 0, 4, 0, 0x7F7F7F7F, 0, 0x7D7D7D7D);
+        }
+    }
+}
+
+// A lane's per-column constants (column p = lane >> 4), read once per block.
+struct NarrowLane {
+    float wf0, wf1, wf2, slackf, thrf;
+    bool live;  // p < n_pheno
+};
+
+// Lane (r = lane & 15, p = lane >> 4) holds D_0, D_1, D_2 (units of 0.5) and N1 / 2 of pair (table row rt * 16 + r,
+// column p) in acc[rt]: MAC predicate, float32 pre-screen, the exact double-precision test where a wave has a pair near
+// its threshold, survivor keys.
+__device__ __forceinline__ void narrow_test(const NarrowArgs& a, const NarrowCol* cols, const NarrowLane& L, const nv4f (&acc)[NRT],
+                                            uint32_t lane, uint64_t rbase, bool mac_any, uint32_t span, uint32_t& tested_local) {
+    const uint32_t r = lane & 15u, p = lane >> 4;
+    const uint64_t left = a.n_rows - rbase;
+    const uint32_t rows_here = left < 64u ? (uint32_t)left : 64u;
+    const float Nf = (float)a.S;
+    uint32_t maybe = 0;  // bit rt: this lane's pair of row tile rt may pass
+#pragma unroll
+    for (int rt = 0; rt < NRT; rt++) {
+        const uint32_t n1 = (uint32_t)(2.0f * acc[rt][3]);  // the ones row, in units of 0.5
+        const bool ok = mac_any && (rt * 16u + r < rows_here) && ((n1 - a.min_count) <= span);
+        tested_local += (ok && p == 0u) ? 1u : 0u;
+        // float32 pre-screen: |r| <= N |yc| (1 + 2^-10) + slack (every rounding and N1 |N c - sum|, N E, pad in slackf)
+        const float ycf = L.wf0 * acc[rt][0] + L.wf1 * acc[rt][1] + L.wf2 * acc[rt][2];
+        const float lf = (fabsf(Nf * ycf) + L.slackf) * 1.001f;
+        const float f1 = (float)n1;
+        if (ok && L.live && !(lf * lf < L.thrf * (f1 * (Nf - f1)) * 0.998f)) maybe |= 1u << rt;  // NaN threshold: decided below
+    }
+    if (__ballot(maybe != 0u)) {  // rare: about one wave pass in a hundred at one column
+        uint32_t hit = 0;
+        if (maybe) {
+            const NarrowCol& cc = cols[p];
+            const double Nd = (double)a.S, thr = a.thr[p];
+#pragma unroll
+            for (int rt = 0; rt < NRT; rt++)
+                if (maybe & (1u << rt)) {
+                    const double N1 = (double)(2.0f * acc[rt][3]);
+                    const double yc = cc.w[0] * (double)acc[rt][0] + cc.w[1] * (double)acc[rt][1] + cc.w[2] * (double)acc[rt][2];
+                    const double rc = Nd * yc + N1 * cc.t1;
+                    const double e = cc.eg + fmin(cc.rall, N1 * cc.rmax);
+                    const double lhs = (fabs(rc) + Nd * e) * (1.0 + 0x1p-30) + cc.pad;
+                    if (lhs * lhs >= thr * (N1 * (Nd - N1)) * (1.0 - 0x1p-30)) hit |= 1u << rt;  // NaN threshold: never
+                }
+        }
+        if (__ballot(hit != 0u)) {
+            const uint32_t cnt = __popc(hit);
+            uint32_t incl = cnt;
+#pragma unroll
+            for (int dd = 1; dd < 64; dd <<= 1) {
+                const uint32_t t = __shfl_up(incl, dd);
+                if ((int)lane >= dd) incl += t;
+            }
+            const uint32_t total = __shfl(incl, 63);
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(a.key_count, total);
+            base = __shfl(base, 0) + incl - cnt;
+#pragma unroll
+            for (int rt = 0; rt < NRT; rt++)
+                if (hit & (1u << rt)) {
+                    if (base < a.key_cap) a.keys[base] = (p << a.row_bits) | (uint32_t)(a.row_off + rbase + rt * 16u + r);
+                    base++;
+                }
+        }
+    }
+}
+
+__device__ __forceinline__ NarrowLane narrow_lane_constants(const NarrowArgs& a, const NarrowCol* cols, uint32_t lane) {
+    NarrowLane L;
+    const uint32_t p = lane >> 4;
+    L.live = p < a.n_pheno;
+    const NarrowCol& cc = cols[L.live ? p : 0u];
+    L.wf0 = cc.wf[0];
+    L.wf1 = cc.wf[1];
+    L.wf2 = cc.wf[2];
+    L.slackf = cc.slackf;
+    L.thrf = (float)a.thr[L.live ? p : 0u];
+    return L;
+}
+
+// Rows fetched by the lanes that use them: lane (r, kb) loads its own 16 bytes of table row r. Adjacent lanes then read
+// addresses a row apart (136 bytes at 1024 samples): 64 separate requests per load instruction. The fall-back for
+// launches whose rows are not 16-byte aligned or do not fit the staged kernel's LDS, and for a launch's last rows.
+__global__ void __launch_bounds__(256) narrow_kernel(NarrowArgs a, uint32_t rows_per_block) {
+    extern __shared__ uint4 nlds[];  // [n_steps][64 lanes][2] slice operands, then the column constants
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // an SGPR: pass addresses are scalar
+    const uint32_t kb = lane >> 4, m = lane & 15u;
+    const uint32_t n_steps = a.n_kgroups * 4u;
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(a.Bn);
+        for (uint32_t i = threadIdx.x; i < n_steps * 128u; i += blockDim.x) nlds[i] = src[i];
+    }
+    NarrowCol* lcols = reinterpret_cast<NarrowCol*>(nlds + n_steps * 128u);
+    if (threadIdx.x < a.n_pheno * (sizeof(NarrowCol) / 8u))
+        reinterpret_cast<double*>(lcols)[threadIdx.x] = reinterpret_cast<const double*>(a.cols)[threadIdx.x];
+    __syncthreads();
+    const NarrowLane L = narrow_lane_constants(a, lcols, lane);
+    const char* rows_base = reinterpret_cast<const char*>(a.src.base);
+    const uint32_t avail_b = a.src.avail_dw * 4u;
+    const uint64_t blk_row0 = (uint64_t)blockIdx.x * rows_per_block;
+    uint32_t tested_local = 0;
+    const bool mac_any = a.S >= 2u * a.min_count;
+    const uint32_t span = a.S - 2u * a.min_count;
+
+    for (uint32_t ps = 0; (ps * 4u + wave) * 64u < rows_per_block; ps++) {
+        const uint64_t rbase = blk_row0 + (uint64_t)(ps * 4u + wave) * 64u;
+        if (rbase >= a.n_rows) break;  // wave-uniform
+        uint64_t ro[NRT];
+#pragma unroll
+        for (int rt = 0; rt < NRT; rt++) {
+            uint64_t r = rbase + rt * 16u + m;
+            if (r >= a.n_rows) r = a.n_rows - 1;
+            ro[rt] = (r * a.src.stride_dw + a.src.off_dw) * 4ull;
+        }
+        nv4f acc[NRT];
+#pragma unroll
+        for (int rt = 0; rt < NRT; rt++) acc[rt] = (nv4f){0.0f, 0.0f, 0.0f, 0.0f};
+        uint32_t piece[NRT][4];
+        for (uint32_t g = 0; g < a.n_kgroups; g++) {
+            // beyond the row's data the loads are clamped onto its last 8 bytes: whatever bits arrive there meet zero
+            // operands (sample slots >= S are zero in every slice)
+            uint32_t b0 = 64u * g + 16u * kb, b1 = b0 + 8u;
+            b0 = b0 + 8u <= avail_b ? b0 : avail_b - 8u;
+            b1 = b1 + 8u <= avail_b ? b1 : avail_b - 8u;
+#pragma unroll
+            for (int rt = 0; rt < NRT; rt++) {
+                const uint2 lo = *reinterpret_cast<const uint2*>(rows_base + ro[rt] + b0);
+                const uint2 hi = *reinterpret_cast<const uint2*>(rows_base + ro[rt] + b1);
+                piece[rt][0] = lo.x;
+                piece[rt][1] = lo.y;
+                piece[rt][2] = hi.x;
+                piece[rt][3] = hi.y;
+            }
+            narrow_group(piece, nlds + (size_t)g * 4u * 128u + lane * 2u, acc);
+        }
+        narrow_test(a, lcols, L, acc, lane, rbase, mac_any, span, tested_local);
+    }
+    if (a.tested) {
+        uint32_t v = tested_local;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) v += __shfl_xor(v, dd);
+        if (lane == 0u && v) atomicAdd(&a.tested[blockIdx.x % TESTED_SHARDS], (unsigned long long)v);
+    }
+}
+
+// Rows staged through LDS: a wave's 64 rows are one contiguous piece of memory (64 x stride bytes), fetched lane-linear
+// (every load instruction reads 1 KB of consecutive bytes: each cache line is requested once, by one instruction), held
+// in registers while the previous 64 rows are processed, written to the wave's own LDS area and read back from there
+// as the 16-byte pieces the MFMA lanes need. NP = 16-byte pieces per lane = ceil(64 * stride / 1024). The launcher
+// guarantees that every pass that exists can be read in whole KB without leaving the launch's rows.
+template <int NP>
+__global__ void __launch_bounds__(256) narrow_staged_kernel(NarrowArgs a, uint32_t rows_per_block, uint32_t stage_bytes) {
+    extern __shared__ uint4 nlds[];  // slice operands [n_steps][64][2], column constants, then per wave stage_bytes of rows
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // an SGPR: pass addresses are scalar
+    const uint32_t kb = lane >> 4, m = lane & 15u;
+    const uint32_t n_steps = a.n_kgroups * 4u;
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(a.Bn);
+        for (uint32_t i = threadIdx.x; i < n_steps * 128u; i += blockDim.x) nlds[i] = src[i];
+    }
+    NarrowCol* lcols = reinterpret_cast<NarrowCol*>(nlds + n_steps * 128u);
+    if (threadIdx.x < a.n_pheno * (sizeof(NarrowCol) / 8u))
+        reinterpret_cast<double*>(lcols)[threadIdx.x] = reinterpret_cast<const double*>(a.cols)[threadIdx.x];
+    char* stage = reinterpret_cast<char*>(lcols) + 4u * sizeof(NarrowCol) + (size_t)wave * stage_bytes;
+    __syncthreads();
+    const NarrowLane L = narrow_lane_constants(a, lcols, lane);
+    const char* rows_base = reinterpret_cast<const char*>(a.src.base);
+    const uint32_t stride_b = (uint32_t)a.src.stride_dw * 4u, off_b = a.src.off_dw * 4u;
+    const uint32_t avail_b = a.src.avail_dw * 4u;
+    const uint64_t total_b = a.n_rows * (uint64_t)stride_b;  // bytes of this launch's rows
+    const uint64_t blk_row0 = (uint64_t)blockIdx.x * rows_per_block;
+    uint32_t tested_local = 0;
+    const bool mac_any = a.S >= 2u * a.min_count;
+    const uint32_t span = a.S - 2u * a.min_count;
+    auto pass_row0 = [&](uint32_t ps) { return blk_row0 + (uint64_t)(ps * 4u + wave) * 64u; };
+    auto pass_exists = [&](uint32_t ps) { return (ps * 4u + wave) * 64u < rows_per_block && pass_row0(ps) < a.n_rows; };
+    // R: the NEXT pass's rows, lane-linear 16-byte pieces (named scalars, not an array: the compiler keeps a
+    // loop-carried uint4 array in scratch memory)
+    uint4 R0, R1, R2, R3, R4, R5, R6, R7, R8, R9, R10, R11;
+#define NARROW_EACH(X) X(0, R0) X(1, R1) X(2, R2) X(3, R3) X(4, R4) X(5, R5) X(6, R6) X(7, R7) X(8, R8) X(9, R9) X(10, R10) X(11, R11)
+#define NARROW_LOAD(i, r) if (NP > i) r = (KGWAS_NARROW_ABLATE & 32) ? make_uint4(lane, i, (uint32_t)fb, 7u) : *reinterpret_cast<const uint4*>(fetch_ptr + 1024 * i);
+#define NARROW_PUT(i, r) if (NP > i) *reinterpret_cast<uint4*>(stage + 16u * (64u * i + lane)) = r;
+    {
+        const uint64_t fb = pass_row0(0u) * stride_b;
+        const char* fetch_ptr = rows_base + fb + 16u * lane;
+        if (fb < total_b) {
+            NARROW_EACH(NARROW_LOAD)
+        }
+    }
+    // where this lane's pieces of the four row tiles sit in the wave's stage
+    uint32_t pofs[NRT];
+#pragma unroll
+    for (int rt = 0; rt < NRT; rt++) pofs[rt] = (rt * 16u + m) * stride_b + off_b;
+    for (uint32_t ps = 0; pass_exists(ps); ps++) {
+        const uint64_t rbase = pass_row0(ps);
+        NARROW_EACH(NARROW_PUT)  // (the last piece may reach past the 64 rows: the stage area is sized in whole KB)
+        {
+            const uint64_t fb = pass_row0(ps + 1u) * stride_b;  // in flight while these 64 rows are processed
+            const char* fetch_ptr = rows_base + fb + 16u * lane;
+            if (fb < total_b && ((ps + 1u) * 4u + wave) * 64u < rows_per_block) {  // (scalar)
+                NARROW_EACH(NARROW_LOAD)
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        nv4f acc[NRT];
+#pragma unroll
+        for (int rt = 0; rt < NRT; rt++) acc[rt] = (nv4f){0.0f, 0.0f, 0.0f, 0.0f};
+        for (uint32_t g = 0; g < a.n_kgroups; g++) {
+            uint32_t b0 = 64u * g + 16u * kb, b1 = b0 + 8u;
+            b0 = b0 + 8u <= avail_b ? b0 : avail_b - 8u;
+            b1 = b1 + 8u <= avail_b ? b1 : avail_b - 8u;
+            uint32_t piece[NRT][4];
+#pragma unroll
+            for (int rt = 0; rt < NRT; rt++) {
+                const char* rp = stage + pofs[rt];
+                uint2 lo, hi;
+                if (KGWAS_NARROW_ABLATE & 8) {
+                    lo = make_uint2(lane * 2654435761u + g, rt + b0);
+                    hi = make_uint2(lane + b1, lane * 40503u);
+                } else {
+                    lo = *reinterpret_cast<const uint2*>(rp + b0);
+                    hi = *reinterpret_cast<const uint2*>(rp + b1);
+                }
+                piece[rt][0] = lo.x;
+                piece[rt][1] = lo.y;
+                piece[rt][2] = hi.x;
+                piece[rt][3] = hi.y;
+            }
+            narrow_group(piece, nlds + (size_t)g * 4u * 128u + lane * 2u, acc);
+        }
+        if (KGWAS_NARROW_ABLATE & 4) {
+            float x = 0;
+#pragma unroll
+            for (int rt = 0; rt < NRT; rt++) x += acc[rt][0] + acc[rt][1] + acc[rt][2] + acc[rt][3];
+            if (x == 12345.678f) tested_local++;
+        } else {
+            narrow_test(a, lcols, L, acc, lane, rbase, mac_any, span, tested_local);
+        }
+        __builtin_amdgcn_wave_barrier();  // the pass's piece reads are done before the next pass's rows are stored
+    }
+#undef NARROW_EACH
+#undef NARROW_LOAD
+#undef NARROW_PUT
+    if (a.tested) {
+        uint32_t v = tested_local;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) v += __shfl_xor(v, dd);
+        if (lane == 0u && v) atomicAdd(&a.tested[blockIdx.x % TESTED_SHARDS], (unsigned long long)v);
+    }
+}
+
+size_t narrow_lds_bytes(uint32_t n_kgroups) { return (size_t)n_kgroups * 4u * 2048u + 4u * sizeof(NarrowCol); }
+
+template <int NP>
+static hipError_t launch_staged_t(const NarrowArgs& a, uint32_t rows_per_block, uint32_t n_blocks, uint32_t stage_bytes, size_t lds,
+                                  hipStream_t st) {
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)narrow_staged_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((narrow_staged_kernel<NP>), dim3(n_blocks), dim3(256), lds, st, a, rows_per_block, stage_bytes);
+    return hipGetLastError();
+}
+
+hipError_t launch_narrow(const NarrowArgs& a, uint32_t rows_per_block, hipStream_t st) {
+    if (a.n_rows == 0) return hipSuccess;
+    if (a.n_pheno < 1 || a.n_pheno > NARROW_MAX_COLS) return hipErrorInvalidValue;
+    rows_per_block = (rows_per_block + 255u) / 256u * 256u;
+    // staged rows: 64 x stride bytes per wave beside the operands, three blocks per CU; the rows must start on a 16-byte
+    // boundary
+    const uint32_t stride_b = (uint32_t)a.src.stride_dw * 4u;
+    const int np = (int)((64u * stride_b + 1023u) / 1024u);
+    const uint32_t stage_bytes = (uint32_t)np * 1024u;  // whole lane-linear pieces
+    const size_t lds_staged = narrow_lds_bytes(a.n_kgroups) + 4u * (size_t)stage_bytes;
+    static const bool no_stage = getenv("KGWAS_NARROW_STAGED") && atoi(getenv("KGWAS_NARROW_STAGED")) == 0;  // experiments
+    // The staged kernel reads a pass (64 rows) as np whole KB, i.e. up to 1 KB - 16 past the 64 rows: it takes the
+    // rows whose passes can be read that way without leaving the launch's rows; the last few rows (fewer than 128 + a
+    // KB's worth) go through the direct kernel in a second, tiny launch.
+    uint64_t n_staged = 0;
+    if (!no_stage && lds_staged <= 53u * 1024u && np <= 12 && (reinterpret_cast<uintptr_t>(a.src.base) & 15u) == 0) {
+        const uint64_t total_b = a.n_rows * (uint64_t)stride_b, over = (uint64_t)np * 1024u - 64ull * stride_b;
+        if (total_b > over) n_staged = (total_b - over) / (64ull * stride_b) * 64ull;
+    }
+    if (n_staged) {
+        NarrowArgs s1 = a;
+        s1.n_rows = n_staged;
+        const uint32_t nb = (uint32_t)((n_staged + rows_per_block - 1) / rows_per_block);
+        hipError_t e = hipSuccess;
+        switch (np) {
+            case 1: e = launch_staged_t<1>(s1, rows_per_block, nb, stage_bytes, lds_staged, st); break;
+            case 2: e = launch_staged_t<2>(s1, rows_per_block, nb, stage_bytes, lds_staged, st); break;
+            case 3: e = launch_staged_t<3>(s1, rows_per_block, nb, stage_bytes, lds_staged, st); break;
+            case 4: e = launch_staged_t<4>(s1, rows_per_block, nb, stage_bytes, lds_staged, st); break;
+            case 5: e = launch_staged_t<5>(s1, rows_per_block, nb, stage_bytes, lds_staged, st); break;
+            case 6: e = launch_staged_t<6>(s1, rows_per_block, nb, stage_bytes, lds_staged, st); break;
+            case 7: e = launch_staged_t<7>(s1, rows_per_block, nb, stage_bytes, lds_staged, st); break;
+            case 8: e = launch_staged_t<8>(s1, rows_per_block, nb, stage_bytes, lds_staged, st); break;
+            case 9: e = launch_staged_t<9>(s1, rows_per_block, nb, stage_bytes, lds_staged, st); break;
+            case 10: e = launch_staged_t<10>(s1, rows_per_block, nb, stage_bytes, lds_staged, st); break;
+            case 11: e = launch_staged_t<11>(s1, rows_per_block, nb, stage_bytes, lds_staged, st); break;
+            default: e = launch_staged_t<12>(s1, rows_per_block, nb, stage_bytes, lds_staged, st); break;
+        }
+        if (e != hipSuccess || n_staged == a.n_rows) return e;
+    }
+    NarrowArgs a2 = a;  // what is left (everything, if the staged kernel does not apply)
+    a2.src.base = a.src.base + n_staged * a.src.stride_dw;
+    a2.n_rows = a.n_rows - n_staged;
+    a2.row_off = (uint32_t)n_staged;
+    const uint32_t n_blocks2 = (uint32_t)((a2.n_rows + rows_per_block - 1) / rows_per_block);
+    const size_t lds = narrow_lds_bytes(a.n_kgroups);
+    if (lds > 160u * 1024u) return hipErrorInvalidValue;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)narrow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(narrow_kernel, dim3(n_blocks2), dim3(256), lds, st, a2, rows_per_block);
+    return hipGetLastError();
+}
+
+}  // namespace kgwas

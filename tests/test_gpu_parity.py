@@ -142,6 +142,37 @@ def test_coarse_filter_shapes(monkeypatch, slices, S, P, shift):
     scan.close()
 
 
+@pytest.mark.parametrize("S_f,S,P,shift,binary,reorder", [(241, 241, 1, 0.0, False, False), (241, 241, 3, 100.0, False, False),
+                                                       (1024, 1024, 1, 0.0, False, False), (1024, 1024, 2, -7.5, True, False),
+                                                       (1135, 1135, 1, 0.0, False, False), (2048, 2048, 3, 0.5, False, False),
+                                                       (300, 257, 2, 3.0, False, True), (64, 64, 1, 0.0, True, False),
+                                                       (1300, 1300, 1, 1e4, False, False), (1024, 1024, 4, 0.0, False, False),
+                                                       (500, 500, 4, 2.0, True, False)])
+def test_narrow_filter_few_columns(S_f, S, P, shift, binary, reorder):
+    """Scans with one to four columns go through the narrow filter under AUTO (FP4 table bits x three FP8 slices per
+    column on the block-scaled MFMA): every sample-group count, direct and squeezed rows, shifted / binary / huge-offset
+    phenotypes, duplicated patterns (ties), many small chunks: survivors, pop order, scores and push counts equal the
+    oracle's; the FT10 example phenotype at 1135 accessions as well."""
+    rows = random_table(50_000, S_f, seed=S + P, dup_frac=0.3)
+    rng = np.random.default_rng(S_f)
+    col = rng.permutation(S_f)[:S].astype(np.uint64) if reorder else np.arange(S, dtype=np.uint64)
+    Y = (phenotypes(S, P - 1, seed=P + 3, binary=binary) + np.float32(shift)).astype(np.float32)
+    if S == 1135:
+        Y[0] = onp.load_phenotypes(os.path.join(GOLD, "FT10.pheno"))[2][0, :S]
+    mac = onp.min_count(S, 0.05, 5)
+    topn = 301
+    exp = ob.associate(rows, S_f, col, Y, topn, mac, batch_size=9000, threads=3)
+    scan = kg.AssociationScan(S_f, col, Y, topn, mac, chunk_rows=4096)
+    scan.feed_host(rows[:20_000], 0)
+    scan.feed_host(rows[20_000:], 20_000)
+    scan.finish()
+    st = scan.stats()
+    assert st["kernel_used"] == kg.KERNEL_NARROW and st["coarse_launches"] > 0
+    _check_topn(scan, exp, P)
+    assert st["rows_tested"] == exp["tested"]
+    scan.close()
+
+
 @pytest.mark.parametrize("slices", [0, 1, 2])
 def test_config3_shape_ft10_phenotype(monkeypatch, slices):
     """BASELINE configs[2] in shape: 1135 accessions x 101 columns, column 0 = the reference's flowering-time example
