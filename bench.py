@@ -165,7 +165,7 @@ def kinship_record(kg, torch, stream, dev, rows=8_000_000, S_f=1135, seed=202406
     kin.close()
     del t
     k_ms = float(np.mean(kern))
-    ops = float(S_f) * S_f * rows  # S_f^2 integer MACs per row using the symmetry
+    ops = 0.5 * float(S_f) * S_f * rows  # SURVEY.md 8d with the symmetry: S_f^2 / 2 MACs = S_f^2 op per row
     return {"workload": "%dM k-mers x %d accessions, maf 0.05 (BASELINE.json configs[4] in shape)" % (rows // 1_000_000, S_f),
             "kernels": "kin_transpose_kernel + kin_gram_kernel", "kernels_ms": k_ms, "wall_ms": float(np.mean(wall)),
             "rows_per_s": rows / (k_ms * 1e-3), "rows_used": int(n_used),

@@ -9,28 +9,49 @@
 //                          sample-major planes T[sample][row/32], 32x32 bit tiles transposed across 32 lanes in five
 //                          butterfly stages (the previous version took one ballot per sample: 1152 per 64 rows,
 //                          half of the whole accumulation's time);
-//   kin_gram_kernel      : C = T T^t on v_mfma_i32_16x16x64_i8. A wave owns a 64 x 128 tile of C (32 accumulators) and
-//                          expands its own operands from the planes ((dword >> j) & 0x01010101: 8 VALU ops per 16
-//                          bytes) - 96 VALU ops per 32 MFMAs, the plane dwords read from LDS once per 8 steps.
-//                          The xor-popcount formulation this replaces does S^2/64 lane-ops per row (VALU-bound,
-//                          146 T pair-updates/s at 1135 samples).
+//   kin_gram_kernel      : C = T T^t on gfx950's block-scaled MFMA with BOTH operands in FP4 (E2M1): a nibble with
+//                          only bit 0, 1 or 2 set is 0.5, 1.0 or 2.0, so `plane dword & (0x11111111 << j)` is an
+//                          operand of eight row bits in ONE lane-op, and the operands' block scales (2^(1-j), exact)
+//                          make every product of two set bits exactly 1.0; bit 3 (the FP4 sign) is shifted first.
+//                          v_mfma_scale_f32_16x16x128_f8f6f4 runs FP4 x FP4 at twice the int8 rate; float32
+//                          accumulation of 0/1 products is exact below 2^24 rows per launch slice. A wave owns a
+//                          64 x 128 tile of C (32 accumulators) and expands its own operands: 60 lane-ops per 128
+//                          MFMAs' worth of operands per 512 rows (the int8 form this replaces: v_mfma_i32_16x16x64_i8,
+//                          (dword >> j) & 0x01010101, 96 lane-ops per 32 MFMAs, 0.33 of the int8 peak). The
+//                          xor-popcount formulation before that does S^2/64 lane-ops per row (VALU-bound, 146 T
+//                          pair-updates/s at 1135 samples).
+#include <stdlib.h>
+
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace kgwas {
 
 typedef int kin_i32x4 __attribute__((ext_vector_type(4)));
+typedef int kin_i32x8 __attribute__((ext_vector_type(8)));
+typedef float kin_f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-// Operand of MFMA step j from four plane dwords (128 rows of one sample): byte e of operand dword q = bit 8e + j of
-// plane dword q, i.e. k-element 4q + e <-> row 32q + 8e + j of the lane's 128. A and B operands use the same map, so
-// the k index pairs a row with itself; two lane-ops per 4 operand bytes.
-__device__ __forceinline__ kin_i32x4 kin_expand_step(const uint4& w, int j) {
-    kin_i32x4 r;
-    r[0] = (int)((w.x >> j) & 0x01010101u);
-    r[1] = (int)((w.y >> j) & 0x01010101u);
-    r[2] = (int)((w.z >> j) & 0x01010101u);
-    r[3] = (int)((w.w >> j) & 0x01010101u);
+// FP4 operand of MFMA step j = 0..3 from four plane dwords (128 rows of one sample): nibble e of operand dword q is
+// bit 4e + j of plane dword q, i.e. k-element 8q + e <-> row 32q + 4e + j of the lane's 128 (A and B operands use the
+// same map, so the k index pairs a row with itself). Steps 0..2 are one AND per dword (values 0.5, 1, 2: the block
+// scale 2^(1-j) makes them 1), step 3 moves the FP4 sign bit down first (value 2, scale 2^-1).
+__device__ __forceinline__ kin_i32x8 kin_expand_step(const uint4& w, int j) {
+    kin_i32x8 r = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (j < 3) {
+        const uint32_t mk = 0x11111111u << j;
+        r[0] = (int)(w.x & mk);
+        r[1] = (int)(w.y & mk);
+        r[2] = (int)(w.z & mk);
+        r[3] = (int)(w.w & mk);
+    } else {
+        r[0] = (int)((w.x >> 1) & 0x44444444u);
+        r[1] = (int)((w.y >> 1) & 0x44444444u);
+        r[2] = (int)((w.z >> 1) & 0x44444444u);
+        r[3] = (int)((w.w >> 1) & 0x44444444u);
+    }
     return r;
 }
 
@@ -148,7 +169,10 @@ __global__ void __launch_bounds__(256) kin_transpose_kernel(const uint64_t* file
 // the rows (blockIdx.y). Block = 2 waves; wave w owns samples ib*128 + 64w .. +63 against all 128 of jb.
 // MFMA k index <-> rows: per round of 512 rows lane (m, kg) holds plane dwords 4kg .. 4kg+3 (rows 128kg .. +127) of
 // its samples and step j = 0..7 takes bit j of each of their bytes (kin_expand_step).
-constexpr uint32_t KIN_KC = 16;  // plane dwords (512 rows) staged per round
+#ifndef KGWAS_KIN_KC
+#define KGWAS_KIN_KC 16
+#endif
+constexpr uint32_t KIN_KC = KGWAS_KIN_KC;  // plane dwords (512 rows) staged per round
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) kin_gram_kernel(const uint32_t* T, uint64_t n_rw, uint32_t S_pad, unsigned long long* C,
                                                        uint64_t rw_per_split) {
     constexpr uint32_t LROW = KIN_KC + 4;  // 80-byte rows: 16-byte aligned for ds_read_b128 / ds_write_b128
@@ -166,11 +190,11 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
     if (k_end > n_rw) k_end = n_rw;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t m = lane & 15u, kg = lane >> 4;
-    kin_i32x4 acc[4][8];
+    kin_f32x4 acc[4][8];
 #pragma unroll
     for (int x = 0; x < 4; x++)
 #pragma unroll
-        for (int y = 0; y < 8; y++) acc[x][y] = (kin_i32x4){0, 0, 0, 0};
+        for (int y = 0; y < 8; y++) acc[x][y] = (kin_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 
     // A round stages KIN_KC plane dwords (512 rows) of the 128 + 128 samples: 16-byte loads, 4 lanes per sample, and the
     // NEXT round's loads are already in flight (registers) while this round's 8 MFMA steps run.
@@ -210,16 +234,21 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
         for (int x = 0; x < 4; x++) wA[x] = *reinterpret_cast<const uint4*>(&LA[wave * 64u + x * 16u + m][4u * kg]);
 #pragma unroll
         for (int y = 0; y < 8; y++) wB[y] = *reinterpret_cast<const uint4*>(&LB[y * 16u + m][4u * kg]);
-#pragma unroll 1
-        for (int j = 0; j < 8; j++) {
-            kin_i32x4 A[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            kin_i32x8 A[4];
 #pragma unroll
             for (int x = 0; x < 4; x++) A[x] = kin_expand_step(wA[x], j);
 #pragma unroll
             for (int y = 0; y < 8; y++) {
-                const kin_i32x4 B = kin_expand_step(wB[y], j);
+                const kin_i32x8 B = kin_expand_step(wB[y], j);
+                // both operands FP4 (cbsz = blgp = 4); block scales 2^1, 2^0, 2^-1, 2^-1 for j = 0..3 on both sides
 #pragma unroll
-                for (int x = 0; x < 4; x++) acc[x][y] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[x], B, acc[x][y], 0, 0, 0);
+                for (int x = 0; x < 4; x++) {
+                    if (j == 0) acc[x][y] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A[x], B, acc[x][y], 4, 4, 0, (int)0x80808080, 0, (int)0x80808080);
+                    if (j == 1) acc[x][y] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A[x], B, acc[x][y], 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+                    if (j >= 2) acc[x][y] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A[x], B, acc[x][y], 4, 4, 0, 0x7E7E7E7E, 0, 0x7E7E7E7E);
+                }
             }
         }
     }
@@ -230,10 +259,10 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
         for (int y = 0; y < 8; y++)
 #pragma unroll
             for (int jj = 0; jj < 4; jj++) {
-                const int v = acc[x][y][jj];
+                const unsigned long long v = (unsigned long long)acc[x][y][jj];  // an exact integer (< 2^24 rows per slice)
                 if (v) {
                     const uint32_t i = ib * 128u + wave * 64u + x * 16u + kg * 4u + jj, j = jb * 128u + y * 16u + m;
-                    atomicAdd(&C[(uint64_t)i * S_pad + j], (unsigned long long)v);
+                    atomicAdd(&C[(uint64_t)i * S_pad + j], v);
                 }
             }
 }
@@ -271,7 +300,11 @@ hipError_t launch_kin_gram(const uint32_t* T, uint64_t n_rw, uint32_t S_pad, uns
     const uint32_t nt = S_pad / 128u;
     const uint32_t tiles = nt * (nt + 1u) / 2u;
     // enough row slices to fill 256 CUs several times over, each a multiple of KIN_KC plane words
-    uint64_t want = (256ull * 12ull + tiles - 1) / tiles;
+    static const uint64_t blocks_env = getenv("KGWAS_KIN_BLOCKS") ? (uint64_t)atoll(getenv("KGWAS_KIN_BLOCKS")) : 0;  // experiments
+    // Row slices per tile: a CU holds four of these 2-wave blocks (two waves per SIMD), the chip 1024, and a launch
+    // that is not close to a whole number of such rounds leaves CUs idle at its end (3105 blocks measured 5.5 ms per
+    // 8 M rows x 1135 samples, 2025 blocks 5.0): as many slices as make about two full rounds.
+    uint64_t want = std::max<uint64_t>(1, (blocks_env ? blocks_env : 2048ull) / tiles);
     uint64_t per = (n_rw + want - 1) / want;
     per = ((per + KIN_KC - 1) / KIN_KC) * KIN_KC;
     if (per < KIN_KC * 4) per = KIN_KC * 4;

@@ -21,9 +21,11 @@ struct kgwas_kinship {
     uint64_t S_f = 0, W_f = 0, min_count = 0;
     uint32_t S_pad = 0;
     uint64_t chunk_rows = 0, n_rw_cap = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, stream_tr = nullptr;  // Gram accumulation / bit transposes
     hipEvent_t ev_user = nullptr, ev0 = nullptr, ev1 = nullptr;
-    uint32_t* d_T = nullptr;
+    hipEvent_t ev_tr[2] = {nullptr, nullptr}, ev_gram[2] = {nullptr, nullptr};
+    bool gram_pending[2] = {false, false};
+    uint32_t* d_T2[2] = {nullptr, nullptr};  // sample-major bit planes of two chunks
     unsigned long long* d_H = nullptr;
     unsigned long long* d_n = nullptr;
     Ingest ingest;  // host / file feeds: three pinned pieces, two device pieces, a copy stream
@@ -31,7 +33,12 @@ struct kgwas_kinship {
     uint64_t launches = 0, rows_fed = 0;
     ~kgwas_kinship() {
         (void)hipSetDevice(device);
-        if (d_T) (void)hipFree(d_T);
+        for (int b = 0; b < 2; b++) {
+            if (d_T2[b]) (void)hipFree(d_T2[b]);
+            if (ev_tr[b]) (void)hipEventDestroy(ev_tr[b]);
+            if (ev_gram[b]) (void)hipEventDestroy(ev_gram[b]);
+        }
+        if (stream_tr) (void)hipStreamDestroy(stream_tr);
         if (d_H) (void)hipFree(d_H);
         if (d_n) (void)hipFree(d_n);
         if (ev_user) (void)hipEventDestroy(ev_user);
@@ -41,23 +48,37 @@ struct kgwas_kinship {
     }
 };
 
+// Chunks of 2^20 rows: the transpose of chunk i + 1 (memory- and LDS-bound) runs on its own stream beside the Gram
+// accumulation of chunk i (matrix-pipe-bound) - two plane buffers, two events per buffer.
 static void kin_feed(kgwas_kinship* k, const uint64_t* d_rows, uint64_t n_rows) {
     const uint64_t stride = 1 + k->W_f;
-    for (uint64_t pos = 0; pos < n_rows; pos += k->chunk_rows) {
+    if (n_rows == 0) return;
+    // the caller's rows are ready on k->stream (kgwas_kinship_feed_device ordered it after the caller's stream)
+    KGWAS_HIP(hipEventRecord(k->ev0, k->stream));
+    KGWAS_HIP(hipStreamWaitEvent(k->stream_tr, k->ev0, 0));
+    uint64_t i = 0;
+    for (uint64_t pos = 0; pos < n_rows; pos += k->chunk_rows, i++) {
         const uint64_t c = std::min<uint64_t>(k->chunk_rows, n_rows - pos);
         const uint64_t n_rw = (c + 511) / 512 * 16;  // u32 words per sample, whole 512-row blocks
-        KGWAS_HIP(hipEventRecord(k->ev0, k->stream));
+        const int b = (int)(i & 1);
+        if (k->gram_pending[b]) KGWAS_HIP(hipStreamWaitEvent(k->stream_tr, k->ev_gram[b], 0));  // buffer b is free again
         KGWAS_HIP(launch_kin_transpose(d_rows + pos * stride, stride, c, (uint32_t)k->S_f, k->S_pad,
-                                       (uint32_t)std::min<uint64_t>(k->min_count, 0xFFFFFFFFull), k->d_T, n_rw, k->d_n,
-                                       k->stream));
-        KGWAS_HIP(launch_kin_gram(k->d_T, n_rw, k->S_pad, k->d_H, k->stream));
-        KGWAS_HIP(hipEventRecord(k->ev1, k->stream));
-        KGWAS_HIP(hipStreamSynchronize(k->stream));
-        float ms = 0;
-        KGWAS_HIP(hipEventElapsedTime(&ms, k->ev0, k->ev1));
-        k->kernel_ms += ms;
+                                       (uint32_t)std::min<uint64_t>(k->min_count, 0xFFFFFFFFull), k->d_T2[b], n_rw, k->d_n,
+                                       k->stream_tr));
+        KGWAS_HIP(hipEventRecord(k->ev_tr[b], k->stream_tr));
+        KGWAS_HIP(hipStreamWaitEvent(k->stream, k->ev_tr[b], 0));
+        KGWAS_HIP(launch_kin_gram(k->d_T2[b], n_rw, k->S_pad, k->d_H, k->stream));
+        KGWAS_HIP(hipEventRecord(k->ev_gram[b], k->stream));
+        k->gram_pending[b] = true;
         k->launches++;
     }
+    KGWAS_HIP(hipEventRecord(k->ev1, k->stream));
+    KGWAS_HIP(hipStreamSynchronize(k->stream));  // the caller may reuse its rows when a feed returns
+    KGWAS_HIP(hipStreamSynchronize(k->stream_tr));
+    k->gram_pending[0] = k->gram_pending[1] = false;
+    float ms = 0;
+    KGWAS_HIP(hipEventElapsedTime(&ms, k->ev0, k->ev1));
+    k->kernel_ms += ms;
     k->rows_fed += n_rows;
 }
 
@@ -87,7 +108,12 @@ int kgwas_kinship_create(int32_t device, uint64_t n_acc_file, uint64_t min_count
         KGWAS_HIP(hipEventCreate(&k->ev_user));
         KGWAS_HIP(hipEventCreate(&k->ev0));
         KGWAS_HIP(hipEventCreate(&k->ev1));
-        KGWAS_HIP(hipMalloc((void**)&k->d_T, (size_t)k->S_pad * k->n_rw_cap * 4));
+        KGWAS_HIP(hipStreamCreateWithFlags(&k->stream_tr, hipStreamNonBlocking));
+        for (int b = 0; b < 2; b++) {
+            KGWAS_HIP(hipMalloc((void**)&k->d_T2[b], (size_t)k->S_pad * k->n_rw_cap * 4));
+            KGWAS_HIP(hipEventCreateWithFlags(&k->ev_tr[b], hipEventDisableTiming));
+            KGWAS_HIP(hipEventCreateWithFlags(&k->ev_gram[b], hipEventDisableTiming));
+        }
         KGWAS_HIP(hipMalloc((void**)&k->d_H, (size_t)k->S_pad * k->S_pad * 8));
         KGWAS_HIP(hipMalloc((void**)&k->d_n, TESTED_SHARDS * 8));
         KGWAS_HIP(hipMemset(k->d_H, 0, (size_t)k->S_pad * k->S_pad * 8));
