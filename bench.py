@@ -203,6 +203,8 @@ def main():
     ap.add_argument("--cpu-sample-rows", type=int, default=6_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-subrecords", action="store_true", help="skip p1_scan / kinship / parity_check")
+    ap.add_argument("--check-merge", action="store_true",
+                    help="N > 1: rank 0 also scans all shards' rows in one session and compares the merged heaps with it (small runs)")
     args = ap.parse_args()
 
     import torch
@@ -336,6 +338,25 @@ def main():
                       "note": "rank 0's shard scanned alone while the other ranks idle: the N = 1 point for this curve"}
         dist.barrier()
 
+    merge_check = None
+    if world > 1 and args.check_merge:
+        # one more merged step (the merge consumed rank 0's session state), then the reference: everything in one session
+        scan_m, _, tested_m = one_step()
+        if rank == 0:
+            full = torch.empty(world * M * W, dtype=torch.int64, device="cuda")
+            kg.synth_rows_device(full.data_ptr(), 0, world * M, S, seed_table, stream)
+            torch.cuda.synchronize()
+            ref = kg.AssociationScan(S, col, Y, args.topn, mac, device=dev, kernel=args.kernel, host_threads=host_threads)
+            ref.feed_device(full.data_ptr(), world * M, 0, stream)
+            ref.finish()
+            merge_check = int(tested_m) == ref.stats()["rows_tested"]
+            for j in range(P):
+                a, b = scan_m.result(j), ref.result(j)
+                merge_check = merge_check and all(x.tobytes() == y.tobytes() for x, y in zip(a, b))
+            ref.close()
+            del full
+        dist.barrier()
+
     if rank == 0:
         ms_per_step = dt * 1e3 / args.steps
         total_rows = M * world
@@ -445,6 +466,8 @@ def main():
         }
         if single is not None:
             out["single_gpu_same_shard"] = single
+        if merge_check is not None:
+            out["merge_check"] = bool(merge_check)
         if world == 1 and not args.no_cpu_baseline:
             rec, ores = cpu_baseline(S, Y, mac, args.topn, seed_table, min(args.cpu_sample_rows, M),
                                      threads=min(usable_cpus(), P))

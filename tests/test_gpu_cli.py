@@ -132,6 +132,24 @@ def test_associate_kmers_gpus_row_sharded(tmp_path, gpus):
     _compare_dirs(str(out_p), str(out_o))
 
 
+@pytest.mark.parametrize("ranks,merge", [(2, "root"), (3, "column")])
+def test_bench_ranks_merge_over_torch_distributed(ranks, merge):
+    """bench.py's N > 1 path with real scan sessions: `ranks` processes (torch.distributed over gloo, all on the one GPU of
+    the test box), each scanning its own row shard, merged with kmersgwas_amd.dist (to the root / by column); rank 0 then
+    scans all the rows in one session and compares every column's heap bytes (--check-merge)."""
+    import json, sys
+    env = dict(os.environ, KGWAS_DIST_BACKEND="gloo", KGWAS_BENCH_MERGE=merge, KGWAS_PIN_THREADS="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(29500 + ranks), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "1", "--warmup", "1",
+           "--rows", "600000", "--samples", "241", "--perms", "12", "--topn", "2001", "--check-merge", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == ranks and j["merge_check"] is True
+    assert j["single_gpu_same_shard"]["value"] > 0
+
+
 def test_emma_kinship_kmers_gpus(tmp_path):
     S_f, k = 173, 31
     rows = random_table(40_001, S_f, seed=78)
