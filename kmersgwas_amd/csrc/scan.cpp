@@ -444,6 +444,7 @@ struct kgwas_scan {
     // candidate), mode[1] = two slices (~1). Both may be resident; each chunk picks one (pick_coarse_mode).
     struct CoarseMode {
         bool ready = false;
+        bool wide = false;  // score_wide.hip: all T tiles' accumulators in registers, operands streamed through LDS
         uint32_t T = 0, n_lgroups = 0, slices = 0;
         float eg_max = 0, rall_max = 0, rmax_max = 0;  // row error term, maxima over the columns (kernels.h)
         DevBuf<int8_t> d_Bq;
@@ -812,6 +813,8 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
             // 768 block slots, so long blocks leave CUs idle at the end of every launch: 4096 rows per block measured
             // 3.4 ms per 100 M rows, 768 rows 3.0)
             KGWAS_HIP(launch_narrow(na, rpb_env ? rpb_env : (n_rows >= (1u << 18) ? 768u : 256u), s->stream));
+        } else if (M.wide) {
+            KGWAS_HIP(launch_wide(c, M.T, rpb_env ? rpb_env : (n_rows >= (1u << 20) ? 1024u : 256u), s->stream));
         } else
         KGWAS_HIP(launch_coarse(c, M.T, rpb_env ? rpb_env : (n_rows >= (1u << 22) ? 4096u : n_rows >= (1u << 20) ? 2048u : 512u), s->stream));
         KGWAS_HIP(hipEventRecord(sl.ev_mid, s->stream));
@@ -1753,6 +1756,22 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                     cper = (P + n_lgroups - 1) / n_lgroups;  // phenotype columns per group
                     T = (uint32_t)(ns * ((cper + 1 + 15) / 16));
                     if (T <= Tmax) break;
+                }
+                // One slice, more tiles than the LDS holds at once, at most 14: the wide kernel keeps every tile's
+                // accumulators in registers and streams the operands (score_wide.hip) - one group, every row expanded once.
+                {
+                    const uint32_t tiles = (uint32_t)((P + 1 + 15) / 16);
+                    // Measured at 2048 samples x 201 columns (T = 13): 34.5 ms per 75.6 M rows against 32.0 ms for
+                    // coarse_kernel's four LDS groups - the matrix pipe is busy 37 % of the time (one wave per SIMD: its
+                    // epilogue, the stage barriers and the vector instructions beside the MFMAs are all exposed) - so
+                    // it stays opt-in (KGWAS_WIDE=1) until it wins.
+                    const bool on = getenv("KGWAS_WIDE") && atoi(getenv("KGWAS_WIDE")) == 1;
+                    if (ns == 1 && n_lgroups > 1 && tiles >= 9 && tiles <= 14 && wide_lds_bytes(tiles) <= 160u * 1024u && on) {
+                        M.wide = true;
+                        n_lgroups = 1;
+                        cper = P;
+                        T = tiles;
+                    }
                 }
                 const uint32_t PG = T / (uint32_t)ns, slots = PG * 16;
                 M.T = T;

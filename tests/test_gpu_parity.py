@@ -142,6 +142,27 @@ def test_coarse_filter_shapes(monkeypatch, slices, S, P, shift):
     scan.close()
 
 
+@pytest.mark.parametrize("S,P", [(2048, 201), (1500, 150), (700, 220)])
+def test_wide_filter_variant(monkeypatch, S, P):
+    """score_wide.hip (opt-in, KGWAS_WIDE=1): the int8 filter with all 9-14 operand tiles' accumulators in registers and
+    the operands streamed through LDS by global_load_lds - same survivors, so the same heaps as the oracle's."""
+    monkeypatch.setenv("KGWAS_WIDE", "1")
+    monkeypatch.setenv("KGWAS_COARSE_SLICES", "1")
+    rows = random_table(40_000, S, seed=S + P, dup_frac=0.2)
+    col = np.arange(S, dtype=np.uint64)
+    Y = phenotypes(S, P - 1, seed=P)
+    mac = onp.min_count(S, 0.05, 5)
+    exp = ob.associate(rows, S, col, Y, 257, mac, batch_size=9000, threads=4)
+    scan = kg.AssociationScan(S, col, Y, 257, mac, kernel=kg.KERNEL_COARSE, chunk_rows=8192)
+    scan.feed_host(rows)
+    scan.finish()
+    st = scan.stats()
+    assert st["coarse_mode_lgroups"][0] == 1 and st["coarse_mode_tiles"][0] == (P + 1 + 15) // 16  # the wide layout: one group
+    _check_topn(scan, exp, P)
+    assert st["rows_tested"] == exp["tested"]
+    scan.close()
+
+
 @pytest.mark.parametrize("S_f,S,P,shift,binary,reorder", [(241, 241, 1, 0.0, False, False), (241, 241, 3, 100.0, False, False),
                                                        (1024, 1024, 1, 0.0, False, False), (1024, 1024, 2, -7.5, True, False),
                                                        (1135, 1135, 1, 0.0, False, False), (2048, 2048, 3, 0.5, False, False),
