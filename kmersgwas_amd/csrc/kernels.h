@@ -145,12 +145,16 @@ struct NarrowArgs {
     const uint8_t* Bn;         // [n_kgroups * 4 steps][64 lanes][32] FP8 E4M3 slice operands, see score_narrow.hip
     const NarrowCol* cols;     // [n_pheno]
     const double* thr;         // [n_pheno]
-    uint32_t* keys;
-    uint32_t* key_count;
-    uint32_t key_cap, row_bits;
+    unsigned long long* bitmap;  // survivors: [n_pheno][words_per_col] 64-bit words, bit r of word w = chunk row 64 w + r; zeroed by the caller
+    uint64_t words_per_col;
     unsigned long long* tested;
-    uint32_t row_off;          // added to the row index in the keys (a launch that starts inside a chunk)
+    uint32_t row_off;          // chunk row of this launch's first row (a launch that starts inside a chunk), a multiple of 64
 };
+// The bitmap's set bits as row-ordered keys (column << row_bits | row), column after column, with each column's range
+// and the total - what launch_surv_sort produces for the coarse filter's key list. blk_scratch: n_pheno * ceil(n_rows / 65536) words.
+hipError_t launch_bitmap_keys(const unsigned long long* bitmap, uint64_t words_per_col, uint64_t n_rows, uint32_t n_pheno, uint32_t* blk_scratch,
+                              uint32_t* keys_sorted, uint32_t key_cap, uint32_t row_bits, uint32_t* surv_off, uint32_t* surv_cnt,
+                              uint32_t* key_count, hipStream_t st);
 size_t narrow_lds_bytes(uint32_t n_kgroups);
 hipError_t launch_narrow(const NarrowArgs& a, uint32_t rows_per_block, hipStream_t st);
 

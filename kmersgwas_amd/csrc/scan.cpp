@@ -454,6 +454,9 @@ struct kgwas_scan {
     bool narrow = false;
     DevBuf<uint8_t> d_Bn;
     DevBuf<NarrowCol> d_ncols;
+    DevBuf<unsigned long long> d_bitmap;  // survivors of the chunk being filtered: [n_pheno][bitmap_words]
+    uint64_t bitmap_words = 0;
+    DevBuf<uint32_t> d_bm_blocks;
     // survivor keys of the chunk being filtered, their sorted copy, each column's range in it; shared by all chunks
     // (consumed by the re-score kernel in stream order)
     DevBuf<uint32_t> d_surv, d_surv_sorted, d_surv_cnt, d_surv_off, d_key_count;
@@ -510,6 +513,7 @@ struct kgwas_scan {
     std::condition_variable rp_cv_work, rp_cv_done;
     std::function<void(size_t)> rp_fn;
     ReplayAcc rp_acc;  // sums over the workers of the current streaming replay
+    std::atomic<uint64_t> prof_scan{0}, prof_heap{0};  // KGWAS_TRACE: TSC ticks in the record scans / in the heap updates
     uint64_t rp_max_busy_ns = 0;
     kgwas_scan_stats st{};
     bool finished = false;
@@ -788,11 +792,10 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
         c.key_cap = s->key_slots;
         c.row_bits = s->row_key_bits;
         c.tested = a.tested;
-        KGWAS_HIP(hipMemsetAsync(s->d_surv.p, 0xFF, (size_t)s->key_slots * sizeof(uint32_t), s->stream));  // sorts last
         static const uint32_t rpb_env = getenv("KGWAS_COARSE_RPB") ? (uint32_t)atoi(getenv("KGWAS_COARSE_RPB")) : 0u;  // experiments
-        // rows per block: the operand tiles (up to 128 KB) are loaded into LDS once per block, so blocks are long
-        // where the launch still fills the chip four times over
         if (s->narrow) {
+            // survivors as a bitmap (zeroed here), turned into row-ordered keys by a popcount scan: no key list, no sort
+            KGWAS_HIP(hipMemsetAsync(s->d_bitmap.p, 0, (size_t)s->n_pheno * s->bitmap_words * 8, s->stream));
             NarrowArgs na;
             memset(&na, 0, sizeof(na));
             na.src = a.src;
@@ -804,16 +807,22 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
             na.Bn = s->d_Bn.p;
             na.cols = s->d_ncols.p;
             na.thr = a.thr;
-            na.keys = s->d_surv.p;
-            na.key_count = s->d_key_count.p;
-            na.key_cap = s->key_slots;
-            na.row_bits = s->row_key_bits;
+            na.bitmap = s->d_bitmap.p;
+            na.words_per_col = s->bitmap_words;
             na.tested = a.tested;
             // (short blocks: three 4-wave blocks share a CU and a launch's block count is rarely a multiple of the
             // 768 block slots, so long blocks leave CUs idle at the end of every launch: 4096 rows per block measured
             // 3.4 ms per 100 M rows, 768 rows 3.0)
             KGWAS_HIP(launch_narrow(na, rpb_env ? rpb_env : (n_rows >= (1u << 18) ? 768u : 256u), s->stream));
-        } else if (M.wide) {
+            KGWAS_HIP(hipEventRecord(sl.ev_mid, s->stream));
+            a.tested = nullptr;  // counted by the filter
+            KGWAS_HIP(launch_bitmap_keys(s->d_bitmap.p, s->bitmap_words, n_rows, (uint32_t)s->n_pheno, s->d_bm_blocks.p, s->d_surv_sorted.p,
+                                         s->key_slots, s->row_key_bits, s->d_surv_off.p, s->d_surv_cnt.p, s->d_key_count.p, s->stream));
+        } else {
+        KGWAS_HIP(hipMemsetAsync(s->d_surv.p, 0xFF, (size_t)s->key_slots * sizeof(uint32_t), s->stream));  // sorts last
+        // rows per block: the operand tiles (up to 128 KB) are loaded into LDS once per block, so blocks are long
+        // where the launch still fills the chip four times over
+        if (M.wide) {
             KGWAS_HIP(launch_wide(c, M.T, rpb_env ? rpb_env : (n_rows >= (1u << 20) ? 1024u : 256u), s->stream));
         } else
         KGWAS_HIP(launch_coarse(c, M.T, rpb_env ? rpb_env : (n_rows >= (1u << 22) ? 4096u : n_rows >= (1u << 20) ? 2048u : 512u), s->stream));
@@ -822,6 +831,7 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
         KGWAS_HIP(launch_surv_sort(s->d_surv.p, s->d_surv_sorted.p, s->key_slots, s->d_key_count.p, s->key_slots,
                                    (uint32_t)s->n_pheno, s->row_key_bits, 32, s->d_surv_off.p, s->d_surv_cnt.p,
                                    s->d_sort_tmp.p, s->d_sort_tmp.n, s->stream));
+        }
         a.so_score = sl.d_so_score.p;
         a.so_kmer = sl.d_so_kmer.p;
         a.so_row = sl.d_so_row.p;
@@ -895,7 +905,10 @@ void replay_group(kgwas_scan* s, Slot& sl, size_t g, ReplayAcc& acc) {
             for (uint32_t i = 0; i < cu.n; i += 8) __builtin_prefetch(cu.km + i);
             for (uint32_t i = 0; i < cu.n; i += 16) __builtin_prefetch(cu.rw + i);
         }
+        const bool prof = s->trace;
+        uint64_t q_scan = 0, q_heap = 0;
         while (n_cols) {
+            const uint64_t q0 = prof ? __builtin_ia32_rdtsc() : 0;
             // next effective record of every column still active
             for (size_t c = 0; c < n_cols;) {
                 Cur& cu = cols[c];
@@ -920,6 +933,8 @@ void replay_group(kgwas_scan* s, Slot& sl, size_t g, ReplayAcc& acc) {
                     cols[c] = cols[--n_cols];
             }
             // lockstep groups of equal heap size (columns that differ, or are not full, go one at a time)
+            const uint64_t q1 = prof ? __builtin_ia32_rdtsc() : 0;
+            q_scan += q1 - q0;
             size_t done = 0;
             while (done < n_cols) {
                 BestHeap* hp[MK];
@@ -961,6 +976,11 @@ void replay_group(kgwas_scan* s, Slot& sl, size_t g, ReplayAcc& acc) {
                 nc += (uint64_t)K;
                 done = c;
             }
+            if (prof) q_heap += __builtin_ia32_rdtsc() - q1;
+        }
+        if (prof) {
+            s->prof_scan.fetch_add(q_scan, std::memory_order_relaxed);
+            s->prof_heap.fetch_add(q_heap, std::memory_order_relaxed);
         }
     } else {
         for (const uint32_t j : members) {
@@ -1249,6 +1269,9 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
         add_replay_stats(s, s->rp_acc);
         // the replay's share of the wall clock: the busiest worker's time (they run side by side)
         s->st.replay_ms += (double)s->rp_max_busy_ns * 1e-6;
+        if (s->trace)
+            fprintf(stderr, "[kgwas] replay ticks: scanning records %.1f M, heap updates %.1f M (TSC, all workers)\n",
+                    (double)s->prof_scan.exchange(0) * 1e-6, (double)s->prof_heap.exchange(0) * 1e-6);
         if (s->trace)
             fprintf(stderr, "[kgwas] streaming replay: %llu units, cpu %.2f ms on %zu workers, busiest worker %.2f ms, wall %.2f ms\n",
                     (unsigned long long)s->rp_acc.units, (double)s->rp_acc.busy_ns * 1e-6, s->pool->size(),
@@ -1741,6 +1764,9 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                 s->d_ncols.alloc(P);
                 KGWAS_HIP(hipMemcpy(s->d_Bn.p, Bn.data(), Bn.size(), hipMemcpyHostToDevice));
                 KGWAS_HIP(hipMemcpy(s->d_ncols.p, ncols.data(), P * sizeof(NarrowCol), hipMemcpyHostToDevice));
+                s->bitmap_words = (s->chunk_max + 63) / 64;
+                s->d_bitmap.alloc(P * s->bitmap_words);
+                s->d_bm_blocks.alloc(P * ((s->bitmap_words + 1023) / 1024) + 4);
             }
             for (int mi = 0; mi < 2; mi++) {
                 if (!want[mi]) continue;

@@ -131,24 +131,25 @@ __device__ __forceinline__ void narrow_test(const NarrowArgs& a, const NarrowCol
                     if (lhs * lhs >= thr * (N1 * (Nd - N1)) * (1.0 - 0x1p-30)) hit |= 1u << rt;  // NaN threshold: never
                 }
         }
-        if (__ballot(hit != 0u)) {
-            const uint32_t cnt = __popc(hit);
-            uint32_t incl = cnt;
+        // Survivors as a bitmap: one 64-bit word per (column, wave pass) - bit 16 rt + r = table row rt * 16 + r of the
+        // pass. A ballot per row tile holds the four columns' 16 rows side by side; lane 0 puts the words together and
+        // stores the non-zero ones (the chunk's bitmap is zeroed beforehand). Row order is then a property of the
+        // bitmap, and the ordered key lists come out of a popcount scan (bitmap_*_kernel) instead of a radix sort.
+        unsigned long long bal[NRT];
+        unsigned long long any = 0;
 #pragma unroll
-            for (int dd = 1; dd < 64; dd <<= 1) {
-                const uint32_t t = __shfl_up(incl, dd);
-                if ((int)lane >= dd) incl += t;
+        for (int rt = 0; rt < NRT; rt++) {
+            bal[rt] = __ballot((hit >> rt) & 1u);
+            any |= bal[rt];
+        }
+        if (any && lane == 0u) {
+            const uint64_t word = (a.row_off + rbase) >> 6;
+            for (uint32_t q = 0; q < a.n_pheno; q++) {
+                unsigned long long w = 0;
+#pragma unroll
+                for (int rt = 0; rt < NRT; rt++) w |= ((bal[rt] >> (16u * q)) & 0xFFFFull) << (16 * rt);
+                if (w) a.bitmap[(uint64_t)q * a.words_per_col + word] = w;
             }
-            const uint32_t total = __shfl(incl, 63);
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(a.key_count, total);
-            base = __shfl(base, 0) + incl - cnt;
-#pragma unroll
-            for (int rt = 0; rt < NRT; rt++)
-                if (hit & (1u << rt)) {
-                    if (base < a.key_cap) a.keys[base] = (p << a.row_bits) | (uint32_t)(a.row_off + rbase + rt * 16u + r);
-                    base++;
-                }
         }
     }
 }
@@ -337,6 +338,114 @@ __global__ void __launch_bounds__(256) narrow_staged_kernel(NarrowArgs a, uint32
         for (int dd = 1; dd < 64; dd <<= 1) v += __shfl_xor(v, dd);
         if (lane == 0u && v) atomicAdd(&a.tested[blockIdx.x % TESTED_SHARDS], (unsigned long long)v);
     }
+}
+
+// ---- bitmap -> row-ordered survivor keys, column by column (no sort) ------------------------------------------------
+// Blocks of 1024 words (65 536 rows): counts, a scan of the block counts per column, then every block writes its keys
+// (column << row_bits | row) at its offset, ascending rows. Fills what launch_surv_sort fills for the coarse filter:
+// keys_sorted, surv_off[p], surv_cnt[p], key_count.
+constexpr uint32_t BM_WORDS = 1024;
+
+__global__ void __launch_bounds__(256) bitmap_count_kernel(const unsigned long long* bm, uint64_t words_per_col, uint32_t n_words,
+                                                           uint32_t n_blocks, uint32_t* blk_cnt) {
+    __shared__ uint32_t part[4];
+    const uint32_t p = blockIdx.y, b = blockIdx.x;
+    const unsigned long long* w = bm + (uint64_t)p * words_per_col;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t x = b * BM_WORDS + threadIdx.x * 4u + i;
+        if (x < n_words) c += __popcll(w[x]);
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) c += __shfl_xor(c, d);
+    if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) blk_cnt[p * n_blocks + b] = part[0] + part[1] + part[2] + part[3];
+}
+
+__global__ void __launch_bounds__(256) bitmap_scan_kernel(uint32_t* blk_cnt, uint32_t n_blocks, uint32_t n_pheno, uint32_t* surv_off,
+                                                          uint32_t* surv_cnt, uint32_t* key_count) {
+    __shared__ uint32_t part[256];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t p = 0; p < n_pheno; p++) {
+        const uint32_t col_base = carry;
+        for (uint32_t b0 = 0; b0 < n_blocks; b0 += 256u) {
+            const uint32_t b = b0 + threadIdx.x;
+            const uint32_t v = b < n_blocks ? blk_cnt[p * n_blocks + b] : 0u;
+            part[threadIdx.x] = v;
+            __syncthreads();
+            for (uint32_t d = 1; d < 256u; d <<= 1) {
+                const uint32_t x = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+                __syncthreads();
+                part[threadIdx.x] += x;
+                __syncthreads();
+            }
+            if (b < n_blocks) blk_cnt[p * n_blocks + b] = carry + part[threadIdx.x] - v;  // the block's offset in the key list
+            __syncthreads();
+            if (threadIdx.x == 255u) carry += part[255];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            surv_off[p] = col_base;
+            surv_cnt[p] = carry - col_base;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *key_count = carry;
+}
+
+__global__ void __launch_bounds__(256) bitmap_scatter_kernel(const unsigned long long* bm, uint64_t words_per_col, uint32_t n_words,
+                                                             uint32_t n_blocks, const uint32_t* blk_off, uint32_t* keys, uint32_t key_cap,
+                                                             uint32_t row_bits) {
+    __shared__ uint32_t part[4];
+    const uint32_t p = blockIdx.y, b = blockIdx.x;
+    const unsigned long long* w = bm + (uint64_t)p * words_per_col;
+    unsigned long long x[4];
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t idx = b * BM_WORDS + threadIdx.x * 4u + i;
+        x[i] = idx < n_words ? w[idx] : 0ull;
+        c += __popcll(x[i]);
+    }
+    if (!__syncthreads_or(c != 0u)) return;  // nothing in this block (the common case)
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(incl, d);
+        if ((int)lane >= d) incl += t;
+    }
+    if (lane == 63u) part[wave] = incl;
+    __syncthreads();
+    uint32_t o = blk_off[p * n_blocks + b] + incl - c;
+    for (uint32_t k = 0; k < wave; k++) o += part[k];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        unsigned long long v = x[i];
+        const uint32_t row0 = (b * BM_WORDS + threadIdx.x * 4u + i) * 64u;
+        while (v) {
+            const uint32_t bit = __ffsll((long long)v) - 1u;
+            v &= v - 1ull;
+            if (o < key_cap) keys[o] = (p << row_bits) | (row0 + bit);
+            o++;
+        }
+    }
+}
+
+hipError_t launch_bitmap_keys(const unsigned long long* bitmap, uint64_t words_per_col, uint64_t n_rows, uint32_t n_pheno, uint32_t* blk_scratch,
+                              uint32_t* keys_sorted, uint32_t key_cap, uint32_t row_bits, uint32_t* surv_off, uint32_t* surv_cnt,
+                              uint32_t* key_count, hipStream_t st) {
+    const uint32_t n_words = (uint32_t)((n_rows + 63) / 64);
+    const uint32_t n_blocks = (n_words + BM_WORDS - 1) / BM_WORDS;
+    hipLaunchKernelGGL(bitmap_count_kernel, dim3(n_blocks, n_pheno), dim3(256), 0, st, bitmap, words_per_col, n_words, n_blocks, blk_scratch);
+    hipLaunchKernelGGL(bitmap_scan_kernel, dim3(1), dim3(256), 0, st, blk_scratch, n_blocks, n_pheno, surv_off, surv_cnt, key_count);
+    hipLaunchKernelGGL(bitmap_scatter_kernel, dim3(n_blocks, n_pheno), dim3(256), 0, st, bitmap, words_per_col, n_words, n_blocks, blk_scratch,
+                       keys_sorted, key_cap, row_bits);
+    return hipGetLastError();
 }
 
 size_t narrow_lds_bytes(uint32_t n_kgroups) { return (size_t)n_kgroups * 4u * 2048u + 4u * sizeof(NarrowCol); }
