@@ -77,8 +77,8 @@ hipError_t launch_score_valu(const ScoreArgs& a, hipStream_t st);
 hipError_t launch_score_mfma(const ScoreArgs& a, uint32_t rows_per_block, uint32_t nb_full, hipStream_t st);
 size_t mfma_lds_bytes(uint32_t W_m);
 
-// Coarse int8 filter (score_coarse.hip). Survivors are appended to one key list; after launch_surv_sort,
-// launch_rescore scores them exactly, column by column in row order (it takes the sparse-mode ScoreArgs, with
+// Coarse int8 filter (score_coarse.hip). Survivors are bits of a [column][row] bitmap; launch_bitmap_keys lists them,
+// and launch_rescore scores them exactly, column by column in row order (it takes the sparse-mode ScoreArgs, with
 // Yperm set).
 // Per-slot constants of the coarse filter (score_coarse.hip); a slot is one of the PG*16 operand columns of an LDS
 // group. y_i ~ c + u*(254*q0_i + q1_i) (two slices) or c + u*q0_i (one slice), c = sum/N. A pair survives iff
@@ -98,10 +98,8 @@ struct CoarseArgs {
     const int8_t* Bq;       // [n_lgroups][n_kgroups][8][T][64 lanes][16] int8 slices, see score_coarse.hip
     const CoarseCol* cols;  // [n_lgroups][T/NS*16]
     const double* thr;      // [n_pheno]
-    uint32_t* keys;         // survivor keys (column << row_bits | chunk-local row), one global list
-    uint32_t* key_count;    // keys appended (may exceed key_cap: then the list overflowed)
-    uint32_t key_cap;
-    uint32_t row_bits;
+    unsigned long long* bitmap;  // survivors: [n_pheno][words_per_col] 64-bit words, bit r of word w = chunk row 64 w + r; zeroed by the caller
+    uint64_t words_per_col;
     unsigned long long* tested;
     // E(N1) = eg_max + min(rall_max, N1 * rmax_max) bounds |yigi_ref - yc| / u_p for every column (units of Dc,
     // each the maximum over the columns, rounded up): float32 summation error of the reference chains, the larger
@@ -151,18 +149,14 @@ struct NarrowArgs {
     uint32_t row_off;          // chunk row of this launch's first row (a launch that starts inside a chunk), a multiple of 64
 };
 // The bitmap's set bits as row-ordered keys (column << row_bits | row), column after column, with each column's range
-// and the total - what launch_surv_sort produces for the coarse filter's key list. blk_scratch: n_pheno * ceil(n_rows / 65536) words.
+// (surv_off, surv_cnt) and the total (key_count; above key_cap = overflow, the ranges are then emptied). No sort: counts
+// per 65 536-row block, a scan, a scatter. nibble_transposed: the words come from the int8 filters (quarter word kg,
+// nibble rt = rows 16 rt + 4 kg ..+3). blk_scratch: n_pheno * (ceil(n_rows / 65536) + 1) words.
 hipError_t launch_bitmap_keys(const unsigned long long* bitmap, uint64_t words_per_col, uint64_t n_rows, uint32_t n_pheno, uint32_t* blk_scratch,
                               uint32_t* keys_sorted, uint32_t key_cap, uint32_t row_bits, uint32_t* surv_off, uint32_t* surv_cnt,
-                              uint32_t* key_count, hipStream_t st);
+                              uint32_t* key_count, bool nibble_transposed, hipStream_t st);
 size_t narrow_lds_bytes(uint32_t n_kgroups);
 hipError_t launch_narrow(const NarrowArgs& a, uint32_t rows_per_block, hipStream_t st);
-
-// Survivor keys -> (column, row) order + each column's range (surv_sort.hip). n_slots = size of the key arrays.
-hipError_t surv_sort_temp_bytes(uint32_t n_slots, size_t* bytes);
-hipError_t launch_surv_sort(const uint32_t* keys, uint32_t* keys_sorted, uint32_t n_slots, const uint32_t* key_count,
-                            uint32_t key_cap, uint32_t n_pheno, uint32_t row_bits, uint32_t key_bits, uint32_t* off,
-                            uint32_t* cnt, void* temp, size_t temp_bytes, hipStream_t st);
 
 // --pattern_counter: append hash_presence_absence_pattern of every MAC-passing row to out[*out_count ...];
 // count_distinct_u64 sorts the collected hashes in place (device) and returns how many are distinct.

@@ -457,13 +457,12 @@ struct kgwas_scan {
     DevBuf<unsigned long long> d_bitmap;  // survivors of the chunk being filtered: [n_pheno][bitmap_words]
     uint64_t bitmap_words = 0;
     DevBuf<uint32_t> d_bm_blocks;
-    // survivor keys of the chunk being filtered, their sorted copy, each column's range in it; shared by all chunks
-    // (consumed by the re-score kernel in stream order)
-    DevBuf<uint32_t> d_surv, d_surv_sorted, d_surv_cnt, d_surv_off, d_key_count;
+    // survivors of the chunk being filtered: bitmap [column][64-row word], then row-ordered keys per column with each
+    // column's range; shared by all chunks (consumed by the re-score kernel in stream order)
+    DevBuf<uint32_t> d_surv_sorted, d_surv_cnt, d_surv_off, d_key_count;  // row-ordered keys per column, the columns' ranges, the total
     DevBuf<uint32_t> d_tile_pref, d_tile_cnt, d_tile_off;  // tiles of 256 survivors (launch_rescore)
     DevBuf<double> d_tmp_score;                            // exact score of every survivor (-inf: not a candidate)
     uint32_t key_slots = 0;  // capacity of the key list = n_pheno * cap
-    DevBuf<uint8_t> d_sort_tmp;
     uint32_t row_key_bits = 32;
     // --pattern_counter
     bool count_patterns = false;
@@ -787,15 +786,13 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
         c.rall_max = M.rall_max;
         c.rmax_max = M.rmax_max;
         c.thr = a.thr;
-        c.keys = s->d_surv.p;
-        c.key_count = s->d_key_count.p;
-        c.key_cap = s->key_slots;
-        c.row_bits = s->row_key_bits;
         c.tested = a.tested;
         static const uint32_t rpb_env = getenv("KGWAS_COARSE_RPB") ? (uint32_t)atoi(getenv("KGWAS_COARSE_RPB")) : 0u;  // experiments
+        // Survivors leave the filter as a bitmap [column][64-row word] of this chunk (zeroed here), which a popcount
+        // scan turns into row-ordered keys per column: no key list, no sort (launch_bitmap_keys).
+        const uint64_t n_words = (n_rows + 63) / 64;
+        KGWAS_HIP(hipMemsetAsync(s->d_bitmap.p, 0, (size_t)s->n_pheno * n_words * 8, s->stream));
         if (s->narrow) {
-            // survivors as a bitmap (zeroed here), turned into row-ordered keys by a popcount scan: no key list, no sort
-            KGWAS_HIP(hipMemsetAsync(s->d_bitmap.p, 0, (size_t)s->n_pheno * s->bitmap_words * 8, s->stream));
             NarrowArgs na;
             memset(&na, 0, sizeof(na));
             na.src = a.src;
@@ -808,30 +805,26 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
             na.cols = s->d_ncols.p;
             na.thr = a.thr;
             na.bitmap = s->d_bitmap.p;
-            na.words_per_col = s->bitmap_words;
+            na.words_per_col = n_words;
             na.tested = a.tested;
             // (short blocks: three 4-wave blocks share a CU and a launch's block count is rarely a multiple of the
             // 768 block slots, so long blocks leave CUs idle at the end of every launch: 4096 rows per block measured
             // 3.4 ms per 100 M rows, 768 rows 3.0)
             KGWAS_HIP(launch_narrow(na, rpb_env ? rpb_env : (n_rows >= (1u << 18) ? 768u : 256u), s->stream));
-            KGWAS_HIP(hipEventRecord(sl.ev_mid, s->stream));
-            a.tested = nullptr;  // counted by the filter
-            KGWAS_HIP(launch_bitmap_keys(s->d_bitmap.p, s->bitmap_words, n_rows, (uint32_t)s->n_pheno, s->d_bm_blocks.p, s->d_surv_sorted.p,
-                                         s->key_slots, s->row_key_bits, s->d_surv_off.p, s->d_surv_cnt.p, s->d_key_count.p, s->stream));
         } else {
-        KGWAS_HIP(hipMemsetAsync(s->d_surv.p, 0xFF, (size_t)s->key_slots * sizeof(uint32_t), s->stream));  // sorts last
-        // rows per block: the operand tiles (up to 128 KB) are loaded into LDS once per block, so blocks are long
-        // where the launch still fills the chip four times over
-        if (M.wide) {
-            KGWAS_HIP(launch_wide(c, M.T, rpb_env ? rpb_env : (n_rows >= (1u << 20) ? 1024u : 256u), s->stream));
-        } else
-        KGWAS_HIP(launch_coarse(c, M.T, rpb_env ? rpb_env : (n_rows >= (1u << 22) ? 4096u : n_rows >= (1u << 20) ? 2048u : 512u), s->stream));
-        KGWAS_HIP(hipEventRecord(sl.ev_mid, s->stream));
-        a.tested = nullptr;  // counted by the coarse pass
-        KGWAS_HIP(launch_surv_sort(s->d_surv.p, s->d_surv_sorted.p, s->key_slots, s->d_key_count.p, s->key_slots,
-                                   (uint32_t)s->n_pheno, s->row_key_bits, 32, s->d_surv_off.p, s->d_surv_cnt.p,
-                                   s->d_sort_tmp.p, s->d_sort_tmp.n, s->stream));
+            c.bitmap = s->d_bitmap.p;
+            c.words_per_col = n_words;
+            // rows per block: the operand tiles (up to 128 KB) are loaded into LDS once per block, so blocks are long
+            // where the launch still fills the chip four times over
+            if (M.wide)
+                KGWAS_HIP(launch_wide(c, M.T, rpb_env ? rpb_env : (n_rows >= (1u << 20) ? 1024u : 256u), s->stream));
+            else
+                KGWAS_HIP(launch_coarse(c, M.T, rpb_env ? rpb_env : (n_rows >= (1u << 22) ? 4096u : n_rows >= (1u << 20) ? 2048u : 512u), s->stream));
         }
+        KGWAS_HIP(hipEventRecord(sl.ev_mid, s->stream));
+        a.tested = nullptr;  // counted by the filter
+        KGWAS_HIP(launch_bitmap_keys(s->d_bitmap.p, n_words, n_rows, (uint32_t)s->n_pheno, s->d_bm_blocks.p, s->d_surv_sorted.p, s->key_slots,
+                                     s->row_key_bits, s->d_surv_off.p, s->d_surv_cnt.p, s->d_key_count.p, /*nibble_transposed=*/!s->narrow, s->stream));
         a.so_score = sl.d_so_score.p;
         a.so_kmer = sl.d_so_kmer.p;
         a.so_row = sl.d_so_row.p;
@@ -1764,9 +1757,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                 s->d_ncols.alloc(P);
                 KGWAS_HIP(hipMemcpy(s->d_Bn.p, Bn.data(), Bn.size(), hipMemcpyHostToDevice));
                 KGWAS_HIP(hipMemcpy(s->d_ncols.p, ncols.data(), P * sizeof(NarrowCol), hipMemcpyHostToDevice));
-                s->bitmap_words = (s->chunk_max + 63) / 64;
-                s->d_bitmap.alloc(P * s->bitmap_words);
-                s->d_bm_blocks.alloc(P * ((s->bitmap_words + 1023) / 1024) + 4);
+
             }
             for (int mi = 0; mi < 2; mi++) {
                 if (!want[mi]) continue;
@@ -1852,8 +1843,10 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                 M.ready = true;
             }
             s->key_slots = (uint32_t)std::min<uint64_t>((uint64_t)s->cap * P, 0x7FFFFFFFull);
-            s->d_surv.alloc(s->key_slots);
             s->d_surv_sorted.alloc(s->key_slots);
+            s->bitmap_words = (s->chunk_max + 63) / 64;
+            s->d_bitmap.alloc(P * s->bitmap_words);
+            s->d_bm_blocks.alloc(P * ((s->bitmap_words + 1023) / 1024 + 1) + 4);
             s->d_surv_cnt.alloc(P);
             s->d_surv_off.alloc(P);
             s->d_key_count.alloc(1);
@@ -1862,9 +1855,6 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
             s->d_tile_off.alloc((size_t)s->key_slots / 256 + P + 2);
             s->d_tmp_score.alloc(s->key_slots);
             KGWAS_HIP(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
-            size_t tb = 0;
-            KGWAS_HIP(surv_sort_temp_bytes(s->key_slots, &tb));
-            s->d_sort_tmp.alloc(std::max<size_t>(tb, 16));
             s->row_key_bits = 1;
             while (s->row_key_bits < 32 && (1ull << s->row_key_bits) < s->chunk_max) s->row_key_bits++;
         }

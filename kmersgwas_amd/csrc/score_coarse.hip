@@ -34,7 +34,6 @@
 
 #include "score_common.h"
 
-#define COARSE_SBUF 2048u  // survivor keys a block buffers in LDS
 #ifndef KGWAS_COARSE_PHASES
 #define KGWAS_COARSE_PHASES 1  // pin the per-step order: LDS reads, operand expansion, MFMAs
 #endif
@@ -103,16 +102,12 @@ __global__ void __launch_bounds__(512) coarse_kernel(CoarseArgs a, uint32_t rows
     const uint32_t group_vec = n_kgroups * 8u * T * 64u;  // i32x4 elements per LDS group
     float* colc = reinterpret_cast<float*>(blds + group_vec);
     const int* colp = reinterpret_cast<const int*>(colc + 2 * SLOTS);
-    // Survivors are keys (column << row_bits | chunk-local row). A block collects them in LDS and appends them to the
-    // global list with ONE atomic at its end (per-column counters bumped once per wave pass were ~9e5 device-scope
-    // atomics per launch on ~100 addresses: they serialise at the memory side and cost more than the MFMAs).
-    uint32_t* sctl = reinterpret_cast<uint32_t*>(colc + 3 * SLOTS);  // [0] reserved, [1] start of the first reservation that did not fit, [2] global base, [3] n
-    uint32_t* sbuf = sctl + 4;
-    float* wscr = reinterpret_cast<float*>(sbuf + COARSE_SBUF) + wave * 192u;  // wave-private: 64 x N1, 64 x (sqrt(d), E)
-    if (threadIdx.x == 0) {
-        sctl[0] = 0u;
-        sctl[1] = 0xFFFFFFFFu;
-    }
+    // Survivors leave as a bitmap: one 64-bit word per (phenotype column, 64 rows of a wave pass), bit = row of the pass
+    // (the chunk's bitmap is zeroed beforehand; only non-zero words are stored). Row order is then a property of the
+    // bitmap and the ordered per-column key lists come out of a popcount scan (launch_bitmap_keys) - the first version
+    // appended keys to one global list (per-block LDS buffering, one device atomic per block) that a radix sort then
+    // had to put in (column, row) order: 4.6 ms of a 22 ms pass at 101 columns.
+    float* wscr = colc + 3 * SLOTS + wave * 192u;  // wave-private: 64 x N1, 64 x (sqrt(d), E)
     const uint32_t rows_per_pass = (blockDim.x >> 6) * (RT * 16u);
     const uint64_t blk_row0 = (uint64_t)rb * rows_per_block;
     const float Nf = (float)a.S;
@@ -318,7 +313,7 @@ __global__ void __launch_bounds__(512) coarse_kernel(CoarseArgs a, uint32_t rows
 #pragma unroll
             for (int i = 0; i < RT * 4; i++) hit_any |= hit[i];
             if ((KGWAS_COARSE_ABLATE & 32) && hit_any) {  // tests only: a token side effect instead of the emission
-                if (lane == 0) atomicAdd(&sctl[0], 0u);
+                if (lane == 0) atomicAdd(&a.tested[0], 0ull);
                 hit_any = 0;
             }
             // mb[g] bit i = pair (row slot i, column g*16 + m) survives; rebuilt for the row slots that had a hit.
@@ -339,78 +334,16 @@ __global__ void __launch_bounds__(512) coarse_kernel(CoarseArgs a, uint32_t rows
                 }
             }
             if (hit_any) {  // wave-uniform
-                uint32_t lane_cnt = 0;
+                // Column (g, m)'s 64 row bits of this pass sit in four lanes (kg = 0..3; bit i = 4 rt + jj of mb[g] is row
+                // rt * 16 + 4 kg + jj). Each lane stores its 16 bits as quarter kg of the column's word: no cross-lane
+                // traffic, and launch_bitmap_keys(nibble_transposed = true) puts the word's nibbles back in row order.
+                unsigned short* bm16 = reinterpret_cast<unsigned short*>(a.bitmap) + (rbase >> 6) * 4u + kg;
 #pragma unroll
-                for (int g = 0; g < PG; g++) lane_cnt += __popc(mb[g]);
-                // keys of this lane's survivors go to slots k, k + 1, ... of the block buffer (fits) or of the global list
-                auto write_keys = [&](uint32_t k, bool fits) {
-#pragma unroll
-                    for (int g = 0; g < PG; g++) {
-                        uint32_t mbits = mb[g];
-                        const uint32_t pk = (uint32_t)colp[g * 16 + m] << a.row_bits;  // column >= 0 wherever a bit is set
-                        while (mbits) {
-                            const uint32_t b = __ffs(mbits) - 1u;
-                            mbits &= mbits - 1u;
-                            const uint32_t key = pk | (uint32_t)(rbase + (b >> 2) * 16u + kg * 4u + (b & 3u));
-                            if (fits)
-                                sbuf[k] = key;
-                            else if (k < a.key_cap)
-                                a.keys[k] = key;
-                            k++;
-                        }
-                    }
-                };
-                if (__popcll(__ballot(lane_cnt != 0u)) <= 8) {
-                    // Steady state: a couple of lanes hold a survivor or two. Each reserves its own slots with one LDS
-                    // atomic (a wave-wide scan plus a leader's reservation is a chain of nine dependent LDS-pipe
-                    // round trips, ~1500 cycles per pass that nothing overlaps).
-                    if (lane_cnt) {
-                        const uint32_t base = atomicAdd(&sctl[0], lane_cnt);  // LDS
-                        const bool fits = base + lane_cnt <= COARSE_SBUF;
-                        uint32_t gb = 0;
-                        if (!fits) {
-                            atomicMin(&sctl[1], base);
-                            gb = atomicAdd(a.key_count, lane_cnt);
-                        }
-                        write_keys(fits ? base : gb, fits);
-                    }
-                } else {
-                    uint32_t incl = lane_cnt;  // inclusive scan over the wave
-#pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) {
-                        const uint32_t t = __shfl_up(incl, d);
-                        if ((int)lane >= d) incl += t;
-                    }
-                    const uint32_t total = __shfl(incl, 63);
-                    uint32_t wbase = 0;
-                    if (lane == 0) wbase = atomicAdd(&sctl[0], total);  // LDS
-                    wbase = __shfl(wbase, 0);
-                    const bool fits = wbase + total <= COARSE_SBUF;  // wave-uniform
-                    uint32_t gb = 0;
-                    if (!fits) {  // dense survivors (ramp chunks): this wave appends to the global list itself
-                        if (lane == 0) {
-                            atomicMin(&sctl[1], wbase);
-                            gb = atomicAdd(a.key_count, total);
-                        }
-                        gb = __shfl(gb, 0);
-                    }
-                    write_keys((fits ? wbase : gb) + (incl - lane_cnt), fits);
-                }
+                for (int g = 0; g < PG; g++)
+                    if (mb[g]) bm16[(uint64_t)colp[g * 16 + m] * a.words_per_col * 4u] = (unsigned short)mb[g];  // column >= 0 wherever a bit is set
             }
             TL_STAMP(53);  // hits resolved, survivors emitted
         }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t n = sctl[0] < sctl[1] ? sctl[0] : sctl[1];
-        sctl[3] = n;
-        sctl[2] = n ? atomicAdd(a.key_count, n) : 0u;
-    }
-    __syncthreads();
-    {
-        const uint32_t n = sctl[3], gb = sctl[2];
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
-            if (gb + i < a.key_cap) a.keys[gb + i] = sbuf[i];
     }
     if (a.tested) {
         uint32_t v = tested_local;  // every lane counted one row per pass
@@ -592,9 +525,9 @@ hipError_t launch_chunk_prep(uint32_t* cand_cnt, uint32_t n_pheno, unsigned long
     return hipGetLastError();
 }
 
-// B operands of one LDS group + the group's per-column constants (3 x up to 128 words) + the block's survivor buffer
-// + the eight waves' row-term exchange areas
-size_t coarse_lds_bytes(uint32_t n_kgroups, uint32_t T) { return (size_t)n_kgroups * 8u * T * 1024u + 1536u + 16u + 4u * COARSE_SBUF + 8u * 768u; }
+// B operands of one LDS group + the group's per-column constants (3 x up to 128 words) + the eight waves' row-term
+// exchange areas
+size_t coarse_lds_bytes(uint32_t n_kgroups, uint32_t T) { return (size_t)n_kgroups * 8u * T * 1024u + 1536u + 8u * 768u; }
 
 template <int T, int NS>
 static hipError_t launch_coarse_t(const CoarseArgs& a, uint32_t rows_per_block, uint32_t n_rowblocks, size_t lds,

@@ -342,8 +342,7 @@ __global__ void __launch_bounds__(256) narrow_staged_kernel(NarrowArgs a, uint32
 
 // ---- bitmap -> row-ordered survivor keys, column by column (no sort) ------------------------------------------------
 // Blocks of 1024 words (65 536 rows): counts, a scan of the block counts per column, then every block writes its keys
-// (column << row_bits | row) at its offset, ascending rows. Fills what launch_surv_sort fills for the coarse filter:
-// keys_sorted, surv_off[p], surv_cnt[p], key_count.
+// (column << row_bits | row) at its offset, ascending rows: keys_sorted, surv_off[p], surv_cnt[p], key_count.
 constexpr uint32_t BM_WORDS = 1024;
 
 __global__ void __launch_bounds__(256) bitmap_count_kernel(const unsigned long long* bm, uint64_t words_per_col, uint32_t n_words,
@@ -364,42 +363,66 @@ __global__ void __launch_bounds__(256) bitmap_count_kernel(const unsigned long l
     if (threadIdx.x == 0) blk_cnt[p * n_blocks + b] = part[0] + part[1] + part[2] + part[3];
 }
 
-__global__ void __launch_bounds__(256) bitmap_scan_kernel(uint32_t* blk_cnt, uint32_t n_blocks, uint32_t n_pheno, uint32_t* surv_off,
-                                                          uint32_t* surv_cnt, uint32_t* key_count) {
+// block p: exclusive scan of column p's block counts (in place) and the column's total
+__global__ void __launch_bounds__(256) bitmap_scan_kernel(uint32_t* blk_cnt, uint32_t n_blocks, uint32_t* col_total) {
+    __shared__ uint32_t part[256];
+    __shared__ uint32_t carry;
+    const uint32_t p = blockIdx.x;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < n_blocks; b0 += 256u) {
+        const uint32_t b = b0 + threadIdx.x;
+        const uint32_t v = b < n_blocks ? blk_cnt[p * n_blocks + b] : 0u;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (uint32_t d = 1; d < 256u; d <<= 1) {
+            const uint32_t x = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+            __syncthreads();
+            part[threadIdx.x] += x;
+            __syncthreads();
+        }
+        if (b < n_blocks) blk_cnt[p * n_blocks + b] = carry + part[threadIdx.x] - v;  // offset inside the column's range
+        __syncthreads();
+        if (threadIdx.x == 255u) carry += part[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) col_total[p] = carry;
+}
+
+// each column's range in the key list and the total
+__global__ void __launch_bounds__(256) bitmap_bases_kernel(const uint32_t* col_total, uint32_t n_pheno, uint32_t key_cap, uint32_t* surv_off,
+                                                           uint32_t* surv_cnt, uint32_t* key_count) {
     __shared__ uint32_t part[256];
     __shared__ uint32_t carry;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
-    for (uint32_t p = 0; p < n_pheno; p++) {
-        const uint32_t col_base = carry;
-        for (uint32_t b0 = 0; b0 < n_blocks; b0 += 256u) {
-            const uint32_t b = b0 + threadIdx.x;
-            const uint32_t v = b < n_blocks ? blk_cnt[p * n_blocks + b] : 0u;
-            part[threadIdx.x] = v;
+    for (uint32_t p0 = 0; p0 < n_pheno; p0 += 256u) {
+        const uint32_t p = p0 + threadIdx.x;
+        const uint32_t v = p < n_pheno ? col_total[p] : 0u;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (uint32_t d = 1; d < 256u; d <<= 1) {
+            const uint32_t x = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
             __syncthreads();
-            for (uint32_t d = 1; d < 256u; d <<= 1) {
-                const uint32_t x = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
-                __syncthreads();
-                part[threadIdx.x] += x;
-                __syncthreads();
-            }
-            if (b < n_blocks) blk_cnt[p * n_blocks + b] = carry + part[threadIdx.x] - v;  // the block's offset in the key list
-            __syncthreads();
-            if (threadIdx.x == 255u) carry += part[255];
+            part[threadIdx.x] += x;
             __syncthreads();
         }
-        if (threadIdx.x == 0) {
-            surv_off[p] = col_base;
-            surv_cnt[p] = carry - col_base;
+        if (p < n_pheno) {
+            surv_off[p] = carry + part[threadIdx.x] - v;
+            surv_cnt[p] = v;
         }
         __syncthreads();
+        if (threadIdx.x == 255u) carry += part[255];
+        __syncthreads();
     }
-    if (threadIdx.x == 0) *key_count = carry;
+    if (threadIdx.x == 0) *key_count = carry;  // the host compares it with the capacity
+    if (carry > key_cap)  // overflow: the chunk is redone in halves; leave nothing for the re-score kernels to walk
+        for (uint32_t p = threadIdx.x; p < n_pheno; p += 256u) surv_cnt[p] = 0u;
 }
 
 __global__ void __launch_bounds__(256) bitmap_scatter_kernel(const unsigned long long* bm, uint64_t words_per_col, uint32_t n_words,
-                                                             uint32_t n_blocks, const uint32_t* blk_off, uint32_t* keys, uint32_t key_cap,
-                                                             uint32_t row_bits) {
+                                                             uint32_t n_blocks, const uint32_t* blk_off, const uint32_t* surv_off, uint32_t* keys,
+                                                             uint32_t key_cap, uint32_t row_bits, bool nibble_transposed) {
     __shared__ uint32_t part[4];
     const uint32_t p = blockIdx.y, b = blockIdx.x;
     const unsigned long long* w = bm + (uint64_t)p * words_per_col;
@@ -412,6 +435,18 @@ __global__ void __launch_bounds__(256) bitmap_scatter_kernel(const unsigned long
         c += __popcll(x[i]);
     }
     if (!__syncthreads_or(c != 0u)) return;  // nothing in this block (the common case)
+    if (nibble_transposed) {  // the int8 filters write nibble 4 kg + rt for rows 16 rt + 4 kg ..+3: back to row order
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (!x[i]) continue;
+            unsigned long long y = 0;
+#pragma unroll
+            for (int kg = 0; kg < 4; kg++)
+#pragma unroll
+                for (int rt = 0; rt < 4; rt++) y |= ((x[i] >> (4 * (4 * kg + rt))) & 0xFull) << (4 * (4 * rt + kg));
+            x[i] = y;
+        }
+    }
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t incl = c;
 #pragma unroll
@@ -421,7 +456,7 @@ __global__ void __launch_bounds__(256) bitmap_scatter_kernel(const unsigned long
     }
     if (lane == 63u) part[wave] = incl;
     __syncthreads();
-    uint32_t o = blk_off[p * n_blocks + b] + incl - c;
+    uint32_t o = surv_off[p] + blk_off[p * n_blocks + b] + incl - c;
     for (uint32_t k = 0; k < wave; k++) o += part[k];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -438,13 +473,15 @@ __global__ void __launch_bounds__(256) bitmap_scatter_kernel(const unsigned long
 
 hipError_t launch_bitmap_keys(const unsigned long long* bitmap, uint64_t words_per_col, uint64_t n_rows, uint32_t n_pheno, uint32_t* blk_scratch,
                               uint32_t* keys_sorted, uint32_t key_cap, uint32_t row_bits, uint32_t* surv_off, uint32_t* surv_cnt,
-                              uint32_t* key_count, hipStream_t st) {
+                              uint32_t* key_count, bool nibble_transposed, hipStream_t st) {
     const uint32_t n_words = (uint32_t)((n_rows + 63) / 64);
     const uint32_t n_blocks = (n_words + BM_WORDS - 1) / BM_WORDS;
     hipLaunchKernelGGL(bitmap_count_kernel, dim3(n_blocks, n_pheno), dim3(256), 0, st, bitmap, words_per_col, n_words, n_blocks, blk_scratch);
-    hipLaunchKernelGGL(bitmap_scan_kernel, dim3(1), dim3(256), 0, st, blk_scratch, n_blocks, n_pheno, surv_off, surv_cnt, key_count);
+    uint32_t* col_total = blk_scratch + (size_t)n_pheno * n_blocks;
+    hipLaunchKernelGGL(bitmap_scan_kernel, dim3(n_pheno), dim3(256), 0, st, blk_scratch, n_blocks, col_total);
+    hipLaunchKernelGGL(bitmap_bases_kernel, dim3(1), dim3(256), 0, st, col_total, n_pheno, key_cap, surv_off, surv_cnt, key_count);
     hipLaunchKernelGGL(bitmap_scatter_kernel, dim3(n_blocks, n_pheno), dim3(256), 0, st, bitmap, words_per_col, n_words, n_blocks, blk_scratch,
-                       keys_sorted, key_cap, row_bits);
+                       surv_off, keys_sorted, key_cap, row_bits, nibble_transposed);
     return hipGetLastError();
 }
 

@@ -19,8 +19,6 @@
 
 #include "score_common.h"
 
-#define WIDE_SBUF 2048u  // survivor keys a block buffers in LDS
-
 namespace kgwas {
 
 typedef int wi32x4 __attribute__((ext_vector_type(4)));
@@ -28,7 +26,7 @@ typedef int wi32x4 __attribute__((ext_vector_type(4)));
 template <int T>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 wide_kernel(CoarseArgs a, uint32_t rows_per_block, uint32_t n_rowblocks) {
-    extern __shared__ wi32x4 wlds[];  // two stages of [4 steps][T][64] x 16 bytes, colc[3][T*16], survivor buffer, exchange areas
+    extern __shared__ wi32x4 wlds[];  // two stages of [4 steps][T][64] x 16 bytes, colc[3][T*16], exchange areas
     constexpr int RT = 4;
     constexpr int SLOTS = T * 16;
     constexpr uint32_t STAGE_VEC = 4u * T * 64u;  // i32x4 elements of a stage
@@ -40,13 +38,7 @@ wide_kernel(CoarseArgs a, uint32_t rows_per_block, uint32_t n_rowblocks) {
     const uint32_t n_stages = 2u * a.n_kgroups;
     float* colc = reinterpret_cast<float*>(wlds + 2u * STAGE_VEC);
     const int* colp = reinterpret_cast<const int*>(colc + 2 * SLOTS);
-    uint32_t* sctl = reinterpret_cast<uint32_t*>(colc + 3 * SLOTS);  // [0] reserved, [1] first reservation that did not fit, [2] global base, [3] n
-    uint32_t* sbuf = sctl + 4;
-    float* wscr = reinterpret_cast<float*>(sbuf + WIDE_SBUF) + wave * 192u;  // wave-private: 64 x N1, 64 x (sqrt(d), E)
-    if (threadIdx.x == 0) {
-        sctl[0] = 0u;
-        sctl[1] = 0xFFFFFFFFu;
-    }
+    float* wscr = colc + 3 * SLOTS + wave * 192u;  // wave-private: 64 x N1, 64 x (sqrt(d), E)
     if (threadIdx.x < SLOTS) {
         const CoarseCol cc = a.cols[threadIdx.x];
         float al = __builtin_huge_valf();  // padding / N1 column: nothing survives
@@ -253,59 +245,12 @@ wide_kernel(CoarseArgs a, uint32_t rows_per_block, uint32_t n_rowblocks) {
                     }
                 }
             }
-            uint32_t lane_cnt = 0;
+            // survivors as quarter words of the bitmap (see coarse_kernel; nibble-transposed words)
+            unsigned short* bm16 = reinterpret_cast<unsigned short*>(a.bitmap) + (rbase >> 6) * 4u + kg;
 #pragma unroll
-            for (int g = 0; g < T; g++) lane_cnt += __popc(mb[g]);
-            auto write_keys = [&](uint32_t k, bool fits) {
-#pragma unroll
-                for (int g = 0; g < T; g++) {
-                    uint32_t mbits = mb[g];
-                    const uint32_t pk = (uint32_t)colp[g * 16 + m] << a.row_bits;  // column >= 0 wherever a bit is set
-                    while (mbits) {
-                        const uint32_t b = __ffs(mbits) - 1u;
-                        mbits &= mbits - 1u;
-                        const uint32_t key = pk | (uint32_t)(rbase + (b >> 2) * 16u + kg * 4u + (b & 3u));
-                        if (fits)
-                            sbuf[k] = key;
-                        else if (k < a.key_cap)
-                            a.keys[k] = key;
-                        k++;
-                    }
-                }
-            };
-            uint32_t incl = lane_cnt;  // inclusive scan over the wave
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t t = __shfl_up(incl, d);
-                if ((int)lane >= d) incl += t;
-            }
-            const uint32_t total = __shfl(incl, 63);
-            uint32_t wbase = 0;
-            if (lane == 0) wbase = atomicAdd(&sctl[0], total);  // LDS
-            wbase = __shfl(wbase, 0);
-            const bool fits = wbase + total <= WIDE_SBUF;  // wave-uniform
-            uint32_t gb = 0;
-            if (!fits) {  // dense survivors: this wave appends to the global list itself
-                if (lane == 0) {
-                    atomicMin(&sctl[1], wbase);
-                    gb = atomicAdd(a.key_count, total);
-                }
-                gb = __shfl(gb, 0);
-            }
-            write_keys((fits ? wbase : gb) + (incl - lane_cnt), fits);
+            for (int g = 0; g < T; g++)
+                if (mb[g]) bm16[(uint64_t)colp[g * 16 + m] * a.words_per_col * 4u] = (unsigned short)mb[g];
         }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t n = sctl[0] < sctl[1] ? sctl[0] : sctl[1];
-        sctl[3] = n;
-        sctl[2] = n ? atomicAdd(a.key_count, n) : 0u;
-    }
-    __syncthreads();
-    {
-        const uint32_t n = sctl[3], gb = sctl[2];
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
-            if (gb + i < a.key_cap) a.keys[gb + i] = sbuf[i];
     }
     if (a.tested) {
         uint32_t v = tested_local;  // every lane counted one row per pass
@@ -315,7 +260,7 @@ wide_kernel(CoarseArgs a, uint32_t rows_per_block, uint32_t n_rowblocks) {
     }
 }
 
-size_t wide_lds_bytes(uint32_t T) { return (size_t)2u * 4u * T * 1024u + 3u * T * 16u * 4u + 16u + 4u * WIDE_SBUF + 4u * 768u; }
+size_t wide_lds_bytes(uint32_t T) { return (size_t)2u * 4u * T * 1024u + 3u * T * 16u * 4u + 4u * 768u; }
 
 template <int T>
 static hipError_t launch_wide_t(const CoarseArgs& a, uint32_t rows_per_block, uint32_t n_rowblocks, size_t lds, hipStream_t st) {
