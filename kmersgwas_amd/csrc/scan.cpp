@@ -450,6 +450,9 @@ struct kgwas_scan {
         DevBuf<int8_t> d_Bq;
         DevBuf<CoarseCol> d_cols;
     } cmode[2];
+    double infl_obs[2] = {4.0, 1.1};  // survivors per candidate of the last finished chunk of each mode
+    double mode_k = 0.09;
+    uint64_t sum_topn = 0;  // over the columns
     // narrow filter (1-3 columns, score_narrow.hip): replaces coarse_kernel in the same pipeline
     bool narrow = false;
     DevBuf<uint8_t> d_Bn;
@@ -725,18 +728,23 @@ void run_dense(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, uint64_t 
     s->st.dense_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - td0).count();
 }
 
-// count_hist: first (and only) scoring of these rows in the sparse phase -> their candidates feed the
-// device-side threshold histograms. Overflow re-runs must not count the same rows twice.
-// Which operand set a sparse chunk of n_rows uses: the one-slice filter when its ~2.5x longer survivor lists
-// still fit the per-column capacity with room to spare (the long steady chunks), the two-slice one otherwise
-// (the ramp, where chunks are sized to fill a third of the capacity with candidates alone).
-int pick_coarse_mode(const kgwas_scan* s, uint64_t n_rows) {
+// Which operand set the next sparse chunk uses. The one-slice filter does half (or less) of the matrix work per row
+// but lists several survivors per candidate, and every survivor costs an exact re-score (S lane-ops x 4); the
+// two-slice filter lists ~1.1. Per row: tile-slices x S x 0.014 ps of filter against survivors x S x 0.15 ps of
+// re-score (both measured at 1135 x 101 and 2048 x 201), so one slice wins once
+//     candidates per row x (infl[0] - infl[1]) < mode_k x (tile-slices[1] - tile-slices[0]),  mode_k ~ 0.09,
+// i.e. early in a scan (low thresholds, many candidates per row) the chunks take two slices, later one. infl[] are the
+// survivors per candidate the finished chunks of each mode reported (fetch_records).
+int pick_coarse_mode(const kgwas_scan* s) {
     if (!s->cmode[0].ready) return 1;
     if (!s->cmode[1].ready) return 0;
-    const double per_col = (double)s->max_topn * (double)n_rows / (double)std::max<uint64_t>(s->rows_submitted, 1);
-    return 2.5 * per_col <= 0.6 * (double)s->cap ? 0 : 1;
+    const double cand_row = (double)s->sum_topn / (double)std::max<uint64_t>(s->rows_submitted, 1);
+    const double tiles0 = (double)s->cmode[0].T * s->cmode[0].n_lgroups, tiles1 = (double)s->cmode[1].T * s->cmode[1].n_lgroups;
+    return cand_row * std::max(0.0, s->infl_obs[0] - s->infl_obs[1]) < s->mode_k * (tiles1 - tiles0) ? 0 : 1;
 }
 
+// count_hist: first (and only) scoring of these rows in the sparse phase -> their candidates feed the
+// device-side threshold histograms. Overflow re-runs must not count the same rows twice.
 void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_rows, uint64_t first_row,
                    bool count_hist) {
     ScoreArgs a;
@@ -775,7 +783,7 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
         c.n_pheno = a.n_pheno;
         c.min_count = a.min_count;
         c.n_kgroups = s->n_kgroups;
-        const int cm = s->narrow ? 0 : pick_coarse_mode(s, n_rows);
+        const int cm = s->narrow ? 0 : pick_coarse_mode(s);
         const kgwas_scan::CoarseMode& M = s->cmode[cm];
         sl.coarse_mode = cm;
         c.n_lgroups = M.n_lgroups;
@@ -1096,11 +1104,19 @@ void process_range_sync(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_
 
 uint64_t next_sparse_chunk(const kgwas_scan* s) {
     // The device keeps its thresholds current with everything submitted so far (thr_update_kernel), so a
-    // chunk of c rows ships about topn * c / rows_submitted records per column. Keep that under cap / 3.
+    // chunk of c rows ships about topn * c / rows_submitted records per column. Exact scorer: each column's list
+    // holds cap records, keep that under cap / 3. Int8 filters: the survivor keys of all columns share one list of
+    // key_slots (and so do the records); plan for half of it with the survivors per candidate that the finished
+    // chunks of the coming chunk's mode reported (~1 for the narrow filter).
     const double m = (double)std::max<uint64_t>(s->rows_submitted, 1);
-    // (the one-slice coarse filter lists ~2.5 survivors per candidate, the two-slice one ~1)
-    const double infl = (s->coarse && !s->narrow && !s->cmode[1].ready) ? 2.5 : 1.0;  // (the narrow filter's survivors are its candidates)
-    double c = m * (double)s->cap / (3.0 * infl * (double)std::max<uint64_t>(s->max_topn, 1));
+    static const double fill = getenv("KGWAS_FILL") ? atof(getenv("KGWAS_FILL")) : 0.4;  // experiments
+    double c;
+    if (s->coarse) {
+        const double infl = s->narrow ? 1.0 : std::max(1.0, s->infl_obs[pick_coarse_mode(s)]);
+        c = fill * m * (double)s->key_slots / (infl * (double)std::max<uint64_t>(s->sum_topn, 1));
+    } else {
+        c = m * (double)s->cap / (3.0 * (double)std::max<uint64_t>(s->max_topn, 1));
+    }
     uint64_t ci = (uint64_t)std::min<double>(c, (double)s->chunk_max);
     ci = std::max<uint64_t>(ci, std::min<uint64_t>(s->dense_rows, s->chunk_max));
     ci = std::min<uint64_t>(ci, s->chunk_max);
@@ -1131,6 +1147,8 @@ void fetch_records(kgwas_scan* s, Slot& sl) {
     if (!sl.used_coarse) return;
     wait_event(s, sl.ev_counts);
     const uint32_t n = sl.h_meta.p[2 * s->n_pheno];
+    if (!s->narrow && n >= 1024)
+        s->infl_obs[sl.coarse_mode] = std::min(64.0, std::max(1.0, (double)sl.h_meta.p[2 * s->n_pheno + 1] / (double)n));
     if (n && sl.h_meta.p[2 * s->n_pheno + 1] <= s->key_slots) {
         KGWAS_HIP(hipMemcpyAsync(sl.so_score.p, sl.d_so_score.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s->copy_stream));
         KGWAS_HIP(hipMemcpyAsync(sl.so_row.p, sl.d_so_row.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, s->copy_stream));
@@ -1445,6 +1463,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         for (uint64_t j = 0; j < s->n_pheno; j++) {
             if (s->topn[j] == 0) throw Error(KGWAS_ERR_ARG, "heap size must be >= 1");
             s->max_topn = std::max(s->max_topn, s->topn[j]);
+            s->sum_topn += s->topn[j];
         }
         s->direct = true;
         for (uint64_t i = 0; i < s->S; i++) s->direct = s->direct && (s->col[i] == i);
@@ -1506,10 +1525,12 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         // Dense chunks of a feed: enough rows to fill the largest heap with a margin for the MAC filter (more
         // dense chunks follow while a heap is still short); everything after goes through the sparse path.
         s->dense_chunk = std::min<uint64_t>(s->dense_rows, std::max<uint64_t>(1024, (s->max_topn + s->max_topn / 8 + 512 + 127) / 128 * 128));
-        const uint64_t budget = 4ull << 20;  // candidate records per slot (x 24 B x n_slots of mapped pinned memory)
+        if (getenv("KGWAS_MODE_K")) s->mode_k = atof(getenv("KGWAS_MODE_K"));  // experiments
+        const uint64_t budget = getenv("KGWAS_CAP_BUDGET") ? strtoull(getenv("KGWAS_CAP_BUDGET"), nullptr, 10) : (4ull << 20);  // candidate records per slot
         // (few columns: longer lists, so that the ramp takes ~6 chunks instead of ~13 - a chunk's fixed costs, not its
         // rows, are what a one-column scan pays for)
-        uint64_t cap = std::min<uint64_t>((s->narrow ? 8 : 2) * s->max_topn + 4096, std::max<uint64_t>(budget / s->n_pheno, 1024));
+        const uint64_t cap_mult = getenv("KGWAS_CAP_MULT") ? strtoull(getenv("KGWAS_CAP_MULT"), nullptr, 10) : (s->narrow ? 8 : 2);  // experiments
+        uint64_t cap = std::min<uint64_t>(cap_mult * s->max_topn + 4096, std::max<uint64_t>(budget / s->n_pheno, 1024));
         s->cap = (uint32_t)std::min<uint64_t>(cap, 0x7FFFFFFFull);
 
         KGWAS_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
