@@ -191,6 +191,9 @@ hipError_t launch_kin_transpose(const uint64_t* file_rows, uint64_t file_stride_
                                 unsigned long long* n_used, hipStream_t st);
 // rows per transpose block the LDS allows for this table shape (256, 128, 64; 0 = too many accessions)
 uint32_t kin_transpose_rows_per_block(uint64_t file_stride_w, uint32_t S_pad);
-hipError_t launch_kin_gram(const uint32_t* T, uint64_t n_rw, uint32_t S_pad, unsigned long long* H, hipStream_t st);
+// scratch: kin_gram_scratch_bytes(S_pad) bytes (the row slices' partial tiles, reduced into H by a second kernel)
+size_t kin_gram_scratch_bytes(uint32_t S_pad);
+hipError_t launch_kin_gram(const uint32_t* T, uint64_t n_rw, uint32_t S_pad, unsigned long long* H, void* scratch, size_t scratch_bytes,
+                           hipStream_t st);
 
 }  // namespace kgwas

@@ -26,6 +26,10 @@
 
 #include "kernels.h"
 
+#ifndef KGWAS_KIN_ABLATE
+#define KGWAS_KIN_ABLATE 0
+#endif
+
 namespace kgwas {
 
 typedef int kin_i32x4 __attribute__((ext_vector_type(4)));
@@ -173,19 +177,29 @@ __global__ void __launch_bounds__(256) kin_transpose_kernel(const uint64_t* file
 #define KGWAS_KIN_KC 16
 #endif
 constexpr uint32_t KIN_KC = KGWAS_KIN_KC;  // plane dwords (512 rows) staged per round
-__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) kin_gram_kernel(const uint32_t* T, uint64_t n_rw, uint32_t S_pad, unsigned long long* C,
-                                                       uint64_t rw_per_split) {
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) kin_gram_kernel(const uint32_t* T, uint64_t n_rw, uint32_t S_pad, kin_f32x4* part,
+                                                       uint64_t rw_per_split, uint32_t tiles) {
     constexpr uint32_t LROW = KIN_KC + 4;  // 80-byte rows: 16-byte aligned for ds_read_b128 / ds_write_b128
     __shared__ __attribute__((aligned(16))) uint32_t LA[128][LROW];
     __shared__ __attribute__((aligned(16))) uint32_t LB[128][LROW];
-    uint32_t tix = blockIdx.x, ib = 0;  // upper-triangular tile index -> (ib, jb), jb >= ib
+    // Blocks go to XCD (block id % 8) in launch order; each XCD takes a contiguous range of (slice, tile) work items,
+    // slice-major, so that the ~45 tiles of a row slice - which read the same plane words round after round - run beside
+    // each other under ONE L2 (each 128-sample block of planes is an operand of nt + 1 tiles: ten times the planes'
+    // size crosses the L2 per chunk; spread over all XCDs by the default order it all came from the MALL / HBM).
+    uint32_t wg;
+    {
+        const uint32_t nwg = gridDim.x, xcd = blockIdx.x & 7u, q = nwg >> 3, r = nwg & 7u;
+        wg = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
+    const uint32_t split = wg / tiles, tile = wg % tiles;
+    uint32_t tix = tile, ib = 0;  // upper-triangular tile index -> (ib, jb), jb >= ib
     const uint32_t nt = S_pad / 128u;
     while (tix >= nt - ib) {
         tix -= nt - ib;
         ib++;
     }
     const uint32_t jb = ib + tix;
-    const uint64_t k_begin = (uint64_t)blockIdx.y * rw_per_split;
+    const uint64_t k_begin = (uint64_t)split * rw_per_split;
     uint64_t k_end = k_begin + rw_per_split;
     if (k_end > n_rw) k_end = n_rw;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -196,39 +210,52 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
         for (int y = 0; y < 8; y++) acc[x][y] = (kin_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 
-    // A round stages KIN_KC plane dwords (512 rows) of the 128 + 128 samples: 16-byte loads, 4 lanes per sample, and the
-    // NEXT round's loads are already in flight (registers) while this round's 8 MFMA steps run.
-    constexpr int NLD = (2 * 128 * KIN_KC / 4) / 128;  // uint4 loads per lane and round
-    uint4 nxt[NLD];
-    auto issue = [&](uint64_t k0) {
-#pragma unroll
-        for (int q = 0; q < NLD; q++) {
-            const uint32_t e = q * 128u + threadIdx.x;            // 0 .. 2*128*KIN_KC/4 - 1
-            const uint32_t row = e / (KIN_KC / 4u), part = e % (KIN_KC / 4u);  // row 0..255 (A then B), 4-dword part
-            const uint32_t srow = (row < 128u ? ib * 128u + row : jb * 128u + (row - 128u));
-            uint64_t kw = k0 + 4u * part;
-            if (kw + 4u > n_rw) kw = n_rw - 4u;  // n_rw is a multiple of 16: clamp instead of branching (tail is masked below)
-            nxt[q] = *reinterpret_cast<const uint4*>(T + ((kw >> 3) * S_pad + srow) * 8u + (kw & 7u));
-        }
-    };
-    auto land = [&](uint64_t k0) {
-#pragma unroll
-        for (int q = 0; q < NLD; q++) {
-            const uint32_t e = q * 128u + threadIdx.x;
-            const uint32_t row = e / (KIN_KC / 4u), part = e % (KIN_KC / 4u);
-            uint32_t* dst = (row < 128u ? &LA[row][4u * part] : &LB[row - 128u][4u * part]);
-            const uint64_t kw = k0 + 4u * part;
-            const uint32_t v[4] = {nxt[q].x, nxt[q].y, nxt[q].z, nxt[q].w};
-#pragma unroll
-            for (int c = 0; c < 4; c++) dst[c] = (kw + c < k_end) ? v[c] : 0u;  // beyond this block's slice: zero bits
-        }
-    };
-    if (k_begin < k_end) issue(k_begin);
+    // A round stages KIN_KC = 16 plane dwords (512 rows) of the 128 + 128 samples: 16-byte loads, 4 lanes per sample,
+    // and the NEXT round's loads are already in flight (registers) while this round's MFMA steps run. Slices are whole
+    // rounds (rw_per_split and n_rw are multiples of KIN_KC), so nothing is clamped or masked. Load q of a lane takes
+    // sample row q * 32 + tid / 4 (A: q < 4, B: q >= 4), dwords 4 * (tid % 4) ..+3 of the round: with the tile-major planes
+    // T[8-dword group][sample][8] that is ONE 32-bit lane offset per operand + an immediate, on a scalar base that
+    // advances by KIN_KC * S_pad dwords per round (the per-load 64-bit address arithmetic this replaces spilled, and
+    // its reloads made every pair of loads wait for the pair before).
+    static_assert(KIN_KC == 16, "one round = two 8-dword plane groups");
+    // (eight named registers, not an array: the compiler moved an array indexed inside lambdas to LDS - every load
+    // was then waited for right after its issue)
+    uint4 n0, n1, n2, n3, n4, n5, n6, n7;
+    const uint32_t qd = threadIdx.x & 3u, r4 = threadIdx.x >> 2;
+    const uint32_t offA = ((qd >> 1) * S_pad + ib * 128u + r4) * 8u + 4u * (qd & 1u);
+    const uint32_t offB = ((qd >> 1) * S_pad + jb * 128u + r4) * 8u + 4u * (qd & 1u);
+    uint32_t* const dstA = &LA[r4][4u * qd];
+    uint32_t* const dstB = &LB[r4][4u * qd];
+#define KIN_ISSUE(k0)                                                  \
+    {                                                                  \
+        const uint32_t* base = T + (k0) * S_pad; /* wave-uniform */    \
+        n0 = *reinterpret_cast<const uint4*>(base + offA);             \
+        n1 = *reinterpret_cast<const uint4*>(base + offA + 256u);      \
+        n2 = *reinterpret_cast<const uint4*>(base + offA + 512u);      \
+        n3 = *reinterpret_cast<const uint4*>(base + offA + 768u);      \
+        n4 = *reinterpret_cast<const uint4*>(base + offB);             \
+        n5 = *reinterpret_cast<const uint4*>(base + offB + 256u);      \
+        n6 = *reinterpret_cast<const uint4*>(base + offB + 512u);      \
+        n7 = *reinterpret_cast<const uint4*>(base + offB + 768u);      \
+    }
+#define KIN_LAND()                                                     \
+    {                                                                  \
+        *reinterpret_cast<uint4*>(dstA) = n0;                          \
+        *reinterpret_cast<uint4*>(dstA + 32u * LROW) = n1;             \
+        *reinterpret_cast<uint4*>(dstA + 64u * LROW) = n2;             \
+        *reinterpret_cast<uint4*>(dstA + 96u * LROW) = n3;             \
+        *reinterpret_cast<uint4*>(dstB) = n4;                          \
+        *reinterpret_cast<uint4*>(dstB + 32u * LROW) = n5;             \
+        *reinterpret_cast<uint4*>(dstB + 64u * LROW) = n6;             \
+        *reinterpret_cast<uint4*>(dstB + 96u * LROW) = n7;             \
+    }
+    n0 = n1 = n2 = n3 = n4 = n5 = n6 = n7 = make_uint4(0u, 0u, 0u, 0u);
+    if (k_begin < k_end) KIN_ISSUE(k_begin);
     for (uint64_t k0 = k_begin; k0 < k_end; k0 += KIN_KC) {
         __syncthreads();
-        land(k0);
+        KIN_LAND();
         __syncthreads();
-        if (k0 + KIN_KC < k_end) issue(k0 + KIN_KC);
+        if (k0 + KIN_KC < k_end && !(KGWAS_KIN_ABLATE & 2)) KIN_ISSUE(k0 + KIN_KC);
         uint4 wA[4], wB[8];
 #pragma unroll
         for (int x = 0; x < 4; x++) wA[x] = *reinterpret_cast<const uint4*>(&LA[wave * 64u + x * 16u + m][4u * kg]);
@@ -245,6 +272,10 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
                 // both operands FP4 (cbsz = blgp = 4); block scales 2^1, 2^0, 2^-1, 2^-1 for j = 0..3 on both sides
 #pragma unroll
                 for (int x = 0; x < 4; x++) {
+                    if (KGWAS_KIN_ABLATE & 1) {  // experiments: operands kept alive, no matrix work
+                        acc[x][y][0] += __int_as_float((A[x][0] ^ B[1]) & 1);
+                        continue;
+                    }
                     if (j == 0) acc[x][y] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A[x], B, acc[x][y], 4, 4, 0, (int)0x80808080, 0, (int)0x80808080);
                     if (j == 1) acc[x][y] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A[x], B, acc[x][y], 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
                     if (j >= 2) acc[x][y] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A[x], B, acc[x][y], 4, 4, 0, 0x7E7E7E7E, 0, 0x7E7E7E7E);
@@ -252,19 +283,42 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
             }
         }
     }
-    // D[row = 4kg + jj][col = m] of tile (x, y)
+    // The slice's 128 x 128 partial goes to its own 64 KB piece of `part` as the accumulator fragments lie in the
+    // registers (one 16-byte store per lane and 16 x 16 sub-tile, 1 KB per instruction); kin_reduce_kernel adds the
+    // slices of a tile into C. (Per-element 64-bit atomicAdds - 33 M per 2^20-row chunk at 1135 samples - were a
+    // quarter of this kernel's time.)
+    kin_f32x4* out = part + ((uint64_t)split * tiles + tile) * 4096u + wave * 2048u + lane;
 #pragma unroll
     for (int x = 0; x < 4; x++)
 #pragma unroll
-        for (int y = 0; y < 8; y++)
+        for (int y = 0; y < 8; y++) out[(x * 8 + y) * 64] = acc[x][y];
+}
+
+// C[i][j] += sum over the row slices of tile (ib, jb)'s partials. Thread = one accumulator fragment (4 rows x 1 column):
+// fragment f = (wave, x, y, lane) holds D[row = 4 kg + jj][col = m] of sub-tile (x, y), values exact integers in float.
+__global__ void __launch_bounds__(256) kin_reduce_kernel(const kin_f32x4* part, uint32_t tiles, uint32_t splits, uint32_t S_pad,
+                                                         unsigned long long* C) {
+    uint32_t tix = blockIdx.y, ib = 0;
+    const uint32_t nt = S_pad / 128u;
+    while (tix >= nt - ib) {
+        tix -= nt - ib;
+        ib++;
+    }
+    const uint32_t jb = ib + tix;
+    const uint32_t f = blockIdx.x * 256u + threadIdx.x;  // 0 .. 4095
+    unsigned long long v[4] = {0, 0, 0, 0};
+    for (uint32_t sp = 0; sp < splits; sp++) {
+        const kin_f32x4 t = part[((uint64_t)sp * tiles + blockIdx.y) * 4096u + f];
 #pragma unroll
-            for (int jj = 0; jj < 4; jj++) {
-                const unsigned long long v = (unsigned long long)acc[x][y][jj];  // an exact integer (< 2^24 rows per slice)
-                if (v) {
-                    const uint32_t i = ib * 128u + wave * 64u + x * 16u + kg * 4u + jj, j = jb * 128u + y * 16u + m;
-                    atomicAdd(&C[(uint64_t)i * S_pad + j], v);
-                }
-            }
+        for (int jj = 0; jj < 4; jj++) v[jj] += (unsigned long long)t[jj];  // < 2^24 rows per slice: exact
+    }
+    const uint32_t wave = f >> 11, xy = (f >> 6) & 31u, lane = f & 63u;
+    const uint32_t x = xy >> 3, y = xy & 7u, m = lane & 15u, kg = lane >> 4;
+#pragma unroll
+    for (int jj = 0; jj < 4; jj++) {
+        const uint32_t i = ib * 128u + wave * 64u + x * 16u + kg * 4u + jj, j = jb * 128u + y * 16u + m;
+        if (v[jj]) C[(uint64_t)i * S_pad + j] += v[jj];
+    }
 }
 
 size_t kin_transpose_lds_bytes(uint64_t file_stride_w, uint32_t S_pad, uint32_t rpb) {
@@ -295,21 +349,41 @@ hipError_t launch_kin_transpose(const uint64_t* file_rows, uint64_t file_stride_
     return hipGetLastError();
 }
 
-hipError_t launch_kin_gram(const uint32_t* T, uint64_t n_rw, uint32_t S_pad, unsigned long long* C, hipStream_t st) {
-    if (n_rw == 0) return hipSuccess;
-    const uint32_t nt = S_pad / 128u;
-    const uint32_t tiles = nt * (nt + 1u) / 2u;
-    // enough row slices to fill 256 CUs several times over, each a multiple of KIN_KC plane words
+// Row slices per 128 x 128 tile and plane words per slice for a chunk of n_rw plane words.
+static void kin_gram_split(uint64_t n_rw, uint32_t tiles, uint64_t* per_out, uint32_t* splits_out) {
     static const uint64_t blocks_env = getenv("KGWAS_KIN_BLOCKS") ? (uint64_t)atoll(getenv("KGWAS_KIN_BLOCKS")) : 0;  // experiments
     // Row slices per tile: a CU holds four of these 2-wave blocks (two waves per SIMD), the chip 1024, and a launch
     // that is not close to a whole number of such rounds leaves CUs idle at its end (3105 blocks measured 5.5 ms per
     // 8 M rows x 1135 samples, 2025 blocks 5.0): as many slices as make about two full rounds.
-    uint64_t want = std::max<uint64_t>(1, (blocks_env ? blocks_env : 2048ull) / tiles);
+    uint64_t want = std::max<uint64_t>(1, (blocks_env ? blocks_env : 1024ull) / tiles);
     uint64_t per = (n_rw + want - 1) / want;
     per = ((per + KIN_KC - 1) / KIN_KC) * KIN_KC;
     if (per < KIN_KC * 4) per = KIN_KC * 4;
-    const uint32_t splits = (uint32_t)((n_rw + per - 1) / per);
-    hipLaunchKernelGGL(kin_gram_kernel, dim3(tiles, splits), dim3(128), 0, st, T, n_rw, S_pad, C, per);
+    *per_out = per;
+    *splits_out = (uint32_t)((n_rw + per - 1) / per);
+}
+
+// one 64 KB partial per (tile, row slice); a chunk never has more slices than kin_gram_split's `want`
+size_t kin_gram_scratch_bytes(uint32_t S_pad) {
+    const uint32_t nt = S_pad / 128u;
+    const uint32_t tiles = nt * (nt + 1u) / 2u;
+    uint64_t per;
+    uint32_t splits;
+    kin_gram_split(1ull << 40, tiles, &per, &splits);  // (n_rw >> want: splits == want)
+    return (size_t)splits * tiles * 65536u;
+}
+
+hipError_t launch_kin_gram(const uint32_t* T, uint64_t n_rw, uint32_t S_pad, unsigned long long* C, void* scratch, size_t scratch_bytes,
+                           hipStream_t st) {
+    if (n_rw == 0) return hipSuccess;
+    const uint32_t nt = S_pad / 128u;
+    const uint32_t tiles = nt * (nt + 1u) / 2u;
+    uint64_t per;
+    uint32_t splits;
+    kin_gram_split(n_rw, tiles, &per, &splits);
+    if ((size_t)splits * tiles * 65536u > scratch_bytes) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(kin_gram_kernel, dim3(tiles * splits), dim3(128), 0, st, T, n_rw, S_pad, (kin_f32x4*)scratch, per, tiles);
+    hipLaunchKernelGGL(kin_reduce_kernel, dim3(16, tiles), dim3(256), 0, st, (const kin_f32x4*)scratch, tiles, splits, S_pad, C);
     return hipGetLastError();
 }
 

@@ -27,6 +27,8 @@ struct kgwas_kinship {
     bool gram_pending[2] = {false, false};
     uint32_t* d_T2[2] = {nullptr, nullptr};  // sample-major bit planes of two chunks
     unsigned long long* d_H = nullptr;
+    void* d_part = nullptr;  // partial tiles of a chunk's row slices (kin_gram_scratch_bytes)
+    size_t part_bytes = 0;
     unsigned long long* d_n = nullptr;
     Ingest ingest;  // host / file feeds: three pinned pieces, two device pieces, a copy stream
     double kernel_ms = 0;
@@ -39,6 +41,7 @@ struct kgwas_kinship {
             if (ev_gram[b]) (void)hipEventDestroy(ev_gram[b]);
         }
         if (stream_tr) (void)hipStreamDestroy(stream_tr);
+        if (d_part) (void)hipFree(d_part);
         if (d_H) (void)hipFree(d_H);
         if (d_n) (void)hipFree(d_n);
         if (ev_user) (void)hipEventDestroy(ev_user);
@@ -62,12 +65,14 @@ static void kin_feed(kgwas_kinship* k, const uint64_t* d_rows, uint64_t n_rows) 
         const uint64_t n_rw = (c + 511) / 512 * 16;  // u32 words per sample, whole 512-row blocks
         const int b = (int)(i & 1);
         if (k->gram_pending[b]) KGWAS_HIP(hipStreamWaitEvent(k->stream_tr, k->ev_gram[b], 0));  // buffer b is free again
+        static const bool no_tr = getenv("KGWAS_KIN_NO_TR") != nullptr;  // experiments: the Gram kernel alone (wrong results)
+        if (!no_tr || i < 2)
         KGWAS_HIP(launch_kin_transpose(d_rows + pos * stride, stride, c, (uint32_t)k->S_f, k->S_pad,
                                        (uint32_t)std::min<uint64_t>(k->min_count, 0xFFFFFFFFull), k->d_T2[b], n_rw, k->d_n,
                                        k->stream_tr));
         KGWAS_HIP(hipEventRecord(k->ev_tr[b], k->stream_tr));
         KGWAS_HIP(hipStreamWaitEvent(k->stream, k->ev_tr[b], 0));
-        KGWAS_HIP(launch_kin_gram(k->d_T2[b], n_rw, k->S_pad, k->d_H, k->stream));
+        KGWAS_HIP(launch_kin_gram(k->d_T2[b], n_rw, k->S_pad, k->d_H, k->d_part, k->part_bytes, k->stream));
         KGWAS_HIP(hipEventRecord(k->ev_gram[b], k->stream));
         k->gram_pending[b] = true;
         k->launches++;
@@ -115,6 +120,8 @@ int kgwas_kinship_create(int32_t device, uint64_t n_acc_file, uint64_t min_count
             KGWAS_HIP(hipEventCreateWithFlags(&k->ev_gram[b], hipEventDisableTiming));
         }
         KGWAS_HIP(hipMalloc((void**)&k->d_H, (size_t)k->S_pad * k->S_pad * 8));
+        k->part_bytes = kin_gram_scratch_bytes(k->S_pad);
+        KGWAS_HIP(hipMalloc(&k->d_part, k->part_bytes));
         KGWAS_HIP(hipMalloc((void**)&k->d_n, TESTED_SHARDS * 8));
         KGWAS_HIP(hipMemset(k->d_H, 0, (size_t)k->S_pad * k->S_pad * 8));
         KGWAS_HIP(hipMemset(k->d_n, 0, TESTED_SHARDS * 8));
