@@ -44,6 +44,13 @@ namespace {
 // scale 2^(1-j) makes them 1), step 3 moves the FP4 sign bit down first (value 2, scale 2^-1).
 __device__ __forceinline__ kin_i32x8 kin_expand_step(const uint4& w, int j) {
     kin_i32x8 r = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (KGWAS_KIN_ABLATE & 32) {  // experiments: no expansion work
+        r[0] = (int)w.x;
+        r[1] = (int)w.y;
+        r[2] = (int)w.z;
+        r[3] = (int)w.w;
+        return r;
+    }
     if (j < 3) {
         const uint32_t mk = 0x11111111u << j;
         r[0] = (int)(w.x & mk);
@@ -179,9 +186,9 @@ __global__ void __launch_bounds__(256) kin_transpose_kernel(const uint64_t* file
 constexpr uint32_t KIN_KC = KGWAS_KIN_KC;  // plane dwords (512 rows) staged per round
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) kin_gram_kernel(const uint32_t* T, uint64_t n_rw, uint32_t S_pad, kin_f32x4* part,
                                                        uint64_t rw_per_split, uint32_t tiles) {
-    constexpr uint32_t LROW = KIN_KC + 4;  // 80-byte rows: 16-byte aligned for ds_read_b128 / ds_write_b128
-    __shared__ __attribute__((aligned(16))) uint32_t LA[128][LROW];
-    __shared__ __attribute__((aligned(16))) uint32_t LB[128][LROW];
+    // A wave's operands of one round, as its lanes will hold them: slot s (0..3 = its 4 x 16 A samples, 4..11 = the 8 x 16
+    // B samples) x 64 lanes x 16 bytes. Wave-private: no block barrier anywhere in this kernel.
+    __shared__ __attribute__((aligned(16))) uint4 stage[2][12][64];
     // Blocks go to XCD (block id % 8) in launch order; each XCD takes a contiguous range of (slice, tile) work items,
     // slice-major, so that the ~45 tiles of a row slice - which read the same plane words round after round - run beside
     // each other under ONE L2 (each 128-sample block of planes is an operand of nt + 1 tiles: ten times the planes'
@@ -210,57 +217,58 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
         for (int y = 0; y < 8; y++) acc[x][y] = (kin_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 
-    // A round stages KIN_KC = 16 plane dwords (512 rows) of the 128 + 128 samples: 16-byte loads, 4 lanes per sample,
-    // and the NEXT round's loads are already in flight (registers) while this round's MFMA steps run. Slices are whole
-    // rounds (rw_per_split and n_rw are multiples of KIN_KC), so nothing is clamped or masked. Load q of a lane takes
-    // sample row q * 32 + tid / 4 (A: q < 4, B: q >= 4), dwords 4 * (tid % 4) ..+3 of the round: with the tile-major planes
-    // T[8-dword group][sample][8] that is ONE 32-bit lane offset per operand + an immediate, on a scalar base that
-    // advances by KIN_KC * S_pad dwords per round (the per-load 64-bit address arithmetic this replaces spilled, and
-    // its reloads made every pair of loads wait for the pair before).
+    // A round is KIN_KC = 16 plane dwords (512 rows) of the wave's 64 + 128 samples. Lane (m, kg) multiplies dwords
+    // 4 kg ..+3 of sample 16 s + m for each of its 12 operand slots s, and with the tile-major planes
+    // T[8-dword group][sample][8] those 16 bytes are contiguous: every lane fetches exactly its own operands, slot by
+    // slot, with `global_load_lds_dwordx4` (global -> LDS without registers, lane l's 16 bytes land at slot base +
+    // 16 l) one round ahead, and picks them up with one ds_read_b128 per slot when the round starts. The LDS is only a
+    // register-free landing zone here - nothing staged is shared, so the two waves of a block never wait for each other
+    // (the version that shared the B samples through LDS spent a third of its time at two barriers per round). Slices
+    // are whole rounds (rw_per_split and n_rw are multiples of KIN_KC): nothing is clamped or masked.
     static_assert(KIN_KC == 16, "one round = two 8-dword plane groups");
-    // (eight named registers, not an array: the compiler moved an array indexed inside lambdas to LDS - every load
-    // was then waited for right after its issue)
-    uint4 n0, n1, n2, n3, n4, n5, n6, n7;
-    const uint32_t qd = threadIdx.x & 3u, r4 = threadIdx.x >> 2;
-    const uint32_t offA = ((qd >> 1) * S_pad + ib * 128u + r4) * 8u + 4u * (qd & 1u);
-    const uint32_t offB = ((qd >> 1) * S_pad + jb * 128u + r4) * 8u + 4u * (qd & 1u);
-    uint32_t* const dstA = &LA[r4][4u * qd];
-    uint32_t* const dstB = &LB[r4][4u * qd];
-#define KIN_ISSUE(k0)                                                  \
-    {                                                                  \
-        const uint32_t* base = T + (k0) * S_pad; /* wave-uniform */    \
-        n0 = *reinterpret_cast<const uint4*>(base + offA);             \
-        n1 = *reinterpret_cast<const uint4*>(base + offA + 256u);      \
-        n2 = *reinterpret_cast<const uint4*>(base + offA + 512u);      \
-        n3 = *reinterpret_cast<const uint4*>(base + offA + 768u);      \
-        n4 = *reinterpret_cast<const uint4*>(base + offB);             \
-        n5 = *reinterpret_cast<const uint4*>(base + offB + 256u);      \
-        n6 = *reinterpret_cast<const uint4*>(base + offB + 512u);      \
-        n7 = *reinterpret_cast<const uint4*>(base + offB + 768u);      \
-    }
-#define KIN_LAND()                                                     \
-    {                                                                  \
-        *reinterpret_cast<uint4*>(dstA) = n0;                          \
-        *reinterpret_cast<uint4*>(dstA + 32u * LROW) = n1;             \
-        *reinterpret_cast<uint4*>(dstA + 64u * LROW) = n2;             \
-        *reinterpret_cast<uint4*>(dstA + 96u * LROW) = n3;             \
-        *reinterpret_cast<uint4*>(dstB) = n4;                          \
-        *reinterpret_cast<uint4*>(dstB + 32u * LROW) = n5;             \
-        *reinterpret_cast<uint4*>(dstB + 64u * LROW) = n6;             \
-        *reinterpret_cast<uint4*>(dstB + 96u * LROW) = n7;             \
-    }
-    n0 = n1 = n2 = n3 = n4 = n5 = n6 = n7 = make_uint4(0u, 0u, 0u, 0u);
-    if (k_begin < k_end) KIN_ISSUE(k_begin);
+    const uint32_t offA = ((kg >> 1) * S_pad + ib * 128u + wave * 64u + m) * 8u + 4u * (kg & 1u);
+    const uint32_t offB = ((kg >> 1) * S_pad + jb * 128u + m) * 8u + 4u * (kg & 1u);
+    uint4* const wstage = &stage[wave][0][0];  // wave-uniform
+    auto issue = [&](uint64_t k0) {
+        const uint32_t* base = T + k0 * S_pad;  // wave-uniform
+#pragma unroll
+        for (int sl = 0; sl < 12; sl++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (sl < 4 ? offA + sl * 128u : offB + (sl - 4) * 128u)),
+                                             (__attribute__((address_space(3))) void*)(wstage + sl * 64), 16, 0, 0);
+    };
+    if (k_begin < k_end) issue(k_begin);
+    // (Two waves share a SIMD and walk their rounds in step; starting the odd wave slot half a round late changed
+    // nothing. Decomposition at 8 M rows x 1135, transposes excluded: 2.7 ms, of which the MFMA stream alone 2.3 - the
+    // chip runs this FP4 stream at ~1.7 GHz (GRBM_GUI_ACTIVE), not 2.4 -, operand reads 0.2, expansion 0.2.)
+    uint4 wA[4], wB[8];
     for (uint64_t k0 = k_begin; k0 < k_end; k0 += KIN_KC) {
-        __syncthreads();
-        KIN_LAND();
-        __syncthreads();
-        if (k0 + KIN_KC < k_end && !(KGWAS_KIN_ABLATE & 2)) KIN_ISSUE(k0 + KIN_KC);
-        uint4 wA[4], wB[8];
+        __builtin_amdgcn_s_waitcnt(0);  // this round's operands have landed
+        asm volatile("" ::: "memory");
+        if (!(KGWAS_KIN_ABLATE & 64) || k0 == k_begin) {
 #pragma unroll
-        for (int x = 0; x < 4; x++) wA[x] = *reinterpret_cast<const uint4*>(&LA[wave * 64u + x * 16u + m][4u * kg]);
+            for (int x = 0; x < 4; x++) wA[x] = wstage[x * 64 + lane];
 #pragma unroll
-        for (int y = 0; y < 8; y++) wB[y] = *reinterpret_cast<const uint4*>(&LB[y * 16u + m][4u * kg]);
+            for (int y = 0; y < 8; y++) wB[y] = wstage[(4 + y) * 64 + lane];
+        }
+        if (KGWAS_KIN_ABLATE & 64) {
+#pragma unroll
+            for (int x = 0; x < 4; x++) asm volatile("" : "+v"(wA[x].x), "+v"(wA[x].y), "+v"(wA[x].z), "+v"(wA[x].w));
+#pragma unroll
+            for (int y = 0; y < 8; y++) asm volatile("" : "+v"(wB[y].x), "+v"(wB[y].y), "+v"(wB[y].z), "+v"(wB[y].w));
+        }
+        if (KGWAS_KIN_ABLATE & 16) {  // experiments: same instruction stream on all-zero operands (power / clocks)
+            uint32_t z = 0;
+            asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+#pragma unroll
+            for (int x = 0; x < 4; x++) wA[x] = make_uint4(wA[x].x & z, wA[x].y & z, wA[x].z & z, wA[x].w & z);
+#pragma unroll
+            for (int y = 0; y < 8; y++) wB[y] = make_uint4(wB[y].x & z, wB[y].y & z, wB[y].z & z, wB[y].w & z);
+        }
+        if (k0 + KIN_KC < k_end && !(KGWAS_KIN_ABLATE & 2)) {
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0);  // ... and are in registers: the landing zone is free for the next round's
+            issue(k0 + KIN_KC);
+        }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             kin_i32x8 A[4];
@@ -327,6 +335,8 @@ size_t kin_transpose_lds_bytes(uint64_t file_stride_w, uint32_t S_pad, uint32_t 
 
 // Rows per transpose block: the most (256, 128, 64) whose verbatim rows + planes fit the 160 KB of LDS; 0 = none does.
 uint32_t kin_transpose_rows_per_block(uint64_t file_stride_w, uint32_t S_pad) {
+    static const uint32_t rpb_env = getenv("KGWAS_KIN_RPB") ? (uint32_t)atoi(getenv("KGWAS_KIN_RPB")) : 0u;  // experiments
+    if (rpb_env && kin_transpose_lds_bytes(file_stride_w, S_pad, rpb_env) <= 160u * 1024u) return rpb_env;
     for (uint32_t rpb : {256u, 128u, 64u})
         if (kin_transpose_lds_bytes(file_stride_w, S_pad, rpb) <= 160u * 1024u) return rpb;
     return 0u;
