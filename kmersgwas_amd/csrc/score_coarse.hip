@@ -397,6 +397,45 @@ __global__ void __launch_bounds__(256) tile_prefix_kernel(const uint32_t* surv_c
 }
 
 // Same arithmetic as score_valu_kernel: the reference's select-and-add chains, then the exact candidate test.
+// One 128-sample block of the four float32 chains of calculate_kmer_score (src/kmer_general.cpp:155-167): lane l of the
+// reference's SSE register adds `bit ? y : +0.0f` for samples 128 b + 32 l + 31 - s, s = 0..31.
+// The column's values are the same for every lane: they are read through the constant address space, i.e. by scalar
+// loads into SGPRs (yb is wave-uniform). As vector loads - 32 x 16 bytes per lane and block, every lane the same
+// address - they kept the CU's 64 B/clk vector-memory return path busier than the lane-ops kept the SIMDs.
+typedef __attribute__((address_space(4))) const float* kconst_f32p;
+__device__ __forceinline__ void rescore_block(const uint32_t (&w)[4], const float* yb, float (&acc)[4]) {
+    kconst_f32p yc = (kconst_f32p)yb;
+#pragma unroll
+    for (int s = 0; s < 32; s++) {
+        const float yv[4] = {yc[4 * s], yc[4 * s + 1], yc[4 * s + 2], yc[4 * s + 3]};
+#pragma unroll
+        for (int l = 0; l < 4; l++) {
+            // bit 31 - s as 0 / -1 in one v_bfe_i32, kept from the optimiser, which turns bfe & y (like a shift pair)
+            // into and + compare + select: 3.5 lane-ops per sample, 2.5 this way with the packed add
+            int mk = __builtin_amdgcn_sbfe((int)w[l], 31 - s, 1);
+            asm volatile("" : "+v"(mk));
+            acc[l] = acc[l] + __int_as_float(mk & __float_as_int(yv[l]));
+        }
+    }
+}
+
+// exact score of one survivor from its chain sums -> tmp_score (or -inf), and the tile's candidate count
+__device__ __forceinline__ void rescore_finish(const ScoreArgs& a, uint32_t p, bool valid, uint32_t gi, const float (&acc)[4], uint32_t n1,
+                                               double* tmp_score, uint32_t* tile_cnt, uint32_t t, uint32_t* wcnt) {
+    const float yf = ((acc[0] + acc[1]) + acc[2]) + acc[3];
+    double q, d, sc, out = -__builtin_huge_val();
+    score_terms(a, yf, n1, a.sums[p], q, d);
+    if (valid && mac_pass(a, n1) && candidate_score(a, p, q, d, a.thr[p], sc)) out = sc;
+    if (valid) tmp_score[gi] = out;
+    const uint32_t c = __popcll(__ballot(out != -__builtin_huge_val()));
+    if ((threadIdx.x & 63u) == 0u) wcnt[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_cnt[t] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    __syncthreads();
+}
+
+// Rows are read in place by their own lane, 8 bytes x 2 per 128-sample block. (Staging a wave's 64 rows through LDS with
+// coalesced copies - every line fetched once - measured 30-50 % SLOWER: the gathers are not what this kernel waits for.)
 __global__ void __launch_bounds__(256) rescore_kernel(ScoreArgs a, const uint32_t* keys, const uint32_t* surv_off,
                                                       const uint32_t* surv_cnt, const uint32_t* tile_pref, uint32_t row_mask,
                                                       double* tmp_score, uint32_t* tile_cnt) {
@@ -405,7 +444,7 @@ __global__ void __launch_bounds__(256) rescore_kernel(ScoreArgs a, const uint32_
     const uint32_t L = 64u * a.W_m;
     const uint32_t nblk = a.W_m / 2u;
     for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        const uint32_t p = tile_column(tile_pref, a.n_pheno, t);
+        const uint32_t p = __builtin_amdgcn_readfirstlane(tile_column(tile_pref, a.n_pheno, t));
         const uint32_t i = (t - tile_pref[p]) * 256u + threadIdx.x;
         const bool valid = i < surv_cnt[p];
         const uint32_t gi = surv_off[p] + (valid ? i : 0u);
@@ -413,35 +452,28 @@ __global__ void __launch_bounds__(256) rescore_kernel(ScoreArgs a, const uint32_
         const uint32_t* rp = a.src.base + r * a.src.stride_dw + a.src.off_dw;
         float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         uint32_t n1 = 0;
+        // the row's words for block b + 1 are asked for before block b's 320 lane-ops start
+        uint2 nx[2];
+        auto fetch = [&](uint32_t b) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                nx[h] = make_uint2(0u, 0u);
+                if (4u * b + 2u * h + 1u < a.src.avail_dw) nx[h] = *reinterpret_cast<const uint2*>(rp + 4u * b + 2u * h);
+            }
+        };
+        if (nblk) fetch(0);
         for (uint32_t b = 0; b < nblk; b++) {
             uint32_t w[4];
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                uint2 v = make_uint2(0u, 0u);
-                if (4u * b + 2u * h + 1u < a.src.avail_dw) v = *reinterpret_cast<const uint2*>(rp + 4u * b + 2u * h);
-                w[2 * h] = v.x & a.dmask[4 * b + 2 * h];
-                w[2 * h + 1] = v.y & a.dmask[4 * b + 2 * h + 1];
+                w[2 * h] = nx[h].x & a.dmask[4 * b + 2 * h];
+                w[2 * h + 1] = nx[h].y & a.dmask[4 * b + 2 * h + 1];
             }
+            if (b + 1u < nblk) fetch(b + 1u);
             n1 += __popc(w[0]) + __popc(w[1]) + __popc(w[2]) + __popc(w[3]);
-            const float* yb = a.Yperm + (size_t)p * L + 128u * b;
-#pragma unroll
-            for (int s = 0; s < 32; s++)
-#pragma unroll
-                for (int l = 0; l < 4; l++) {
-                    const int mk = ((int)(w[l] << s)) >> 31;
-                    acc[l] = acc[l] + __int_as_float(mk & __float_as_int(yb[4 * s + l]));
-                }
+            rescore_block(w, a.Yperm + (size_t)p * L + 128u * b, acc);
         }
-        const float yf = ((acc[0] + acc[1]) + acc[2]) + acc[3];
-        double q, d, sc, out = -__builtin_huge_val();
-        score_terms(a, yf, n1, a.sums[p], q, d);
-        if (valid && mac_pass(a, n1) && candidate_score(a, p, q, d, a.thr[p], sc)) out = sc;
-        if (valid) tmp_score[gi] = out;
-        const uint32_t c = __popcll(__ballot(out != -__builtin_huge_val()));
-        if ((threadIdx.x & 63u) == 0u) wcnt[threadIdx.x >> 6] = c;
-        __syncthreads();
-        if (threadIdx.x == 0) tile_cnt[t] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-        __syncthreads();
+        rescore_finish(a, p, valid, gi, acc, n1, tmp_score, tile_cnt, t, wcnt);
     }
 }
 
@@ -489,7 +521,7 @@ __global__ void __launch_bounds__(256) compact_kernel(ScoreArgs a, const uint32_
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         if (tile_off[t + 1] == tile_off[t]) continue;  // block-uniform: no candidate in this tile
-        const uint32_t p = tile_column(tile_pref, a.n_pheno, t);
+        const uint32_t p = __builtin_amdgcn_readfirstlane(tile_column(tile_pref, a.n_pheno, t));  // the column's values come by scalar loads
         const uint32_t i = (t - tile_pref[p]) * 256u + threadIdx.x;
         const bool valid = i < surv_cnt[p];
         const uint32_t gi = surv_off[p] + (valid ? i : 0u);
