@@ -91,17 +91,33 @@ __global__ void __launch_bounds__(256) thr_update_kernel(const uint32_t* hist, c
     for (uint32_t i = 0; i < per; i++) s += h[t * per + i];
     part[t] = s;
     __syncthreads();
+    // suffix sums over the 256 segments (Hillis-Steele from the top): above[t] = scores counted in segments > t; the
+    // segment that takes the count past N is found by its own thread (one thread walking all 256 took 30 us per launch)
+    __shared__ unsigned long long suf[256];
+    __shared__ int seg_s;
+    __shared__ unsigned long long run_s;
+    suf[t] = s;
+    if (t == 0) seg_s = -1;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256u; d <<= 1) {
+        const unsigned long long x = t + d < 256u ? suf[t + d] : 0ull;
+        __syncthreads();
+        suf[t] += x;
+        __syncthreads();
+    }
+    {
+        const unsigned long long N = topn[p];
+        const unsigned long long above = suf[t] - s;  // segments t + 1 .. 255
+        if (above < N && above + s >= N) {  // exactly one t (or none: fewer than N scores counted)
+            seg_s = (int)t;
+            run_s = above;
+        }
+    }
+    __syncthreads();
     if (t == 0) {
         const unsigned long long N = topn[p];
-        unsigned long long run = 0;
-        int seg = -1;
-        for (int u = 255; u >= 0; u--) {
-            if (run + part[u] >= N) {
-                seg = u;
-                break;
-            }
-            run += part[u];
-        }
+        unsigned long long run = seg_s >= 0 ? run_s : 0ull;
+        const int seg = seg_s;
         double cur = thr[p];
         const double th = thr_host[p];
         if (seg >= 0) {
