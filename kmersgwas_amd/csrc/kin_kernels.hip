@@ -92,7 +92,16 @@ __device__ __forceinline__ uint32_t lane_xor_dpp(uint32_t x) {
 // 16-lane row and goes through the LDS crossbar.
 template <int J>
 __device__ __forceinline__ void transpose_stage(uint32_t& x, uint32_t& m, uint32_t lane) {
-    const uint32_t y = J == 16 ? (uint32_t)__shfl_xor((int)x, 16) : lane_xor_dpp<J>(x);
+    uint32_t y;
+    if (J == 16) {
+        // x of lane ^ 16 without the LDS crossbar: v_permlane16_swap_b32 exchanges the odd 16-lane rows of its first
+        // operand with the even rows of its second; with x as both, the first result holds rows (0, 0, 2, 2) of x and
+        // the second rows (1, 1, 3, 3)
+        const auto sw = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+        y = (lane & 16u) ? sw[0] : sw[1];
+    } else {
+        y = lane_xor_dpp<J>(x);
+    }
     const bool lo = (lane & (uint32_t)J) == 0u;
     const uint32_t a = lo ? x : y, b = lo ? y : x;
     const uint32_t t = ((a >> J) ^ b) & m;
@@ -155,24 +164,23 @@ __global__ void __launch_bounds__(256) kin_transpose_kernel(const uint64_t* file
         uint32_t x = (pass && d < in_dw) ? masked(d) : 0u;
         x = transpose32(x, lane);
         // lane s of 32-lane group g now holds sample 32d + s over the group's 32 rows
-        lout[(32u * d + (lane & 31u)) * wpb + wave * 2u + (lane >> 5)] = x;
+        // (the word index is XORed with bits 3..5 of the sample where a sample has 8 plane words: 64 lanes, 64 banks)
+        const uint32_t smp = 32u * d + (lane & 31u), wd = wave * 2u + (lane >> 5);
+        lout[smp * wpb + (wpb == 8u ? (wd ^ ((smp >> 3) & 7u)) : wd)] = x;
     }
     if (lane == 0 && kept) atomicAdd(&n_used[blockIdx.x % TESTED_SHARDS], kept);  // each wave adds the rows it counted
     __syncthreads();
     if (rpb == 256u) {
         // this block's 256 rows of all samples are one contiguous 32*S_pad-byte piece; the Gram kernel's round (16
         // plane words of 128 samples) is two 4 KB pieces
-        uint4* dst = reinterpret_cast<uint4*>(T + (uint64_t)blockIdx.x * S_pad * 8u);
-        const uint4* src = reinterpret_cast<const uint4*>(lout);
-        for (uint32_t e = threadIdx.x; e < S_pad * 2u; e += 256u) dst[e] = src[e];
+        uint32_t* dst = T + (uint64_t)blockIdx.x * S_pad * 8u;
+        for (uint32_t e = threadIdx.x; e < S_pad * 8u; e += 256u) dst[e] = lout[(e & ~7u) + ((e & 7u) ^ ((e >> 6) & 7u))];
     } else {
         const uint32_t per_tile = 256u / rpb;  // blocks per tile of 8 plane words
         const uint64_t tile = blockIdx.x / per_tile;
         const uint32_t w0 = (blockIdx.x % per_tile) * wpb;
-        uint2* dst = reinterpret_cast<uint2*>(T + tile * S_pad * 8u + w0);  // sample c: dst[c * 4 + i], i < wpb / 2
-        const uint2* src = reinterpret_cast<const uint2*>(lout);
-        const uint32_t h = wpb / 2u;
-        for (uint32_t e = threadIdx.x; e < S_pad * h; e += rpb) dst[(e / h) * 4u + (e % h)] = src[e];
+        uint32_t* dst = T + tile * S_pad * 8u + w0;  // sample c: dst[c * 8 + i], i < wpb
+        for (uint32_t e = threadIdx.x; e < S_pad * wpb; e += rpb) dst[(e / wpb) * 8u + (e % wpb)] = lout[e];
     }
 }
 
