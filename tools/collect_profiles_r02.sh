@@ -17,6 +17,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $O/p1_fetch -- python tools/
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $O/p1_write -- python tools/one_column.py > $O/p1_write.log 2>&1
 # 3. kinship
 KIN_CPU_ROWS=500 rocprofv3 --kernel-trace --stats -f csv -d $O/kin_stats -- python tools/kin_line.py > $O/kin_stats.log 2>&1
+bash tools/pmc_kin.sh > $O/kin_pmc_summary.txt 2>&1
 # 4. configs[3] shape on one GPU (100 M rows)
 python bench.py --samples 2048 --perms 200 --rows 100000000 --steps 5 --warmup 2 --no-cpu-baseline --no-subrecords > $O/config4_line.json 2> $O/config4_line.err
 # 5. the bench line itself (all sub-records)

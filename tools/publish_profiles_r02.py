@@ -74,3 +74,13 @@ with open("profiles/r02_coarse_pmc_sq_summary.txt", "w") as f:
         for k, (v, n) in sorted(counters(one(p + "/*/*_counter_collection.csv"), "coarse_kernel<7, 1>", 2048 * 512).items()):
             f.write("%-32s %16.0f  (%d launches)\n" % (k, v, n))
 print(open("profiles/r02_coarse_pmc_sq_summary.txt").read())
+
+# kinship Gram kernel: SQ counters per launch (tools/pmc_kin.sh)
+if os.path.exists(os.path.join(src, "kin_pmc_summary.txt")):
+    with open("profiles/r02_kinship_pmc_sq_summary.txt", "w") as f:
+        f.write("SQ counters of kin_gram_kernel (one 2^20-row chunk x 1135 accessions, 990 blocks of 128), averages per launch;\n"
+                "*_CYCLES / ACTIVE_* / WAIT_* count quad-cycles; SQ_VALU_MFMA_BUSY_CYCLES cycles; GRBM_GUI_ACTIVE summed over 8 XCDs\n")
+        for l in open(os.path.join(src, "kin_pmc_summary.txt")):
+            if l.startswith(("SQ_", "GRBM", "TCC")):
+                f.write(l)
+    print(open("profiles/r02_kinship_pmc_sq_summary.txt").read())
