@@ -151,10 +151,10 @@ struct NarrowArgs {
 // The bitmap's set bits as row-ordered keys (column << row_bits | row), column after column, with each column's range
 // (surv_off, surv_cnt) and the total (key_count; above key_cap = overflow, the ranges are then emptied). No sort: counts
 // per 65 536-row block, a scan, a scatter. nibble_transposed: the words come from the int8 filters (quarter word kg,
-// nibble rt = rows 16 rt + 4 kg ..+3). blk_scratch: n_pheno * (ceil(n_rows / 65536) + 1) words.
+// nibble rt = rows 16 rt + 4 kg ..+3). tile_pref[n_pheno + 1]: launch_rescore's tile table (first tile of each column). blk_scratch: n_pheno * (ceil(n_rows / 65536) + 1) words.
 hipError_t launch_bitmap_keys(const unsigned long long* bitmap, uint64_t words_per_col, uint64_t n_rows, uint32_t n_pheno, uint32_t* blk_scratch,
                               uint32_t* keys_sorted, uint32_t key_cap, uint32_t row_bits, uint32_t* surv_off, uint32_t* surv_cnt,
-                              uint32_t* key_count, bool nibble_transposed, hipStream_t st);
+                              uint32_t* key_count, uint32_t* tile_pref, bool nibble_transposed, hipStream_t st);
 size_t narrow_lds_bytes(uint32_t n_kgroups);
 hipError_t launch_narrow(const NarrowArgs& a, uint32_t rows_per_block, hipStream_t st);
 

@@ -832,7 +832,7 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
         KGWAS_HIP(hipEventRecord(sl.ev_mid, s->stream));
         a.tested = nullptr;  // counted by the filter
         KGWAS_HIP(launch_bitmap_keys(s->d_bitmap.p, n_words, n_rows, (uint32_t)s->n_pheno, s->d_bm_blocks.p, s->d_surv_sorted.p, s->key_slots,
-                                     s->row_key_bits, s->d_surv_off.p, s->d_surv_cnt.p, s->d_key_count.p, /*nibble_transposed=*/!s->narrow, s->stream));
+                                     s->row_key_bits, s->d_surv_off.p, s->d_surv_cnt.p, s->d_key_count.p, s->d_tile_pref.p, /*nibble_transposed=*/!s->narrow, s->stream));
         a.so_score = sl.d_so_score.p;
         a.so_kmer = sl.d_so_kmer.p;
         a.so_row = sl.d_so_row.p;
@@ -1529,7 +1529,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         const uint64_t budget = getenv("KGWAS_CAP_BUDGET") ? strtoull(getenv("KGWAS_CAP_BUDGET"), nullptr, 10) : (4ull << 20);  // candidate records per slot
         // (few columns: longer lists, so that the ramp takes ~6 chunks instead of ~13 - a chunk's fixed costs, not its
         // rows, are what a one-column scan pays for)
-        const uint64_t cap_mult = getenv("KGWAS_CAP_MULT") ? strtoull(getenv("KGWAS_CAP_MULT"), nullptr, 10) : (s->narrow ? 8 : 2);  // experiments
+        const uint64_t cap_mult = getenv("KGWAS_CAP_MULT") ? strtoull(getenv("KGWAS_CAP_MULT"), nullptr, 10) : (s->narrow ? 16 : 2);  // experiments
         uint64_t cap = std::min<uint64_t>(cap_mult * s->max_topn + 4096, std::max<uint64_t>(budget / s->n_pheno, 1024));
         s->cap = (uint32_t)std::min<uint64_t>(cap, 0x7FFFFFFFull);
 

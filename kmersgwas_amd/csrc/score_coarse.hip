@@ -354,7 +354,7 @@ __global__ void __launch_bounds__(512) coarse_kernel(CoarseArgs a, uint32_t rows
 }
 
 // ---- survivors -> exact candidates, compacted in (column, row) order --------------------------------------------
-// The sorted key list is cut into tiles of 256 survivors that never straddle a column (tile_prefix_kernel); the three
+// The sorted key list is cut into tiles of 256 survivors that never straddle a column (launch_bitmap_keys fills tile_pref); the three
 // kernels below walk the tiles with a fixed grid:
 //   rescore_kernel      exact re-scoring of a tile's survivors (one lane each, the column wave-uniform), exact test
 //                       against thr, threshold histogram; score (or -inf: not a candidate) to HBM, candidates per tile
@@ -371,29 +371,6 @@ __device__ __forceinline__ uint32_t tile_column(const uint32_t* tile_pref, uint3
         if (tile_pref[mid] <= t) lo = mid; else hi = mid;
     }
     return lo;
-}
-
-__global__ void __launch_bounds__(256) tile_prefix_kernel(const uint32_t* surv_cnt, uint32_t n_pheno, uint32_t* tile_pref) {
-    __shared__ uint32_t carry, part[256];
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (uint32_t p0 = 0; p0 < n_pheno; p0 += 256u) {
-        const uint32_t p = p0 + threadIdx.x;
-        const uint32_t v = p < n_pheno ? (surv_cnt[p] + 255u) / 256u : 0u;
-        part[threadIdx.x] = v;
-        __syncthreads();
-        for (uint32_t d = 1; d < 256u; d <<= 1) {  // inclusive scan
-            const uint32_t x = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
-            __syncthreads();
-            part[threadIdx.x] += x;
-            __syncthreads();
-        }
-        if (p < n_pheno) tile_pref[p] = carry + part[threadIdx.x] - v;
-        __syncthreads();
-        if (threadIdx.x == 255u) carry += part[255];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) tile_pref[n_pheno] = carry;
 }
 
 // Same arithmetic as score_valu_kernel: the reference's select-and-add chains, then the exact candidate test.
@@ -622,7 +599,6 @@ hipError_t launch_rescore(const ScoreArgs& a, const uint32_t* keys, const uint32
                           const uint32_t* key_count, uint32_t* meta, hipStream_t st) {
     if (a.n_pheno == 0) return hipSuccess;
     const uint32_t row_mask = row_bits >= 32 ? 0xFFFFFFFFu : ((1u << row_bits) - 1u);
-    hipLaunchKernelGGL(tile_prefix_kernel, dim3(1), dim3(256), 0, st, surv_cnt, a.n_pheno, tile_pref);
     // fixed grid, tiles handed out round-robin: 8 blocks of 256 per CU (the tile count is only known on the device)
     hipLaunchKernelGGL(rescore_kernel, dim3(2048), dim3(256), 0, st, a, keys, surv_off, surv_cnt, tile_pref, row_mask, tmp_score,
                        tile_cnt);

@@ -391,7 +391,7 @@ __global__ void __launch_bounds__(256) bitmap_scan_kernel(uint32_t* blk_cnt, uin
 
 // each column's range in the key list and the total
 __global__ void __launch_bounds__(256) bitmap_bases_kernel(const uint32_t* col_total, uint32_t n_pheno, uint32_t key_cap, uint32_t* surv_off,
-                                                           uint32_t* surv_cnt, uint32_t* key_count) {
+                                                           uint32_t* surv_cnt, uint32_t* key_count, uint32_t* tile_pref) {
     __shared__ uint32_t part[256];
     __shared__ uint32_t carry;
     if (threadIdx.x == 0) carry = 0;
@@ -416,8 +416,30 @@ __global__ void __launch_bounds__(256) bitmap_bases_kernel(const uint32_t* col_t
         __syncthreads();
     }
     if (threadIdx.x == 0) *key_count = carry;  // the host compares it with the capacity
-    if (carry > key_cap)  // overflow: the chunk is redone in halves; leave nothing for the re-score kernels to walk
+    const bool over = carry > key_cap;  // overflow: the chunk is redone in halves; leave nothing for the re-score kernels to walk
+    __syncthreads();
+    if (over)
         for (uint32_t p = threadIdx.x; p < n_pheno; p += 256u) surv_cnt[p] = 0u;
+    // the re-score kernels' tiles of 256 survivors, never straddling a column: tile_pref[p] = first tile of column p
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t p0 = 0; p0 < n_pheno; p0 += 256u) {
+        const uint32_t p = p0 + threadIdx.x;
+        const uint32_t v = (p < n_pheno && !over) ? (col_total[p] + 255u) / 256u : 0u;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (uint32_t d = 1; d < 256u; d <<= 1) {
+            const uint32_t x = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+            __syncthreads();
+            part[threadIdx.x] += x;
+            __syncthreads();
+        }
+        if (p < n_pheno) tile_pref[p] = carry + part[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 255u) carry += part[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tile_pref[n_pheno] = carry;
 }
 
 __global__ void __launch_bounds__(256) bitmap_scatter_kernel(const unsigned long long* bm, uint64_t words_per_col, uint32_t n_words,
@@ -473,13 +495,13 @@ __global__ void __launch_bounds__(256) bitmap_scatter_kernel(const unsigned long
 
 hipError_t launch_bitmap_keys(const unsigned long long* bitmap, uint64_t words_per_col, uint64_t n_rows, uint32_t n_pheno, uint32_t* blk_scratch,
                               uint32_t* keys_sorted, uint32_t key_cap, uint32_t row_bits, uint32_t* surv_off, uint32_t* surv_cnt,
-                              uint32_t* key_count, bool nibble_transposed, hipStream_t st) {
+                              uint32_t* key_count, uint32_t* tile_pref, bool nibble_transposed, hipStream_t st) {
     const uint32_t n_words = (uint32_t)((n_rows + 63) / 64);
     const uint32_t n_blocks = (n_words + BM_WORDS - 1) / BM_WORDS;
     hipLaunchKernelGGL(bitmap_count_kernel, dim3(n_blocks, n_pheno), dim3(256), 0, st, bitmap, words_per_col, n_words, n_blocks, blk_scratch);
     uint32_t* col_total = blk_scratch + (size_t)n_pheno * n_blocks;
     hipLaunchKernelGGL(bitmap_scan_kernel, dim3(n_pheno), dim3(256), 0, st, blk_scratch, n_blocks, col_total);
-    hipLaunchKernelGGL(bitmap_bases_kernel, dim3(1), dim3(256), 0, st, col_total, n_pheno, key_cap, surv_off, surv_cnt, key_count);
+    hipLaunchKernelGGL(bitmap_bases_kernel, dim3(1), dim3(256), 0, st, col_total, n_pheno, key_cap, surv_off, surv_cnt, key_count, tile_pref);
     hipLaunchKernelGGL(bitmap_scatter_kernel, dim3(n_blocks, n_pheno), dim3(256), 0, st, bitmap, words_per_col, n_words, n_blocks, blk_scratch,
                        surv_off, keys_sorted, key_cap, row_bits, nibble_transposed);
     return hipGetLastError();
