@@ -401,6 +401,7 @@ struct Slot {
     hipEvent_t ev_sq0 = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_done = nullptr, ev_mid = nullptr;
     bool used_coarse = false;
     int coarse_mode = 0;
+    double cand_est = 0;  // candidates the chunk was planned for (sum of topn x rows / rows before it)
     const uint64_t* rows = nullptr;
     uint64_t first_row = 0, n_rows = 0;
     bool squeezed = false, busy = false;
@@ -786,6 +787,7 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
         const int cm = s->narrow ? 0 : pick_coarse_mode(s);
         const kgwas_scan::CoarseMode& M = s->cmode[cm];
         sl.coarse_mode = cm;
+        sl.cand_est = (double)s->sum_topn * (double)n_rows / (double)std::max<uint64_t>(s->rows_submitted, 1);
         c.n_lgroups = M.n_lgroups;
         c.Bq = M.d_Bq.p;
         c.n_slices = M.slices;
@@ -1147,8 +1149,11 @@ void fetch_records(kgwas_scan* s, Slot& sl) {
     if (!sl.used_coarse) return;
     wait_event(s, sl.ev_counts);
     const uint32_t n = sl.h_meta.p[2 * s->n_pheno];
-    if (!s->narrow && n >= 1024)
-        s->infl_obs[sl.coarse_mode] = std::min(64.0, std::max(1.0, (double)sl.h_meta.p[2 * s->n_pheno + 1] / (double)n));
+    const uint32_t n_surv = sl.h_meta.p[2 * s->n_pheno + 1];
+    if (!s->narrow && n_surv > s->key_slots)  // the list overflowed (the chunk is redone by the exact scorer): plan the next chunks for what it saw
+        s->infl_obs[sl.coarse_mode] = std::min(256.0, std::max(s->infl_obs[sl.coarse_mode], 1.25 * (double)n_surv / std::max(sl.cand_est, 1.0)));
+    else if (!s->narrow && n >= 1024)
+        s->infl_obs[sl.coarse_mode] = std::min(64.0, std::max(1.0, (double)n_surv / (double)n));
     if (n && sl.h_meta.p[2 * s->n_pheno + 1] <= s->key_slots) {
         KGWAS_HIP(hipMemcpyAsync(sl.so_score.p, sl.d_so_score.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s->copy_stream));
         KGWAS_HIP(hipMemcpyAsync(sl.so_row.p, sl.d_so_row.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, s->copy_stream));
