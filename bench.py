@@ -385,8 +385,8 @@ def main():
             # executed int8 work: per operand set, padded samples x padded operand columns x rows filtered with it
             ex_ops = 0.0
             for mi in range(2):
-                T, lgroups = stats[-1]["coarse_mode_tiles"][mi], stats[-1]["coarse_mode_lgroups"][mi]
-                ex_ops += 2.0 * (kgroups * 512) * (lgroups * T * 16) * sum(st_["coarse_mode_rows"][mi] for st_ in stats)
+                tile_slices = stats[-1]["coarse_mode_tile_slices"][mi]
+                ex_ops += 2.0 * (kgroups * 512) * (tile_slices * 16) * sum(st_["coarse_mode_rows"][mi] for st_ in stats)
             rows_scored = sum(sum(st_["coarse_mode_rows"]) for st_ in stats)
             achieved_tflops = flop_per_row * rows_scored / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
             executed = ex_ops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
@@ -434,6 +434,7 @@ def main():
                          "frac": achieved_tflops / peak, "executed_TOPs": executed,
                          "coarse_sets": ([{"int8_slices": mi + 1, "tiles_per_lds_group": stats[-1]["coarse_mode_tiles"][mi],
                                             "lds_groups": stats[-1]["coarse_mode_lgroups"][mi],
+                                            "tile_slices_per_row": stats[-1]["coarse_mode_tile_slices"][mi],
                                             "launches_per_step": sum(st_["coarse_mode_launches"][mi] for st_ in stats) / args.steps,
                                             "rows_per_step": sum(st_["coarse_mode_rows"][mi] for st_ in stats) // args.steps,
                                             "ms_per_step": sum(st_["coarse_mode_ms"][mi] for st_ in stats) / args.steps}

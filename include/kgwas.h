@@ -144,13 +144,14 @@ typedef struct kgwas_scan_stats {
     uint32_t direct_mode;       /* 1 = scorer read the file layout in place (no squeeze pass) */
     uint64_t patterns;          /* distinct pattern hashes among tested rows (count_patterns; valid after finish) */
     /* coarse filter, per operand set: [0] = one int8 slice per phenotype column, [1] = two slices */
-    uint32_t coarse_mode_tiles[2];     /* 16-column int8 operand tiles per LDS group (0 = set not built) */
-    uint32_t coarse_mode_lgroups[2];   /* LDS groups a block walks */
+    uint32_t coarse_mode_tiles[2];     /* 16-column int8 operand tiles per LDS group of the set's main launch (0 = set not built) */
+    uint32_t coarse_mode_lgroups[2];   /* LDS groups a row passes through (all launches of the set) */
     uint64_t coarse_mode_launches[2];
     uint64_t coarse_mode_rows[2];      /* rows filtered with this set */
     double coarse_mode_ms[2];          /* hipEvent time of its coarse_kernel launches */
     double replay_cpu_ms;       /* CPU time of the replay summed over the workers (replay_ms: the busiest worker's share) */
     double replay_tail_ms;      /* wall time the replay still needed after the GPU had finished the feed's last chunk */
+    uint32_t coarse_mode_tile_slices[2]; /* operand tiles a row is multiplied with, over all LDS groups and launches of the set */
 } kgwas_scan_stats;
 
 int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out);

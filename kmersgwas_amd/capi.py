@@ -72,6 +72,7 @@ class ScanStats(C.Structure):
         ("coarse_mode_launches", C.c_uint64 * 2), ("coarse_mode_rows", C.c_uint64 * 2),
         ("coarse_mode_ms", C.c_double * 2),
         ("replay_cpu_ms", C.c_double), ("replay_tail_ms", C.c_double),
+        ("coarse_mode_tile_slices", C.c_uint32 * 2),
     ]
 
     def as_dict(self):

@@ -443,13 +443,20 @@ struct kgwas_scan {
     uint32_t coarse_T = 0, n_kgroups = 0;  // coarse_T: most operand tiles the LDS can hold
     // Operand sets of the filter: mode[0] = one int8 slice per column (half the matrix work, ~2.5 survivors per
     // candidate), mode[1] = two slices (~1). Both may be resident; each chunk picks one (pick_coarse_mode).
-    struct CoarseMode {
-        bool ready = false;
+    struct CoarsePart {  // one launch of the filter: n_lgroups LDS groups of T operand tiles over a range of columns
         bool wide = false;  // score_wide.hip: all T tiles' accumulators in registers, operands streamed through LDS
-        uint32_t T = 0, n_lgroups = 0, slices = 0;
-        float eg_max = 0, rall_max = 0, rmax_max = 0;  // row error term, maxima over the columns (kernels.h)
+        uint32_t T = 0, n_lgroups = 0;
         DevBuf<int8_t> d_Bq;
         DevBuf<CoarseCol> d_cols;
+    };
+    struct CoarseMode {
+        bool ready = false;
+        uint32_t slices = 0, n_parts = 0;
+        uint32_t tile_slices = 0;  // operand tiles a row is multiplied with, all parts and groups
+        float eg_max = 0, rall_max = 0, rmax_max = 0;  // row error term, maxima over the columns (kernels.h)
+        // Full LDS groups first; columns that would only fill part of another full-size group go into a second launch
+        // with as few tiles as they need (201 columns at 2048 samples: 3 groups x 4 tiles + 1 tile instead of 4 x 4).
+        CoarsePart part[2];
     } cmode[2];
     double infl_obs[2] = {4.0, 1.1};  // survivors per candidate of the last finished chunk of each mode
     double mode_k = 0.09;
@@ -740,7 +747,7 @@ int pick_coarse_mode(const kgwas_scan* s) {
     if (!s->cmode[0].ready) return 1;
     if (!s->cmode[1].ready) return 0;
     const double cand_row = (double)s->sum_topn / (double)std::max<uint64_t>(s->rows_submitted, 1);
-    const double tiles0 = (double)s->cmode[0].T * s->cmode[0].n_lgroups, tiles1 = (double)s->cmode[1].T * s->cmode[1].n_lgroups;
+    const double tiles0 = (double)s->cmode[0].tile_slices, tiles1 = (double)s->cmode[1].tile_slices;
     return cand_row * std::max(0.0, s->infl_obs[0] - s->infl_obs[1]) < s->mode_k * (tiles1 - tiles0) ? 0 : 1;
 }
 
@@ -788,10 +795,7 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
         const kgwas_scan::CoarseMode& M = s->cmode[cm];
         sl.coarse_mode = cm;
         sl.cand_est = (double)s->sum_topn * (double)n_rows / (double)std::max<uint64_t>(s->rows_submitted, 1);
-        c.n_lgroups = M.n_lgroups;
-        c.Bq = M.d_Bq.p;
         c.n_slices = M.slices;
-        c.cols = M.d_cols.p;
         c.eg_max = M.eg_max;
         c.rall_max = M.rall_max;
         c.rmax_max = M.rmax_max;
@@ -826,10 +830,17 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
             c.words_per_col = n_words;
             // rows per block: the operand tiles (up to 128 KB) are loaded into LDS once per block, so blocks are long
             // where the launch still fills the chip four times over
-            if (M.wide)
-                KGWAS_HIP(launch_wide(c, M.T, rpb_env ? rpb_env : (n_rows >= (1u << 20) ? 1024u : 256u), s->stream));
-            else
-                KGWAS_HIP(launch_coarse(c, M.T, rpb_env ? rpb_env : (n_rows >= (1u << 22) ? 4096u : n_rows >= (1u << 20) ? 2048u : 512u), s->stream));
+            for (uint32_t pi = 0; pi < M.n_parts; pi++) {
+                const kgwas_scan::CoarsePart& Pt = M.part[pi];
+                c.n_lgroups = Pt.n_lgroups;
+                c.Bq = Pt.d_Bq.p;
+                c.cols = Pt.d_cols.p;
+                c.tested = pi == 0 ? a.tested : nullptr;  // every launch sees every row: one of them counts
+                if (Pt.wide)
+                    KGWAS_HIP(launch_wide(c, Pt.T, rpb_env ? rpb_env : (n_rows >= (1u << 20) ? 1024u : 256u), s->stream));
+                else
+                    KGWAS_HIP(launch_coarse(c, Pt.T, rpb_env ? rpb_env : (n_rows >= (1u << 22) ? 4096u : n_rows >= (1u << 20) ? 2048u : 512u), s->stream));
+            }
         }
         KGWAS_HIP(hipEventRecord(sl.ev_mid, s->stream));
         a.tested = nullptr;  // counted by the filter
@@ -1800,6 +1811,27 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                     T = (uint32_t)(ns * ((cper + 1 + 15) / 16));
                     if (T <= Tmax) break;
                 }
+                // plan[i] = {first column, columns, T, LDS groups, columns per group}
+                struct Plan {
+                    uint64_t j0, n, T, groups, cper;
+                    bool wide;
+                };
+                std::vector<Plan> plan;
+                plan.push_back(Plan{0, P, T, n_lgroups, cper, false});
+                if (n_lgroups > 1) {
+                    // The balanced split pads every group (201 columns, 4 tiles per group: 4 x (51 + ones) of 4 x 64
+                    // slots = 16 tiles for 13 tiles' worth of columns). Alternative: groups filled to the last slot and
+                    // ONE smaller launch for the rest - taken when it multiplies fewer tiles with no more row passes.
+                    const uint64_t cpf = (uint64_t)(Tmax / (uint32_t)ns) * 16 - 1;  // columns of a full group
+                    const uint64_t full = P / cpf, rem = P - full * cpf;
+                    const uint64_t Tr = rem ? (uint64_t)ns * ((rem + 1 + 15) / 16) : 0;
+                    static const bool no_split = getenv("KGWAS_COARSE_NOSPLIT") != nullptr;  // experiments
+                    if (full >= 1 && full + (rem ? 1 : 0) <= n_lgroups && full * Tmax + Tr < n_lgroups * T && !no_split) {
+                        plan.clear();
+                        plan.push_back(Plan{0, full * cpf, Tmax, full, cpf, false});
+                        if (rem) plan.push_back(Plan{full * cpf, rem, Tr, 1, rem, false});
+                    }
+                }
                 // One slice, more tiles than the LDS holds at once, at most 14: the wide kernel keeps every tile's
                 // accumulators in registers and streams the operands (score_wide.hip) - one group, every row expanded once.
                 {
@@ -1810,62 +1842,72 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                     // it stays opt-in (KGWAS_WIDE=1) until it wins.
                     const bool on = getenv("KGWAS_WIDE") && atoi(getenv("KGWAS_WIDE")) == 1;
                     if (ns == 1 && n_lgroups > 1 && tiles >= 9 && tiles <= 14 && wide_lds_bytes(tiles) <= 160u * 1024u && on) {
-                        M.wide = true;
-                        n_lgroups = 1;
-                        cper = P;
-                        T = tiles;
+                        plan.clear();
+                        plan.push_back(Plan{0, P, tiles, 1, P, true});
                     }
                 }
-                const uint32_t PG = T / (uint32_t)ns, slots = PG * 16;
-                M.T = T;
                 M.slices = (uint32_t)ns;
-                M.n_lgroups = (uint32_t)n_lgroups;
-                s->st.coarse_mode_tiles[mi] = T;
-                s->st.coarse_mode_lgroups[mi] = (uint32_t)n_lgroups;
-                std::vector<int8_t> Bq(n_lgroups * n_kgroups * 8ull * T * 1024ull, 0);
-                std::vector<CoarseCol> cols(n_lgroups * slots);
-                for (auto& cc : cols) {
-                    memset(&cc, 0, sizeof(cc));
-                    cc.pheno = -1;
-                }
-                auto put = [&](uint64_t lg, uint64_t slot, const std::vector<int>& v0, const std::vector<int>& v1) {
-                    const uint64_t pgl = slot / 16, n = slot % 16;
-                    for (uint64_t g = 0; g < n_kgroups; g++)
-                        for (uint64_t jj = 0; jj < 8; jj++)
-                            for (uint64_t kg = 0; kg < 4; kg++)
-                                for (uint64_t e = 0; e < 16; e++) {
-                                    // k-element e of step jj <-> sample (score_coarse.hip: expand_step)
-                                    const uint64_t smp = 512 * g + 128 * kg + 32 * (e / 4) + 8 * (e % 4) + jj;
-                                    if (smp >= S) continue;
-                                    const uint64_t lane = kg * 16 + n;
-                                    const uint64_t base = (((lg * n_kgroups + g) * 8 + jj) * T);
-                                    if (ns == 1) {
-                                        Bq[((base + pgl) * 64 + lane) * 16 + e] = (int8_t)v0[smp];
-                                    } else {
-                                        Bq[((base + 2 * pgl) * 64 + lane) * 16 + e] = (int8_t)v0[smp];
-                                        Bq[((base + 2 * pgl + 1) * 64 + lane) * 16 + e] = (int8_t)v1[smp];
+                M.n_parts = (uint32_t)plan.size();
+                M.tile_slices = 0;
+                uint32_t groups_all = 0;
+                for (size_t pi = 0; pi < plan.size(); pi++) {
+                    const Plan& pl = plan[pi];
+                    kgwas_scan::CoarsePart& Pt = M.part[pi];
+                    const uint32_t Tp = (uint32_t)pl.T;
+                    const uint32_t PG = Tp / (uint32_t)ns, slots = PG * 16;
+                    Pt.T = Tp;
+                    Pt.n_lgroups = (uint32_t)pl.groups;
+                    Pt.wide = pl.wide;
+                    M.tile_slices += Tp * (uint32_t)pl.groups;
+                    groups_all += (uint32_t)pl.groups;
+                    std::vector<int8_t> Bq(pl.groups * n_kgroups * 8ull * Tp * 1024ull, 0);
+                    std::vector<CoarseCol> cols(pl.groups * slots);
+                    for (auto& cc : cols) {
+                        memset(&cc, 0, sizeof(cc));
+                        cc.pheno = -1;
+                    }
+                    auto put = [&](uint64_t lg, uint64_t slot, const std::vector<int>& v0, const std::vector<int>& v1) {
+                        const uint64_t pgl = slot / 16, n = slot % 16;
+                        for (uint64_t g = 0; g < n_kgroups; g++)
+                            for (uint64_t jj = 0; jj < 8; jj++)
+                                for (uint64_t kg = 0; kg < 4; kg++)
+                                    for (uint64_t e = 0; e < 16; e++) {
+                                        // k-element e of step jj <-> sample (score_coarse.hip: expand_step)
+                                        const uint64_t smp = 512 * g + 128 * kg + 32 * (e / 4) + 8 * (e % 4) + jj;
+                                        if (smp >= S) continue;
+                                        const uint64_t lane = kg * 16 + n;
+                                        const uint64_t base = (((lg * n_kgroups + g) * 8 + jj) * Tp);
+                                        if (ns == 1) {
+                                            Bq[((base + pgl) * 64 + lane) * 16 + e] = (int8_t)v0[smp];
+                                        } else {
+                                            Bq[((base + 2 * pgl) * 64 + lane) * 16 + e] = (int8_t)v0[smp];
+                                            Bq[((base + 2 * pgl + 1) * 64 + lane) * 16 + e] = (int8_t)v1[smp];
+                                        }
                                     }
-                                }
-                };
-                for (uint64_t j = 0; j < P; j++) {
-                    const uint64_t lg = j / cper, slot = j % cper;
-                    CoarseCol& cc = cols[lg * slots + slot];
-                    ErrBound eb;
-                    quantise(j, ns, cc, eb);
-                    M.eg_max = std::max(M.eg_max, eb.egD);
-                    M.rall_max = std::max(M.rall_max, eb.rallD);
-                    M.rmax_max = std::max(M.rmax_max, eb.rmaxD);
-                    cc.pheno = (int32_t)j;
-                    put(lg, slot, q0, q1);
+                    };
+                    for (uint64_t j = pl.j0; j < pl.j0 + pl.n; j++) {
+                        const uint64_t lg = (j - pl.j0) / pl.cper, slot = (j - pl.j0) % pl.cper;
+                        CoarseCol& cc = cols[lg * slots + slot];
+                        ErrBound eb;
+                        quantise(j, ns, cc, eb);
+                        M.eg_max = std::max(M.eg_max, eb.egD);
+                        M.rall_max = std::max(M.rall_max, eb.rallD);
+                        M.rmax_max = std::max(M.rmax_max, eb.rmaxD);
+                        cc.pheno = (int32_t)j;
+                        put(lg, slot, q0, q1);
+                    }
+                    {  // ones column: Dc = N1 (one slice: q0 = 1; two slices: Dc = 254*D0 + D1 with q0 = 0, q1 = 1)
+                        std::vector<int> ones(S, 1), zeros(S, 0);
+                        for (uint64_t lg = 0; lg < pl.groups; lg++) put(lg, slots - 1, ns == 1 ? ones : zeros, ones);
+                    }
+                    Pt.d_Bq.alloc(Bq.size());
+                    Pt.d_cols.alloc(cols.size());
+                    KGWAS_HIP(hipMemcpy(Pt.d_Bq.p, Bq.data(), Bq.size(), hipMemcpyHostToDevice));
+                    KGWAS_HIP(hipMemcpy(Pt.d_cols.p, cols.data(), cols.size() * sizeof(CoarseCol), hipMemcpyHostToDevice));
                 }
-                {  // ones column: Dc = N1 (one slice: q0 = 1; two slices: Dc = 254*D0 + D1 with q0 = 0, q1 = 1)
-                    std::vector<int> ones(S, 1), zeros(S, 0);
-                    for (uint64_t lg = 0; lg < n_lgroups; lg++) put(lg, slots - 1, ns == 1 ? ones : zeros, ones);
-                }
-                M.d_Bq.alloc(Bq.size());
-                M.d_cols.alloc(cols.size());
-                KGWAS_HIP(hipMemcpy(M.d_Bq.p, Bq.data(), Bq.size(), hipMemcpyHostToDevice));
-                KGWAS_HIP(hipMemcpy(M.d_cols.p, cols.data(), cols.size() * sizeof(CoarseCol), hipMemcpyHostToDevice));
+                s->st.coarse_mode_tiles[mi] = M.part[0].T;
+                s->st.coarse_mode_lgroups[mi] = groups_all;
+                s->st.coarse_mode_tile_slices[mi] = M.tile_slices;
                 M.ready = true;
             }
             s->key_slots = (uint32_t)std::min<uint64_t>((uint64_t)s->cap * P, 0x7FFFFFFFull);
@@ -2298,6 +2340,7 @@ int kgwas_scan_reset(kgwas_scan* s) {
         for (int mi = 0; mi < 2; mi++) {
             s->st.coarse_mode_tiles[mi] = old.coarse_mode_tiles[mi];
             s->st.coarse_mode_lgroups[mi] = old.coarse_mode_lgroups[mi];
+            s->st.coarse_mode_tile_slices[mi] = old.coarse_mode_tile_slices[mi];
         }
     });
 }

@@ -89,12 +89,23 @@ __device__ __forceinline__ i32x4 expand_step(const uint32_t (&w)[4], int j) {
 // sample (0 elsewhere), so its dot product IS the masked popcount - no masks, no popcounts, no mask loads in the
 // main loop, and bits of unphenotyped samples or row padding meet zeros in every operand column.
 template <int T, int NS>
-__global__ void __launch_bounds__(512) coarse_kernel(CoarseArgs a, uint32_t rows_per_block, uint32_t n_rowblocks) {
+__global__ void __launch_bounds__(512) coarse_kernel(CoarseArgs a, uint32_t rows_per_block, uint32_t n_rowblocks, uint32_t grid_lg) {
     extern __shared__ i32x4 blds[];  // [n_kgroups][8][T][64] x 16 bytes, colc[3][PG*16] (alpha, 1/u, column index), survivor buffer
     constexpr int PG = T / NS;       // column groups (of 16) per LDS group
     constexpr int RT = 4;
     constexpr int SLOTS = PG * 16;
-    const uint32_t rb = blockIdx.x;
+    // Several LDS groups: either this block walks them one after the other over its rows (grid_lg = 0: every pass over
+    // the rows re-reads them, 1 MB per block and pass, far more than the L2 keeps across a pass) or every (row block,
+    // group) pair is a block of its own (grid_lg = 1). Blocks go to XCD (id % 8) in id order, so the groups of a row
+    // block get consecutive ids on ONE XCD: they start within a few per cent of a block's run time of each other and
+    // stream through the same rows together - one of them fetches a row from HBM, the others find it in the L2.
+    uint32_t rb = blockIdx.x, lg0 = 0, lg1 = a.n_lgroups;
+    if (grid_lg) {
+        const uint32_t idx = blockIdx.x >> 3;
+        rb = (idx / a.n_lgroups) * 8u + (blockIdx.x & 7u);
+        lg0 = idx % a.n_lgroups;
+        lg1 = lg0 + 1u;
+    }
     if (rb >= n_rowblocks) return;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t kg = lane >> 4, m = lane & 15u;
@@ -115,8 +126,8 @@ __global__ void __launch_bounds__(512) coarse_kernel(CoarseArgs a, uint32_t rows
     const uint32_t avail_b = a.src.avail_dw * 4u;
     uint32_t tested_local = 0;
 
-    for (uint32_t lg = 0; lg < a.n_lgroups; lg++) {
-        if (lg) __syncthreads();
+    for (uint32_t lg = lg0; lg < lg1; lg++) {
+        if (lg != lg0) __syncthreads();
         {
             const i32x4* src = reinterpret_cast<const i32x4*>(a.Bq) + (size_t)lg * group_vec;
             for (uint32_t i = threadIdx.x; i < group_vec; i += blockDim.x) blds[i] = src[i];
@@ -546,7 +557,10 @@ static hipError_t launch_coarse_t(const CoarseArgs& a, uint32_t rows_per_block, 
                                            (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((coarse_kernel<T, NS>), dim3(n_rowblocks), dim3(512), lds, st, a, rows_per_block, n_rowblocks);
+    static const int grid_env = getenv("KGWAS_COARSE_GRIDLG") ? atoi(getenv("KGWAS_COARSE_GRIDLG")) : -1;  // experiments
+    const uint32_t grid_lg = (grid_env >= 0 ? grid_env != 0 : true) && a.n_lgroups > 1 ? 1u : 0u;
+    const uint32_t grid = grid_lg ? (n_rowblocks + 7u) / 8u * 8u * a.n_lgroups : n_rowblocks;
+    hipLaunchKernelGGL((coarse_kernel<T, NS>), dim3(grid), dim3(512), lds, st, a, rows_per_block, n_rowblocks, grid_lg);
     return hipGetLastError();
 }
 
