@@ -1,0 +1,269 @@
+// heap_soa_bench.cpp — microbenchmark (not part of the product): the replay's K-way lockstep heap update on 16-byte
+// (score, slot) entries (heap.h today) against a split layout, scores f64 and slots u32 in two arrays (half the bytes
+// on the compare path). T threads x H = K heaps of N entries; checks that both end in the same layout.
+// build: g++ -O3 -march=native -std=c++17 -pthread tools/heap_soa_bench.cpp -o tools/bin/heap_soa_bench
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <random>
+#include <thread>
+#include <vector>
+
+struct Ent {
+    double score;
+    uint32_t slot;
+};
+
+template <int K>
+static inline void replace_aos(Ent* const* a, ptrdiff_t n, Ent* x) {
+    Ent v[K];
+    ptrdiff_t h[K], c[K];
+    const ptrdiff_t len = n - 1, lim = (len - 1) / 2;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        v[k] = a[k][n - 1];
+        x[k].slot = a[k][0].slot;
+        h[k] = 0;
+        c[k] = 0;
+    }
+    for (;;) {
+        bool any = false;
+    #pragma unroll
+    for (int k = 0; k < K; k++) {
+            if (c[k] < lim) {
+                ptrdiff_t cc = 2 * (c[k] + 1);
+                cc -= (a[k][cc].score > a[k][cc - 1].score) ? 1 : 0;
+                a[k][h[k]] = a[k][cc];
+                h[k] = cc;
+                c[k] = cc;
+                any = true;
+            }
+        }
+        if (!any) break;
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        if ((len & 1) == 0 && c[k] == (len - 2) / 2) {
+            c[k] = 2 * (c[k] + 1);
+            a[k][h[k]] = a[k][c[k] - 1];
+            h[k] = c[k] - 1;
+        }
+        ptrdiff_t hh = h[k], p = (hh - 1) / 2;
+        while (hh > 0 && a[k][p].score > v[k].score) {
+            a[k][hh] = a[k][p];
+            hh = p;
+            p = (hh - 1) / 2;
+        }
+        a[k][hh] = v[k];
+        hh = n - 1;
+        p = (hh - 1) / 2;
+        while (hh > 0 && a[k][p].score > x[k].score) {
+            a[k][hh] = a[k][p];
+            hh = p;
+            p = (hh - 1) / 2;
+        }
+        a[k][hh] = x[k];
+    }
+}
+
+template <int K, typename SlotT>
+static inline void replace_soa(double* const* sc, SlotT* const* sl, ptrdiff_t n, const double* xs, SlotT* evicted) {
+    double vs[K];
+    SlotT vl[K], xl[K];
+    ptrdiff_t h[K], c[K];
+    const ptrdiff_t len = n - 1, lim = (len - 1) / 2;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        vs[k] = sc[k][n - 1];
+        vl[k] = sl[k][n - 1];
+        xl[k] = sl[k][0];
+        evicted[k] = xl[k];
+        h[k] = 0;
+        c[k] = 0;
+    }
+    for (;;) {
+        bool any = false;
+    #pragma unroll
+    for (int k = 0; k < K; k++) {
+            if (c[k] < lim) {
+                ptrdiff_t cc = 2 * (c[k] + 1);
+                const double r = sc[k][cc], l = sc[k][cc - 1];
+                const bool left = r > l;
+                cc -= left ? 1 : 0;
+                sc[k][h[k]] = left ? l : r;
+                sl[k][h[k]] = sl[k][cc];
+                h[k] = cc;
+                c[k] = cc;
+                any = true;
+            }
+        }
+        if (!any) break;
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        if ((len & 1) == 0 && c[k] == (len - 2) / 2) {
+            c[k] = 2 * (c[k] + 1);
+            sc[k][h[k]] = sc[k][c[k] - 1];
+            sl[k][h[k]] = sl[k][c[k] - 1];
+            h[k] = c[k] - 1;
+        }
+        ptrdiff_t hh = h[k], p = (hh - 1) / 2;
+        while (hh > 0 && sc[k][p] > vs[k]) {
+            sc[k][hh] = sc[k][p];
+            sl[k][hh] = sl[k][p];
+            hh = p;
+            p = (hh - 1) / 2;
+        }
+        sc[k][hh] = vs[k];
+        sl[k][hh] = vl[k];
+        hh = n - 1;
+        p = (hh - 1) / 2;
+        while (hh > 0 && sc[k][p] > xs[k]) {
+            sc[k][hh] = sc[k][p];
+            sl[k][hh] = sl[k][p];
+            hh = p;
+            p = (hh - 1) / 2;
+        }
+        sc[k][hh] = xs[k];
+        sl[k][hh] = xl[k];
+    }
+}
+
+template <int K>
+static void run(int T, int N, int pushes) {
+    for (int variant = 0; variant < 3; variant++) {
+        std::vector<double> ns(T);
+        std::vector<uint64_t> chk(T);
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; t++)
+            th.emplace_back([&, t]() {
+                std::mt19937_64 rng(1234 + t);
+                std::uniform_real_distribution<double> U(0.0, 1.0);
+                std::vector<std::vector<Ent>> heaps(K);
+                std::vector<std::vector<double>> hs(K);
+                std::vector<std::vector<uint32_t>> hl32(K);
+                std::vector<std::vector<uint16_t>> hl16(K);
+                std::vector<std::vector<uint64_t>> km(K), rw(K);
+                struct Greater {
+                    bool operator()(const Ent& l, const Ent& r) const { return l.score > r.score; }
+                };
+                for (int h = 0; h < K; h++) {
+                    for (int i = 0; i < N; i++) {
+                        heaps[h].push_back(Ent{U(rng), (uint32_t)i});
+                        std::push_heap(heaps[h].begin(), heaps[h].end(), Greater());
+                    }
+                    for (int i = 0; i < N; i++) {
+                        hs[h].push_back(heaps[h][i].score);
+                        hl32[h].push_back(heaps[h][i].slot);
+                        hl16[h].push_back((uint16_t)heaps[h][i].slot);
+                    }
+                    km[h].resize(N);
+                    rw[h].resize(N);
+                }
+                std::vector<double> u((size_t)pushes * K);
+                for (auto& x : u) x = U(rng);
+                auto t0 = std::chrono::steady_clock::now();
+                if (variant == 0) {
+                    Ent* a[K];
+                    for (int k = 0; k < K; k++) a[k] = heaps[k].data();
+                    for (int i = 0; i < pushes; i++) {
+                        Ent x[K];
+                        uint32_t s0[K];
+                    #pragma unroll
+    for (int k = 0; k < K; k++) {
+                            const double lo = a[k][0].score;
+                            x[k] = Ent{lo + (1.0 - lo) * u[(size_t)k * pushes + i], 0};
+                            s0[k] = a[k][0].slot;
+                        }
+                        replace_aos<K>(a, N, x);
+                    #pragma unroll
+    for (int k = 0; k < K; k++) {
+                            km[k][s0[k]] = i;
+                            rw[k][s0[k]] = i;
+                        }
+                    }
+                } else if (variant == 1) {
+                    double* sc[K];
+                    uint32_t* sl[K];
+                #pragma unroll
+    for (int k = 0; k < K; k++) {
+                        sc[k] = hs[k].data();
+                        sl[k] = hl32[k].data();
+                    }
+                    for (int i = 0; i < pushes; i++) {
+                        double xs[K];
+                        uint32_t ev[K];
+                    #pragma unroll
+    for (int k = 0; k < K; k++) {
+                            const double lo = sc[k][0];
+                            xs[k] = lo + (1.0 - lo) * u[(size_t)k * pushes + i];
+                        }
+                        replace_soa<K, uint32_t>(sc, sl, N, xs, ev);
+                    #pragma unroll
+    for (int k = 0; k < K; k++) {
+                            km[k][ev[k]] = i;
+                            rw[k][ev[k]] = i;
+                        }
+                    }
+                } else {
+                    double* sc[K];
+                    uint16_t* sl[K];
+                #pragma unroll
+    for (int k = 0; k < K; k++) {
+                        sc[k] = hs[k].data();
+                        sl[k] = hl16[k].data();
+                    }
+                    for (int i = 0; i < pushes; i++) {
+                        double xs[K];
+                        uint16_t ev[K];
+                    #pragma unroll
+    for (int k = 0; k < K; k++) {
+                            const double lo = sc[k][0];
+                            xs[k] = lo + (1.0 - lo) * u[(size_t)k * pushes + i];
+                        }
+                        replace_soa<K, uint16_t>(sc, sl, N, xs, ev);
+                    #pragma unroll
+    for (int k = 0; k < K; k++) {
+                            km[k][ev[k]] = i;
+                            rw[k][ev[k]] = i;
+                        }
+                    }
+                }
+                const double el = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count();
+                ns[t] = el / ((double)pushes * K);
+                uint64_t c = 0;
+                for (int k = 0; k < K; k++)
+                    for (int i = 0; i < N; i++) {
+                        uint64_t sbits;
+                        const double s = variant == 0 ? heaps[k][i].score : hs[k][i];
+                        const uint32_t slot = variant == 0 ? heaps[k][i].slot : variant == 1 ? hl32[k][i] : hl16[k][i];
+                        memcpy(&sbits, &s, 8);
+                        c = c * 1099511628211ull + (sbits ^ slot);
+                    }
+                chk[t] = c;
+            });
+        for (auto& x : th) x.join();
+        double mean = 0, mx = 0;
+        for (double v : ns) {
+            mean += v / T;
+            mx = std::max(mx, v);
+        }
+        printf("K=%d variant %d (%s): %.1f ns per push (slowest thread %.1f), layout checksum %016llx\n", K, variant,
+               variant == 0 ? "16-byte entries" : variant == 1 ? "f64 scores + u32 slots" : "f64 scores + u16 slots", mean, mx,
+               (unsigned long long)chk[0]);
+    }
+}
+
+int main(int argc, char** argv) {
+    const int T = argc > 1 ? atoi(argv[1]) : 16;
+    const int N = argc > 2 ? atoi(argv[2]) : 10001;
+    const int pushes = argc > 3 ? atoi(argv[3]) : 300000;
+    run<6>(T, N, pushes);
+    run<7>(T, N, pushes);
+    run<4>(T, N, pushes);
+    return 0;
+}
