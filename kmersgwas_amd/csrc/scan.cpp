@@ -371,7 +371,7 @@ inline size_t ring_size(size_t forced, uint64_t topn) {
     return (size_t)std::min<double>(std::max<double>(r, 256.0), 1048576.0);
 }
 
-constexpr int MAX_SLOTS = 16;  // upper bound on sparse chunks the GPU may run ahead of the host replay
+constexpr int MAX_SLOTS = 48;  // upper bound on sparse chunks the GPU may run ahead of the host replay
 
 // What a worker adds up while replaying (chunk, column group) units.
 struct ReplayAcc {
@@ -387,9 +387,10 @@ struct Slot {
     // coarse filter: the chunk's candidates compacted in (column, row) order - in HBM (d_so_*), and the host copy the
     // control thread orders on the copy stream once the counts are known (exactly `total` records per array);
     // h_meta: [0, P) candidates per column, [P, 2P) their offsets, [2P] total, [2P + 1] survivor keys emitted
-    PinBuf<double> so_score;
-    PinBuf<uint64_t> so_kmer;
-    PinBuf<uint32_t> so_row;
+    double* so_score = nullptr;   // host copies: a piece of the session's pinned record ring (fetch_records)
+    uint64_t* so_kmer = nullptr;
+    uint32_t* so_row = nullptr;
+    size_t ring_end = 0;          // ring offset behind this chunk's records (where the ring is free again once it is replayed)
     DevBuf<double> d_so_score;
     DevBuf<uint64_t> d_so_kmer;
     DevBuf<uint32_t> d_so_row;
@@ -481,6 +482,13 @@ struct kgwas_scan {
     DevBuf<unsigned long long> d_pat_cnt;  // how many
     uint64_t pat_upper = 0;                // host-side upper bound of that count (rows fed)
     Slot slot[MAX_SLOTS];
+    // Host copies of the coarse chunks' candidate records: ONE pinned ring, a chunk takes exactly its 20 B x candidates
+    // when its counts are known and gives them back when it is replayed (FIFO). Slots used to own worst-case buffers
+    // (cap x P records each), which capped the chunks in flight at 12 for 201 columns: with host and GPU level the GPU
+    // then idled while the host digested the ramp.
+    PinBuf<uint8_t> ring;
+    size_t ring_size = 0, ring_head = 0, ring_tail = 0;  // used: [tail, head) circularly; head == tail: empty
+    uint64_t ring_freed = 0;                              // chunks (of this feed) whose records have been given back
     Slot redo;  // coarse mode: the only slot with exact-scorer candidate records (synchronous overflow re-runs)
     int n_slots = MAX_SLOTS;  // as many as fit 1 GiB of mapped pinned candidate memory (at least 4)
     // dense mode
@@ -909,7 +917,7 @@ void replay_group(kgwas_scan* s, Slot& sl, size_t g, ReplayAcc& acc) {
             const uint32_t n = sl.h_meta.p[j];
             if (!n) continue;
             const uint64_t o = sl.h_meta.p[s->n_pheno + j];
-            cols[n_cols++] = Cur{sl.so_score.p + o, sl.so_kmer.p + o, sl.so_row.p + o, 0, n, &s->heaps[j], j};
+            cols[n_cols++] = Cur{sl.so_score + o, sl.so_kmer + o, sl.so_row + o, 0, n, &s->heaps[j], j};
         }
         // The records were just written by the GPU (no CPU cache holds them) and the replay walks several short
         // streams at once, more than the hardware prefetchers track: pull them in up front, a line at a time.
@@ -1169,21 +1177,56 @@ void wait_event(kgwas_scan* s, hipEvent_t ev) {
 
 // Coarse chunk: wait for its counts, then order the copy of exactly that many candidate records (three arrays) from
 // HBM on the copy stream; ev_done follows the copies. Other chunks recorded ev_done at submission.
-void fetch_records(kgwas_scan* s, Slot& sl) {
-    if (!sl.used_coarse) return;
+// Returns false if the record ring has no room yet (nothing was ordered: retry after more chunks are replayed).
+bool fetch_records(kgwas_scan* s, Slot& sl) {
+    if (!sl.used_coarse) return true;
     wait_event(s, sl.ev_counts);
     const uint32_t n = sl.h_meta.p[2 * s->n_pheno];
     const uint32_t n_surv = sl.h_meta.p[2 * s->n_pheno + 1];
+    const bool copy = n && n_surv <= s->key_slots;
+    {
+        // give back what the replay has finished with (chunks are replayed, hence freed, in order); before this slot's
+        // ring_end is overwritten below: its previous chunk is among them
+        const uint64_t rep = s->seq_replayed.load(std::memory_order_acquire);
+        while (s->ring_freed < rep) {
+            s->ring_tail = s->slot[(size_t)(s->ring_freed % (uint64_t)s->n_slots)].ring_end;
+            s->ring_freed++;
+        }
+        if (s->ring_tail == s->ring_head) s->ring_head = s->ring_tail = 0;  // empty: start over at the bottom
+    }
+    if (copy) {
+        const size_t need = ((size_t)n * 20 + 63) / 64 * 64;
+        size_t at;
+        if (s->ring_head >= s->ring_tail) {  // used part does not wrap (or the ring is empty)
+            if (s->ring_size - s->ring_head >= need)
+                at = s->ring_head;
+            else if (s->ring_tail > need)  // wrap: the bytes up to the end stay unused until this chunk is freed
+                at = 0;
+            else
+                return false;
+        } else {
+            if (s->ring_tail - s->ring_head > need)
+                at = s->ring_head;
+            else
+                return false;
+        }
+        sl.so_score = reinterpret_cast<double*>(s->ring.p + at);
+        sl.so_kmer = reinterpret_cast<uint64_t*>(s->ring.p + at + (size_t)n * 8);
+        sl.so_row = reinterpret_cast<uint32_t*>(s->ring.p + at + (size_t)n * 16);
+        s->ring_head = at + need;
+    }
+    sl.ring_end = s->ring_head;
     if (!s->narrow && n_surv > s->key_slots)  // the list overflowed (the chunk is redone by the exact scorer): plan the next chunks for what it saw
         s->infl_obs[sl.coarse_mode] = std::min(256.0, std::max(s->infl_obs[sl.coarse_mode], 1.25 * (double)n_surv / std::max(sl.cand_est, 1.0)));
     else if (!s->narrow && n >= 1024)
         s->infl_obs[sl.coarse_mode] = std::min(64.0, std::max(1.0, (double)n_surv / (double)n));
-    if (n && sl.h_meta.p[2 * s->n_pheno + 1] <= s->key_slots) {
-        KGWAS_HIP(hipMemcpyAsync(sl.so_score.p, sl.d_so_score.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s->copy_stream));
-        KGWAS_HIP(hipMemcpyAsync(sl.so_row.p, sl.d_so_row.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, s->copy_stream));
-        KGWAS_HIP(hipMemcpyAsync(sl.so_kmer.p, sl.d_so_kmer.p, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost, s->copy_stream));
+    if (copy) {
+        KGWAS_HIP(hipMemcpyAsync(sl.so_score, sl.d_so_score.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s->copy_stream));
+        KGWAS_HIP(hipMemcpyAsync(sl.so_row, sl.d_so_row.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, s->copy_stream));
+        KGWAS_HIP(hipMemcpyAsync(sl.so_kmer, sl.d_so_kmer.p, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost, s->copy_stream));
     }
     KGWAS_HIP(hipEventRecord(sl.ev_done, s->copy_stream));
+    return true;
 }
 
 // ---- streaming replay ----------------------------------------------------------------------------------------
@@ -1323,6 +1366,8 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
     s->seq_submitted.store(0);
     s->seq_published.store(0);
     s->seq_replayed.store(0);
+    s->ring_head = s->ring_tail = 0;
+    s->ring_freed = 0;
     for (size_t g = 0; g < s->n_groups; g++) {
         s->gstate[g].done.store(0);
         s->gstate[g].busy.store(0);
@@ -1354,9 +1399,16 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
             // chunk's copy if this chunk's counts are already there, so the copy engine never waits for this thread.
             if (cpy < sub && (cpy == pub || hipEventQuery(s->slot[(size_t)(cpy % (uint64_t)s->n_slots)].ev_counts) == hipSuccess ||
                               !s->slot[(size_t)(cpy % (uint64_t)s->n_slots)].used_coarse)) {
-                fetch_records(s, s->slot[(size_t)(cpy % (uint64_t)s->n_slots)]);
-                cpy++;
-                continue;
+                if (fetch_records(s, s->slot[(size_t)(cpy % (uint64_t)s->n_slots)])) {
+                    cpy++;
+                    continue;
+                }
+                // the record ring is full: publish what is fetched; if all of that is published, wait for the replay
+                if (pub == cpy) {
+                    wait_replayed(replayed() + 1);
+                    if (s->rp_failed.load(std::memory_order_acquire)) break;
+                    continue;
+                }
             }
             if (pub < cpy) {  // publish the oldest chunk the GPU still owes
                 Slot& sl = s->slot[(size_t)(pub % (uint64_t)s->n_slots)];
@@ -1942,16 +1994,21 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         if (!s->direct) s->d_sq.alloc(s->chunk_max * 2 * W_m);
 
         {
-            const uint64_t slot_bytes = (uint64_t)s->cap * P * (s->coarse ? 20 : sizeof(Cand));
-            s->n_slots = (int)std::min<uint64_t>(MAX_SLOTS, std::max<uint64_t>(4, (1ull << 30) / std::max<uint64_t>(slot_bytes, 1)));
+            if (s->coarse) {
+                // device side: 20 B x key_slots of HBM per slot, up to 4 GiB in all; host side: the record ring
+                const uint64_t slot_bytes = (uint64_t)s->key_slots * 20;
+                s->n_slots = (int)std::min<uint64_t>(MAX_SLOTS, std::max<uint64_t>(4, (4ull << 30) / std::max<uint64_t>(slot_bytes, 1)));
+                s->ring_size = (size_t)std::max<uint64_t>(std::min<uint64_t>(1ull << 30, (uint64_t)s->n_slots * slot_bytes), 2 * slot_bytes + 4096);
+                s->ring.alloc(s->ring_size);
+            } else {
+                const uint64_t slot_bytes = (uint64_t)s->cap * P * sizeof(Cand);
+                s->n_slots = (int)std::min<uint64_t>(16, std::max<uint64_t>(4, (1ull << 30) / std::max<uint64_t>(slot_bytes, 1)));
+            }
         }
         for (int si = 0; si < s->n_slots + (s->coarse ? 1 : 0); si++) {
             const bool is_redo = si == s->n_slots;
             Slot& sl = is_redo ? s->redo : s->slot[si];
             if (s->coarse && !is_redo) {
-                sl.so_score.alloc(s->key_slots);
-                sl.so_kmer.alloc(s->key_slots);
-                sl.so_row.alloc(s->key_slots);
                 sl.d_so_score.alloc(s->key_slots);
                 sl.d_so_kmer.alloc(s->key_slots);
                 sl.d_so_row.alloc(s->key_slots);
