@@ -140,6 +140,95 @@ __global__ void __launch_bounds__(256) thr_update_kernel(const uint32_t* hist, c
 // ------------------------------------------------------------------------------------------
 // Launchers
 // ------------------------------------------------------------------------------------------
+// ---- dense start: the heaps' minima-to-be, selected on the device ----------------------------------------------------
+// After the first dense chunk every MAC-passing row is pushed into every heap (src/best_associations_heap.cpp:43-59), so
+// a column's heap minimum afterwards is simply the topn[p]-th largest of the chunk's scores - if the chunk has that many
+// MAC-passing rows. One block per column finds it by radix select over the doubles' bit patterns (order-preserving key),
+// so the sparse chunks can start against these thresholds while the host is still pushing the dense rows.
+// info[0] = MAC-passing rows of the chunk, info[1] = 1 if any of their scores is NaN (the caller then takes the plain path).
+__global__ void __launch_bounds__(256) dense_select_kernel(const double* dense, const uint32_t* n1, uint32_t n_rows, uint32_t S,
+                                                           uint32_t min_count, const uint64_t* topn, double* thr_a, double* thr_b,
+                                                           double* thr_host_copy, uint32_t* info) {
+    __shared__ uint32_t hist[256];
+    __shared__ unsigned long long prefix_s, need_s;
+    __shared__ uint32_t kept_s, nan_s;
+    const uint32_t p = blockIdx.x, t = threadIdx.x;
+    const double* sc = dense + (size_t)p * n_rows;
+    auto pass_mac = [&](uint32_t r) {
+        const uint32_t c = n1[r];
+        return S >= min_count && c >= min_count && c <= S - min_count;
+    };
+    auto key_of = [](double v) {
+        unsigned long long b = (unsigned long long)__double_as_longlong(v);
+        return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+    };
+    if (t == 0) {
+        kept_s = 0;
+        nan_s = 0;
+    }
+    __syncthreads();
+    {
+        uint32_t k = 0, bad = 0;
+        for (uint32_t r = t; r < n_rows; r += 256u)
+            if (pass_mac(r)) {
+                k++;
+                const double v = sc[r];
+                bad |= (v != v) ? 1u : 0u;
+            }
+        atomicAdd(&kept_s, k);
+        if (bad) atomicOr(&nan_s, 1u);
+    }
+    __syncthreads();
+    const uint32_t kept = kept_s;
+    if (p == 0 && t == 0) info[0] = kept;
+    if (t == 0 && nan_s) atomicOr(&info[1], 1u);
+    const unsigned long long N = topn[p];
+    if (kept < N || nan_s) return;  // (block-uniform) not enough rows to fill this heap: the caller falls back
+    if (t == 0) {
+        prefix_s = 0;
+        need_s = N;
+    }
+    for (int byte = 7; byte >= 0; byte--) {
+        hist[t] = 0;
+        __syncthreads();
+        const unsigned long long prefix = prefix_s;
+        for (uint32_t r = t; r < n_rows; r += 256u)
+            if (pass_mac(r)) {
+                const unsigned long long k = key_of(sc[r]);
+                if (byte == 7 || (k >> (8 * (byte + 1))) == prefix) atomicAdd(&hist[(uint32_t)(k >> (8 * byte)) & 255u], 1u);
+            }
+        __syncthreads();
+        if (t == 0) {
+            unsigned long long need = need_s;
+            int b = 255;
+            for (; b > 0; b--) {
+                if (hist[b] >= need) break;
+                need -= hist[b];
+            }
+            need_s = need;
+            prefix_s = (prefix << 8) | (unsigned long long)b;
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        const unsigned long long k = prefix_s;
+        const unsigned long long b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+        const double v = __longlong_as_double((long long)b);
+        thr_a[p] = v;
+        thr_b[p] = v;
+        thr_host_copy[p] = v;
+    }
+}
+
+hipError_t launch_dense_select(const double* dense, const uint32_t* n1, uint32_t n_rows, uint32_t n_pheno, uint32_t S, uint32_t min_count,
+                               const uint64_t* topn, double* thr_a, double* thr_b, double* thr_host_copy, uint32_t* info, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(info, 0, 2 * sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(dense_select_kernel, dim3(n_pheno), dim3(256), 0, st, dense, n1, n_rows, S, min_count, topn, thr_a, thr_b,
+                       thr_host_copy, info);
+    return hipGetLastError();
+}
+
 hipError_t launch_thr_update(const uint32_t* hist, const uint32_t* hist_base, uint32_t bins, const uint64_t* topn,
                              const double* thr_host, double* thr, uint32_t n_pheno, hipStream_t st) {
     if (n_pheno == 0 || bins % 256u) return hipErrorInvalidValue;

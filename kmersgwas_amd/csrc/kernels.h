@@ -71,6 +71,12 @@ constexpr uint32_t HIST_BINS = 16384;   // 64 binades above the threshold at spa
 hipError_t launch_thr_update(const uint32_t* hist, const uint32_t* hist_base, uint32_t bins, const uint64_t* topn,
                              const double* thr_host, double* thr, uint32_t n_pheno, hipStream_t st);
 
+// Dense start: thr_a[p] = thr_b[p] = thr_host_copy[p] = the topn[p]-th largest score of column p among the chunk's
+// MAC-passing rows (dense: [n_pheno][n_rows]); info[0] = MAC-passing rows, info[1] = 1 if one of their scores is NaN.
+// Columns with fewer than topn[p] such rows are left alone.
+hipError_t launch_dense_select(const double* dense, const uint32_t* n1, uint32_t n_rows, uint32_t n_pheno, uint32_t S, uint32_t min_count,
+                               const uint64_t* topn, double* thr_a, double* thr_b, double* thr_host_copy, uint32_t* info, hipStream_t st);
+
 // Scoring kernels. rows_per_block only matters for the MFMA kernel (multiple of 128).
 hipError_t launch_score_valu(const ScoreArgs& a, hipStream_t st);
 // nb_full = leading 128-sample blocks whose four dwords all exist in the row and need no masking.

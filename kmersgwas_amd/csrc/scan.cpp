@@ -459,6 +459,12 @@ struct kgwas_scan {
         // with as few tiles as they need (201 columns at 2048 samples: 3 groups x 4 tiles + 1 tile instead of 4 x 4).
         CoarsePart part[2];
     } cmode[2];
+    // dense start overlapped with the first sparse chunks: thresholds selected on the device (launch_dense_select)
+    DevBuf<double> d_sel;
+    PinBuf<double> h_sel;
+    DevBuf<uint32_t> d_sel_info;
+    PinBuf<uint32_t> h_sel_info;
+    bool sel_valid = false;  // h_sel holds the minima the heaps will have once the pending dense rows are pushed
     double infl_obs[2] = {4.0, 1.1};  // survivors per candidate of the last finished chunk of each mode
     double mode_k = 0.09;
     uint64_t sum_topn = 0;  // over the columns
@@ -650,7 +656,8 @@ void hash_patterns(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows) {
 void upload_thresholds(kgwas_scan* s) {
     double* h = s->h_thr.p + (s->thr_flip % 8u) * s->n_pheno;  // ring: uploads may queue behind long kernels
     s->thr_flip++;
-    for (uint64_t j = 0; j < s->n_pheno; j++) h[j] = s->heaps[j].lowest();
+    // (a heap that is still filling has no bound to offer: its smallest entry so far may well exceed its final minimum)
+    for (uint64_t j = 0; j < s->n_pheno; j++) h[j] = s->heaps[j].full() ? s->heaps[j].lowest() : 0.0;
     KGWAS_HIP(hipMemcpyAsync(s->d_thr_host.p, h, s->n_pheno * sizeof(double), hipMemcpyHostToDevice, s->stream));
     if (!s->hist_ready)
         KGWAS_HIP(hipMemcpyAsync(s->d_thr.p, h, s->n_pheno * sizeof(double), hipMemcpyHostToDevice, s->stream));
@@ -659,7 +666,7 @@ void upload_thresholds(kgwas_scan* s) {
 // First sparse chunk: histogram bin 0 of every column starts at its current exact minimum.
 void start_histograms(kgwas_scan* s) {
     for (uint64_t j = 0; j < s->n_pheno; j++) {
-        const double low = s->heaps[j].lowest();
+        const double low = s->sel_valid ? s->h_sel.p[j] : s->heaps[j].lowest();
         uint64_t bits = 0;
         if (low == low && low > 0) memcpy(&bits, &low, 8);
         s->h_hist_base.p[j] = (uint32_t)(bits >> HIST_SHIFT);
@@ -677,8 +684,13 @@ void refresh_full(kgwas_scan* s) {
 }
 
 // Dense chunk: every score comes back; replay every kept row into every heap.
+void dense_fill(kgwas_scan* s, uint64_t n_rows, uint64_t first_row, std::chrono::steady_clock::time_point td0,
+                const std::function<void()>* meanwhile = nullptr);
+
+// select: also pick each column's topn-th largest score of the chunk on the device and make it the device's threshold
+// (d_thr, d_thr_host) - see feed_device_impl; h_sel / h_sel_info arrive with the scores.
 void run_dense(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, uint64_t first_row, double* out_scores,
-               uint32_t* out_n1, bool replay) {
+               uint32_t* out_n1, bool replay, bool select = false) {
     ScoreArgs a;
     auto td0 = std::chrono::steady_clock::now();
     hipEvent_t e0 = s->ev_d0, e1 = s->ev_d1, es = s->ev_ds;
@@ -693,6 +705,13 @@ void run_dense(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, uint64_t 
     KGWAS_HIP(hipEventRecord(e0, s->stream));
     launch_score(s, a);
     KGWAS_HIP(hipEventRecord(e1, s->stream));
+    if (select) {
+        KGWAS_HIP(launch_dense_select(s->d_dense.p, s->d_n1.p, (uint32_t)n_rows, (uint32_t)s->n_pheno, (uint32_t)s->S,
+                                      (uint32_t)std::min<uint64_t>(s->min_count, 0xFFFFFFFFull), s->d_topn.p, s->d_thr.p, s->d_thr_host.p,
+                                      s->d_sel.p, s->d_sel_info.p, s->stream));
+        KGWAS_HIP(hipMemcpyAsync(s->h_sel.p, s->d_sel.p, s->n_pheno * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+        KGWAS_HIP(hipMemcpyAsync(s->h_sel_info.p, s->d_sel_info.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    }
     KGWAS_HIP(hipMemcpyAsync(s->h_dense.p, s->d_dense.p, s->n_pheno * n_rows * sizeof(double), hipMemcpyDeviceToHost,
                              s->stream));
     KGWAS_HIP(hipMemcpyAsync(s->h_n1.p, s->d_n1.p, n_rows * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
@@ -708,8 +727,14 @@ void run_dense(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, uint64_t 
     s->st.chunks++;
     if (out_scores) memcpy(out_scores, s->h_dense.p, s->n_pheno * n_rows * sizeof(double));
     if (out_n1) memcpy(out_n1, s->h_n1.p, n_rows * sizeof(uint32_t));
-    if (!replay) return;
+    if (!replay || select) return;  // select: the caller pushes the rows (dense_fill) after submitting sparse chunks
+    dense_fill(s, n_rows, first_row, td0);
+}
 
+// The host half of a dense chunk: every MAC-passing row into every heap. meanwhile: run by the calling thread while the
+// pool's workers push (the control thread submits the first sparse chunks there).
+void dense_fill(kgwas_scan* s, uint64_t n_rows, uint64_t first_row, std::chrono::steady_clock::time_point td0,
+                const std::function<void()>* meanwhile) {
     auto t0 = std::chrono::steady_clock::now();
     const uint64_t S = s->S, mc = s->min_count;
     uint64_t kept = 0;
@@ -720,7 +745,7 @@ void run_dense(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, uint64_t 
     s->st.rows_tested += kept;
     s->st.candidates += kept * s->n_pheno;
     std::atomic<uint64_t> pushes(0);
-    s->pool->parallel_for(s->n_pheno, [&](size_t j) {
+    const std::function<void(size_t)> push_column = [&](size_t j) {
         BestHeap& h = s->heaps[j];
         const double* sc = s->h_dense.p + j * n_rows;
         uint64_t local = 0;
@@ -734,7 +759,10 @@ void run_dense(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, uint64_t 
         }
         if (s->record_history) _mm_sfence();  // streaming stores of the history log
         pushes += local;
-    });
+    };
+    s->pool->start(s->n_pheno, push_column);
+    if (meanwhile) (*meanwhile)();
+    s->pool->wait();
     s->st.heap_pushes += pushes.load();
     s->st.replay_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     s->rows_done += n_rows;
@@ -1378,6 +1406,41 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
                 wait_replayed(sub);  // (nothing is in flight here in practice: heaps never un-fill)
                 stop_async();
                 const uint64_t c = std::min<uint64_t>(s->dense_chunk, n_rows - pos);
+                // First dense chunk of an empty session with sparse work behind it: the device also selects each
+                // column's topn-th largest score of the chunk - the minimum its heap WILL have once these rows are
+                // pushed - and takes it as its threshold, so the first sparse chunks are submitted before the host
+                // pushes the 1.2 M (2.4 M at 201 columns) dense scores: the GPU filters while the heaps fill (2 ms of
+                // a 28 ms step at 101 columns, 8 of 126 at 250 M rows x 201).
+                static const bool no_overlap = getenv("KGWAS_NO_DENSE_OVERLAP") != nullptr;  // experiments
+                bool empty = s->coarse && !no_overlap && n_rows - pos > c && sub == 0;
+                for (uint64_t j = 0; j < s->n_pheno && empty; j++) empty = s->heaps[j].size() == 0;
+                if (empty) {
+                    const auto td0 = std::chrono::steady_clock::now();
+                    run_dense(s, d_rows + pos * stride, c, first_row + pos, nullptr, nullptr, true, /*select=*/true);
+                    const uint64_t dense_first = first_row + pos;
+                    pos += c;
+                    // every heap will be full after these rows, and no score is a NaN (the heap's order with NaNs in it is
+                    // not a total one: plain path)
+                    const bool early = s->h_sel_info.p[0] >= s->max_topn && s->h_sel_info.p[1] == 0;
+                    const std::function<void()> presubmit = [&]() {  // (the replay workers start after the fill)
+                        s->sel_valid = true;
+                        s->rows_submitted = std::max(s->rows_submitted, s->rows_done + c);
+                        while (pos < n_rows && sub < std::min<uint64_t>(depth, 12)) {  // enough GPU work for the duration of the fill
+                            const uint64_t cs = std::min<uint64_t>(next_sparse_chunk(s), n_rows - pos);
+                            const size_t si = (size_t)(sub % (uint64_t)s->n_slots);
+                            s->slot_left[si].store((uint32_t)s->n_groups, std::memory_order_release);
+                            submit_sparse(s, s->slot[si], d_rows + pos * stride, cs, first_row + pos, /*count_hist=*/true);
+                            s->rows_submitted += cs;
+                            sub++;
+                            s->seq_submitted.store(sub, std::memory_order_release);
+                            pos += cs;
+                        }
+                        s->sel_valid = false;
+                    };
+                    dense_fill(s, c, dense_first, td0, early ? &presubmit : nullptr);
+                    if (sub) start_async();  // chunks are in flight: the replay workers take over from the fill
+                    continue;
+                }
                 run_dense(s, d_rows + pos * stride, c, first_row + pos, nullptr, nullptr, true);
                 pos += c;
                 continue;
@@ -1683,6 +1746,10 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         KGWAS_HIP(hipMemset(s->d_thr.p, 0, P * sizeof(double)));  // 0 = "nothing is filtered" until the heaps say otherwise
         KGWAS_HIP(hipMemset(s->d_thr_host.p, 0, P * sizeof(double)));
         s->d_topn.alloc(P);
+        s->d_sel.alloc(P);
+        s->h_sel.alloc(P);
+        s->d_sel_info.alloc(2);
+        s->h_sel_info.alloc(2);
         KGWAS_HIP(hipMemcpy(s->d_topn.p, s->topn.data(), P * 8, hipMemcpyHostToDevice));
         KGWAS_HIP(hipMemcpy(s->d_dmask.p, dmask.data(), dmask.size() * 4, hipMemcpyHostToDevice));
         KGWAS_HIP(hipMemcpy(s->d_colmap.p, colmap.data(), colmap.size() * 4, hipMemcpyHostToDevice));
