@@ -88,8 +88,8 @@ __device__ __forceinline__ i32x4 expand_step(const uint32_t (&w)[4], int j) {
 // N1 comes out of the matrix pipe as well: the last operand column of every LDS group holds 1 for each phenotyped
 // sample (0 elsewhere), so its dot product IS the masked popcount - no masks, no popcounts, no mask loads in the
 // main loop, and bits of unphenotyped samples or row padding meet zeros in every operand column.
-template <int T, int NS>
-__global__ void __launch_bounds__(512) coarse_kernel(CoarseArgs a, uint32_t rows_per_block, uint32_t n_rowblocks, uint32_t grid_lg) {
+template <int T, int NS, int TH = 512>
+__global__ void __launch_bounds__(TH) coarse_kernel(CoarseArgs a, uint32_t rows_per_block, uint32_t n_rowblocks, uint32_t grid_lg) {
     extern __shared__ i32x4 blds[];  // [n_kgroups][8][T][64] x 16 bytes, colc[3][PG*16] (alpha, 1/u, column index), survivor buffer
     constexpr int PG = T / NS;       // column groups (of 16) per LDS group
     constexpr int RT = 4;
@@ -549,18 +549,19 @@ hipError_t launch_chunk_prep(uint32_t* cand_cnt, uint32_t n_pheno, unsigned long
 // exchange areas
 size_t coarse_lds_bytes(uint32_t n_kgroups, uint32_t T) { return (size_t)n_kgroups * 8u * T * 1024u + 1536u + 8u * 768u; }
 
-template <int T, int NS>
+template <int T, int NS, int TH = 512>
 static hipError_t launch_coarse_t(const CoarseArgs& a, uint32_t rows_per_block, uint32_t n_rowblocks, size_t lds,
                                   hipStream_t st) {
+    lds += (size_t)(TH / 64 - 8) * 768u;  // per-wave scratch of the waves beyond eight
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)coarse_kernel<T, NS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute((const void*)coarse_kernel<T, NS, TH>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds);
         if (e != hipSuccess) return e;
     }
     static const int grid_env = getenv("KGWAS_COARSE_GRIDLG") ? atoi(getenv("KGWAS_COARSE_GRIDLG")) : -1;  // experiments
     const uint32_t grid_lg = (grid_env >= 0 ? grid_env != 0 : true) && a.n_lgroups > 1 ? 1u : 0u;
     const uint32_t grid = grid_lg ? (n_rowblocks + 7u) / 8u * 8u * a.n_lgroups : n_rowblocks;
-    hipLaunchKernelGGL((coarse_kernel<T, NS>), dim3(grid), dim3(512), lds, st, a, rows_per_block, n_rowblocks, grid_lg);
+    hipLaunchKernelGGL((coarse_kernel<T, NS, TH>), dim3(grid), dim3(TH), lds, st, a, rows_per_block, n_rowblocks, grid_lg);
     return hipGetLastError();
 }
 
@@ -568,7 +569,10 @@ hipError_t launch_coarse(const CoarseArgs& a, uint32_t T, uint32_t rows_per_bloc
     if (a.n_rows == 0) return hipSuccess;
     const size_t lds = coarse_lds_bytes(a.n_kgroups, T);
     if (lds > 160u * 1024u) return hipErrorInvalidValue;
-    const uint32_t threads = 512;
+    // Few tiles per LDS group leave registers for a third wave per SIMD (T <= 4: <= 168 VGPRs at 768 threads)
+    static const int th_env = getenv("KGWAS_COARSE_TH") ? atoi(getenv("KGWAS_COARSE_TH")) : 768;  // experiments (512: eight waves as for T > 4)
+    const bool wide_block = th_env == 768 && a.n_slices == 1 && T <= 4 && lds + 4u * 768u <= 160u * 1024u;
+    const uint32_t threads = wide_block ? 768 : 512;
     if ((a.n_rows * a.src.stride_dw + a.src.off_dw + a.src.avail_dw) * 4ull >= (1ull << 32)) return hipErrorInvalidValue;  // 32-bit byte offsets
     const uint32_t rpp = (threads >> 6) * 64u;
     rows_per_block = (rows_per_block + rpp - 1) / rpp * rpp;
@@ -578,6 +582,14 @@ hipError_t launch_coarse(const CoarseArgs& a, uint32_t T, uint32_t rows_per_bloc
     if (a.n_slices == 2 && T == 8) return launch_coarse_t<8, 2>(a, rows_per_block, n_rowblocks, lds, st);
     return hipErrorInvalidValue;
 #else
+    if (wide_block) {
+        switch (T) {
+            case 1: return launch_coarse_t<1, 1, 768>(a, rows_per_block, n_rowblocks, lds, st);
+            case 2: return launch_coarse_t<2, 1, 768>(a, rows_per_block, n_rowblocks, lds, st);
+            case 3: return launch_coarse_t<3, 1, 768>(a, rows_per_block, n_rowblocks, lds, st);
+            case 4: return launch_coarse_t<4, 1, 768>(a, rows_per_block, n_rowblocks, lds, st);
+        }
+    }
     if (a.n_slices == 1) {
         switch (T) {
             case 1: return launch_coarse_t<1, 1>(a, rows_per_block, n_rowblocks, lds, st);
