@@ -215,7 +215,7 @@ class alignas(128) BestHeap {
     }
 
     // add_association for a record that is known not to beat a full heap's minimum: only the call counter moves.
-    inline void note_rejected() { inserted_++; }
+    inline void note_rejected(uint64_t n = 1) { inserted_ += n; }
 
     // output_to_file_with_scores order (:82-92): ascending pops from a copy.
     void pop_all(std::vector<uint64_t>& kmer, std::vector<double>& score, std::vector<uint64_t>& row) const {

@@ -976,20 +976,23 @@ void replay_group(kgwas_scan* s, Slot& sl, size_t g, ReplayAcc& acc) {
             for (size_t c = 0; c < n_cols;) {
                 Cur& cu = cols[c];
                 bool ready = false;
+                // (nothing touches this column's heap while its records are scanned: bound and fill state in registers)
+                const bool open = !cu.h->full();
+                const double low = cu.h->lowest();
+                uint64_t rejected = 0;
                 while (cu.i < cu.n) {
                     const double v = cu.sc[cu.i];
-                    if (v == none) {  // a survivor of the coarse bound that is not a candidate
+                    if (open || v > low) {  // (-inf, "not a candidate", never gets here: the device ships candidates only)
+                        ready = v != none;
+                        if (ready) break;
                         advance(cu);
                         continue;
                     }
-                    if (!cu.h->full() || v > cu.h->lowest()) {
-                        ready = true;
-                        break;
-                    }
-                    nc++;
-                    cu.h->note_rejected();
+                    rejected++;
                     advance(cu);
                 }
+                nc += rejected;
+                cu.h->note_rejected(rejected);
                 if (ready)
                     c++;
                 else
