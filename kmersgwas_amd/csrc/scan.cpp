@@ -2069,6 +2069,9 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                 const uint64_t slot_bytes = (uint64_t)s->key_slots * 20;
                 s->n_slots = (int)std::min<uint64_t>(MAX_SLOTS, std::max<uint64_t>(4, (4ull << 30) / std::max<uint64_t>(slot_bytes, 1)));
                 s->ring_size = (size_t)std::max<uint64_t>(std::min<uint64_t>(1ull << 30, (uint64_t)s->n_slots * slot_bytes), 2 * slot_bytes + 4096);
+                // (tests: a ring barely larger than one chunk's worst case, so that it wraps and fills up)
+                if (getenv("KGWAS_RING_BYTES"))
+                    s->ring_size = (size_t)std::max<uint64_t>(strtoull(getenv("KGWAS_RING_BYTES"), nullptr, 10), slot_bytes + 4096);
                 s->ring.alloc(s->ring_size);
             } else {
                 const uint64_t slot_bytes = (uint64_t)s->cap * P * sizeof(Cand);

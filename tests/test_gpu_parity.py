@@ -496,6 +496,31 @@ def test_adversarial_order_overflows_candidate_lists(kernel):
     scan.close()
 
 
+def test_record_ring_wraps_and_fills(monkeypatch):
+    """The host copies of the candidate records live in one pinned ring (FIFO, exact sizes). With a ring barely larger
+    than one chunk's worst case the allocations wrap around and the control thread has to wait for the replay to give
+    memory back - results must not change."""
+    S = 128
+    rows = random_table(600_000, S, seed=77)
+    col = np.arange(S, dtype=np.uint64)
+    Y = phenotypes(S, 24, seed=5)
+    mac = onp.min_count(S, 0.05, 5)
+    topn = 1500
+    exp = ob.associate(rows, S, col, Y, topn, mac)
+    monkeypatch.setenv("KGWAS_RING_BYTES", "1")  # clamped to one chunk's worst case + 4 KB
+    scan = kg.AssociationScan(S, col, Y, topn, mac, chunk_rows=32768)
+    monkeypatch.delenv("KGWAS_RING_BYTES")
+    scan.feed_host(rows[:250_000], 0)
+    scan.feed_host(rows[250_000:], 250_000)
+    scan.finish()
+    _check_topn(scan, exp, 24)
+    st = scan.stats()
+    assert st["rows_tested"] == exp["tested"]
+    # more record bytes than the ring holds went through it
+    assert st["candidates"] * 20 > (2 * topn + 4096) * 24 * 20 + 4096
+    scan.close()
+
+
 @pytest.mark.parametrize("S_f,S,reorder", [(241, 241, False), (300, 257, True), (64, 64, False), (1030, 1030, False)])
 def test_pattern_counter(S_f, S, reorder):
     """--pattern_counter: distinct hash_presence_absence_pattern values over the tested rows, with many
