@@ -19,6 +19,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <memory_resource>
 #include <vector>
 
 namespace kgwas {
@@ -38,7 +39,17 @@ class alignas(128) BestHeap {
     };
 
    public:
-    explicit BestHeap(size_t max_results) : n_res_(max_results), inserted_(0), pushes_(0), lowest_(0) {}
+    // mr: where the entry and payload arrays live (a scan session packs all its heaps into one huge-page arena - a
+    // heap walk touches 13 levels of a 160 KB array and a random 16-byte payload slot, and with 4 KB pages the dTLB
+    // misses cost 5-7 % of a push; tools/heap_soa_bench.cpp). With a resource both arrays are reserved in full up front.
+    explicit BestHeap(size_t max_results, std::pmr::memory_resource* mr = nullptr)
+        : n_res_(max_results), v_(mr ? mr : std::pmr::get_default_resource()), pay_(mr ? mr : std::pmr::get_default_resource()),
+          inserted_(0), pushes_(0), lowest_(0) {
+        if (mr) {
+            v_.reserve(max_results);
+            pay_.reserve(max_results);
+        }
+    }
 
     // add_association (src/best_associations_heap.cpp:43-59). Returns true if the heap changed.
     inline bool add(uint64_t kmer, double score, size_t row) {
@@ -219,7 +230,7 @@ class alignas(128) BestHeap {
 
     // output_to_file_with_scores order (:82-92): ascending pops from a copy.
     void pop_all(std::vector<uint64_t>& kmer, std::vector<double>& score, std::vector<uint64_t>& row) const {
-        std::vector<Ent> tmp(v_);
+        std::vector<Ent> tmp(v_.begin(), v_.end());
         const size_t n = tmp.size();
         kmer.resize(n);
         score.resize(n);
@@ -269,7 +280,7 @@ class alignas(128) BestHeap {
         Ent* a[K];
         const size_t n = hp[0]->v_.size();
         for (int k = 0; k < K; k++) {
-            tmp[k] = hp[k]->v_;
+            tmp[k].assign(hp[k]->v_.begin(), hp[k]->v_.end());
             a[k] = tmp[k].data();
             kmer[k]->resize(n);
             score[k]->resize(n);
@@ -399,8 +410,8 @@ class alignas(128) BestHeap {
         }
     }
     size_t n_res_;
-    std::vector<Ent> v_;
-    std::vector<Pay> pay_;
+    std::pmr::vector<Ent> v_;
+    std::pmr::vector<Pay> pay_;
     std::vector<Rec> ring_;
     uint64_t evicted_ = 0;
     uint64_t inserted_, pushes_;

@@ -36,6 +36,7 @@
 #include <immintrin.h>
 #include <pthread.h>
 #include <sched.h>
+#include <sys/mman.h>
 
 #include "common.h"
 #include "heap.h"
@@ -510,6 +511,13 @@ struct kgwas_scan {
     DevBuf<uint64_t> d_stage;  // kgwas_scan_scores_dense staging
     Ingest ingest;
 
+    // all heaps' arrays in one 2 MB-aligned, MADV_HUGEPAGE arena (make_heaps); declared before the heaps: destroyed after
+    struct HugeArena {
+        void* p = nullptr;
+        size_t bytes = 0;
+        ~HugeArena() { free(p); }
+    } heap_arena;
+    std::unique_ptr<std::pmr::monotonic_buffer_resource> heap_mr;
     std::vector<BestHeap> heaps;
     std::vector<History> hist;
     std::vector<uint64_t> exp_kmer, exp_row;  // scratch of kgwas_scan_history_above / kgwas_scan_heaps_export
@@ -1558,6 +1566,35 @@ void scan_patterns_peek(kgwas_scan* s, const uint64_t** d_hashes, uint64_t* n, i
     *n = c;
     *device = s->device;
 }
+// (Re)create the session's empty heaps. Their entry and payload arrays are carved out of one huge-page arena when the
+// heap sizes allow it (up to 2 GiB in all), each reserved in full; larger requests grow on the ordinary heap as before.
+void make_heaps(kgwas_scan* s) {
+    s->heaps.clear();
+    uint64_t need = 4096;
+    for (uint64_t j = 0; j < s->n_pheno; j++) need += (uint64_t)s->topn[j] * 32 + 512;
+    std::pmr::memory_resource* mr = nullptr;
+    static const bool no_huge = getenv("KGWAS_NO_HUGE_HEAPS") != nullptr;  // experiments
+    if (need <= (2ull << 30) && !no_huge) {
+        const size_t bytes = (size_t)((need + (2u << 20) - 1) / (2u << 20) * (2u << 20));
+        if (!s->heap_arena.p) {
+            s->heap_arena.p = aligned_alloc(2u << 20, bytes);
+            if (s->heap_arena.p) {
+                s->heap_arena.bytes = bytes;
+                (void)madvise(s->heap_arena.p, bytes, MADV_HUGEPAGE);
+            }
+        }
+        if (s->heap_arena.p) {
+            s->heap_mr.reset(new std::pmr::monotonic_buffer_resource(s->heap_arena.p, s->heap_arena.bytes, std::pmr::new_delete_resource()));
+            mr = s->heap_mr.get();
+        }
+    }
+    s->heaps.reserve(s->n_pheno);
+    for (uint64_t j = 0; j < s->n_pheno; j++) {
+        s->heaps.emplace_back((size_t)s->topn[j], mr);
+        if (s->history_ring) s->heaps.back().enable_ring(ring_size(s->history_ring, s->topn[j]));
+    }
+}
+
 }  // namespace kgwas
 
 extern "C" {
@@ -2112,10 +2149,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         s->h_kmer.alloc(s->dense_rows);
         s->d_tested_dense.alloc(TESTED_SHARDS);
 
-        for (uint64_t j = 0; j < P; j++) {
-            s->heaps.emplace_back((size_t)s->topn[j]);
-            if (s->history_ring) s->heaps.back().enable_ring(ring_size(s->history_ring, s->topn[j]));
-        }
+        make_heaps(s.get());
         s->hist.resize(P);
         s->keys.resize(P);
         s->col_ms.assign(P, 0.0);
@@ -2463,11 +2497,7 @@ int kgwas_scan_reset(kgwas_scan* s) {
         if (!s) throw Error(KGWAS_ERR_ARG, "kgwas_scan_reset: null");
         KGWAS_HIP(hipSetDevice(s->device));
         KGWAS_HIP(hipStreamSynchronize(s->stream));
-        s->heaps.clear();
-        for (uint64_t j = 0; j < s->n_pheno; j++) {
-            s->heaps.emplace_back((size_t)s->topn[j]);
-            if (s->history_ring) s->heaps.back().enable_ring(ring_size(s->history_ring, s->topn[j]));
-        }
+        make_heaps(s);
         for (auto& h : s->hist) h.clear();
         s->all_full = false;
         s->hist_ready = false;
