@@ -130,11 +130,20 @@ def test_min_count_matches_the_reference_rule():
 
 @pytest.mark.parametrize("N,n,levels", [(1, 60, 3), (2, 100, 3), (3, 200, 2), (10, 500, 4), (64, 4000, 9), (200, 150, 5), (33, 3000, 2),
                                         (1000, 30000, 40), (1001, 30000, 2000)])
-def test_heap_mirror_equals_oracle_heap_under_ties(N, n, levels):
+@pytest.mark.parametrize("flavour", ["nan", "plain", "negative"])
+def test_heap_mirror_equals_oracle_heap_under_ties(N, n, levels, flavour):
+    """(plain: scores in +0 .. +inf, the heap compares their bit patterns as integers; nan / negative: it must notice
+    and compare as doubles)"""
     rng = np.random.default_rng(N * 31 + n)
     k = np.arange(n, dtype=np.uint64) + 7
     s = rng.integers(0, levels, size=n).astype(np.float64) / 8.0
-    s[rng.random(n) < 0.01] = np.nan
+    if flavour == "nan":
+        s[rng.random(n) < 0.01] = np.nan
+    elif flavour == "negative":
+        s -= 0.25
+        s[rng.random(n) < 0.05] = -0.0
+    else:
+        s[rng.random(n) < 0.01] = np.inf
     r = np.arange(n, dtype=np.uint64) * 3
     h = kg.BestAssociationsHeap(N)
     h.add_associations(k[: n // 2], s[: n // 2], r[: n // 2])

@@ -71,6 +71,64 @@ static inline void replace_aos(Ent* const* a, ptrdiff_t n, Ent* x) {
     }
 }
 
+// the same moves with the scores compared as int64 bit patterns (valid for non-negative, non-NaN doubles: IEEE order
+// is integer order there): integer loads and compares have 4 + 1 cycles of latency where ucomisd from memory has 7 + 3
+struct EntI {
+    int64_t key;
+    uint32_t slot;
+};
+template <int K>
+static inline void replace_aos_int(EntI* const* a, ptrdiff_t n, EntI* x) {
+    EntI v[K];
+    ptrdiff_t h[K], c[K];
+    const ptrdiff_t len = n - 1, lim = (len - 1) / 2;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        v[k] = a[k][n - 1];
+        x[k].slot = a[k][0].slot;
+        h[k] = 0;
+        c[k] = 0;
+    }
+    for (;;) {
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if (c[k] < lim) {
+                ptrdiff_t cc = 2 * (c[k] + 1);
+                cc -= (a[k][cc].key > a[k][cc - 1].key) ? 1 : 0;
+                a[k][h[k]] = a[k][cc];
+                h[k] = cc;
+                c[k] = cc;
+                any = true;
+            }
+        }
+        if (!any) break;
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        if ((len & 1) == 0 && c[k] == (len - 2) / 2) {
+            c[k] = 2 * (c[k] + 1);
+            a[k][h[k]] = a[k][c[k] - 1];
+            h[k] = c[k] - 1;
+        }
+        ptrdiff_t hh = h[k], p = (hh - 1) / 2;
+        while (hh > 0 && a[k][p].key > v[k].key) {
+            a[k][hh] = a[k][p];
+            hh = p;
+            p = (hh - 1) / 2;
+        }
+        a[k][hh] = v[k];
+        hh = n - 1;
+        p = (hh - 1) / 2;
+        while (hh > 0 && a[k][p].key > x[k].key) {
+            a[k][hh] = a[k][p];
+            hh = p;
+            p = (hh - 1) / 2;
+        }
+        a[k][hh] = x[k];
+    }
+}
+
 template <int K, typename SlotT>
 static inline void replace_soa(double* const* sc, SlotT* const* sl, ptrdiff_t n, const double* xs, SlotT* evicted) {
     double vs[K];
@@ -136,7 +194,7 @@ static inline void replace_soa(double* const* sc, SlotT* const* sl, ptrdiff_t n,
 
 template <int K>
 static void run(int T, int N, int pushes) {
-    for (int variant = 0; variant < 4; variant++) {
+    for (int variant = 0; variant < 5; variant++) {
         std::vector<double> ns(T);
         std::vector<uint64_t> chk(T);
         std::vector<std::thread> th;
@@ -211,6 +269,26 @@ static void run(int T, int N, int pushes) {
                     }
                     if (variant == 3)
                         for (int k = 0; k < K; k++) memcpy(heaps[k].data(), a[k], (size_t)N * sizeof(Ent));
+                } else if (variant == 4) {
+                    EntI* a[K];
+                    for (int k = 0; k < K; k++) a[k] = reinterpret_cast<EntI*>(heaps[k].data());
+                    for (int i = 0; i < pushes; i++) {
+                        EntI x[K];
+                        uint32_t s0[K];
+                        for (int k = 0; k < K; k++) {
+                            double lo;
+                            memcpy(&lo, &a[k][0].key, 8);
+                            const double xv = lo + (1.0 - lo) * u[(size_t)k * pushes + i];
+                            memcpy(&x[k].key, &xv, 8);
+                            x[k].slot = 0;
+                            s0[k] = a[k][0].slot;
+                        }
+                        replace_aos_int<K>(a, N, x);
+                        for (int k = 0; k < K; k++) {
+                            km[k][s0[k]] = i;
+                            rw[k][s0[k]] = i;
+                        }
+                    }
                 } else if (variant == 1) {
                     double* sc[K];
                     uint32_t* sl[K];
@@ -264,8 +342,8 @@ static void run(int T, int N, int pushes) {
                 for (int k = 0; k < K; k++)
                     for (int i = 0; i < N; i++) {
                         uint64_t sbits;
-                        const double s = (variant == 0 || variant == 3) ? heaps[k][i].score : hs[k][i];
-                        const uint32_t slot = (variant == 0 || variant == 3) ? heaps[k][i].slot : variant == 1 ? hl32[k][i] : hl16[k][i];
+                        const double s = (variant == 0 || variant >= 3) ? heaps[k][i].score : hs[k][i];
+                        const uint32_t slot = (variant == 0 || variant >= 3) ? heaps[k][i].slot : variant == 1 ? hl32[k][i] : hl16[k][i];
                         memcpy(&sbits, &s, 8);
                         c = c * 1099511628211ull + (sbits ^ slot);
                     }
@@ -278,7 +356,7 @@ static void run(int T, int N, int pushes) {
             mx = std::max(mx, v);
         }
         printf("K=%d variant %d (%s): %.1f ns per push (slowest thread %.1f), layout checksum %016llx\n", K, variant,
-               variant == 0 ? "16-byte entries" : variant == 1 ? "f64 scores + u32 slots" : variant == 2 ? "f64 scores + u16 slots" : "16-byte entries, huge pages", mean, mx,
+               variant == 0 ? "16-byte entries" : variant == 1 ? "f64 scores + u32 slots" : variant == 2 ? "f64 scores + u16 slots" : variant == 3 ? "16-byte entries, huge pages" : "16-byte entries, integer compares", mean, mx,
                (unsigned long long)chk[0]);
     }
 }
@@ -289,5 +367,6 @@ int main(int argc, char** argv) {
     const int pushes = argc > 3 ? atoi(argv[3]) : 300000;
     run<7>(T, N, pushes);
     run<6>(T, N, pushes);
+    run<1>(T, N, pushes);
     return 0;
 }
