@@ -129,6 +129,122 @@ static inline void replace_aos_int(EntI* const* a, ptrdiff_t n, EntI* x) {
     }
 }
 
+// integer compares + both climbs in lockstep, branch-free per heap (one loop-exit misprediction per round, not per heap)
+template <int K>
+static inline void replace_aos_int2(EntI* const* a, ptrdiff_t n, EntI* x) {
+    EntI v[K];
+    ptrdiff_t h[K], c[K];
+    const ptrdiff_t len = n - 1, lim = (len - 1) / 2;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        v[k] = a[k][n - 1];
+        x[k].slot = a[k][0].slot;
+        h[k] = 0;
+        c[k] = 0;
+    }
+    for (;;) {
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if (c[k] < lim) {
+                ptrdiff_t cc = 2 * (c[k] + 1);
+                cc -= (a[k][cc].key > a[k][cc - 1].key) ? 1 : 0;
+                a[k][h[k]] = a[k][cc];
+                h[k] = cc;
+                c[k] = cc;
+                any = true;
+            }
+        }
+        if (!any) break;
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        if ((len & 1) == 0 && c[k] == (len - 2) / 2) {
+            c[k] = 2 * (c[k] + 1);
+            a[k][h[k]] = a[k][c[k] - 1];
+            h[k] = c[k] - 1;
+        }
+    }
+    for (int phase = 0; phase < 2; phase++) {
+        ptrdiff_t hh[K];
+        EntI val[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            hh[k] = phase == 0 ? h[k] : n - 1;
+            val[k] = phase == 0 ? v[k] : x[k];
+        }
+        for (;;) {
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const ptrdiff_t p = hh[k] > 0 ? (hh[k] - 1) / 2 : 0;
+                const bool go = (hh[k] > 0) & (a[k][p].key > val[k].key);
+                const EntI src = go ? a[k][p] : val[k];
+                a[k][hh[k]] = src;  // (the final position gets the value itself, again and again once the heap is done)
+                hh[k] = go ? p : hh[k];
+                any |= go;
+            }
+            if (!any) break;
+        }
+    }
+}
+
+// integer compares; the hole walk without its per-level bounds test: every path has at least `sure` levels (all indices
+// of depth d are below lim while 2^(d+1) - 2 < lim), only the last one or two are conditional; hole = the previous child
+template <int K>
+static inline void replace_aos_int3(EntI* const* a, ptrdiff_t n, EntI* x) {
+    EntI v[K];
+    ptrdiff_t c[K];
+    const ptrdiff_t len = n - 1, lim = (len - 1) / 2;
+    int sure = 0;
+    while ((((ptrdiff_t)2) << sure) - 2 < lim) sure++;  // depths 0 .. sure - 1 are below lim whatever the path
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        v[k] = a[k][n - 1];
+        x[k].slot = a[k][0].slot;
+        c[k] = 0;
+    }
+    for (int lvl = 0; lvl < sure; lvl++) {
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            ptrdiff_t cc = 2 * (c[k] + 1);
+            cc -= (a[k][cc].key > a[k][cc - 1].key) ? 1 : 0;
+            a[k][c[k]] = a[k][cc];
+            c[k] = cc;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        while (c[k] < lim) {
+            ptrdiff_t cc = 2 * (c[k] + 1);
+            cc -= (a[k][cc].key > a[k][cc - 1].key) ? 1 : 0;
+            a[k][c[k]] = a[k][cc];
+            c[k] = cc;
+        }
+        ptrdiff_t hh = c[k];
+        if ((len & 1) == 0 && c[k] == (len - 2) / 2) {
+            const ptrdiff_t c2 = 2 * (c[k] + 1);
+            a[k][hh] = a[k][c2 - 1];
+            hh = c2 - 1;
+        }
+        ptrdiff_t p = (hh - 1) / 2;
+        while (hh > 0 && a[k][p].key > v[k].key) {
+            a[k][hh] = a[k][p];
+            hh = p;
+            p = (hh - 1) / 2;
+        }
+        a[k][hh] = v[k];
+        hh = n - 1;
+        p = (hh - 1) / 2;
+        while (hh > 0 && a[k][p].key > x[k].key) {
+            a[k][hh] = a[k][p];
+            hh = p;
+            p = (hh - 1) / 2;
+        }
+        a[k][hh] = x[k];
+    }
+}
+
 template <int K, typename SlotT>
 static inline void replace_soa(double* const* sc, SlotT* const* sl, ptrdiff_t n, const double* xs, SlotT* evicted) {
     double vs[K];
@@ -194,7 +310,7 @@ static inline void replace_soa(double* const* sc, SlotT* const* sl, ptrdiff_t n,
 
 template <int K>
 static void run(int T, int N, int pushes) {
-    for (int variant = 0; variant < 5; variant++) {
+    for (int variant = 0; variant < 7; variant++) {
         std::vector<double> ns(T);
         std::vector<uint64_t> chk(T);
         std::vector<std::thread> th;
@@ -269,7 +385,7 @@ static void run(int T, int N, int pushes) {
                     }
                     if (variant == 3)
                         for (int k = 0; k < K; k++) memcpy(heaps[k].data(), a[k], (size_t)N * sizeof(Ent));
-                } else if (variant == 4) {
+                } else if (variant >= 4) {
                     EntI* a[K];
                     for (int k = 0; k < K; k++) a[k] = reinterpret_cast<EntI*>(heaps[k].data());
                     for (int i = 0; i < pushes; i++) {
@@ -283,7 +399,7 @@ static void run(int T, int N, int pushes) {
                             x[k].slot = 0;
                             s0[k] = a[k][0].slot;
                         }
-                        replace_aos_int<K>(a, N, x);
+                        if (variant == 4) replace_aos_int<K>(a, N, x); else if (variant == 5) replace_aos_int2<K>(a, N, x); else replace_aos_int3<K>(a, N, x);
                         for (int k = 0; k < K; k++) {
                             km[k][s0[k]] = i;
                             rw[k][s0[k]] = i;
@@ -356,7 +472,7 @@ static void run(int T, int N, int pushes) {
             mx = std::max(mx, v);
         }
         printf("K=%d variant %d (%s): %.1f ns per push (slowest thread %.1f), layout checksum %016llx\n", K, variant,
-               variant == 0 ? "16-byte entries" : variant == 1 ? "f64 scores + u32 slots" : variant == 2 ? "f64 scores + u16 slots" : variant == 3 ? "16-byte entries, huge pages" : "16-byte entries, integer compares", mean, mx,
+               variant == 0 ? "16-byte entries" : variant == 1 ? "f64 scores + u32 slots" : variant == 2 ? "f64 scores + u16 slots" : variant == 3 ? "16-byte entries, huge pages" : variant == 4 ? "16-byte entries, integer compares" : variant == 5 ? "integer compares, lockstep branch-free climbs" : "integer compares, unconditional levels", mean, mx,
                (unsigned long long)chk[0]);
     }
 }
