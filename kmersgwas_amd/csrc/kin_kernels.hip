@@ -125,28 +125,33 @@ __device__ __forceinline__ uint32_t transpose32(uint32_t x, uint32_t lane) {
 // plane words (76 KB of LDS at 1135 samples: two blocks per CU, so one's loads overlap the other's transposes); where
 // 256 verbatim rows plus their planes do not fit the LDS (more than ~2500 accessions) a block takes 128 or 64 rows,
 // i.e. 4 or 2 of a tile's 8 plane words (launch_kin_transpose).
-__global__ void __launch_bounds__(256) kin_transpose_kernel(const uint64_t* file_rows, uint64_t file_stride_w, uint64_t n_rows,
+// Two threads per row (blockDim.x = 2 x rows per block): thread (row, half h) counts and transposes half of the row's
+// dwords, so a block's phases - copy in, count, transpose, copy out - run on twice the waves for the same LDS footprint
+// (the footprint, not the registers, is what limits a CU to two of these blocks).
+__global__ void __launch_bounds__(1024) kin_transpose_kernel(const uint64_t* file_rows, uint64_t file_stride_w, uint64_t n_rows,
                                                             uint32_t S_f, uint32_t S_pad, uint32_t min_count, uint32_t* T,
-                                                            uint64_t n_rw, unsigned long long* n_used) {
+                                                            uint64_t n_rw, unsigned long long* n_used, uint32_t rpb) {
     extern __shared__ uint32_t kin_lds[];
-    const uint32_t rpb = blockDim.x;     // rows per block: 256, 128 or 64
-    const uint32_t wpb = rpb / 32u;      // plane words per block and sample
+    const uint32_t tpr = blockDim.x / rpb;  // threads per row (rows per block: 256, 128 or 64)
+    const uint32_t wpb = rpb / 32u;        // plane words per block and sample
     const uint32_t stride_dw = (uint32_t)(2u * file_stride_w);
     uint32_t* lin = kin_lds;                        // [rpb][stride_dw] verbatim rows (k-mer word included)
     uint32_t* lout = kin_lds + rpb * stride_dw;     // [S_pad][wpb]
+    uint32_t* pn = lout + S_pad * wpb;              // [tpr][rpb] partial popcounts of the parts of a row
     const uint32_t in_dw = 2u * ((S_f + 63u) / 64u);
     const uint64_t row0 = (uint64_t)blockIdx.x * rpb;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t rr = threadIdx.x % rpb, half = threadIdx.x / rpb;
+    const uint32_t lane = threadIdx.x & 63u, wave = rr >> 6;  // wave: of the row set
     if (row0 < n_rows) {  // coalesced verbatim copy of up to rpb contiguous rows
         const uint64_t left = n_rows - row0;
         const uint32_t n2 = (uint32_t)((left < rpb ? left : rpb) * file_stride_w);
         const uint2* src = reinterpret_cast<const uint2*>(file_rows + row0 * file_stride_w);
         uint2* dst = reinterpret_cast<uint2*>(lin);
-        for (uint32_t i = threadIdx.x; i < n2; i += rpb) dst[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < n2; i += blockDim.x) dst[i] = src[i];
     }
     __syncthreads();
-    const uint64_t r = row0 + threadIdx.x;
-    const uint32_t* my = lin + (size_t)threadIdx.x * stride_dw + 2u;
+    const uint64_t r = row0 + rr;
+    const uint32_t* my = lin + (size_t)rr * stride_dw + 2u;
     // file padding bits (>= S_f) count neither in the predicate nor in the planes: calculate_unsqueezed_popcnt masks
     // with m_map_mask (src/kmers_multiple_databases.cpp:149-154)
     auto masked = [&](uint32_t d) {
@@ -154,13 +159,21 @@ __global__ void __launch_bounds__(256) kin_transpose_kernel(const uint64_t* file
         if (32u * d + 32u > S_f) x &= (32u * d < S_f) ? ((1u << (S_f - 32u * d)) - 1u) : 0u;
         return x;
     };
+    const uint32_t n_d = S_pad / 32u, d_half = (n_d + tpr - 1u) / tpr;
+    const uint32_t d0 = half * d_half < n_d ? half * d_half : n_d, d1 = (d0 + d_half < n_d) ? d0 + d_half : n_d;
+    {
+        uint32_t c = 0;
+        if (r < n_rows)
+            for (uint32_t d = d0; d < d1 && d < in_dw; d++) c += __popc(masked(d));
+        pn[half * rpb + rr] = c;
+    }
+    __syncthreads();
     uint32_t n1 = 0;
-    if (r < n_rows)
-        for (uint32_t d = 0; d < in_dw; d++) n1 += __popc(masked(d));
+    for (uint32_t q = 0; q < tpr; q++) n1 += pn[q * rpb + rr];
     // src/emma_kinship_kmers.cpp:83,89 -> load_kmers' predicate with all S_f columns
     const bool pass = (r < n_rows) && (S_f >= min_count) && (n1 >= min_count) && (n1 <= S_f - min_count);
-    const unsigned long long kept = __popcll(__ballot(pass));
-    for (uint32_t d = 0; d < S_pad / 32u; d++) {
+    const unsigned long long kept = half == 0u ? __popcll(__ballot(pass)) : 0ull;  // (half is wave-uniform: rpb >= 64)
+    for (uint32_t d = d0; d < d1; d++) {
         uint32_t x = (pass && d < in_dw) ? masked(d) : 0u;
         x = transpose32(x, lane);
         // lane s of 32-lane group g now holds sample 32d + s over the group's 32 rows
@@ -174,13 +187,13 @@ __global__ void __launch_bounds__(256) kin_transpose_kernel(const uint64_t* file
         // this block's 256 rows of all samples are one contiguous 32*S_pad-byte piece; the Gram kernel's round (16
         // plane words of 128 samples) is two 4 KB pieces
         uint32_t* dst = T + (uint64_t)blockIdx.x * S_pad * 8u;
-        for (uint32_t e = threadIdx.x; e < S_pad * 8u; e += 256u) dst[e] = lout[(e & ~7u) + ((e & 7u) ^ ((e >> 6) & 7u))];
+        for (uint32_t e = threadIdx.x; e < S_pad * 8u; e += blockDim.x) dst[e] = lout[(e & ~7u) + ((e & 7u) ^ ((e >> 6) & 7u))];
     } else {
         const uint32_t per_tile = 256u / rpb;  // blocks per tile of 8 plane words
         const uint64_t tile = blockIdx.x / per_tile;
         const uint32_t w0 = (blockIdx.x % per_tile) * wpb;
         uint32_t* dst = T + tile * S_pad * 8u + w0;  // sample c: dst[c * 8 + i], i < wpb
-        for (uint32_t e = threadIdx.x; e < S_pad * wpb; e += rpb) dst[(e / wpb) * 8u + (e % wpb)] = lout[e];
+        for (uint32_t e = threadIdx.x; e < S_pad * wpb; e += blockDim.x) dst[(e / wpb) * 8u + (e % wpb)] = lout[e];
     }
 }
 
@@ -338,7 +351,7 @@ __global__ void __launch_bounds__(256) kin_reduce_kernel(const kin_f32x4* part, 
 }
 
 size_t kin_transpose_lds_bytes(uint64_t file_stride_w, uint32_t S_pad, uint32_t rpb) {
-    return ((size_t)rpb * 2u * file_stride_w + (size_t)S_pad * (rpb / 32u)) * 4u;
+    return ((size_t)rpb * 2u * file_stride_w + (size_t)S_pad * (rpb / 32u) + 4u * rpb) * 4u;
 }
 
 // Rows per transpose block: the most (256, 128, 64) whose verbatim rows + planes fit the 160 KB of LDS; 0 = none does.
@@ -361,9 +374,11 @@ hipError_t launch_kin_transpose(const uint64_t* file_rows, uint64_t file_stride_
         hipError_t e = hipFuncSetAttribute((const void*)kin_transpose_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
+    static const uint32_t tpr_env = getenv("KGWAS_KIN_TPR") ? (uint32_t)atoi(getenv("KGWAS_KIN_TPR")) : 0u;  // experiments
+    const uint32_t tpr = tpr_env ? tpr_env : 4u;  // threads per row (1: 3.55 ms per 8 M rows x 1135, 2: 3.16, 4: 3.11)
     // every word of T up to n_rw is written (blocks beyond the rows write zeros): n_rw / 8 tiles x 256 / rpb blocks
-    hipLaunchKernelGGL(kin_transpose_kernel, dim3((uint32_t)(n_rw / 8u * (256u / rpb))), dim3(rpb), lds, st, file_rows,
-                       file_stride_w, n_rows, S_f, S_pad, min_count, T, n_rw, n_used);
+    hipLaunchKernelGGL(kin_transpose_kernel, dim3((uint32_t)(n_rw / 8u * (256u / rpb))), dim3(tpr * rpb), lds, st, file_rows,
+                       file_stride_w, n_rows, S_f, S_pad, min_count, T, n_rw, n_used, rpb);
     return hipGetLastError();
 }
 
