@@ -38,6 +38,9 @@ class alignas(128) BestHeap {
     struct Greater {
         inline bool operator()(const Ent& l, const Ent& r) const { return l.score > r.score; }
     };
+    struct GreaterInt {
+        inline bool operator()(const Ent& l, const Ent& r) const { return gt<true>(l, r); }
+    };
     // l.score > r.score. INT: on the doubles' bit patterns as int64 - the same answer for non-negative, non-NaN
     // scores (IEEE order is integer order there; ints_ok_ tracks that every score ever inserted was one), and the
     // compare a hole walk's next address waits for costs an integer load + cmp (4 + 1 cycles) instead of a load into
@@ -80,7 +83,10 @@ class alignas(128) BestHeap {
             const uint32_t slot = (uint32_t)v_.size();
             pay_.push_back(Pay{kmer, (uint64_t)row});
             v_.push_back(Ent{score, slot});
-            std::push_heap(v_.begin(), v_.end(), Greater());
+            if (ints_ok_)
+                std::push_heap(v_.begin(), v_.end(), GreaterInt());  // (same answers, hence the same moves)
+            else
+                std::push_heap(v_.begin(), v_.end(), Greater());
             pushes_++;
             lowest_ = v_.front().score;
             return true;

@@ -110,6 +110,7 @@ class Pool {
         fn_ = nullptr;
     }
     size_t size() const { return th_.size(); }
+    bool finished() const { return done_.load(std::memory_order_acquire) != 0; }  // every worker is through the started items
 
    private:
     // Own items first, in increasing order; then take whatever nobody has started yet, from the far end
@@ -773,6 +774,10 @@ void dense_fill(kgwas_scan* s, uint64_t n_rows, uint64_t first_row, std::chrono:
     s->pool->wait();
     s->st.heap_pushes += pushes.load();
     s->st.replay_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (s->trace)
+        fprintf(stderr, "[kgwas] dense chunk rows=%llu: device part %.3f ms, host fill %.3f ms\n", (unsigned long long)n_rows,
+                std::chrono::duration<double, std::milli>(t0 - td0).count(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     s->rows_done += n_rows;
     s->rows_submitted = std::max(s->rows_submitted, s->rows_done);
     refresh_full(s);
@@ -1436,7 +1441,9 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
                     const std::function<void()> presubmit = [&]() {  // (the replay workers start after the fill)
                         s->sel_valid = true;
                         s->rows_submitted = std::max(s->rows_submitted, s->rows_done + c);
-                        while (pos < n_rows && sub < std::min<uint64_t>(depth, 12)) {  // enough GPU work for the duration of the fill
+                        // GPU work for the duration of the fill: at least two chunks, more only while the workers are
+                        // still pushing (a submission costs this thread 0.1-0.2 ms; the replay starts when both are done)
+                        while (pos < n_rows && sub < std::min<uint64_t>(depth, 12) && (sub < 2 || !s->pool->finished())) {
                             const uint64_t cs = std::min<uint64_t>(next_sparse_chunk(s), n_rows - pos);
                             const size_t si = (size_t)(sub % (uint64_t)s->n_slots);
                             s->slot_left[si].store((uint32_t)s->n_groups, std::memory_order_release);
@@ -1456,8 +1463,12 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
                 pos += c;
                 continue;
             }
-            // submit while slots are free
-            while (pos < n_rows && sub - replayed() < depth) {
+            // Submit ONE chunk per turn of this loop while slots are free, then look (without blocking) for counts that
+            // have arrived and copies that have landed: a submission costs this thread 0.1-0.2 ms, and submitting every
+            // free slot's chunk first - 24 of them at 100 M rows - kept the first chunk's records from the replay for
+            // 2-3 ms after the GPU had delivered them. The blocking waits below are only taken when nothing can be
+            // submitted.
+            if (pos < n_rows && sub - replayed() < depth) {
                 start_async();
                 const uint64_t c = std::min<uint64_t>(next_sparse_chunk(s), n_rows - pos);
                 const size_t si = (size_t)(sub % (uint64_t)s->n_slots);  // its previous chunk was replayed n_slots chunks ago
@@ -1471,7 +1482,8 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
             // Coarse chunks hand their records over in two steps: counts first (compute stream), then exactly that many
             // records on the copy stream, ordered here as soon as the counts are in - before waiting for an older
             // chunk's copy if this chunk's counts are already there, so the copy engine never waits for this thread.
-            if (cpy < sub && (cpy == pub || hipEventQuery(s->slot[(size_t)(cpy % (uint64_t)s->n_slots)].ev_counts) == hipSuccess ||
+            const bool can_submit = pos < n_rows && sub - replayed() < depth;
+            if (cpy < sub && ((cpy == pub && !can_submit) || hipEventQuery(s->slot[(size_t)(cpy % (uint64_t)s->n_slots)].ev_counts) == hipSuccess ||
                               !s->slot[(size_t)(cpy % (uint64_t)s->n_slots)].used_coarse)) {
                 if (fetch_records(s, s->slot[(size_t)(cpy % (uint64_t)s->n_slots)])) {
                     cpy++;
@@ -1484,7 +1496,8 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
                     continue;
                 }
             }
-            if (pub < cpy) {  // publish the oldest chunk the GPU still owes
+            if (pub < cpy && (!can_submit || hipEventQuery(s->slot[(size_t)(pub % (uint64_t)s->n_slots)].ev_done) == hipSuccess)) {
+                // publish the oldest chunk the GPU still owes
                 Slot& sl = s->slot[(size_t)(pub % (uint64_t)s->n_slots)];
                 wait_event(s, sl.ev_done);  // records and counts are in host memory
                 if (chunk_complete(s, sl)) {
@@ -1513,6 +1526,7 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
                 }
                 continue;
             }
+            if (can_submit) continue;
             if (pos < n_rows) {  // every slot holds a chunk that is still being replayed
                 wait_replayed(replayed() + 1);
                 if (s->rp_failed.load(std::memory_order_acquire)) break;
