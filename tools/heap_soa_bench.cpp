@@ -245,6 +245,62 @@ static inline void replace_aos_int3(EntI* const* a, ptrdiff_t n, EntI* x) {
     }
 }
 
+// integer compares, top-down: the hole stops where the old last leaf v belongs (first path node with key > v) instead of
+// walking to a leaf and climbing back - the same final array (the path's keys never decrease downwards, so "climb while
+// parent > v" ends exactly there)
+template <int K>
+static inline void replace_aos_int4(EntI* const* a, ptrdiff_t n, EntI* x) {
+    EntI v[K];
+    ptrdiff_t c[K];
+    bool act[K];
+    const ptrdiff_t len = n - 1, lim = (len - 1) / 2;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        v[k] = a[k][n - 1];
+        x[k].slot = a[k][0].slot;
+        c[k] = 0;
+        act[k] = true;
+    }
+    for (;;) {
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if (act[k] && c[k] < lim) {
+                ptrdiff_t cc = 2 * (c[k] + 1);
+                cc -= (a[k][cc].key > a[k][cc - 1].key) ? 1 : 0;
+                if (a[k][cc].key > v[k].key) {
+                    act[k] = false;  // v belongs at c[k]
+                } else {
+                    a[k][c[k]] = a[k][cc];
+                    c[k] = cc;
+                    any = true;
+                }
+            }
+        }
+        if (!any) break;
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        ptrdiff_t hh = c[k];
+        if (act[k] && (len & 1) == 0 && c[k] == (len - 2) / 2) {  // the last inner node has a single (left) child
+            const ptrdiff_t c2 = 2 * (c[k] + 1);
+            if (!(a[k][c2 - 1].key > v[k].key)) {
+                a[k][hh] = a[k][c2 - 1];
+                hh = c2 - 1;
+            }
+        }
+        a[k][hh] = v[k];
+        hh = n - 1;
+        ptrdiff_t p = (hh - 1) / 2;
+        while (hh > 0 && a[k][p].key > x[k].key) {
+            a[k][hh] = a[k][p];
+            hh = p;
+            p = (hh - 1) / 2;
+        }
+        a[k][hh] = x[k];
+    }
+}
+
 template <int K, typename SlotT>
 static inline void replace_soa(double* const* sc, SlotT* const* sl, ptrdiff_t n, const double* xs, SlotT* evicted) {
     double vs[K];
@@ -310,7 +366,7 @@ static inline void replace_soa(double* const* sc, SlotT* const* sl, ptrdiff_t n,
 
 template <int K>
 static void run(int T, int N, int pushes) {
-    for (int variant = 0; variant < 7; variant++) {
+    for (int variant = 0; variant < 8; variant++) {
         std::vector<double> ns(T);
         std::vector<uint64_t> chk(T);
         std::vector<std::thread> th;
@@ -399,7 +455,7 @@ static void run(int T, int N, int pushes) {
                             x[k].slot = 0;
                             s0[k] = a[k][0].slot;
                         }
-                        if (variant == 4) replace_aos_int<K>(a, N, x); else if (variant == 5) replace_aos_int2<K>(a, N, x); else replace_aos_int3<K>(a, N, x);
+                        if (variant == 4) replace_aos_int<K>(a, N, x); else if (variant == 5) replace_aos_int2<K>(a, N, x); else if (variant == 6) replace_aos_int3<K>(a, N, x); else replace_aos_int4<K>(a, N, x);
                         for (int k = 0; k < K; k++) {
                             km[k][s0[k]] = i;
                             rw[k][s0[k]] = i;
@@ -472,7 +528,7 @@ static void run(int T, int N, int pushes) {
             mx = std::max(mx, v);
         }
         printf("K=%d variant %d (%s): %.1f ns per push (slowest thread %.1f), layout checksum %016llx\n", K, variant,
-               variant == 0 ? "16-byte entries" : variant == 1 ? "f64 scores + u32 slots" : variant == 2 ? "f64 scores + u16 slots" : variant == 3 ? "16-byte entries, huge pages" : variant == 4 ? "16-byte entries, integer compares" : variant == 5 ? "integer compares, lockstep branch-free climbs" : "integer compares, unconditional levels", mean, mx,
+               variant == 0 ? "16-byte entries" : variant == 1 ? "f64 scores + u32 slots" : variant == 2 ? "f64 scores + u16 slots" : variant == 3 ? "16-byte entries, huge pages" : variant == 4 ? "16-byte entries, integer compares" : variant == 5 ? "integer compares, lockstep branch-free climbs" : variant == 6 ? "integer compares, unconditional levels" : "integer compares, top-down early stop", mean, mx,
                (unsigned long long)chk[0]);
     }
 }
