@@ -332,14 +332,14 @@ class alignas(128) BestHeap {
             kmer[i] = pay_[a[0].slot].kmer;
             score[i] = a[0].score;
             row[i] = pay_[a[0].slot].row;
-            pop_top(a, (ptrdiff_t)(n - i));
+            if (ints_ok_) pop_top<true>(a, (ptrdiff_t)(n - i)); else pop_top<false>(a, (ptrdiff_t)(n - i));
         }
     }
 
     // std::pop_heap(a, a + n, Greater()) minus the store of the old top into a[n-1] (the caller drops it):
     // same hole walk and climb as in replace_top.
+    template <bool INT>
     static inline void pop_top(Ent* a, ptrdiff_t n) {
-        constexpr bool INT = false;  // (finish: not the hot path)
         if (n <= 1) return;
         const Ent value = a[n - 1];
         const ptrdiff_t len = n - 1;
@@ -366,6 +366,30 @@ class alignas(128) BestHeap {
 
     // pop_all for K heaps of equal size() at once: the K pop sequences advance in lockstep (same idea as
     // replace_top_multi; each heap's moves are those of pop_top).
+    // K heaps of equal size() (1 <= K <= 8): pop_all of each, in lockstep; integer compares if all of them allow it
+    static void pop_all_n(int K, const BestHeap* const* hp, std::vector<uint64_t>* const* kmer, std::vector<double>* const* score,
+                          std::vector<uint64_t>* const* row) {
+        bool ints = true;
+        for (int k = 0; k < K; k++) ints = ints && hp[k]->ints_ok_;
+        if (K == 1) {
+            hp[0]->pop_all(*kmer[0], *score[0], *row[0]);
+            return;
+        }
+#define KGWAS_POP_CASE(N)                                                                       \
+    case N:                                                                                     \
+        if (ints) pop_all_multi<N, true>(hp, kmer, score, row); else pop_all_multi<N, false>(hp, kmer, score, row); \
+        break;
+        switch (K) {
+            KGWAS_POP_CASE(2)
+            KGWAS_POP_CASE(3)
+            KGWAS_POP_CASE(4)
+            KGWAS_POP_CASE(5)
+            KGWAS_POP_CASE(6)
+            KGWAS_POP_CASE(7)
+            default: if (ints) pop_all_multi<8, true>(hp, kmer, score, row); else pop_all_multi<8, false>(hp, kmer, score, row);
+        }
+#undef KGWAS_POP_CASE
+    }
     template <int K, bool INT = false>
     static void pop_all_multi(const BestHeap* const* hp, std::vector<uint64_t>* const* kmer, std::vector<double>* const* score,
                               std::vector<uint64_t>* const* row) {

@@ -2278,7 +2278,7 @@ int kgwas_scan_finish(kgwas_scan* s) {
         s->res_kmer.resize(s->n_pheno);
         s->res_row.resize(s->n_pheno);
         s->res_score.resize(s->n_pheno);
-        // A worker pops its columns (w, w+T, ...) four at a time in lockstep where their sizes agree.
+        // A worker pops its columns (w, w+T, ...) up to eight at a time in lockstep where their sizes agree.
         const size_t Tw = s->pool->size();
         s->pool->parallel_for(std::min<size_t>(Tw, s->n_pheno), [&](size_t w) {
             std::vector<size_t> mine;
@@ -2286,10 +2286,10 @@ int kgwas_scan_finish(kgwas_scan* s) {
             size_t i = 0;
             while (i < mine.size()) {
                 size_t K = 1;
-                while (K < 4 && i + K < mine.size() && s->heaps[mine[i + K]].size() == s->heaps[mine[i]].size()) K++;
-                const BestHeap* hp[4];
-                std::vector<uint64_t>*km[4], *rw[4];
-                std::vector<double>* sc[4];
+                while (K < 8 && i + K < mine.size() && s->heaps[mine[i + K]].size() == s->heaps[mine[i]].size()) K++;
+                const BestHeap* hp[8];
+                std::vector<uint64_t>*km[8], *rw[8];
+                std::vector<double>* sc[8];
                 for (size_t k = 0; k < K; k++) {
                     const size_t j = mine[i + k];
                     hp[k] = &s->heaps[j];
@@ -2297,10 +2297,7 @@ int kgwas_scan_finish(kgwas_scan* s) {
                     sc[k] = &s->res_score[j];
                     rw[k] = &s->res_row[j];
                 }
-                if (K == 4) BestHeap::pop_all_multi<4>(hp, km, sc, rw);
-                else if (K == 3) BestHeap::pop_all_multi<3>(hp, km, sc, rw);
-                else if (K == 2) BestHeap::pop_all_multi<2>(hp, km, sc, rw);
-                else s->heaps[mine[i]].pop_all(s->res_kmer[mine[i]], s->res_score[mine[i]], s->res_row[mine[i]]);
+                BestHeap::pop_all_n((int)K, hp, km, sc, rw);
                 i += K;
             }
         });
