@@ -301,6 +301,70 @@ static inline void replace_aos_int4(EntI* const* a, ptrdiff_t n, EntI* x) {
     }
 }
 
+// integer compares; `sure` unconditional levels, then the remaining one or two levels BRANCH-FREE (a path ends at depth
+// 12 or 13 with even odds at n = 10001: the bounds test of the last level is a coin flip for the predictor)
+template <int K>
+static inline void replace_aos_int5(EntI* const* a, ptrdiff_t n, EntI* x) {
+    EntI v[K];
+    ptrdiff_t c[K];
+    const ptrdiff_t len = n - 1, lim = (len - 1) / 2;
+    int sure = 0;
+    while ((((ptrdiff_t)2) << sure) - 2 < lim) sure++;
+    int extra = 0;  // levels that only some paths have
+    while ((((ptrdiff_t)1) << (sure + extra)) - 1 < lim) extra++;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        v[k] = a[k][n - 1];
+        x[k].slot = a[k][0].slot;
+        c[k] = 0;
+    }
+    for (int lvl = 0; lvl < sure; lvl++) {
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            ptrdiff_t cc = 2 * (c[k] + 1);
+            cc -= (a[k][cc].key > a[k][cc - 1].key) ? 1 : 0;
+            a[k][c[k]] = a[k][cc];
+            c[k] = cc;
+        }
+    }
+    for (int e = 0; e < extra; e++) {
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const bool go = c[k] < lim;
+            const ptrdiff_t base = go ? c[k] : 0;  // (a harmless in-range stand-in when this path has ended)
+            ptrdiff_t cc = 2 * (base + 1);
+            cc -= (a[k][cc].key > a[k][cc - 1].key) ? 1 : 0;
+            const ptrdiff_t src = go ? cc : c[k];
+            a[k][c[k]] = a[k][src];
+            c[k] = src;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        ptrdiff_t hh = c[k];
+        if ((len & 1) == 0 && c[k] == (len - 2) / 2) {
+            const ptrdiff_t c2 = 2 * (c[k] + 1);
+            a[k][hh] = a[k][c2 - 1];
+            hh = c2 - 1;
+        }
+        ptrdiff_t p = (hh - 1) / 2;
+        while (hh > 0 && a[k][p].key > v[k].key) {
+            a[k][hh] = a[k][p];
+            hh = p;
+            p = (hh - 1) / 2;
+        }
+        a[k][hh] = v[k];
+        hh = n - 1;
+        p = (hh - 1) / 2;
+        while (hh > 0 && a[k][p].key > x[k].key) {
+            a[k][hh] = a[k][p];
+            hh = p;
+            p = (hh - 1) / 2;
+        }
+        a[k][hh] = x[k];
+    }
+}
+
 template <int K, typename SlotT>
 static inline void replace_soa(double* const* sc, SlotT* const* sl, ptrdiff_t n, const double* xs, SlotT* evicted) {
     double vs[K];
@@ -366,7 +430,7 @@ static inline void replace_soa(double* const* sc, SlotT* const* sl, ptrdiff_t n,
 
 template <int K>
 static void run(int T, int N, int pushes) {
-    for (int variant = 0; variant < 8; variant++) {
+    for (int variant = 0; variant < 9; variant++) {
         std::vector<double> ns(T);
         std::vector<uint64_t> chk(T);
         std::vector<std::thread> th;
@@ -455,7 +519,7 @@ static void run(int T, int N, int pushes) {
                             x[k].slot = 0;
                             s0[k] = a[k][0].slot;
                         }
-                        if (variant == 4) replace_aos_int<K>(a, N, x); else if (variant == 5) replace_aos_int2<K>(a, N, x); else if (variant == 6) replace_aos_int3<K>(a, N, x); else replace_aos_int4<K>(a, N, x);
+                        if (variant == 4) replace_aos_int<K>(a, N, x); else if (variant == 5) replace_aos_int2<K>(a, N, x); else if (variant == 6) replace_aos_int3<K>(a, N, x); else if (variant == 7) replace_aos_int4<K>(a, N, x); else replace_aos_int5<K>(a, N, x);
                         for (int k = 0; k < K; k++) {
                             km[k][s0[k]] = i;
                             rw[k][s0[k]] = i;
@@ -528,7 +592,7 @@ static void run(int T, int N, int pushes) {
             mx = std::max(mx, v);
         }
         printf("K=%d variant %d (%s): %.1f ns per push (slowest thread %.1f), layout checksum %016llx\n", K, variant,
-               variant == 0 ? "16-byte entries" : variant == 1 ? "f64 scores + u32 slots" : variant == 2 ? "f64 scores + u16 slots" : variant == 3 ? "16-byte entries, huge pages" : variant == 4 ? "16-byte entries, integer compares" : variant == 5 ? "integer compares, lockstep branch-free climbs" : variant == 6 ? "integer compares, unconditional levels" : "integer compares, top-down early stop", mean, mx,
+               variant == 0 ? "16-byte entries" : variant == 1 ? "f64 scores + u32 slots" : variant == 2 ? "f64 scores + u16 slots" : variant == 3 ? "16-byte entries, huge pages" : variant == 4 ? "16-byte entries, integer compares" : variant == 5 ? "integer compares, lockstep branch-free climbs" : variant == 6 ? "integer compares, unconditional levels" : variant == 7 ? "integer compares, top-down early stop" : "integer compares, branch-free last levels", mean, mx,
                (unsigned long long)chk[0]);
     }
 }
