@@ -430,7 +430,7 @@ static inline void replace_soa(double* const* sc, SlotT* const* sl, ptrdiff_t n,
 
 template <int K>
 static void run(int T, int N, int pushes) {
-    for (int variant = 0; variant < 9; variant++) {
+    for (int variant = 0; variant < 10; variant++) {
         std::vector<double> ns(T);
         std::vector<uint64_t> chk(T);
         std::vector<std::thread> th;
@@ -505,6 +505,26 @@ static void run(int T, int N, int pushes) {
                     }
                     if (variant == 3)
                         for (int k = 0; k < K; k++) memcpy(heaps[k].data(), a[k], (size_t)N * sizeof(Ent));
+                } else if (variant == 9) {  // integer compares; payloads appended to one sequential log instead of random slot writes
+                    EntI* a[K];
+                    for (int k = 0; k < K; k++) a[k] = reinterpret_cast<EntI*>(heaps[k].data());
+                    std::vector<uint64_t> log((size_t)pushes * K * 2 + 16);
+                    uint64_t* lp = log.data();
+                    t0 = std::chrono::steady_clock::now();
+                    for (int i = 0; i < pushes; i++) {
+                        EntI x[K];
+                        for (int k = 0; k < K; k++) {
+                            double lo;
+                            memcpy(&lo, &a[k][0].key, 8);
+                            const double xv = lo + (1.0 - lo) * u[(size_t)k * pushes + i];
+                            memcpy(&x[k].key, &xv, 8);
+                            x[k].slot = 0;
+                            lp[0] = ((uint64_t)a[k][0].slot << 32) | (uint32_t)i;
+                            lp[1] = (uint64_t)i;
+                            lp += 2;
+                        }
+                        replace_aos_int<K>(a, N, x);
+                    }
                 } else if (variant >= 4) {
                     EntI* a[K];
                     for (int k = 0; k < K; k++) a[k] = reinterpret_cast<EntI*>(heaps[k].data());
@@ -592,7 +612,7 @@ static void run(int T, int N, int pushes) {
             mx = std::max(mx, v);
         }
         printf("K=%d variant %d (%s): %.1f ns per push (slowest thread %.1f), layout checksum %016llx\n", K, variant,
-               variant == 0 ? "16-byte entries" : variant == 1 ? "f64 scores + u32 slots" : variant == 2 ? "f64 scores + u16 slots" : variant == 3 ? "16-byte entries, huge pages" : variant == 4 ? "16-byte entries, integer compares" : variant == 5 ? "integer compares, lockstep branch-free climbs" : variant == 6 ? "integer compares, unconditional levels" : variant == 7 ? "integer compares, top-down early stop" : "integer compares, branch-free last levels", mean, mx,
+               variant == 0 ? "16-byte entries" : variant == 1 ? "f64 scores + u32 slots" : variant == 2 ? "f64 scores + u16 slots" : variant == 3 ? "16-byte entries, huge pages" : variant == 4 ? "16-byte entries, integer compares" : variant == 5 ? "integer compares, lockstep branch-free climbs" : variant == 6 ? "integer compares, unconditional levels" : variant == 7 ? "integer compares, top-down early stop" : variant == 8 ? "integer compares, branch-free last levels" : "integer compares, payload log", mean, mx,
                (unsigned long long)chk[0]);
     }
 }
