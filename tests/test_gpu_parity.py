@@ -508,7 +508,7 @@ def test_record_ring_wraps_and_fills(monkeypatch):
     topn = 1500
     exp = ob.associate(rows, S, col, Y, topn, mac)
     monkeypatch.setenv("KGWAS_RING_BYTES", "1")  # clamped to one chunk's worst case + 4 KB
-    scan = kg.AssociationScan(S, col, Y, topn, mac, chunk_rows=32768)
+    scan = kg.AssociationScan(S, col, Y, topn, mac, chunk_rows=8192)  # (more chunks than slots as well: the slots wrap around too)
     monkeypatch.delenv("KGWAS_RING_BYTES")
     scan.feed_host(rows[:250_000], 0)
     scan.feed_host(rows[250_000:], 250_000)
