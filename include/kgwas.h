@@ -35,6 +35,11 @@ extern "C" {
 const char* kgwas_last_error(void);
 int kgwas_version(void);
 int kgwas_device_count(int* n_devices);
+/* CPUs this process may really keep busy: the cgroup CPU quota if there is one, else the hardware thread count. What
+ * kgwas_scan_params.host_threads = 0 resolves to; the command-line tools raise a smaller --parallel to it (the
+ * reference's --parallel sizes a pool of scoring tasks, kmers_gwas.py passes 1 by default - pipeline_parser.py:31 -
+ * and here the threads replay heap pushes beside the GPU: one thread would be ~20x slower than the GPU it serves). */
+uint32_t kgwas_host_cpu_quota(void);
 
 /* ------------------------------------------------------------------------------------
  * .table / .names reader.
@@ -100,7 +105,7 @@ typedef struct kgwas_scan kgwas_scan;
 #define KGWAS_KERNEL_AUTO 0
 #define KGWAS_KERNEL_VALU 1 /* exact-order select+add on the vector ALU */
 #define KGWAS_KERNEL_MFMA 2 /* exact-order f32 MFMA (v_mfma_f32_16x16x4_f32) */
-#define KGWAS_KERNEL_COARSE 3 /* int8-MFMA coarse filter with a rigorous bound + exact re-scoring of survivors;
+#define KGWAS_KERNEL_COARSE 3 /* matrix-pipe coarse filter (block-scaled FP4 x FP6/FP4, or int8 with KGWAS_COARSE_MX=0) with a rigorous bound + exact re-scoring of survivors;
                                 the dense phase and overflow re-runs use an exact kernel. Same results. */
 #define KGWAS_KERNEL_NARROW 4 /* reported in kgwas_scan_stats.kernel_used only: the filter of scans with 1-4 phenotype
                                 columns (FP4 table bits x FP8 phenotype slices on the block-scaled MFMA; requested
@@ -140,7 +145,7 @@ typedef struct kgwas_scan_stats {
     double dense_ms;            /* host wall time of the dense (heap-filling) phase, GPU + replay */
     double coarse_kernel_ms;    /* sum of hipEvent durations of coarse_kernel alone (KGWAS_KERNEL_COARSE) */
     uint64_t coarse_launches;   /* its launches */
-    uint32_t kernel_used;       /* KGWAS_KERNEL_VALU, _MFMA or _COARSE */
+    uint32_t kernel_used;       /* KGWAS_KERNEL_VALU, _MFMA, _COARSE or _NARROW */
     uint32_t direct_mode;       /* 1 = scorer read the file layout in place (no squeeze pass) */
     uint64_t patterns;          /* distinct pattern hashes among tested rows (count_patterns; valid after finish) */
     /* coarse filter, per operand set: [0] = one int8 slice per phenotype column, [1] = two slices */
@@ -152,6 +157,12 @@ typedef struct kgwas_scan_stats {
     double replay_cpu_ms;       /* CPU time of the replay summed over the workers (replay_ms: the busiest worker's share) */
     double replay_tail_ms;      /* wall time the replay still needed after the GPU had finished the feed's last chunk */
     uint32_t coarse_mode_tile_slices[2]; /* operand tiles a row is multiplied with, over all LDS groups and launches of the set */
+    uint32_t coarse_mx;         /* 1 = the filter is the block-scaled one (score_mx.hip: FP4 table bits x FP6 / FP4 slices on
+                                   v_mfma_scale_f32_16x16x128_f8f6f4; coarse_mode_tiles then counts COLUMN tiles, each carrying
+                                   all slices of its 16 columns), 0 = the int8 one (KGWAS_COARSE_MX=0) */
+    uint32_t coarse_mx_s1_fp6;  /* block-scaled filter: the second slice is FP6 (else FP4) */
+    uint32_t coarse_mx_steps;   /* block-scaled filter: MFMA steps (K = 128) per row tile, column tile and slice */
+    uint32_t replay_threads;    /* host threads replaying heap pushes in this session */
 } kgwas_scan_stats;
 
 int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out);

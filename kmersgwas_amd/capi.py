@@ -73,6 +73,8 @@ class ScanStats(C.Structure):
         ("coarse_mode_ms", C.c_double * 2),
         ("replay_cpu_ms", C.c_double), ("replay_tail_ms", C.c_double),
         ("coarse_mode_tile_slices", C.c_uint32 * 2),
+        ("coarse_mx", C.c_uint32), ("coarse_mx_s1_fp6", C.c_uint32), ("coarse_mx_steps", C.c_uint32),
+        ("replay_threads", C.c_uint32),
     ]
 
     def as_dict(self):

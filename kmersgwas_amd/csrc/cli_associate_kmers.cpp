@@ -123,7 +123,21 @@ int main(int argc, char* argv[]) {
         sp.topn = topn.data();
         sp.min_count = min_count;
         sp.chunk_rows = 0;
-        sp.host_threads = (uint32_t)threads;
+        // --parallel: the reference's pool of scoring tasks (src/associate_kmers.cpp:104-148), 4 by default and 1 from the
+        // pipeline (src/py/pipeline_parser.py:31). Here the host threads replay heap pushes beside the GPU(s), and fewer
+        // than the CPUs this process may use only makes the scan host-bound: a smaller --parallel is raised to the CPU
+        // quota (KGWAS_STRICT_PARALLEL=1 keeps it as given); a larger one is honoured.
+        uint64_t replay_threads = threads ? threads : 1;
+        {
+            const uint64_t quota = kgwas_host_cpu_quota();
+            const char* strict = getenv("KGWAS_STRICT_PARALLEL");
+            if (!(strict && atoi(strict) != 0) && replay_threads < quota) {
+                cerr << "[kgwas] --parallel " << threads << " is below the " << quota << " CPUs this process may use: " << quota
+                     << " replay threads (KGWAS_STRICT_PARALLEL=1 keeps --parallel)" << endl;
+                replay_threads = quota;
+            }
+        }
+        sp.host_threads = (uint32_t)replay_threads;
         sp.kernel = (uint32_t)vm.u64("kernel", 0);
         sp.record_history = 0;
         sp.count_patterns = vm.count("pattern_counter") ? 1 : 0;
@@ -216,9 +230,13 @@ int main(int argc, char* argv[]) {
             fout << st.rows_tested << endl;
         }
         cerr << "[kgwas] kernel="
-             << (st.kernel_used == KGWAS_KERNEL_COARSE ? "coarse_i8+exact" : st.kernel_used == KGWAS_KERNEL_MFMA ? "mfma_f32" : "valu")
+             << (st.kernel_used == KGWAS_KERNEL_COARSE   ? "coarse_filter+exact"
+                 : st.kernel_used == KGWAS_KERNEL_NARROW ? "narrow_fp4+exact"
+                 : st.kernel_used == KGWAS_KERNEL_MFMA   ? "mfma_f32"
+                                                         : "valu")
              << " direct=" << st.direct_mode << " chunks=" << st.chunks << " score_kernel_ms=" << st.score_kernel_ms
              << " candidates=" << st.candidates << " heap_pushes=" << st.heap_pushes << endl;
+        cerr << "[kgwas] replay_threads=" << replay_threads << " replay_threads_per_gpu=" << std::max<uint64_t>(1, replay_threads / n_gpus) << endl;
         if (mscan)
             cerr << "[kgwas] gpus=" << n_gpus << " scan_ms=" << scan_ms << " merge_ms=" << merge_ms << " rescans=" << rescans << endl;
         if (mscan) kgwas_multiscan_destroy(mscan);

@@ -114,6 +114,32 @@ struct CoarseArgs {
 };
 size_t coarse_lds_bytes(uint32_t n_kgroups, uint32_t T);
 hipError_t launch_coarse(const CoarseArgs& a, uint32_t T, uint32_t rows_per_block, hipStream_t st);
+// Block-scaled coarse filter (score_mx.hip): FP4 table bits x FP6 / FP4 phenotype slices on
+// v_mfma_scale_f32_16x16x128_f8f6f4, the slices of a column accumulated into ONE float32 accumulator through the block
+// scales; same survivors' bitmap, same per-slot constants (CoarseCol, in accumulator units) and error terms as the int8
+// filter. Samples are taken in n_full = S / 512 whole groups of 512 (four MFMA steps each) and n_quarter <= 4 quarter groups of
+// 128 (one step each).
+struct MxArgs {
+    RowSrc src;
+    uint64_t n_rows;
+    uint32_t S, n_pheno, min_count;
+    uint32_t n_full, n_quarter;
+    uint32_t n_lgroups;     // LDS groups of CT x 16 operand columns
+    uint32_t n_slices;      // 1: FP6 only, 2: FP6 + second slice
+    uint32_t s1_fp6;        // second slice in FP6 (else FP4)
+    uint32_t scale0;        // E8M0 block scale of the first slice, replicated in all four bytes (the second slice's is 2^0)
+    const uint8_t* Bq;      // [n_lgroups][4 n_full + n_quarter steps][CT][step bytes], see score_mx.hip
+    const CoarseCol* cols;  // [n_lgroups][CT*16]
+    const double* thr;      // [n_pheno]
+    unsigned long long* bitmap;  // as CoarseArgs
+    uint64_t words_per_col;
+    unsigned long long* tested;
+    float eg_max, rall_max, rmax_max;  // as CoarseArgs, in accumulator units
+};
+size_t mx_lds_bytes(uint32_t n_steps, uint32_t CT, uint32_t n_slices, uint32_t s1_fp6);
+uint32_t mx_step_bytes_rt(uint32_t n_slices, uint32_t s1_fp6);
+uint32_t mx_row_tiles(uint32_t CT);  // 16-row tiles per wave pass for this many column tiles
+hipError_t launch_mx(const MxArgs& a, uint32_t CT, uint32_t rows_per_block, hipStream_t st);
 // Survivors (sorted keys, per-column ranges) -> exact candidates compacted in (column, row) order into a.so_score /
 // a.so_kmer / a.so_row (HBM); meta[0..P) = candidates per column, meta[P..2P) = their offsets, meta[2P] = total,
 // meta[2P + 1] = survivor keys emitted. tile_pref [P + 1], tile_cnt / tile_off [key_cap / 256 + P + 1], tmp_score [key_cap].

@@ -42,6 +42,8 @@ struct kgwas_multiscan {
     double merge_ms = 0, scan_ms = 0;
     uint64_t rescans = 0, runs = 0;
     uint64_t rows_tested = 0, patterns = 0;
+    // counters of the later shards' earlier runs (kgwas_scan_reset clears a session's statistics before every run)
+    uint64_t prev_rows_fed = 0, prev_candidates = 0, prev_heap_pushes = 0, prev_chunks = 0, prev_score_launches = 0, prev_coarse_launches = 0;
     bool finished = false;
     ~kgwas_multiscan() {
         for (kgwas_scan* s : sess)
@@ -85,6 +87,19 @@ void ck(int rc) {
     if (rc != KGWAS_OK) throw Error(rc, kgwas_last_error());
 }
 
+// A later shard's session starts empty at every run call; its counters of the run before are kept in the totals.
+void reset_shard(kgwas_multiscan* m, size_t g) {
+    kgwas_scan_stats st;
+    ck(kgwas_scan_get_stats(m->sess[g], &st));
+    m->prev_rows_fed += st.rows_fed;
+    m->prev_candidates += st.candidates;
+    m->prev_heap_pushes += st.heap_pushes;
+    m->prev_chunks += st.chunks;
+    m->prev_score_launches += st.score_launches;
+    m->prev_coarse_launches += st.coarse_launches;
+    ck(kgwas_scan_reset(m->sess[g]));
+}
+
 // scan_shard(g, session): feed shard g's rows into the given session (used for the first scan and for re-scans).
 template <class ScanShard>
 void run_and_merge(kgwas_multiscan* m, ScanShard&& scan_shard) {
@@ -108,9 +123,11 @@ void run_and_merge(kgwas_multiscan* m, ScanShard&& scan_shard) {
                 if (rc == KGWAS_ERR_STATE) {
                     // the eviction ring was too short for this bound (shards of very different score levels): scan the
                     // shard again keeping the full push log
+                    // (the replacement is created first: if that fails - out of memory for the log - the old session
+                    // stays in place and the object remains usable)
+                    kgwas_scan* fresh = make_session(m, g, 1);
                     kgwas_scan_destroy(m->sess[g]);
-                    m->sess[g] = nullptr;
-                    m->sess[g] = make_session(m, g, 1);
+                    m->sess[g] = fresh;
                     scan_shard(g, m->sess[g]);
                     m->rescans++;
                     rc = kgwas_scan_history_above(m->sess[g], run.data(), &counts[(g - 1) * P], &kp[g - 1], &sp[g - 1], &rp[g - 1]);
@@ -163,7 +180,7 @@ int kgwas_multiscan_run_table(kgwas_multiscan* m, kgwas_table* t, uint64_t row0,
         if (m->runs && m->par.count_patterns && G > 1)
             throw Error(KGWAS_ERR_STATE, "kgwas_multiscan: with count_patterns the rows must be handed over in one run call");
         m->runs++;
-        for (size_t g = 1; g < G; g++) ck(kgwas_scan_reset(m->sess[g]));
+        for (size_t g = 1; g < G; g++) reset_shard(m, g);
         m->finished = false;
         run_and_merge(m, [&](size_t g, kgwas_scan* s) {
             const uint64_t lo = row0 + n_rows / G * g + std::min<uint64_t>(g, n_rows % G);
@@ -182,7 +199,7 @@ int kgwas_multiscan_run_device(kgwas_multiscan* m, const void* const* d_rows, co
         m->runs++;
         for (size_t g = 1; g < G; g++) {
             if (first_row[g] != first_row[g - 1] + n_rows[g - 1]) throw Error(KGWAS_ERR_ARG, "kgwas_multiscan_run_device: shards must be contiguous, in row order");
-            ck(kgwas_scan_reset(m->sess[g]));
+            reset_shard(m, g);
         }
         m->finished = false;
         run_and_merge(m, [&](size_t g, kgwas_scan* s) { ck(kgwas_scan_feed_device(s, d_rows[g], n_rows[g], first_row[g], nullptr)); });
@@ -264,6 +281,12 @@ int kgwas_multiscan_get_stats(const kgwas_multiscan* m, kgwas_scan_stats* total,
                 t.replay_cpu_ms += st.replay_cpu_ms;
             }
         }
+        t.rows_fed += m->prev_rows_fed;
+        t.candidates += m->prev_candidates;
+        t.heap_pushes += m->prev_heap_pushes;
+        t.chunks += m->prev_chunks;
+        t.score_launches += m->prev_score_launches;
+        t.coarse_launches += m->prev_coarse_launches;
         t.rows_tested += m->rows_tested;  // later shards' counts, summed at every merge (their sessions are reset)
         if (m->par.count_patterns && m->finished) t.patterns = m->patterns;
         *total = t;

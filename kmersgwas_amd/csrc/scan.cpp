@@ -454,6 +454,9 @@ struct kgwas_scan {
     };
     struct CoarseMode {
         bool ready = false;
+        // block-scaled filter (score_mx.hip): FP6 (+ FP4 / FP6) slices instead of int8 ones; part[].T = column tiles
+        bool mx = false;
+        uint32_t mx_full = 0, mx_quarter = 0, mx_s1_fp6 = 0, mx_scale0 = 0;
         uint32_t slices = 0, n_parts = 0;
         uint32_t tile_slices = 0;  // operand tiles a row is multiplied with, all parts and groups
         float eg_max = 0, rall_max = 0, rmax_max = 0;  // row error term, maxima over the columns (kernels.h)
@@ -885,7 +888,31 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
                 c.Bq = Pt.d_Bq.p;
                 c.cols = Pt.d_cols.p;
                 c.tested = pi == 0 ? a.tested : nullptr;  // every launch sees every row: one of them counts
-                if (Pt.wide)
+                if (M.mx) {
+                    MxArgs x;
+                    memset(&x, 0, sizeof(x));
+                    x.src = c.src;
+                    x.n_rows = n_rows;
+                    x.S = c.S;
+                    x.n_pheno = c.n_pheno;
+                    x.min_count = c.min_count;
+                    x.n_full = M.mx_full;
+                    x.n_quarter = M.mx_quarter;
+                    x.n_lgroups = Pt.n_lgroups;
+                    x.n_slices = M.slices;
+                    x.s1_fp6 = M.mx_s1_fp6;
+                    x.scale0 = M.mx_scale0;
+                    x.Bq = reinterpret_cast<const uint8_t*>(Pt.d_Bq.p);
+                    x.cols = Pt.d_cols.p;
+                    x.thr = c.thr;
+                    x.bitmap = c.bitmap;
+                    x.words_per_col = c.words_per_col;
+                    x.tested = c.tested;
+                    x.eg_max = c.eg_max;
+                    x.rall_max = c.rall_max;
+                    x.rmax_max = c.rmax_max;
+                    KGWAS_HIP(launch_mx(x, Pt.T, rpb_env ? rpb_env : (n_rows >= (1u << 22) ? 4096u : n_rows >= (1u << 20) ? 2048u : 512u), s->stream));
+                } else if (Pt.wide)
                     KGWAS_HIP(launch_wide(c, Pt.T, rpb_env ? rpb_env : (n_rows >= (1u << 20) ? 1024u : 256u), s->stream));
                 else
                     KGWAS_HIP(launch_coarse(c, Pt.T, rpb_env ? rpb_env : (n_rows >= (1u << 22) ? 4096u : n_rows >= (1u << 20) ? 2048u : 512u), s->stream));
@@ -1222,7 +1249,7 @@ void wait_event(kgwas_scan* s, hipEvent_t ev) {
 // Coarse chunk: wait for its counts, then order the copy of exactly that many candidate records (three arrays) from
 // HBM on the copy stream; ev_done follows the copies. Other chunks recorded ev_done at submission.
 // Returns false if the record ring has no room yet (nothing was ordered: retry after more chunks are replayed).
-bool fetch_records(kgwas_scan* s, Slot& sl) {
+bool fetch_records(kgwas_scan* s, Slot& sl, uint64_t seq) {
     if (!sl.used_coarse) return true;
     wait_event(s, sl.ev_counts);
     const uint32_t n = sl.h_meta.p[2 * s->n_pheno];
@@ -1236,7 +1263,10 @@ bool fetch_records(kgwas_scan* s, Slot& sl) {
             s->ring_tail = s->slot[(size_t)(s->ring_freed % (uint64_t)s->n_slots)].ring_end;
             s->ring_freed++;
         }
-        if (s->ring_tail == s->ring_head) s->ring_head = s->ring_tail = 0;  // empty: start over at the bottom
+        // empty: start over at the bottom - but only when every chunk fetched before this one has been freed: a fetched,
+        // not yet replayed chunk without records (or one that overflowed) carries a ring_end taken from the old head,
+        // and freeing it later would move the tail back over records placed at the bottom in the meantime
+        if (s->ring_tail == s->ring_head && s->ring_freed == seq) s->ring_head = s->ring_tail = 0;
     }
     if (copy) {
         const size_t need = ((size_t)n * 20 + 63) / 64 * 64;
@@ -1468,7 +1498,11 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
             // free slot's chunk first - 24 of them at 100 M rows - kept the first chunk's records from the replay for
             // 2-3 ms after the GPU had delivered them. The blocking waits below are only taken when nothing can be
             // submitted.
-            if (pos < n_rows && sub - replayed() < depth) {
+            // ONE read of the replay's progress per turn: the decisions below and the waits' targets must come from the
+            // same value (a target taken from a fresher read can lie beyond everything that is published - the wait
+            // would then never end)
+            const uint64_t rep_now = replayed();
+            if (pos < n_rows && sub - rep_now < depth) {
                 start_async();
                 const uint64_t c = std::min<uint64_t>(next_sparse_chunk(s), n_rows - pos);
                 const size_t si = (size_t)(sub % (uint64_t)s->n_slots);  // its previous chunk was replayed n_slots chunks ago
@@ -1482,16 +1516,16 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
             // Coarse chunks hand their records over in two steps: counts first (compute stream), then exactly that many
             // records on the copy stream, ordered here as soon as the counts are in - before waiting for an older
             // chunk's copy if this chunk's counts are already there, so the copy engine never waits for this thread.
-            const bool can_submit = pos < n_rows && sub - replayed() < depth;
+            const bool can_submit = pos < n_rows && sub - rep_now < depth;
             if (cpy < sub && ((cpy == pub && !can_submit) || hipEventQuery(s->slot[(size_t)(cpy % (uint64_t)s->n_slots)].ev_counts) == hipSuccess ||
                               !s->slot[(size_t)(cpy % (uint64_t)s->n_slots)].used_coarse)) {
-                if (fetch_records(s, s->slot[(size_t)(cpy % (uint64_t)s->n_slots)])) {
+                if (fetch_records(s, s->slot[(size_t)(cpy % (uint64_t)s->n_slots)], cpy)) {
                     cpy++;
                     continue;
                 }
                 // the record ring is full: publish what is fetched; if all of that is published, wait for the replay
                 if (pub == cpy) {
-                    wait_replayed(replayed() + 1);
+                    wait_replayed(rep_now + 1);
                     if (s->rp_failed.load(std::memory_order_acquire)) break;
                     continue;
                 }
@@ -1528,7 +1562,7 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
             }
             if (can_submit) continue;
             if (pos < n_rows) {  // every slot holds a chunk that is still being replayed
-                wait_replayed(replayed() + 1);
+                wait_replayed(rep_now + 1);
                 if (s->rp_failed.load(std::memory_order_acquire)) break;
                 continue;
             }
@@ -1612,6 +1646,8 @@ void make_heaps(kgwas_scan* s) {
 }  // namespace kgwas
 
 extern "C" {
+
+uint32_t kgwas_host_cpu_quota(void) { return usable_cpus(); }
 
 int kgwas_device_count(int* n_devices) {
     return guarded([&] {
@@ -1982,8 +2018,227 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                 KGWAS_HIP(hipMemcpy(s->d_ncols.p, ncols.data(), P * sizeof(NarrowCol), hipMemcpyHostToDevice));
 
             }
+            // ---- block-scaled filter (score_mx.hip), the default: FP6 (+ FP4 / FP6) slices on the integer grids
+            //   A6 = {0..15, 16..30 step 2, 32..60 step 4} (E2M3 x 8),  A4 = {0, 1, 2, 3, 4, 6, 8, 12} (E2M1 x 2):
+            //   y_i - c ~ w * t_i,  t_i = a6_i (one slice), 8 a6_i + a4_i (FP4 second slice) or 32 a6_i + a6'_i (FP6 second
+            //   slice); the accumulator is kappa * sum_i g_i t_i, kappa = 1/16, 1/4, 1/16, so one accumulator unit is
+            //   u = w / kappa phenotype units and everything above (kalpha, the error terms in units of Dc) carries over
+            //   with that u. The ones column has t = 1 / kappa: its accumulator is N1.
+            const bool use_mx = !(getenv("KGWAS_COARSE_MX") && atoi(getenv("KGWAS_COARSE_MX")) == 0);
+            if (use_mx && !s->narrow && getenv("KGWAS_COARSE_SLICES") == nullptr) want[0] = false;  // one FP6 slice alone: only on request
+            auto build_mx = [&](int mi) {
+                const int ns = mi + 1;
+                kgwas_scan::CoarseMode& M = s->cmode[mi];
+                std::vector<int> G6, G4;  // the signed grids, ascending
+                for (int q = 60; q >= 32; q -= 4) G6.push_back(-q);
+                for (int q = 30; q >= 16; q -= 2) G6.push_back(-q);
+                for (int q = 15; q >= -15; q--) G6.push_back(-q);
+                for (int q = 16; q <= 30; q += 2) G6.push_back(q);
+                for (int q = 32; q <= 60; q += 4) G6.push_back(q);
+                for (int h : {-12, -8, -6, -4, -3, -2, -1, 0, 1, 2, 3, 4, 6, 8, 12}) G4.push_back(h);
+                auto nearest = [](const std::vector<int>& g, double v) {  // index of the grid value closest to v
+                    size_t hi = std::lower_bound(g.begin(), g.end(), v, [](int a, double b) { return (double)a < b; }) - g.begin();
+                    if (hi == 0) return (size_t)0;
+                    if (hi == g.size()) return g.size() - 1;
+                    return (v - (double)g[hi - 1] <= (double)g[hi] - v) ? hi - 1 : hi;
+                };
+                auto e2m3 = [](int q) -> uint32_t {  // E2M3 code of q / 8
+                    const uint32_t sg = q < 0 ? 0x20u : 0u;
+                    const int a = std::abs(q);
+                    if (a < 8) return sg | (uint32_t)a;
+                    int e = 1, base = 8;
+                    while (a >= 2 * base) base *= 2, e++;
+                    return sg | ((uint32_t)e << 3) | (uint32_t)((a - base) / (base / 8));
+                };
+                auto e2m1 = [](int h) -> uint32_t {  // E2M1 code of h / 2
+                    static const int tab[8] = {0, 1, 2, 3, 4, 6, 8, 12};
+                    uint32_t i = 0;
+                    while (tab[i] != std::abs(h)) i++;
+                    return (h < 0 ? 8u : 0u) | i;
+                };
+                // whole 512-sample groups (the kernel reads all 64 bytes of those without a bounds check) + up to four quarter groups
+                const uint32_t n_full = (uint32_t)(S / 512), nq = (uint32_t)((S % 512 + 127) / 128);
+                const uint32_t n_steps = 4 * n_full + nq;
+                // column tiles per LDS group the LDS can hold, and the LDS groups that takes, for a second-slice format
+                auto ct_max = [&](uint32_t fp6) {
+                    for (uint32_t ct = 7; ct >= 1; ct--)
+                        if (mx_lds_bytes(n_steps, ct, (uint32_t)ns, fp6) <= 160u * 1024u) return ct;
+                    return 0u;
+                };
+                auto groups_for = [&](uint32_t ctm) {
+                    uint64_t g = 1;
+                    while (((P + g - 1) / g + 1 + 15) / 16 > ctm) g++;
+                    return g;
+                };
+                uint32_t s1_fp6 = 0;
+                if (ns == 2 && ct_max(1) && ct_max(0) && groups_for(ct_max(1)) == groups_for(ct_max(0))) s1_fp6 = 1;
+                if (const char* e = getenv("KGWAS_MX_S1")) s1_fp6 = atoi(e) == 6 && ct_max(1) ? 1u : 0u;  // experiments
+                const uint32_t CTmax = ct_max(s1_fp6);
+                if (!CTmax) throw Error(KGWAS_ERR_ARG, "coarse filter: too many accessions for the LDS");
+                const int sh = ns == 1 ? 0 : (s1_fp6 ? 5 : 3);                 // t = 2^sh * a6 + a1
+                const double kappa = (ns == 2 && !s1_fp6) ? 0.25 : 0.0625;     // accumulator = kappa * sum g t
+                const int t_ones = (int)(1.0 / kappa);                         // in the LAST slice (a6 = 0 with two slices)
+                const double t_max = ns == 1 ? 60.0 : (s1_fp6 ? 32.0 * 60.0 + 60.0 : 8.0 * 60.0 + 12.0);
+                const std::vector<int>& G1 = s1_fp6 ? G6 : G4;
+                std::vector<int> a0(S), a1(S);
+                auto quantise_mx = [&](uint64_t j, CoarseCol& cc, ErrBound& eb) {
+                    const double Nd = (double)S, sum = (double)sums[j];
+                    const double c = sum / Nd;
+                    double mx = 0, A = 0;
+                    for (uint64_t i = 0; i < S; i++) {
+                        const double y = (double)s->Y[j * S + i];
+                        mx = std::max(mx, std::fabs(y - c));
+                        A += std::fabs(y);
+                    }
+                    const double w = mx > 0 ? mx / t_max : 1.0;
+                    const double u = w / kappa;  // one accumulator unit in phenotype units
+                    double rpos = 0, rneg = 0, rmax = 0;
+                    for (uint64_t i = 0; i < S; i++) {
+                        const double y = (double)s->Y[j * S + i] - c;
+                        const double x = y / w;
+                        int b0 = 0, b1 = 0;
+                        if (ns == 1) {
+                            b0 = G6[nearest(G6, x)];
+                        } else {
+                            // the first slice's neighbours of x / 2^sh, each with its best second slice
+                            const double sc = (double)(1 << sh);
+                            const size_t k0 = nearest(G6, x / sc);
+                            double best = 1e300;
+                            for (size_t k = k0 ? k0 - 1 : 0; k <= std::min(k0 + 1, G6.size() - 1); k++) {
+                                const int c1 = G1[nearest(G1, x - sc * G6[k])];
+                                const double r = std::fabs(x - sc * G6[k] - c1);
+                                if (r < best) best = r, b0 = G6[k], b1 = c1;
+                            }
+                        }
+                        a0[i] = b0;
+                        a1[i] = b1;
+                        const double r = y - w * ((double)(1 << sh) * b0 + b1);
+                        if (r > 0) rpos += r; else rneg -= r;
+                        rmax = std::max(rmax, std::fabs(r));
+                    }
+                    const double rho = Nd * std::fabs(Nd * c - sum) * 2.0 + 1e-9 * (1.0 + std::fabs(sum));
+                    const double Eg = gamma * A * (1.0 + 1e-6) + 1e-12 * (1.0 + A);
+                    cc.kalpha = (1.0 - std::ldexp(1.0, -19)) / (Nd * u);
+                    cc.iu = up(1.0 / u * (1.0 + 1e-6));
+                    eb.eg = up((Eg + rho / Nd) * (1.0 + 1e-6) + 1e-30);
+                    eb.rall = up(std::max(rpos, rneg) * (1.0 + 1e-6));
+                    eb.rmax = up(rmax * (1.0 + 1e-6));
+                    const double iu = 1.0 / u * (1.0 + 1e-6);
+                    eb.egD = up((double)eb.eg * iu);
+                    eb.rallD = up((double)eb.rall * iu);
+                    eb.rmaxD = up((double)eb.rmax * iu);
+                };
+                // LDS groups: as few as hold all columns (+ a ones column each); or groups filled to the last slot and one
+                // smaller launch for the rest when that multiplies fewer tiles
+                uint64_t n_lgroups = groups_for(CTmax);
+                uint64_t cper = (P + n_lgroups - 1) / n_lgroups;
+                struct Plan {
+                    uint64_t j0, n, CT, groups, cper;
+                };
+                std::vector<Plan> plan;
+                plan.push_back(Plan{0, P, (cper + 1 + 15) / 16, n_lgroups, cper});
+                if (n_lgroups > 1) {
+                    const uint64_t cpf = (uint64_t)CTmax * 16 - 1;
+                    const uint64_t full = P / cpf, rem = P - full * cpf;
+                    const uint64_t CTr = rem ? (rem + 1 + 15) / 16 : 0;
+                    if (full >= 1 && full + (rem ? 1 : 0) <= n_lgroups && full * CTmax + CTr < n_lgroups * plan[0].CT) {
+                        plan.clear();
+                        plan.push_back(Plan{0, full * cpf, CTmax, full, cpf});
+                        if (rem) plan.push_back(Plan{full * cpf, rem, CTr, 1, rem});
+                    }
+                }
+                M.mx = true;
+                M.mx_full = n_full;
+                M.mx_quarter = nq;
+                M.mx_s1_fp6 = s1_fp6;
+                M.mx_scale0 = 0x01010101u * (uint32_t)(0x7F + (ns == 1 ? 0 : 5));
+                M.slices = (uint32_t)ns;
+                M.n_parts = (uint32_t)plan.size();
+                M.tile_slices = 0;
+                uint32_t groups_all = 0;
+                const uint32_t SB = mx_step_bytes_rt((uint32_t)ns, s1_fp6);
+                for (size_t pi = 0; pi < plan.size(); pi++) {
+                    const Plan& pl = plan[pi];
+                    kgwas_scan::CoarsePart& Pt = M.part[pi];
+                    const uint32_t CT = (uint32_t)pl.CT, slots = CT * 16;
+                    Pt.T = CT;
+                    Pt.n_lgroups = (uint32_t)pl.groups;
+                    Pt.wide = false;
+                    M.tile_slices += CT * (uint32_t)ns * (uint32_t)pl.groups;
+                    groups_all += (uint32_t)pl.groups;
+                    const size_t group_bytes = (size_t)n_steps * CT * SB;
+                    std::vector<uint8_t> Bq(pl.groups * group_bytes, 0);
+                    std::vector<CoarseCol> cols(pl.groups * slots);
+                    for (auto& cc : cols) {
+                        memset(&cc, 0, sizeof(cc));
+                        cc.pheno = -1;
+                    }
+                    // the slice values of operand column `slot` of LDS group lg: v0 on the A6 grid, v1 on the second slice's
+                    auto put = [&](uint64_t lg, uint64_t slot, const std::vector<int>& v0, const std::vector<int>& v1) {
+                        const uint64_t t = slot / 16, n = slot % 16;
+                        for (uint64_t st = 0; st < n_steps; st++) {
+                            uint8_t* blk = &Bq[lg * group_bytes + (st * CT + t) * SB];
+                            for (uint64_t kb = 0; kb < 4; kb++) {
+                                const uint64_t lane = kb * 16 + n;
+                                for (uint64_t e = 0; e < 32; e++) {
+                                    // score_mx.hip: k = 32 kb + e <-> sample
+                                    const uint64_t smp = st < 4ull * n_full ? 512 * (st / 4) + 128 * kb + 32 * (e / 8) + 4 * (e % 8) + st % 4
+                                                                            : 512ull * n_full + 128 * (st - 4ull * n_full) + 32 * kb + 4 * (e % 8) + e / 8;
+                                    if (smp >= S) continue;
+                                    auto put6 = [&](uint8_t* part, int q) {  // 6-bit field e of the lane's 6 dwords: dwords 0-3 | 4-5
+                                        const uint32_t code = e2m3(q);
+                                        for (int b = 0; b < 6; b++)
+                                            if (code & (1u << b)) {
+                                                const uint64_t bit = 6 * e + b, dw = bit / 32;
+                                                uint8_t* d = dw < 4 ? part + lane * 16 + dw * 4 : part + 1024 + lane * 8 + (dw - 4) * 4;
+                                                d[(bit % 32) / 8] |= (uint8_t)(1u << (bit % 8));
+                                            }
+                                    };
+                                    put6(blk, v0[smp]);
+                                    if (ns == 2) {
+                                        if (s1_fp6)
+                                            put6(blk + 1536, v1[smp]);
+                                        else
+                                            blk[1536 + lane * 16 + e / 2] |= (uint8_t)(e2m1(v1[smp]) << (4 * (e % 2)));
+                                    }
+                                }
+                            }
+                        }
+                    };
+                    for (uint64_t j = pl.j0; j < pl.j0 + pl.n; j++) {
+                        const uint64_t lg = (j - pl.j0) / pl.cper, slot = (j - pl.j0) % pl.cper;
+                        CoarseCol& cc = cols[lg * slots + slot];
+                        ErrBound eb;
+                        quantise_mx(j, cc, eb);
+                        M.eg_max = std::max(M.eg_max, eb.egD);
+                        M.rall_max = std::max(M.rall_max, eb.rallD);
+                        M.rmax_max = std::max(M.rmax_max, eb.rmaxD);
+                        cc.pheno = (int32_t)j;
+                        put(lg, slot, a0, a1);
+                    }
+                    {  // ones column: accumulator = N1
+                        std::vector<int> ones(S, t_ones), zeros(S, 0);
+                        for (uint64_t lg = 0; lg < pl.groups; lg++) put(lg, slots - 1, ns == 1 ? ones : zeros, ones);
+                    }
+                    Pt.d_Bq.alloc(Bq.size());
+                    Pt.d_cols.alloc(cols.size());
+                    KGWAS_HIP(hipMemcpy(Pt.d_Bq.p, Bq.data(), Bq.size(), hipMemcpyHostToDevice));
+                    KGWAS_HIP(hipMemcpy(Pt.d_cols.p, cols.data(), cols.size() * sizeof(CoarseCol), hipMemcpyHostToDevice));
+                }
+                s->st.coarse_mode_tiles[mi] = M.part[0].T;
+                s->st.coarse_mode_lgroups[mi] = groups_all;
+                s->st.coarse_mode_tile_slices[mi] = M.tile_slices;
+                s->st.coarse_mx = 1;
+                s->st.coarse_mx_s1_fp6 = s1_fp6;
+                s->st.coarse_mx_steps = n_steps;
+                M.ready = true;
+            };
             for (int mi = 0; mi < 2; mi++) {
                 if (!want[mi]) continue;
+                if (use_mx) {
+                    build_mx(mi);
+                    continue;
+                }
                 const int ns = mi + 1;
                 kgwas_scan::CoarseMode& M = s->cmode[mi];
                 // Operand columns ("slots") per LDS group: the group's share of the phenotype columns, padding, and
@@ -2173,6 +2428,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
             if (atoi(e) > 0) nt = (unsigned)atoi(e);
         nt = (unsigned)std::min<uint64_t>(nt, P);
         s->pool.reset(new Pool(nt, pick_replay_cpus(nt, s->device)));
+        s->st.replay_threads = nt;
         // Column groups of the replay. Worker w owns the columns w, w + T, ... of the first floor(P / T) * T columns,
         // in groups of at most MAX_LOCKSTEP (a group's heaps take their replacements in lockstep, and stay in their
         // worker's cache from chunk to chunk); the P mod T columns left over float: each is a group of its own that
@@ -2521,6 +2777,10 @@ int kgwas_scan_reset(kgwas_scan* s) {
         s->st = kgwas_scan_stats{};
         s->st.kernel_used = old.kernel_used;
         s->st.direct_mode = old.direct_mode;
+        s->st.coarse_mx = old.coarse_mx;
+        s->st.coarse_mx_s1_fp6 = old.coarse_mx_s1_fp6;
+        s->st.coarse_mx_steps = old.coarse_mx_steps;
+        s->st.replay_threads = old.replay_threads;
         for (int mi = 0; mi < 2; mi++) {
             s->st.coarse_mode_tiles[mi] = old.coarse_mode_tiles[mi];
             s->st.coarse_mode_lgroups[mi] = old.coarse_mode_lgroups[mi];

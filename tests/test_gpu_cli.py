@@ -132,6 +132,51 @@ def test_associate_kmers_gpus_row_sharded(tmp_path, gpus):
     _compare_dirs(str(out_p), str(out_o))
 
 
+def _quota():
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(q) // int(p)))
+    except Exception:
+        pass
+    return n
+
+
+def test_associate_kmers_parallel_1_is_raised_to_the_cpu_quota(tmp_path):
+    """kmers_gwas.py passes --parallel 1 by default (src/py/pipeline_parser.py:31); here that would be ONE replay thread per
+    GPU, ~20x slower than the GPU it serves. The tool raises a --parallel below the CPU quota to the quota (divided among
+    the GPUs), says so on stderr, and KGWAS_STRICT_PARALLEL=1 keeps the literal value. Results do not depend on it."""
+    import re
+    names, acc, Y = onp.load_phenotypes(os.path.join(GOLD, "resistence.pheno"))
+    S_f, k = 241, 31
+    rows = random_table(30_001, S_f, seed=91, dup_frac=0.3)
+    base = str(tmp_path / "kmers_table")
+    onp.write_table(base, acc, k, rows[:, 0], rows[:, 1:])
+    outs = []
+    for strict in (False, True):
+        out = tmp_path / ("strict" if strict else "auto")
+        out.mkdir()
+        cmd = [os.path.join(BIN, "associate_kmers"), "-p", os.path.join(GOLD, "resistence.pheno"), "-b", "pheno", "-o", str(out),
+               "-n", "501", "--parallel", "1", "--kmers_table", base, "--kmer_len", "31", "--maf", "0.050000", "--mac", "5", "--gpus", "2"]
+        env = dict(os.environ)
+        env.pop("KGWAS_STRICT_PARALLEL", None)
+        if strict:
+            env["KGWAS_STRICT_PARALLEL"] = "1"
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        m = re.search(r"replay_threads=(\d+) replay_threads_per_gpu=(\d+)", r.stderr)
+        assert m, r.stderr[-2000:]
+        q = _quota()
+        if strict or q <= 1:
+            assert (int(m.group(1)), int(m.group(2))) == (1, 1)
+        else:
+            assert int(m.group(1)) == q and int(m.group(2)) == max(1, q // 2)
+            assert "is below the %d CPUs" % q in r.stderr
+        outs.append(str(out))
+    _compare_dirs(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("ranks,merge", [(2, "root"), (3, "column")])
 def test_bench_ranks_merge_over_torch_distributed(ranks, merge):
     """bench.py's N > 1 path with real scan sessions: `ranks` processes (torch.distributed over gloo, all on the one GPU of

@@ -114,14 +114,18 @@ def test_topn_identities_with_ties(kernel, binary, dup):
     scan.close()
 
 
+@pytest.mark.parametrize("mx", [1, 0])
 @pytest.mark.parametrize("slices", [1, 2])
 @pytest.mark.parametrize("S,P,shift", [(241, 1, 0.0), (241, 5, 0.0), (241, 40, 100.0), (1024, 101, 0.0), (1024, 130, -7.5),
                                        (1500, 23, 3.0), (300, 333, 1.0), (2048, 40, 0.5), (2600, 9, 0.0),
                                        (2048, 201, 0.0)])  # BASELINE configs[3]: 4 sample groups x several LDS groups
-def test_coarse_filter_shapes(monkeypatch, slices, S, P, shift):
-    """The int8 filter in every operand-tile shape (1..8 tiles per LDS group, one or more LDS groups, 1..6
-    512-sample groups), with one and with two int8 slices per column, on shifted phenotypes (the quantisation is
-    centred) and duplicated patterns: survivors, pop order, scores and push counts equal the oracle's."""
+def test_coarse_filter_shapes(monkeypatch, mx, slices, S, P, shift):
+    """The coarse filter - the block-scaled one (mx = 1, the default: FP4 table bits x FP6 (+ FP4 / FP6) slices, full and
+    quarter sample groups, 1..7 column tiles per LDS group, 4 and 8 row tiles per wave) and the int8 one (mx = 0) - in every
+    operand-tile shape (one or more LDS groups, 1..6 512-sample groups), with one and with two slices per column, on
+    shifted phenotypes (the quantisation is centred) and duplicated patterns: survivors, pop order, scores and push
+    counts equal the oracle's."""
+    monkeypatch.setenv("KGWAS_COARSE_MX", str(mx))
     monkeypatch.setenv("KGWAS_COARSE_SLICES", str(slices))
     rows = random_table(40000, S, seed=S + P, dup_frac=0.2)
     col = np.arange(S, dtype=np.uint64)
@@ -136,7 +140,8 @@ def test_coarse_filter_shapes(monkeypatch, slices, S, P, shift):
     assert st["kernel_used"] == kg.KERNEL_COARSE
     mi = slices - 1  # the forced operand set is the only one built, and it covers all columns
     assert st["coarse_mode_tiles"][1 - mi] == 0 and st["coarse_mode_launches"][mi] > 0
-    assert st["coarse_mode_tiles"][mi] * st["coarse_mode_lgroups"][mi] >= slices * ((P + 15) // 16)
+    # (block-scaled filter: a column tile carries both slices)
+    assert st["coarse_mode_tiles"][mi] * st["coarse_mode_lgroups"][mi] >= (1 if mx else slices) * ((P + 15) // 16)
     _check_topn(scan, exp, P)
     assert st["rows_tested"] == exp["tested"]
     scan.close()
@@ -146,6 +151,7 @@ def test_coarse_filter_shapes(monkeypatch, slices, S, P, shift):
 def test_wide_filter_variant(monkeypatch, S, P):
     """score_wide.hip (opt-in, KGWAS_WIDE=1): the int8 filter with all 9-14 operand tiles' accumulators in registers and
     the operands streamed through LDS by global_load_lds - same survivors, so the same heaps as the oracle's."""
+    monkeypatch.setenv("KGWAS_COARSE_MX", "0")
     monkeypatch.setenv("KGWAS_WIDE", "1")
     monkeypatch.setenv("KGWAS_COARSE_SLICES", "1")
     rows = random_table(40_000, S, seed=S + P, dup_frac=0.2)
@@ -194,12 +200,14 @@ def test_narrow_filter_few_columns(S_f, S, P, shift, binary, reorder):
     scan.close()
 
 
+@pytest.mark.parametrize("mx", [1, 0])
 @pytest.mark.parametrize("slices", [0, 1, 2])
-def test_config3_shape_ft10_phenotype(monkeypatch, slices):
+def test_config3_shape_ft10_phenotype(monkeypatch, slices, mx):
     """BASELINE configs[2] in shape: 1135 accessions x 101 columns, column 0 = the reference's flowering-time example
     (examples/flowering_time_arabidopsis/FT10.pheno, first 1135 accessions, raw values: all large and positive, which
     stresses the centred quantisation of the int8 filter), columns 1..100 its permutations. slices = 0 leaves the choice
     of the operand set to the session (both sets resident, chunk by chunk)."""
+    monkeypatch.setenv("KGWAS_COARSE_MX", str(mx))
     if slices:
         monkeypatch.setenv("KGWAS_COARSE_SLICES", str(slices))
     names, acc, Yf = onp.load_phenotypes(os.path.join(GOLD, "FT10.pheno"))
