@@ -33,7 +33,9 @@ sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 I8_MFMA_PEAK_TOPS = 5000.0    # dense int8 (= fp8 rate, 2x bf16); measured ceiling 3944-4404 TOPS (same guide)
+MX_MFMA_PEAK_TOPS = 10000.0   # dense FP4 / FP6 block-scaled (v_mfma_scale_f32_16x16x128_f8f6f4); measured 8250 (fp4 x fp6) - 9532 (fp4 x fp4), tools/probe_mx6.hip
 HBM_PEAK_GBPS = 8000.0
+PCIE_GEN5_X16_GBPS = 64.0
 
 
 def make_phenotypes(S, n_perm, seed):
@@ -125,7 +127,17 @@ def p1_scan_record(kg, torch, table, stream, M, S, Y, topn, mac, dev, host_threa
                 "filter_kernel_hbm_GBps": gb / (filt_ms * 1e-3) if filt_ms > 0 else None,
                 "filter_kernel_frac_of_8TBps": gb / (filt_ms * 1e-3) / HBM_PEAK_GBPS if filt_ms > 0 else None,
                 "heap_pushes_per_pass": sum(s["heap_pushes"] for s in sts) // passes,
-                "replay_cpu_ms_per_pass": sum(s["replay_cpu_ms"] for s in sts) / passes}
+                "records_per_pass": sum(s["candidates"] for s in sts) // passes,
+                "chunks_per_pass": sum(s["chunks"] for s in sts) // passes,
+                "replay_cpu_ms_per_pass": sum(s["replay_cpu_ms"] for s in sts) / passes,
+                # where a pass goes: the dense start (scores of the first rows + the heap fill, before any replay), the
+                # streaming replay's wall time (ONE heap, one thread: the critical path), of which the part after the
+                # GPU had finished (tail); the GPU's kernels run beside it
+                "breakdown_ms": {"dense_start": sum(s["dense_ms"] for s in sts) / passes,
+                                 "replay_wall": sum(s["replay_wall_ms"] for s in sts) / passes,
+                                 "replay_tail_after_gpu": sum(s["replay_tail_ms"] for s in sts) / passes,
+                                 "gpu_wait": sum(s["gpu_wait_ms"] for s in sts) / passes,
+                                 "finish_pops": (sum(s.get("finish_ms", 0.0) for s in sts) / passes) if "finish_ms" in sts[0] else None}}
     finally:
         scan.close()
 
@@ -169,8 +181,11 @@ def kinship_record(kg, torch, stream, dev, rows=8_000_000, S_f=1135, seed=202406
     return {"workload": "%dM k-mers x %d accessions, maf 0.05 (BASELINE.json configs[4] in shape)" % (rows // 1_000_000, S_f),
             "kernels": "kin_transpose_kernel + kin_gram_kernel", "kernels_ms": k_ms, "wall_ms": float(np.mean(wall)),
             "rows_per_s": rows / (k_ms * 1e-3), "rows_used": int(n_used),
-            "algorithmic_TOPs": 2.0 * ops / (k_ms * 1e-3) / 1e12, "peak_TOPs": I8_MFMA_PEAK_TOPS,
-            "frac": 2.0 * ops / (k_ms * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS,
+            # the Gram kernel multiplies FP4 x FP4 (v_mfma_scale_f32_16x16x128_f8f6f4): its dense peak is the FP4 one
+            "algorithmic_TOPs": 2.0 * ops / (k_ms * 1e-3) / 1e12, "peak_TOPs": MX_MFMA_PEAK_TOPS,
+            "frac": 2.0 * ops / (k_ms * 1e-3) / 1e12 / MX_MFMA_PEAK_TOPS,
+            "frac_rows_used": 2.0 * (0.5 * float(S_f) * S_f * int(n_used)) / (k_ms * 1e-3) / 1e12 / MX_MFMA_PEAK_TOPS,
+            "frac_of_int8_peak_5POPs": 2.0 * ops / (k_ms * 1e-3) / 1e12 / I8_MFMA_PEAK_TOPS,
             "pair_updates_per_s": rows * (S_f * (S_f - 1) / 2.0) / (k_ms * 1e-3),
             "parity_check": bool(ng == n and (Kg == K).all()),
             "cpu_baseline": {"value": cpu_rows / cpu_dt, "unit": "rows/s", "cores": 1, "kind": "port",
@@ -178,6 +193,80 @@ def kinship_record(kg, torch, stream, dev, rows=8_000_000, S_f=1135, seed=202406
                                        "(src/kmers_multiple_databases.cpp:418-438 is single-threaded)" % cpu_rows,
                              "seconds": cpu_dt,
                              "pair_updates_per_s": cpu_rows * (S_f * (S_f - 1) / 2.0) / cpu_dt}}
+
+
+def ingest_record(kg, torch, stream, dev, host_threads, rows=40_000_000, S=1135, n_perm=100, topn=10001, seed=20240601):
+    """The streamed path every command-line user runs (the tools always stream the .table; BASELINE.json configs[2],
+    the 1001G table, never fits HBM as sized there): `rows` rows x 1135 samples x 101 columns through
+    kgwas_scan_feed_host (table in host memory) and through kgwas_scan_feed_table (.table file in the page cache), with the
+    HBM-resident scan of the same rows beside them. GB/s of table bytes, fraction of the PCIe Gen5 x16 bound; never `value`.
+    parity_check: all three give identical heaps (bytes), and the first 2 M rows equal the oracle's."""
+    import tempfile
+    import shutil
+    from oracle import binding as ob
+    W = 1 + (S + 63) // 64
+    Y = make_phenotypes(S, n_perm, 7)
+    P = Y.shape[0]
+    mac = kg.min_count(S, 0.05, 5)
+    col = np.arange(S, dtype=np.uint64)
+    table = torch.empty(rows * W, dtype=torch.int64, device="cuda")
+    kg.synth_rows_device(table.data_ptr(), 0, rows, S, seed, stream)
+    torch.cuda.synchronize()
+    host = table.cpu().numpy().view(np.uint64)
+    d = tempfile.mkdtemp(dir=os.environ.get("KGWAS_BENCH_TMP", "/tmp"))
+    try:
+        base = os.path.join(d, "t")
+        hdr = np.zeros(16, np.uint8)
+        hdr[:4] = np.frombuffer(np.uint32(0xDDCCBBAA).tobytes(), np.uint8)
+        hdr[4:12] = np.frombuffer(np.uint64(S).tobytes(), np.uint8)
+        hdr[12:16] = np.frombuffer(np.uint32(31).tobytes(), np.uint8)
+        with open(base + ".table", "wb") as f:
+            f.write(hdr.tobytes())
+            host.tofile(f)
+        open(base + ".names", "w").write("".join("s%d\n" % i for i in range(S)))
+        tbl = kg.KmersTable(base, 31)
+        scan = kg.AssociationScan(S, col, Y, topn, mac, device=dev, host_threads=host_threads)
+        gb = rows * 8.0 * W / 1e9
+        out = {"workload": "%dM k-mers x %d samples, 1 phenotype + %d permutations, top-%d (BASELINE.json configs[2] in shape)"
+                           % (rows // 1_000_000, S, n_perm, topn), "table_GB": gb, "pcie_gen5_x16_GBps": PCIE_GEN5_X16_GBPS}
+        ref = None
+        same = True
+        for key, fn in (("hbm_resident", lambda: scan.feed_device(table.data_ptr(), rows, 0, stream)),
+                        ("host_memory", lambda: scan.feed_host(host, 0)),
+                        ("table_file_page_cache", lambda: scan.feed_table(tbl, 0, rows))):
+            best = 1e9
+            for _ in range(3):
+                scan.reset()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                fn()
+                scan.finish()
+                best = min(best, time.perf_counter() - t0)
+            res = [scan.result(j) for j in (0, P // 2, P - 1)]
+            if ref is None:
+                ref = [tuple(x.copy() for x in r) for r in res]
+            same = same and all(a.tobytes() == b.tobytes() for r, q in zip(res, ref) for a, b in zip(r, q))
+            out[key] = {"ms": best * 1e3, "GBps": gb / best, "rows_per_s": rows / best, "kmer_pheno_per_s": rows * P / best,
+                        "frac_of_pcie_gen5_x16": (gb / best) / PCIE_GEN5_X16_GBPS if key != "hbm_resident" else None}
+        # the first 2 M rows through the file path against the oracle
+        n_chk = min(2_000_000, rows)
+        exp = ob.associate(host[: n_chk * W].reshape(n_chk, W), S, col, Y, topn, mac, batch_size=10_000_000, threads=min(usable_cpus(), P))
+        scan.reset()
+        scan.feed_table(tbl, 0, n_chk)
+        scan.finish()
+        st = scan.stats()
+        ok = st["heap_pushes"] == exp["pushes"] and st["rows_tested"] == exp["tested"]
+        for j in range(P):
+            k, sc, r = scan.result(j)
+            o = exp["per_pheno"][j]
+            ok = ok and len(k) == len(o["kmer"]) and bool((k == o["kmer"]).all()) and bool((r == o["file_row"]).all()) \
+                and sc.tobytes() == o["score"].tobytes()
+        out["parity_check"] = bool(ok and same)
+        scan.close()
+        tbl.close()
+        return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def cgroup_throttle():
@@ -202,7 +291,9 @@ def main():
     ap.add_argument("--chunk-rows", type=int, default=0)
     ap.add_argument("--cpu-sample-rows", type=int, default=6_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-subrecords", action="store_true", help="skip p1_scan / kinship / parity_check")
+    ap.add_argument("--no-subrecords", action="store_true", help="skip p1_scan / kinship / ingest")
+    ap.add_argument("--no-ingest", action="store_true", help="skip the streamed-path sub-record")
+    ap.add_argument("--ingest-rows", type=int, default=40_000_000)
     ap.add_argument("--check-merge", action="store_true",
                     help="N > 1: rank 0 also scans all shards' rows in one session and compares the merged heaps with it (small runs)")
     args = ap.parse_args()
@@ -322,6 +413,24 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    # what every rank did, side by side: a sub-linear point then says which rank, and which side (host replay, GPU, merge)
+    per_rank = None
+    if world > 1:
+        mine = [float(np.mean(step_ms)), float(np.max(step_ms)),
+                sum(s_["score_kernel_ms"] for s_ in stats) / args.steps, sum(s_["coarse_kernel_ms"] for s_ in stats) / args.steps,
+                sum(s_["replay_ms"] for s_ in stats) / args.steps, sum(s_["replay_cpu_ms"] for s_ in stats) / args.steps,
+                float(stats[-1].get("replay_threads", host_threads)), sum(s_["gpu_wait_ms"] for s_ in stats) / args.steps,
+                sum(s_["replay_tail_ms"] for s_ in stats) / args.steps, sum(s_["dense_ms"] for s_ in stats) / args.steps,
+                float(np.mean(merge_ms[n_merge_warm:])) if merge_ms[n_merge_warm:] else 0.0,
+                sum(s_["heap_pushes"] for s_ in stats) / args.steps, sum(s_["candidates"] for s_ in stats) / args.steps,
+                float(torch.cuda.current_device())]
+        t = torch.tensor(mine, dtype=torch.float64, device=kdist._dev())
+        bufs = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(bufs, t)
+        keys = ["step_ms", "step_ms_max", "kernels_ms", "coarse_kernel_ms", "replay_ms", "replay_cpu_ms", "replay_threads", "gpu_wait_ms",
+                "replay_tail_ms", "dense_phase_ms", "merge_ms", "heap_pushes", "candidates", "device"]
+        per_rank = [dict(zip(keys, [float(x) for x in b.cpu().tolist()]), rank=i) for i, b in enumerate(bufs)]
+
     # the N = 1 reference of a multi-GPU run: rank 0's shard alone, no merge (other ranks wait)
     single = None
     if world > 1:
@@ -336,6 +445,20 @@ def main():
             d1 = (time.perf_counter() - t1) / k1
             single = {"ms_per_step": d1 * 1e3, "value": M * P / d1, "steps": k1,
                       "note": "rank 0's shard scanned alone while the other ranks idle: the N = 1 point for this curve"}
+        dist.barrier()
+
+    shard_parity = None
+    if world > 1 and not args.no_cpu_baseline:
+        if rank == 0:
+            try:
+                from oracle import binding as ob
+                n_chk = min(2_000_000, M)
+                rows_h = kg.synth_rows_host(first_row, n_chk, S, seed_table)
+                exp = ob.associate(rows_h, S, col, Y, args.topn, mac, batch_size=10_000_000, threads=min(usable_cpus(), P))
+                shard_parity = parity_check(kg, table.data_ptr(), stream, S, col, Y, args.topn, mac, n_chk, exp, dev, host_threads)
+            except Exception as e:
+                shard_parity = False
+                print("shard parity check failed: %r" % (e,), file=sys.stderr)
         dist.barrier()
 
     merge_check = None
@@ -372,26 +495,35 @@ def main():
         peak, peak_unit, dtype = F32_MFMA_PEAK_TFLOPS, "TFLOP/s", "f32"
         executed = None
         hbm_bound = False
+        mx = bool(stats[-1].get("coarse_mx", 0))
         if ku == 3:
-            # dominant kernel = the int8 coarse filter; its own launches are timed separately from the exact
+            # dominant kernel = the coarse filter; its own launches are timed separately from the exact
             # re-scoring of the survivors. `achieved` stays ALGORITHMIC (2*S flop per k-mer x column); the
-            # kernel executes 1-2 int8 slices per column and pads columns/samples to its tiles (`executed`).
+            # kernel executes 1-2 slices per column and pads columns/samples to its tiles (`executed`).
+            # `peak` is the dense peak of the instruction it runs: FP4/FP6 block-scaled MFMA for the default filter
+            # (the same line also gives the fraction of the 5 POP/s int8/fp8 peak), int8 MFMA with KGWAS_COARSE_MX=0.
             k_ms = sum(s["coarse_kernel_ms"] for s in stats)
             k_launch = sum(s["coarse_launches"] for s in stats)
             avg_ms = k_ms / max(k_launch, 1)
-            peak, peak_unit, dtype = I8_MFMA_PEAK_TOPS, "TOP/s (int8 MFMA dense)", "i8 filter + f32/f64 exact re-score"
+            if mx:
+                kernel_name = "mx_kernel"
+                peak, peak_unit = MX_MFMA_PEAK_TOPS, "TOP/s (FP4/FP6 block-scaled MFMA dense)"
+                dtype = "fp4 x fp6/fp4 block-scaled filter + f32/f64 exact re-score"
+            else:
+                peak, peak_unit, dtype = I8_MFMA_PEAK_TOPS, "TOP/s (int8 MFMA dense)", "i8 filter + f32/f64 exact re-score"
             Wm = 2 * ((S + 127) // 128)
             kgroups = (Wm + 7) // 8
-            # executed int8 work: per operand set, padded samples x padded operand columns x rows filtered with it
+            k_padded = stats[-1]["coarse_mx_steps"] * 128 if mx else kgroups * 512
+            # executed work: per operand set, padded samples x padded operand columns (x slices) x rows filtered with it
             ex_ops = 0.0
             for mi in range(2):
                 tile_slices = stats[-1]["coarse_mode_tile_slices"][mi]
-                ex_ops += 2.0 * (kgroups * 512) * (tile_slices * 16) * sum(st_["coarse_mode_rows"][mi] for st_ in stats)
+                ex_ops += 2.0 * k_padded * (tile_slices * 16) * sum(st_["coarse_mode_rows"][mi] for st_ in stats)
             rows_scored = sum(sum(st_["coarse_mode_rows"]) for st_ in stats)
             achieved_tflops = flop_per_row * rows_scored / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
             executed = ex_ops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
             # roofline side: 2*S*P op per 8*W bytes against the balance point of the int8 pipe and HBM
-            if flop_per_row / (8.0 * W) < I8_MFMA_PEAK_TOPS * 1e12 / (HBM_PEAK_GBPS * 1e9):
+            if flop_per_row / (8.0 * W) < peak * 1e12 / (HBM_PEAK_GBPS * 1e9):
                 hbm_bound = True
                 peak, peak_unit = HBM_PEAK_GBPS, "GB/s (HBM3E)"
                 achieved_tflops = rows_scored * 8.0 * W / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0  # algorithmic bytes / s
@@ -401,15 +533,25 @@ def main():
         # HBM traffic per launch cannot be read from inside the process (PMC counters need rocprofv3 around it):
         # it is taken from the committed PMC passes of this workload and only when that profile was taken of the
         # kernel that ran here (FETCH_SIZE x2 on gfx950 + WRITE_SIZE); otherwise null.
-        traffic, traffic_src = None, None
-        pmc_name = "r01b_coarse_pmc_hbm_traffic.json" if ku == 3 else "r01a_exactmfma_pmc_hbm_traffic.json"
-        for cand in ("r02_coarse_pmc_hbm_traffic.json", pmc_name):
+        # The profile names the kernel and carries the hash of the kernel source it was taken of: a profile of another
+        # kernel, or of an older version of this one, is not used (traffic: null, traffic_stale_profile: true).
+        traffic, traffic_src, traffic_stale = None, None, False
+        cands = (["r03_mx_pmc_hbm_traffic.json"] if mx else ["r02_coarse_pmc_hbm_traffic.json", "r01b_coarse_pmc_hbm_traffic.json"]) \
+            if ku == 3 else ["r01a_exactmfma_pmc_hbm_traffic.json"]
+        src_file = {"mx_kernel": "score_mx.hip", "coarse_kernel": "score_coarse.hip", "score_mfma_kernel": "score_mfma.hip"}.get(kernel_name)
+        for cand in cands:
             pmc = os.path.join(ROOT, "profiles", cand)
             if S == 1024 and P == 101 and ku in (2, 3) and os.path.exists(pmc):
                 try:
                     j = json.load(open(pmc))
                     if kernel_name not in str(j.get("kernel", kernel_name)):
-                        raise RuntimeError("profile %s is of kernel %r, this run used %r" % (cand, j.get("kernel"), kernel_name))
+                        continue
+                    if "kernel_source_sha16" in j and src_file:
+                        import hashlib
+                        cur = hashlib.sha256(open(os.path.join(ROOT, "kmersgwas_amd", "csrc", src_file), "rb").read()).hexdigest()[:16]
+                        if cur != j["kernel_source_sha16"]:
+                            traffic_stale = True
+                            continue
                     # PMC bytes per row of the steady launches -> GB per average launch of this run
                     traffic = j["traffic_bytes_per_row"] * (rows_scored / max(k_launch, 1)) / 1e9
                     traffic_src = "profiles/" + cand
@@ -432,7 +574,10 @@ def main():
             "roofline": {"bound": "hbm" if hbm_bound else ("mfma" if ku in (2, 3) else "valu"), "kernel": kernel_name,
                          "achieved": achieved_tflops, "peak": peak, "unit": peak_unit,
                          "frac": achieved_tflops / peak, "executed_TOPs": executed,
-                         "coarse_sets": ([{"int8_slices": mi + 1, "tiles_per_lds_group": stats[-1]["coarse_mode_tiles"][mi],
+                         "frac_of_int8_fp8_peak_5POPs": (achieved_tflops / I8_MFMA_PEAK_TOPS) if (ku == 3 and not hbm_bound) else None,
+                         "filter": (("block-scaled MFMA: FP4 table bits x FP6 + %s slices, one accumulator per column tile, %d K=128 steps"
+                                     % ("FP6" if stats[-1]["coarse_mx_s1_fp6"] else "FP4", stats[-1]["coarse_mx_steps"])) if mx else "int8 MFMA") if ku == 3 else None,
+                         "coarse_sets": ([{"slices": mi + 1, "tiles_per_lds_group": stats[-1]["coarse_mode_tiles"][mi],
                                             "lds_groups": stats[-1]["coarse_mode_lgroups"][mi],
                                             "tile_slices_per_row": stats[-1]["coarse_mode_tile_slices"][mi],
                                             "launches_per_step": sum(st_["coarse_mode_launches"][mi] for st_ in stats) / args.steps,
@@ -440,7 +585,7 @@ def main():
                                             "ms_per_step": sum(st_["coarse_mode_ms"][mi] for st_ in stats) / args.steps}
                                            for mi in range(2) if stats[-1]["coarse_mode_tiles"][mi]] if ku == 3 else None),
                          "executed_frac": (executed / peak) if executed else None, "traffic": traffic,
-                         "traffic_from_profile": traffic is not None,
+                         "traffic_from_profile": traffic is not None, "traffic_stale_profile": traffic_stale,
                          "traffic_unit": "GB per average launch (HBM-side, PMC)", "traffic_source": traffic_src,
                          "algorithmic_GB_per_launch": rows_scored / max(k_launch, 1) * 8.0 * W / 1e9,
                          "launches": k_launch, "avg_launch_ms": avg_ms,
@@ -451,12 +596,18 @@ def main():
             "host": {"replay_ms_per_step": sum(s["replay_ms"] for s in stats) / args.steps,
                      "replay_cpu_ms_per_step": sum(s["replay_cpu_ms"] for s in stats) / args.steps,
                      "replay_tail_ms_per_step": sum(s["replay_tail_ms"] for s in stats) / args.steps,
+                     # the replay pool: busiest / mean / least busy worker and the wall time the pool was up (a step is that
+                     # plus the dense start before it)
+                     "replay_worker_busy_ms": {"max": sum(s["replay_ms"] for s in stats) / args.steps,
+                                               "mean": sum(s["replay_cpu_ms"] for s in stats) / args.steps / max(int(stats[-1].get("replay_threads", 1)), 1),
+                                               "min": sum(s["replay_min_ms"] for s in stats) / args.steps},
+                     "replay_wall_ms_per_step": sum(s["replay_wall_ms"] for s in stats) / args.steps,
                      "candidates_per_step": sum(s["candidates"] for s in stats) // args.steps,
                      "heap_pushes_per_step": sum(s["heap_pushes"] for s in stats) // args.steps,
                      "chunks_per_step": sum(s["chunks"] for s in stats) // args.steps,
                      "gpu_wait_ms_per_step": sum(s["gpu_wait_ms"] for s in stats) / args.steps,
                      "dense_phase_ms_per_step": sum(s["dense_ms"] for s in stats) / args.steps,
-                     "cores": usable_cpus(), "replay_threads_per_rank": host_threads, "logical_cpus": os.cpu_count(),
+                     "cores": usable_cpus(), "replay_threads_per_rank": int(stats[-1].get("replay_threads", host_threads)), "logical_cpus": os.cpu_count(),
                      "step_ms": [round(x, 2) for x in (step_ms if len(step_ms) <= 40 else step_ms[:20] + step_ms[-20:])],
                      "step_ms_median": float(np.median(step_ms)), "step_ms_max": float(np.max(step_ms)),
                      # cross-shard merge on rank 0's clock (includes waiting for the slowest rank's scan)
@@ -465,6 +616,11 @@ def main():
                      # CFS bandwidth throttling of this container during the timed region (cpu.stat deltas)
                      "cgroup_nr_throttled": thr1[0] - thr0[0], "cgroup_throttled_ms": (thr1[1] - thr0[1]) / 1e3},
         }
+        if per_rank is not None:
+            out["ranks"] = per_rank
+        if shard_parity is not None:
+            out["parity_check"] = bool(shard_parity)
+            out["parity_check_scope"] = "rank 0: the GPU's heaps over the first 2 M rows of its shard against the oracle's"
         if single is not None:
             out["single_gpu_same_shard"] = single
         if merge_check is not None:
@@ -493,6 +649,12 @@ def main():
                 out["kinship"] = kinship_record(kg, torch, stream, dev)
             except Exception as e:
                 out["kinship"] = {"error": repr(e)}
+            torch.cuda.empty_cache()
+            if not args.no_ingest:
+                try:
+                    out["ingest"] = ingest_record(kg, torch, stream, dev, host_threads, rows=args.ingest_rows)
+                except Exception as e:
+                    out["ingest"] = {"error": repr(e)}
         print(json.dumps(out))
     if last is not None:
         last.close()

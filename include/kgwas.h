@@ -163,6 +163,8 @@ typedef struct kgwas_scan_stats {
     uint32_t coarse_mx_s1_fp6;  /* block-scaled filter: the second slice is FP6 (else FP4) */
     uint32_t coarse_mx_steps;   /* block-scaled filter: MFMA steps (K = 128) per row tile, column tile and slice */
     uint32_t replay_threads;    /* host threads replaying heap pushes in this session */
+    double replay_min_ms;       /* the LEAST busy replay worker's busy time (replay_ms: the busiest one's; replay_cpu_ms / replay_threads: the mean) */
+    double replay_wall_ms;      /* wall time from the start of the streaming replay (first sparse chunk submitted) to its end */
 } kgwas_scan_stats;
 
 int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out);

@@ -22,7 +22,7 @@ KERNEL_AUTO, KERNEL_VALU, KERNEL_MFMA, KERNEL_COARSE, KERNEL_NARROW = 0, 1, 2, 3
 
 # Every symbol include/kgwas.h declares (tests check the library exports each one).
 SYMBOLS = [
-    "kgwas_last_error", "kgwas_version", "kgwas_device_count",
+    "kgwas_last_error", "kgwas_version", "kgwas_device_count", "kgwas_host_cpu_quota",
     "kgwas_table_open", "kgwas_table_info", "kgwas_table_name", "kgwas_table_column_map", "kgwas_table_read_rows",
     "kgwas_table_close",
     "kgwas_pheno_load", "kgwas_pheno_info", "kgwas_pheno_name", "kgwas_pheno_accession", "kgwas_pheno_values",
@@ -75,6 +75,7 @@ class ScanStats(C.Structure):
         ("coarse_mode_tile_slices", C.c_uint32 * 2),
         ("coarse_mx", C.c_uint32), ("coarse_mx_s1_fp6", C.c_uint32), ("coarse_mx_steps", C.c_uint32),
         ("replay_threads", C.c_uint32),
+        ("replay_min_ms", C.c_double), ("replay_wall_ms", C.c_double),
     ]
 
     def as_dict(self):
@@ -131,6 +132,8 @@ _pstr = C.POINTER(C.c_char_p)
 lib.kgwas_last_error.restype = C.c_char_p
 lib.kgwas_version.restype = C.c_int
 lib.kgwas_device_count.argtypes = [C.POINTER(C.c_int)]
+lib.kgwas_host_cpu_quota.argtypes = []
+lib.kgwas_host_cpu_quota.restype = C.c_uint32
 lib.kgwas_table_open.argtypes = [C.c_char_p, _u32, _pp]
 lib.kgwas_table_info.argtypes = [_vp, _pu64, _pu64, _pu64, C.POINTER(_u32)]
 lib.kgwas_table_name.argtypes = [_vp, _u64, _pstr]

@@ -472,6 +472,8 @@ struct kgwas_scan {
     bool sel_valid = false;  // h_sel holds the minima the heaps will have once the pending dense rows are pushed
     double infl_obs[2] = {4.0, 1.1};  // survivors per candidate of the last finished chunk of each mode
     double mode_k = 0.09;
+    std::chrono::steady_clock::time_point t_feed0;  // KGWAS_TRACE: the timeline's origin (start of the current feed)
+    double t_ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_feed0).count(); }
     uint64_t sum_topn = 0;  // over the columns
     // narrow filter (1-3 columns, score_narrow.hip): replaces coarse_kernel in the same pipeline
     bool narrow = false;
@@ -550,7 +552,7 @@ struct kgwas_scan {
     std::function<void(size_t)> rp_fn;
     ReplayAcc rp_acc;  // sums over the workers of the current streaming replay
     std::atomic<uint64_t> prof_scan{0}, prof_heap{0};  // KGWAS_TRACE: TSC ticks in the record scans / in the heap updates
-    uint64_t rp_max_busy_ns = 0;
+    uint64_t rp_max_busy_ns = 0, rp_min_busy_ns = ~0ull;
     kgwas_scan_stats st{};
     bool finished = false;
     std::vector<std::vector<uint64_t>> res_kmer, res_row;
@@ -1348,7 +1350,10 @@ void replay_worker(kgwas_scan* s, size_t w) {
                     continue;
                 }
                 const size_t si = (size_t)(d % (uint64_t)s->n_slots);
+                const double tr0 = s->trace ? s->t_ms() : 0.0;
                 replay_group(s, s->slot[si], best, acc);
+                if (s->trace && (s->n_groups <= 4 || best == 0))
+                    fprintf(stderr, "[kgwas t=%.3f] worker %zu replayed chunk %llu group %zu in %.3f ms\n", s->t_ms(), w, (unsigned long long)d, best, s->t_ms() - tr0);
                 G.done.store(d + 1, std::memory_order_release);
                 G.busy.store(0u, std::memory_order_release);
                 idle_spins = 0;
@@ -1382,6 +1387,7 @@ void replay_worker(kgwas_scan* s, size_t w) {
     s->rp_acc.busy_ns += acc.busy_ns;
     s->rp_acc.units += acc.units;
     s->rp_max_busy_ns = std::max(s->rp_max_busy_ns, acc.busy_ns);
+    s->rp_min_busy_ns = std::min(s->rp_min_busy_ns, acc.busy_ns);
 }
 
 // The GPU runs up to n_slots chunks ahead of the host replay. Heap pushes are front-loaded (60 % of them
@@ -1392,6 +1398,8 @@ void replay_worker(kgwas_scan* s, size_t w) {
 void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, uint64_t first_row) {
     const uint64_t stride = 1 + s->W_f;
     uint64_t pos = 0;
+    s->t_feed0 = std::chrono::steady_clock::now();
+    if (s->trace) fprintf(stderr, "[kgwas t=0.000] feed %llu rows\n", (unsigned long long)n_rows);
     if (s->count_patterns) hash_patterns(s, d_rows, n_rows);
     const uint64_t depth = s->direct ? (uint64_t)s->n_slots : 1;  // squeezed mode has a single squeeze buffer
     uint64_t sub = 0, cpy = 0, pub = 0;  // chunks submitted / record copies ordered / published in this feed
@@ -1403,6 +1411,7 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
         s->rp_quit.store(false, std::memory_order_release);
         s->rp_acc = ReplayAcc();
         s->rp_max_busy_ns = 0;
+        s->rp_min_busy_ns = ~0ull;
         t_start = std::chrono::steady_clock::now();
         s->pool->start(s->pool->size(), s->rp_fn);
         running = true;
@@ -1426,6 +1435,8 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
         add_replay_stats(s, s->rp_acc);
         // the replay's share of the wall clock: the busiest worker's time (they run side by side)
         s->st.replay_ms += (double)s->rp_max_busy_ns * 1e-6;
+        if (s->rp_min_busy_ns != ~0ull) s->st.replay_min_ms += (double)s->rp_min_busy_ns * 1e-6;
+        s->st.replay_wall_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
         if (s->trace)
             fprintf(stderr, "[kgwas] replay ticks: scanning records %.1f M, heap updates %.1f M (TSC, all workers)\n",
                     (double)s->prof_scan.exchange(0) * 1e-6, (double)s->prof_heap.exchange(0) * 1e-6);
@@ -1508,6 +1519,7 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
                 const size_t si = (size_t)(sub % (uint64_t)s->n_slots);  // its previous chunk was replayed n_slots chunks ago
                 s->slot_left[si].store((uint32_t)s->n_groups, std::memory_order_release);
                 submit_sparse(s, s->slot[si], d_rows + pos * stride, c, first_row + pos, /*count_hist=*/true);
+                if (s->trace) fprintf(stderr, "[kgwas t=%.3f] submit chunk %llu (%llu rows)\n", s->t_ms(), (unsigned long long)sub, (unsigned long long)c);
                 s->rows_submitted += c;
                 sub++;
                 s->seq_submitted.store(sub, std::memory_order_release);
@@ -1520,6 +1532,7 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
             if (cpy < sub && ((cpy == pub && !can_submit) || hipEventQuery(s->slot[(size_t)(cpy % (uint64_t)s->n_slots)].ev_counts) == hipSuccess ||
                               !s->slot[(size_t)(cpy % (uint64_t)s->n_slots)].used_coarse)) {
                 if (fetch_records(s, s->slot[(size_t)(cpy % (uint64_t)s->n_slots)], cpy)) {
+                    if (s->trace) fprintf(stderr, "[kgwas t=%.3f] counts of chunk %llu in, record copy ordered\n", s->t_ms(), (unsigned long long)cpy);
                     cpy++;
                     continue;
                 }
@@ -1535,6 +1548,7 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
                 Slot& sl = s->slot[(size_t)(pub % (uint64_t)s->n_slots)];
                 wait_event(s, sl.ev_done);  // records and counts are in host memory
                 if (chunk_complete(s, sl)) {
+                    if (s->trace) fprintf(stderr, "[kgwas t=%.3f] publish chunk %llu\n", s->t_ms(), (unsigned long long)pub);
                     pub++;
                     {
                         std::lock_guard<std::mutex> lk(s->rp_mu);
@@ -2024,7 +2038,27 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
             //   slice); the accumulator is kappa * sum_i g_i t_i, kappa = 1/16, 1/4, 1/16, so one accumulator unit is
             //   u = w / kappa phenotype units and everything above (kalpha, the error terms in units of Dc) carries over
             //   with that u. The ones column has t = 1 / kappa: its accumulator is N1.
-            const bool use_mx = !(getenv("KGWAS_COARSE_MX") && atoi(getenv("KGWAS_COARSE_MX")) == 0);
+            // Which filter (KGWAS_COARSE_MX=1|0 forces one): the block-scaled one wherever its operands (1.25 bytes per
+            // sample and column with two slices) leave a row no more LDS groups to pass through than the int8 filter's single
+            // slice (1 byte) does. Measured: 1024 x 101 (one group each) 9.9 + 4.3 ms of filter + other kernels per 100 M
+            // rows against 10.4 + 4.8; 2048 x 201 (five groups of three column tiles against four groups of four int8
+            // tiles) 45.0 + 10.8 against 38.7 + 14.4 - there every row is loaded, expanded and tested once per group,
+            // and the int8 filter keeps the shape.
+            bool use_mx;
+            if (const char* e = getenv("KGWAS_COARSE_MX")) {
+                use_mx = atoi(e) != 0;
+            } else {
+                auto groups_for = [&](uint32_t tmax) {
+                    uint64_t g = 1;
+                    while (tmax && ((P + g - 1) / g + 1 + 15) / 16 > tmax) g++;
+                    return tmax ? g : ~0ull;
+                };
+                const uint32_t steps = 4u * (uint32_t)(S / 512) + (uint32_t)((S % 512 + 127) / 128);
+                uint32_t ctm = 0;
+                for (uint32_t ct = 7; ct >= 1 && !ctm; ct--)
+                    if (mx_lds_bytes(steps, ct, 2, 0) <= 160u * 1024u) ctm = ct;
+                use_mx = groups_for(ctm) <= groups_for(s->coarse_T);
+            }
             if (use_mx && !s->narrow && getenv("KGWAS_COARSE_SLICES") == nullptr) want[0] = false;  // one FP6 slice alone: only on request
             auto build_mx = [&](int mi) {
                 const int ns = mi + 1;
@@ -2363,7 +2397,16 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
             s->d_tile_cnt.alloc((size_t)s->key_slots / 256 + P + 2);
             s->d_tile_off.alloc((size_t)s->key_slots / 256 + P + 2);
             s->d_tmp_score.alloc(s->key_slots);
-            KGWAS_HIP(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+            // The record copies run as blit kernels (rocprofv3 shows __amd_rocclr_copyBuffer, not SDMA transfers), and at
+            // normal priority they are only dispatched in the gaps of the compute stream: behind a 0.75 ms filter launch
+            // of a one-column scan, a chunk's 1 MB of records reached the host 1.3-2.8 ms after its counts. A high-priority
+            // queue gets them onto the chip between the running launch's workgroups. KGWAS_COPY_PRIO=0: the old behaviour.
+            {
+                int least = 0, greatest = 0;
+                KGWAS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+                const bool hi = !(getenv("KGWAS_COPY_PRIO") && atoi(getenv("KGWAS_COPY_PRIO")) == 0);
+                KGWAS_HIP(hipStreamCreateWithPriority(&s->copy_stream, hipStreamNonBlocking, hi ? greatest : least));
+            }
             s->row_key_bits = 1;
             while (s->row_key_bits < 32 && (1ull << s->row_key_bits) < s->chunk_max) s->row_key_bits++;
         }
@@ -2429,6 +2472,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         nt = (unsigned)std::min<uint64_t>(nt, P);
         s->pool.reset(new Pool(nt, pick_replay_cpus(nt, s->device)));
         s->st.replay_threads = nt;
+        s->ingest.producer_cpus_ = p->host_threads ? p->host_threads : usable_cpus();
         // Column groups of the replay. Worker w owns the columns w, w + T, ... of the first floor(P / T) * T columns,
         // in groups of at most MAX_LOCKSTEP (a group's heaps take their replacements in lockstep, and stay in their
         // worker's cache from chunk to chunk); the P mod T columns left over float: each is a group of its own that

@@ -21,8 +21,8 @@
 //    extremes: 2.5x tighter than the uniform 961-level grid the same two operands would give.
 //  * the operands (the B side: 1.25 bytes per sample and column with an FP4 second slice, 2560 bytes per MFMA step and
 //    16 columns) sit in LDS for the whole block, as before; a wave owns RT x 16 rows and CT column tiles' accumulators
-//    (RT = 4 with 4..7 column tiles, RT = 8 with up to three - the 2048-sample shapes, whose operands only fit three at a
-//    time).
+//    (RT = 4; eight waves per block with 4..7 column tiles, twelve - three per SIMD, 168 registers - with up to three:
+//    the 2048-sample shapes, whose operands only fit three tiles at a time).
 //  * samples beyond the last full 512-sample group are taken in QUARTER groups of 128 (one MFMA step each, the lane's own
 //    dword shifted by 0..3; up to four of them) instead of a whole padded group: 1135 samples are 9 steps, not 12.
 //
@@ -46,6 +46,9 @@
 // stays alive), 2 no operand expansion, 4 no LDS operand reads, 8 no row loads, 32 no survivor emission.
 #ifndef KGWAS_MX_ABLATE
 #define KGWAS_MX_ABLATE 0
+#endif
+#ifndef KGWAS_MX_DEPHASE
+#define KGWAS_MX_DEPHASE 0
 #endif
 // how many units (two column tiles) the LDS operand reads run ahead of the MFMAs where a step has three or more units
 #ifndef KGWAS_MX_PFD
@@ -194,6 +197,9 @@ __global__ void __launch_bounds__(TH) mx_kernel(MxArgs a, uint32_t rows_per_bloc
                 }
             }
         };
+#if KGWAS_MX_DEPHASE
+        if (wave >= (TH / 128)) __builtin_amdgcn_s_sleep(KGWAS_MX_DEPHASE);  // experiments: the second wave of every SIMD starts late
+#endif
         uint32_t piece[RT][4];
         set_rows(ro, wave_row0);
         if (a.n_full && wave_row0 < a.n_rows) load_group(piece, ro, 0);
@@ -467,14 +473,13 @@ __global__ void __launch_bounds__(TH) mx_kernel(MxArgs a, uint32_t rows_per_bloc
 // exchange areas (RT*48 words each: 1536 B per wave at RT = 8)
 size_t mx_lds_bytes(uint32_t n_steps, uint32_t CT, uint32_t n_slices, uint32_t s1_fp6) {
     const uint32_t sb = n_slices == 1 ? MX_PART0 : (s1_fp6 ? 2u * MX_PART0 : MX_PART0 + 1024u);
-    return (size_t)n_steps * CT * sb + 3u * 112u * 4u + 8u * 1536u;
+    return (size_t)n_steps * CT * sb + 3u * 112u * 4u + 12u * 768u;  // (twelve waves where CT <= 3)
 }
 uint32_t mx_step_bytes_rt(uint32_t n_slices, uint32_t s1_fp6) { return n_slices == 1 ? MX_PART0 : (s1_fp6 ? 2u * MX_PART0 : MX_PART0 + 1024u); }
-uint32_t mx_row_tiles(uint32_t CT) { return CT <= 3 ? 8u : 4u; }
+uint32_t mx_row_tiles(uint32_t CT) { return 4u; }
 
-template <int CT, int RT, int NS, int S1F>
+template <int CT, int RT, int NS, int S1F, int TH = 512>
 static hipError_t launch_mx_t(const MxArgs& a, uint32_t rows_per_block, size_t lds, hipStream_t st) {
-    constexpr int TH = 512;
     const uint32_t rpp = (TH / 64) * RT * 16u;
     rows_per_block = (rows_per_block + rpp - 1) / rpp * rpp;
     const uint32_t n_rowblocks = (uint32_t)((a.n_rows + rows_per_block - 1) / rows_per_block);
@@ -491,9 +496,10 @@ static hipError_t launch_mx_t(const MxArgs& a, uint32_t rows_per_block, size_t l
 template <int NS, int S1F>
 static hipError_t launch_mx_ct(const MxArgs& a, uint32_t CT, uint32_t rows_per_block, size_t lds, hipStream_t st) {
     switch (CT) {
-        case 1: return launch_mx_t<1, 8, NS, S1F>(a, rows_per_block, lds, st);
-        case 2: return launch_mx_t<2, 8, NS, S1F>(a, rows_per_block, lds, st);
-        case 3: return launch_mx_t<3, 8, NS, S1F>(a, rows_per_block, lds, st);
+        // up to three column tiles (48 accumulator registers with four row tiles): 168 registers, three waves per SIMD
+        case 1: return launch_mx_t<1, 4, NS, S1F, 768>(a, rows_per_block, lds, st);
+        case 2: return launch_mx_t<2, 4, NS, S1F, 768>(a, rows_per_block, lds, st);
+        case 3: return launch_mx_t<3, 4, NS, S1F, 768>(a, rows_per_block, lds, st);
         case 4: return launch_mx_t<4, 4, NS, S1F>(a, rows_per_block, lds, st);
         case 5: return launch_mx_t<5, 4, NS, S1F>(a, rows_per_block, lds, st);
         case 6: return launch_mx_t<6, 4, NS, S1F>(a, rows_per_block, lds, st);
