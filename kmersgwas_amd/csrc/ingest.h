@@ -2,9 +2,11 @@
 // (replaces the reference's load-a-batch-then-compute loops,
 // src/associate_kmers.cpp:104-148 and src/emma_kinship_kmers.cpp:86-99).
 //
-// Three pinned pieces are filled by producer threads, two device pieces receive them on a copy stream, and the
-// consumer works on piece k while piece k+1 is copied and piece k+2 is produced. The consumer sees the rows in
-// order, so results do not depend on the piece size.
+// Three pinned pieces are filled by producer threads, three device pieces receive them on a copy stream, and the
+// consumer works on piece k while pieces k+1 and k+2 are copied / queued for copying and produced: the consumer's
+// call is synchronous (a piece's scan + replay), and with only two device pieces the copy of piece k+2 could not be
+// queued before it returned - the link idled for the consumer's fixed costs of every piece (43 -> ~50 GB/s). The
+// consumer sees the rows in order, so results do not depend on the piece size.
 #pragma once
 #include <condition_variable>
 #include <cstdlib>
@@ -152,7 +154,10 @@ public:
         {
             // producer threads: a share of the CPUs this process may use (the replay workers of the consumer need the
             // rest; a streamed scan is bound by the producers and the link, not by the replay)
-            uint64_t nt = std::max(3u, std::min(8u, producer_cpus_ / 2));
+            // (measured on 16 quota CPUs, 40 M rows x 1135 samples from the page cache: 5 producers 41.8 GB/s, 8 35.6, 12 31.7)
+            // reading the page cache (the kernel's copy, ~8 GB/s per thread) takes more threads than copying memory:
+            // half of the CPUs for a file feed (8 of 16: 40.8 GB/s; 5: 35 GB/s), a third for a memory feed
+            uint64_t nt = file_feed_ ? std::max(3u, std::min(8u, producer_cpus_ / 2)) : std::max(3u, std::min(6u, producer_cpus_ / 3));
             if (const char* e = getenv("KGWAS_INGEST_THREADS"))
                 if (atoi(e) > 0) nt = (uint64_t)atoi(e);
             uint64_t items = 0;
@@ -161,8 +166,8 @@ public:
         }
 
         auto compute = [&](uint64_t k) {
-            KGWAS_HIP(hipStreamWaitEvent(stream, ev_[k % 2], 0));
-            consume(d_[k % 2].p, k * piece, count_of(k));
+            KGWAS_HIP(hipStreamWaitEvent(stream, ev_[k % 3], 0));
+            consume(d_[k % 3].p, k * piece, count_of(k));
             {
                 std::unique_lock<std::mutex> lk(mu);
                 consumed = k + 1;
@@ -175,22 +180,25 @@ public:
                 cv.wait(lk, [&] { return stop || done[k]; });
                 if (!done[k]) throw Error(KGWAS_ERR_IO, producer_error.empty() ? "ingest stopped" : producer_error);
             }
-            KGWAS_HIP(hipMemcpyAsync(d_[k % 2].p, h_[k % 3].p, count_of(k) * stride * 8, hipMemcpyHostToDevice, copy_stream_));
-            KGWAS_HIP(hipEventRecord(ev_[k % 2], copy_stream_));
-            if (k >= 1) compute(k - 1);
+            // device piece k % 3 is free: compute(k - 3) returned two turns ago
+            KGWAS_HIP(hipMemcpyAsync(d_[k % 3].p, h_[k % 3].p, count_of(k) * stride * 8, hipMemcpyHostToDevice, copy_stream_));
+            KGWAS_HIP(hipEventRecord(ev_[k % 3], copy_stream_));
+            if (k >= 2) compute(k - 2);
         }
+        if (n_pieces >= 2) compute(n_pieces - 2);
         compute(n_pieces - 1);
     }
 
 private:
     PinBuf<uint64_t> h_[3];
-    DevBuf<uint64_t> d_[2];
+    DevBuf<uint64_t> d_[3];
     hipStream_t copy_stream_ = nullptr;
-    hipEvent_t ev_[2] = {nullptr, nullptr};
+    hipEvent_t ev_[3] = {nullptr, nullptr, nullptr};
     uint64_t piece_rows_ = 0;
 
 public:
     unsigned producer_cpus_ = 16;  // CPUs the process may use (the owner sets it: cgroup quota / GPUs sharing the host)
+    bool file_feed_ = false;       // the next run's fill reads a file (set by the owner before run())
 };
 
 }  // namespace kgwas

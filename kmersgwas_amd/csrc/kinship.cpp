@@ -144,6 +144,7 @@ int kgwas_kinship_feed_host(kgwas_kinship* k, const uint64_t* rows, uint64_t n_r
         if (!k || (!rows && n_rows)) throw Error(KGWAS_ERR_ARG, "kgwas_kinship_feed_host: null argument");
         KGWAS_HIP(hipSetDevice(k->device));
         const uint64_t stride = 1 + k->W_f;
+        k->ingest.file_feed_ = false;
         k->ingest.run(
             stride, n_rows, k->chunk_rows, k->stream,
             [&](uint64_t* dst, uint64_t row_off, uint64_t cnt) { memcpy(dst, rows + row_off * stride, cnt * stride * 8); },
@@ -160,6 +161,7 @@ int kgwas_kinship_feed_table(kgwas_kinship* k, kgwas_table* t, uint64_t row0, ui
         if (n_acc != k->S_f) throw Error(KGWAS_ERR_ARG, "kgwas_kinship_feed_table: table and session disagree on the accession count");
         if (row0 > t_rows || n_rows > t_rows - row0) throw Error(KGWAS_ERR_ARG, "kgwas_kinship_feed_table: out of range");
         KGWAS_HIP(hipSetDevice(k->device));
+        k->ingest.file_feed_ = true;
         k->ingest.run(
             1 + k->W_f, n_rows, k->chunk_rows, k->stream,
             [&](uint64_t* dst, uint64_t row_off, uint64_t cnt) {

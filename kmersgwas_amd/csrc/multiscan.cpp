@@ -25,10 +25,10 @@
 using namespace kgwas;
 
 namespace kgwas {
-// scan.cpp: the pattern hashes a session has collected (device buffer, how many), for the cross-shard distinct count
+// scan_host.cpp: the pattern hashes a session has collected (device buffer, how many), for the cross-shard distinct count
 void scan_patterns_peek(kgwas_scan* s, const uint64_t** d_hashes, uint64_t* n, int* device);
 hipError_t count_distinct_u64(uint64_t* keys, uint64_t n, uint64_t* result, hipStream_t st);
-unsigned usable_cpus_quota();  // scan.cpp: the cgroup CPU quota if there is one, else the hardware thread count
+unsigned usable_cpus_quota();  // scan_host.cpp: the cgroup CPU quota if there is one, else the hardware thread count
 }  // namespace kgwas
 
 struct kgwas_multiscan {

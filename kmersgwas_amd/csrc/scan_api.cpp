@@ -1,0 +1,458 @@
+// scan_api.cpp — the C ABI of the scan session apart from its creation (include/kgwas.h): feeds (device / host / .table),
+// finish and results, histories and heap states for the cross-shard merges, statistics; BestAssociationsHeap and the
+// shard merge through the C ABI.
+#include "scan_internal.h"
+
+extern "C" {
+
+uint32_t kgwas_host_cpu_quota(void) { return usable_cpus(); }
+
+int kgwas_device_count(int* n_devices) {
+    return guarded([&] {
+        if (!n_devices) throw Error(KGWAS_ERR_ARG, "null argument");
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        *n_devices = (e == hipSuccess) ? n : 0;
+    });
+}
+
+int kgwas_scan_feed_device(kgwas_scan* s, const void* d_rows, uint64_t n_rows, uint64_t first_row, void* hip_stream) {
+    return guarded([&] {
+        if (!s || (!d_rows && n_rows)) throw Error(KGWAS_ERR_ARG, "kgwas_scan_feed_device: null argument");
+        if (s->finished) throw Error(KGWAS_ERR_STATE, "scan already finished");
+        KGWAS_HIP(hipSetDevice(s->device));
+        // order our stream after whatever the caller queued on theirs (e.g. the generator kernel)
+        KGWAS_HIP(hipEventRecord(s->ev_user, (hipStream_t)hip_stream));
+        KGWAS_HIP(hipStreamWaitEvent(s->stream, s->ev_user, 0));
+        feed_device_impl(s, reinterpret_cast<const uint64_t*>(d_rows), n_rows, first_row);
+    });
+}
+
+namespace {
+
+// Chunked, double-buffered ingest (ingest.h): piece k+1 is produced and copied while piece k is scored and
+// replayed; results do not depend on the piece size (rows are scored in order, thresholds only ever lag).
+void ingest_run(kgwas_scan* s, uint64_t n_rows, uint64_t first_row, const Ingest::Fill& fill) {
+    if (n_rows == 0) {
+        feed_device_impl(s, nullptr, 0, first_row);
+        return;
+    }
+    s->ingest.run(1 + s->W_f, n_rows, s->chunk_max, s->stream, fill,
+                  [&](const uint64_t* d_rows, uint64_t row_off, uint64_t cnt) {
+                      feed_device_impl(s, d_rows, cnt, first_row + row_off);  // returns with the stream idle
+                  });
+}
+
+}  // namespace
+
+int kgwas_scan_feed_host(kgwas_scan* s, const uint64_t* rows, uint64_t n_rows, uint64_t first_row) {
+    return guarded([&] {
+        if (!s || (!rows && n_rows)) throw Error(KGWAS_ERR_ARG, "kgwas_scan_feed_host: null argument");
+        if (s->finished) throw Error(KGWAS_ERR_STATE, "scan already finished");
+        KGWAS_HIP(hipSetDevice(s->device));
+        const uint64_t stride = 1 + s->W_f;
+        s->ingest.file_feed_ = false;
+        ingest_run(s, n_rows, first_row, [&](uint64_t* dst, uint64_t row_off, uint64_t cnt) {
+            memcpy(dst, rows + row_off * stride, cnt * stride * 8);
+        });
+    });
+}
+
+int kgwas_scan_feed_table(kgwas_scan* s, kgwas_table* t, uint64_t row0, uint64_t n_rows) {
+    return guarded([&] {
+        if (!s || !t) throw Error(KGWAS_ERR_ARG, "kgwas_scan_feed_table: null argument");
+        if (s->finished) throw Error(KGWAS_ERR_STATE, "scan already finished");
+        uint64_t n_acc = 0, t_rows = 0, wpr = 0;
+        uint32_t k = 0;
+        if (kgwas_table_info(t, &n_acc, &t_rows, &wpr, &k) != KGWAS_OK) throw Error(KGWAS_ERR_ARG, kgwas_last_error());
+        if (n_acc != s->S_f) throw Error(KGWAS_ERR_ARG, "kgwas_scan_feed_table: table and scan disagree on the accession count");
+        if (row0 > t_rows || n_rows > t_rows - row0) throw Error(KGWAS_ERR_ARG, "kgwas_scan_feed_table: out of range");
+        KGWAS_HIP(hipSetDevice(s->device));
+        s->ingest.file_feed_ = true;
+        ingest_run(s, n_rows, row0, [&](uint64_t* dst, uint64_t row_off, uint64_t cnt) {
+            if (kgwas_table_read_rows(t, row0 + row_off, cnt, dst) != KGWAS_OK) throw Error(KGWAS_ERR_IO, kgwas_last_error());
+        });
+    });
+}
+
+int kgwas_scan_finish(kgwas_scan* s) {
+    return guarded([&] {
+        if (!s) throw Error(KGWAS_ERR_ARG, "kgwas_scan_finish: null");
+        if (s->finished) return;
+        KGWAS_HIP(hipSetDevice(s->device));
+        KGWAS_HIP(hipStreamSynchronize(s->stream));
+        s->res_kmer.resize(s->n_pheno);
+        s->res_row.resize(s->n_pheno);
+        s->res_score.resize(s->n_pheno);
+        // A worker pops its columns (w, w+T, ...) up to eight at a time in lockstep where their sizes agree.
+        const size_t Tw = s->pool->size();
+        s->pool->parallel_for(std::min<size_t>(Tw, s->n_pheno), [&](size_t w) {
+            std::vector<size_t> mine;
+            for (size_t j = w; j < s->n_pheno; j += Tw) mine.push_back(j);
+            size_t i = 0;
+            while (i < mine.size()) {
+                size_t K = 1;
+                while (K < 8 && i + K < mine.size() && s->heaps[mine[i + K]].size() == s->heaps[mine[i]].size()) K++;
+                const BestHeap* hp[8];
+                std::vector<uint64_t>*km[8], *rw[8];
+                std::vector<double>* sc[8];
+                for (size_t k = 0; k < K; k++) {
+                    const size_t j = mine[i + k];
+                    hp[k] = &s->heaps[j];
+                    km[k] = &s->res_kmer[j];
+                    sc[k] = &s->res_score[j];
+                    rw[k] = &s->res_row[j];
+                }
+                BestHeap::pop_all_n((int)K, hp, km, sc, rw);
+                i += K;
+            }
+        });
+        if (s->count_patterns) {
+            unsigned long long n_hashes = 0;
+            KGWAS_HIP(hipMemcpy(&n_hashes, s->d_pat_cnt.p, 8, hipMemcpyDeviceToHost));
+            uint64_t distinct = 0;
+            KGWAS_HIP(count_distinct_u64(s->d_pat.p, n_hashes, &distinct, s->stream));
+            s->st.patterns = distinct;
+        }
+        s->finished = true;
+    });
+}
+
+int kgwas_scan_result(kgwas_scan* s, uint64_t j, uint64_t* n, const uint64_t** kmer, const double** score,
+                      const uint64_t** row) {
+    return guarded([&] {
+        if (!s || j >= s->n_pheno) throw Error(KGWAS_ERR_ARG, "kgwas_scan_result: bad argument");
+        if (!s->finished) throw Error(KGWAS_ERR_STATE, "call kgwas_scan_finish first");
+        if (n) *n = s->res_kmer[j].size();
+        if (kmer) *kmer = s->res_kmer[j].data();
+        if (score) *score = s->res_score[j].data();
+        if (row) *row = s->res_row[j].data();
+    });
+}
+
+int kgwas_scan_history(kgwas_scan* s, uint64_t j, uint64_t* n, const uint64_t** kmer, const double** score,
+                       const uint64_t** row) {
+    return guarded([&] {
+        if (!s || j >= s->n_pheno) throw Error(KGWAS_ERR_ARG, "kgwas_scan_history: bad argument");
+        if (!s->record_history) throw Error(KGWAS_ERR_STATE, "scan was created without record_history");
+        History& h = s->hist[j];
+        _mm_sfence();
+        h.v_kmer.resize(h.n);
+        h.v_score.resize(h.n);
+        h.v_row.resize(h.n);
+        for (size_t i = 0; i < h.n; i++) {
+            h.v_kmer[i] = h.p[i].kmer;
+            h.v_score[i] = h.p[i].score;
+            h.v_row[i] = h.p[i].row;
+        }
+        if (n) *n = h.n;
+        if (kmer) *kmer = h.v_kmer.data();
+        if (score) *score = h.v_score.data();
+        if (row) *row = h.v_row.data();
+    });
+}
+
+int kgwas_scan_history_above(kgwas_scan* s, const double* thr, uint64_t* counts, const uint64_t** kmer,
+                             const double** score, const uint64_t** row) {
+    return guarded([&] {
+        if (!s || !thr || !counts) throw Error(KGWAS_ERR_ARG, "kgwas_scan_history_above: null argument");
+        if (!s->record_history && !s->history_ring) throw Error(KGWAS_ERR_STATE, "scan was created without record_history");
+        const uint64_t P = s->n_pheno;
+        if (s->history_ring) {  // mode 2: the heap's entries and its last evictions above thr, put in row order
+            std::vector<std::vector<BestHeap::Rec>> recs(P);
+            std::vector<char> ok(P, 1);
+            s->pool->parallel_for(P, [&](size_t j) { ok[j] = s->heaps[j].pushes_above(thr[j], recs[j]) ? 1 : 0; });
+            for (uint64_t j = 0; j < P; j++)
+                if (!ok[j])
+                    throw Error(KGWAS_ERR_STATE, "record_history = 2: column " + std::to_string(j) + " needs evictions that left its ring of " +
+                                                     std::to_string(ring_size(s->history_ring, s->topn[j])) + " (raise KGWAS_HISTORY_RING, or use record_history = 1)");
+            std::vector<uint64_t> off(P + 1, 0);
+            for (uint64_t j = 0; j < P; j++) {
+                counts[j] = recs[j].size();
+                off[j + 1] = off[j] + counts[j];
+            }
+            s->exp_kmer.resize(off[P]);
+            s->exp_score.resize(off[P]);
+            s->exp_row.resize(off[P]);
+            s->pool->parallel_for(P, [&](size_t j) {
+                uint64_t o = off[j];
+                for (const BestHeap::Rec& r : recs[j]) {
+                    s->exp_kmer[o] = r.kmer;
+                    s->exp_score[o] = r.score;
+                    s->exp_row[o] = r.row;
+                    o++;
+                }
+            });
+            if (kmer) *kmer = s->exp_kmer.data();
+            if (score) *score = s->exp_score.data();
+            if (row) *row = s->exp_row.data();
+            return;
+        }
+        // entries add_association could still accept after heaps whose minimum is thr[j]: score > thr[j]
+        // (NaN scores never pass; thr = -inf keeps everything, NaN included, as the heap may not be full)
+        auto keep = [&](uint64_t j, double sc) { return thr[j] == -std::numeric_limits<double>::infinity() || sc > thr[j]; };
+        _mm_sfence();
+        s->pool->parallel_for(P, [&](size_t j) {
+            const History& h = s->hist[j];
+            uint64_t c = 0;
+            for (size_t i = 0; i < h.n; i++) c += keep(j, h.p[i].score) ? 1 : 0;
+            counts[j] = c;
+        });
+        std::vector<uint64_t> off(P + 1, 0);
+        for (uint64_t j = 0; j < P; j++) off[j + 1] = off[j] + counts[j];
+        s->exp_kmer.resize(off[P]);
+        s->exp_score.resize(off[P]);
+        s->exp_row.resize(off[P]);
+        s->pool->parallel_for(P, [&](size_t j) {
+            const History& h = s->hist[j];
+            uint64_t o = off[j];
+            for (size_t i = 0; i < h.n; i++)
+                if (keep(j, h.p[i].score)) {
+                    s->exp_kmer[o] = h.p[i].kmer;
+                    s->exp_score[o] = h.p[i].score;
+                    s->exp_row[o] = h.p[i].row;
+                    o++;
+                }
+        });
+        if (kmer) *kmer = s->exp_kmer.data();
+        if (score) *score = s->exp_score.data();
+        if (row) *row = s->exp_row.data();
+    });
+}
+
+int kgwas_scan_heaps_export(kgwas_scan* s, uint64_t n_cols, const uint64_t* cols, uint64_t* sizes, const uint64_t** kmer,
+                            const double** score, const uint64_t** row) {
+    return guarded([&] {
+        if (!s || (n_cols && (!cols || !sizes))) throw Error(KGWAS_ERR_ARG, "kgwas_scan_heaps_export: null argument");
+        std::vector<uint64_t> off(n_cols + 1, 0);
+        for (uint64_t c = 0; c < n_cols; c++) {
+            if (cols[c] >= s->n_pheno) throw Error(KGWAS_ERR_ARG, "kgwas_scan_heaps_export: column out of range");
+            sizes[c] = s->heaps[cols[c]].size();
+            off[c + 1] = off[c] + sizes[c];
+        }
+        s->exp_kmer.resize(off[n_cols]);
+        s->exp_score.resize(off[n_cols]);
+        s->exp_row.resize(off[n_cols]);
+        s->pool->parallel_for(n_cols, [&](size_t c) {
+            s->heaps[cols[c]].export_state(s->exp_kmer.data() + off[c], s->exp_score.data() + off[c], s->exp_row.data() + off[c]);
+        });
+        if (kmer) *kmer = s->exp_kmer.data();
+        if (score) *score = s->exp_score.data();
+        if (row) *row = s->exp_row.data();
+    });
+}
+
+int kgwas_scan_heaps_import(kgwas_scan* s, uint64_t n_cols, const uint64_t* cols, const uint64_t* sizes, const uint64_t* kmer,
+                            const double* score, const uint64_t* row) {
+    return guarded([&] {
+        if (!s || (n_cols && (!cols || !sizes))) throw Error(KGWAS_ERR_ARG, "kgwas_scan_heaps_import: null argument");
+        for (uint64_t c = 0; c < n_cols; c++) {
+            if (cols[c] >= s->n_pheno) throw Error(KGWAS_ERR_ARG, "kgwas_scan_heaps_import: column out of range");
+            if (sizes[c] && (!kmer || !score || !row)) throw Error(KGWAS_ERR_ARG, "kgwas_scan_heaps_import: null data");
+        }
+        std::vector<uint64_t> off(n_cols + 1, 0);
+        for (uint64_t c = 0; c < n_cols; c++) off[c + 1] = off[c] + sizes[c];
+        s->pool->parallel_for(n_cols, [&](size_t c) {
+            s->heaps[cols[c]].import_state((size_t)sizes[c], kmer + off[c], score + off[c], row + off[c]);
+        });
+        s->finished = false;
+        refresh_full(s);
+        // The device's thresholds and score histograms describe the rows behind the heaps that were just replaced:
+        // start them again from the imported minima before anything else is fed (the next sparse chunk re-bases the
+        // histograms, start_histograms).
+        KGWAS_HIP(hipSetDevice(s->device));
+        s->hist_ready = false;
+        upload_thresholds(s);
+    });
+}
+
+int kgwas_scan_lowest(const kgwas_scan* s, double* lowest, uint8_t* full) {
+    return guarded([&] {
+        if (!s || !lowest || !full) throw Error(KGWAS_ERR_ARG, "kgwas_scan_lowest: null argument");
+        for (uint64_t j = 0; j < s->n_pheno; j++) {
+            lowest[j] = s->heaps[j].lowest();
+            full[j] = s->heaps[j].full() ? 1 : 0;
+        }
+    });
+}
+
+int kgwas_scan_absorb(kgwas_scan* s, uint64_t n_shards, const uint64_t* counts, const uint64_t* const* kmer,
+                      const double* const* score, const uint64_t* const* row) {
+    return guarded([&] {
+        if (!s || (n_shards && (!counts || !kmer || !score || !row))) throw Error(KGWAS_ERR_ARG, "kgwas_scan_absorb: null argument");
+        const uint64_t P = s->n_pheno;
+        std::vector<std::vector<uint64_t>> off(n_shards, std::vector<uint64_t>(P + 1, 0));
+        for (uint64_t g = 0; g < n_shards; g++)
+            for (uint64_t j = 0; j < P; j++) off[g][j + 1] = off[g][j] + counts[g * P + j];
+        std::atomic<uint64_t> pushes(0);
+        s->pool->parallel_for(P, [&](size_t j) {
+            BestHeap& h = s->heaps[j];
+            uint64_t local = 0;
+            for (uint64_t g = 0; g < n_shards; g++) {  // shards in row order
+                const uint64_t o = off[g][j], n = counts[g * P + j];
+                for (uint64_t i = 0; i < n; i++)
+                    if (h.add(kmer[g][o + i], score[g][o + i], (size_t)row[g][o + i])) {
+                        local++;
+                        if (s->record_history) s->hist[j].push(kmer[g][o + i], score[g][o + i], row[g][o + i]);
+                    }
+            }
+            if (s->record_history) _mm_sfence();  // streaming stores of the history log
+        pushes += local;
+        });
+        s->st.heap_pushes += pushes.load();
+        s->finished = false;
+        refresh_full(s);
+        // feeding may go on after an absorb: the device thresholds follow the heaps (see kgwas_scan_heaps_import)
+        KGWAS_HIP(hipSetDevice(s->device));
+        s->hist_ready = false;
+        upload_thresholds(s);
+    });
+}
+
+int kgwas_scan_reset(kgwas_scan* s) {
+    return guarded([&] {
+        if (!s) throw Error(KGWAS_ERR_ARG, "kgwas_scan_reset: null");
+        KGWAS_HIP(hipSetDevice(s->device));
+        KGWAS_HIP(hipStreamSynchronize(s->stream));
+        make_heaps(s);
+        for (auto& h : s->hist) h.clear();
+        s->all_full = false;
+        s->hist_ready = false;
+        s->rows_submitted = 0;
+        s->pat_upper = 0;
+        KGWAS_HIP(hipMemset(s->d_pat_cnt.p, 0, 8));
+        s->rows_done = 0;
+        s->finished = false;
+        const kgwas_scan_stats old = s->st;
+        s->st = kgwas_scan_stats{};
+        s->st.kernel_used = old.kernel_used;
+        s->st.direct_mode = old.direct_mode;
+        s->st.coarse_mx = old.coarse_mx;
+        s->st.coarse_mx_s1_fp6 = old.coarse_mx_s1_fp6;
+        s->st.coarse_mx_steps = old.coarse_mx_steps;
+        s->st.replay_threads = old.replay_threads;
+        for (int mi = 0; mi < 2; mi++) {
+            s->st.coarse_mode_tiles[mi] = old.coarse_mode_tiles[mi];
+            s->st.coarse_mode_lgroups[mi] = old.coarse_mode_lgroups[mi];
+            s->st.coarse_mode_tile_slices[mi] = old.coarse_mode_tile_slices[mi];
+        }
+    });
+}
+
+int kgwas_scan_get_stats(const kgwas_scan* s, kgwas_scan_stats* st) {
+    return guarded([&] {
+        if (!s || !st) throw Error(KGWAS_ERR_ARG, "kgwas_scan_get_stats: null");
+        *st = s->st;
+    });
+}
+
+void kgwas_scan_destroy(kgwas_scan* s) { delete s; }
+
+int kgwas_scan_scores_dense(kgwas_scan* s, const void* rows, int rows_on_device, uint64_t n_rows, double* scores,
+                            uint32_t* popcnt) {
+    return guarded([&] {
+        if (!s || (!rows && n_rows) || !scores || !popcnt) throw Error(KGWAS_ERR_ARG, "kgwas_scan_scores_dense: null argument");
+        KGWAS_HIP(hipSetDevice(s->device));
+        const uint64_t stride = 1 + s->W_f;
+        const uint64_t piece = s->dense_rows;
+        if (!rows_on_device && s->d_stage.n < piece * stride) s->d_stage.alloc(piece * stride);
+        std::vector<double> tmp(s->n_pheno * piece);
+        for (uint64_t pos = 0; pos < n_rows; pos += piece) {
+            const uint64_t c = std::min<uint64_t>(piece, n_rows - pos);
+            const uint64_t* d_rows;
+            if (rows_on_device) {
+                d_rows = reinterpret_cast<const uint64_t*>(rows) + pos * stride;
+            } else {
+                KGWAS_HIP(hipMemcpy(s->d_stage.p, reinterpret_cast<const uint64_t*>(rows) + pos * stride, c * stride * 8,
+                                    hipMemcpyHostToDevice));
+                d_rows = s->d_stage.p;
+            }
+            run_dense(s, d_rows, c, pos, tmp.data(), popcnt + pos, false);
+            for (uint64_t j = 0; j < s->n_pheno; j++)
+                memcpy(scores + j * n_rows + pos, tmp.data() + j * c, c * sizeof(double));
+        }
+    });
+}
+
+// ---- BestAssociationsHeap through the C ABI -------------------------------------------------
+struct kgwas_heap {
+    BestHeap h;
+    explicit kgwas_heap(size_t n) : h(n) {}
+};
+
+int kgwas_heap_new(uint64_t max_results, kgwas_heap** out) {
+    return guarded([&] {
+        if (!out || max_results == 0) throw Error(KGWAS_ERR_ARG, "kgwas_heap_new: bad argument");
+        *out = new kgwas_heap((size_t)max_results);
+    });
+}
+int kgwas_heap_add_many(kgwas_heap* h, const uint64_t* kmer, const double* score, const uint64_t* row, uint64_t n) {
+    return guarded([&] {
+        if (!h || (n && (!kmer || !score || !row))) throw Error(KGWAS_ERR_ARG, "kgwas_heap_add_many: null argument");
+        for (uint64_t i = 0; i < n; i++) h->h.add(kmer[i], score[i], (size_t)row[i]);
+    });
+}
+int kgwas_heap_size(const kgwas_heap* h, uint64_t* size, uint64_t* insertions, double* lowest) {
+    return guarded([&] {
+        if (!h) throw Error(KGWAS_ERR_ARG, "kgwas_heap_size: null");
+        if (size) *size = h->h.size();
+        if (insertions) *insertions = h->h.inserted();
+        if (lowest) *lowest = h->h.lowest();
+    });
+}
+int kgwas_heap_pop_all(const kgwas_heap* h, uint64_t* kmer, double* score, uint64_t* row) {
+    return guarded([&] {
+        if (!h) throw Error(KGWAS_ERR_ARG, "kgwas_heap_pop_all: null");
+        std::vector<uint64_t> k, r;
+        std::vector<double> sc;
+        h->h.pop_all(k, sc, r);
+        if (kmer) memcpy(kmer, k.data(), k.size() * 8);
+        if (score) memcpy(score, sc.data(), sc.size() * 8);
+        if (row) memcpy(row, r.data(), r.size() * 8);
+    });
+}
+int kgwas_heap_output_list(const kgwas_heap* h, uint64_t* kmer, uint64_t* rank, uint64_t* row) {
+    return guarded([&] {
+        if (!h || !kmer || !rank || !row) throw Error(KGWAS_ERR_ARG, "kgwas_heap_output_list: null");
+        std::vector<uint64_t> k, r;
+        std::vector<double> sc;
+        h->h.pop_all(k, sc, r);
+        const size_t n = k.size();
+        std::vector<size_t> idx(n);
+        for (size_t i = 0; i < n; i++) idx[i] = i;
+        std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return r[a] < r[b]; });
+        for (size_t i = 0; i < n; i++) {
+            kmer[i] = k[idx[i]];
+            rank[i] = n - idx[i];
+            row[i] = r[idx[i]];
+        }
+    });
+}
+void kgwas_heap_free(kgwas_heap* h) { delete h; }
+
+int kgwas_merge_shards(uint64_t n_pheno, const uint64_t* topn, uint64_t n_shards, const uint64_t* counts,
+                       const uint64_t* const* kmer, const double* const* score, const uint64_t* const* row,
+                       uint32_t threads, kgwas_heap** out_heaps) {
+    return guarded([&] {
+        if (!topn || !counts || !kmer || !score || !row || !out_heaps) throw Error(KGWAS_ERR_ARG, "kgwas_merge_shards: null");
+        for (uint64_t j = 0; j < n_pheno; j++) {
+            if (topn[j] == 0) throw Error(KGWAS_ERR_ARG, "heap size must be >= 1");
+            out_heaps[j] = new kgwas_heap((size_t)topn[j]);
+        }
+        std::vector<std::vector<uint64_t>> off(n_shards, std::vector<uint64_t>(n_pheno + 1, 0));
+        for (uint64_t g = 0; g < n_shards; g++)
+            for (uint64_t j = 0; j < n_pheno; j++) off[g][j + 1] = off[g][j] + counts[g * n_pheno + j];
+        unsigned nt = threads ? threads : usable_cpus();
+        nt = (unsigned)std::min<uint64_t>(nt, n_pheno);
+        Pool pool(nt);
+        pool.parallel_for(n_pheno, [&](size_t j) {
+            BestHeap& h = out_heaps[j]->h;
+            for (uint64_t g = 0; g < n_shards; g++) {  // shards in row order
+                const uint64_t o = off[g][j], n = counts[g * n_pheno + j];
+                for (uint64_t i = 0; i < n; i++) h.add(kmer[g][o + i], score[g][o + i], (size_t)row[g][o + i]);
+            }
+        });
+    });
+}
+
+}  // extern "C"

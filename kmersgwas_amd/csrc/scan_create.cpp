@@ -1,0 +1,847 @@
+// scan_create.cpp — kgwas_scan_create: validation, the constant device data of a session (phenotype layouts of the exact
+// scorers, the operand sets and error bounds of the filters: block-scaled FP4 x FP6/FP4, int8, narrow), buffers and slots.
+#include "scan_internal.h"
+
+extern "C" {
+
+int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
+    return guarded([&] {
+        if (!p || !out) throw Error(KGWAS_ERR_ARG, "kgwas_scan_create: null argument");
+        if (p->struct_size != sizeof(kgwas_scan_params)) throw Error(KGWAS_ERR_ARG, "kgwas_scan_params: size mismatch");
+        if (!p->col || !p->Y || !p->topn || p->n_acc == 0 || p->n_pheno == 0 || p->n_acc_file == 0)
+            throw Error(KGWAS_ERR_ARG, "kgwas_scan_create: empty problem");
+        if (p->n_acc > p->n_acc_file) throw Error(KGWAS_ERR_ARG, "more phenotyped accessions than table columns");
+        if (p->n_acc_file >= (1ull << 31)) throw Error(KGWAS_ERR_ARG, "too many accessions");
+        check_device(p->device);
+        KGWAS_HIP(hipSetDevice(p->device));
+        std::unique_ptr<kgwas_scan> s(new kgwas_scan);
+        s->device = p->device;
+        s->S_f = p->n_acc_file;
+        s->S = p->n_acc;
+        s->W_f = (s->S_f + 63) / 64;
+        s->W_m = 2 * ((s->S + 127) / 128);  // src/kmers_multiple_databases.cpp:51
+        s->L = 64 * s->W_m;
+        s->n_pheno = p->n_pheno;
+        s->min_count = p->min_count;
+        s->col.assign(p->col, p->col + s->S);
+        s->topn.assign(p->topn, p->topn + s->n_pheno);
+        s->Y.assign(p->Y, p->Y + s->n_pheno * s->S);
+        if (p->record_history > 2) throw Error(KGWAS_ERR_ARG, "record_history: 0 (off), 1 (full log) or 2 (eviction ring)");
+        s->record_history = p->record_history == 1;
+        if (p->record_history == 2) {
+            s->history_ring = 1;  // per heap: 16 standard deviations of the rank distance between two shards' N-th scores
+            if (const char* e = getenv("KGWAS_HISTORY_RING"))
+                if (atoll(e) > 0) s->history_ring = (size_t)atoll(e);
+        }
+        s->count_patterns = p->count_patterns != 0;
+        std::vector<bool> seen(s->S_f, false);
+        for (uint64_t i = 0; i < s->S; i++) {
+            if (s->col[i] >= s->S_f) throw Error(KGWAS_ERR_ARG, "column index out of range");
+            if (seen[s->col[i]]) throw Error(KGWAS_ERR_ARG, "duplicate column index");
+            seen[s->col[i]] = true;
+        }
+        for (uint64_t j = 0; j < s->n_pheno; j++) {
+            if (s->topn[j] == 0) throw Error(KGWAS_ERR_ARG, "heap size must be >= 1");
+            s->max_topn = std::max(s->max_topn, s->topn[j]);
+            s->sum_topn += s->topn[j];
+        }
+        s->direct = true;
+        for (uint64_t i = 0; i < s->S; i++) s->direct = s->direct && (s->col[i] == i);
+
+        bool finite = true;
+        for (float v : s->Y) finite = finite && std::isfinite(v);
+        uint32_t kern = p->kernel;
+        const bool mfma_fits = mfma_lds_bytes((uint32_t)s->W_m) <= 160u * 1024u;
+        // Coarse int8 filter + exact re-scoring for the sparse phase (score_coarse.hip): needs finite values,
+        // an exact kernel for the dense phase / re-runs, and T >= 2 int8 tiles of the whole sample axis in LDS.
+        const uint32_t n_kgroups = (uint32_t)((s->W_m + 7) / 8);
+        uint32_t coarse_T = 0;
+        for (uint32_t T : {8u, 7u, 6u, 5u, 4u, 3u, 2u})
+            if (coarse_lds_bytes(n_kgroups, T) <= 152u * 1024u) {
+                coarse_T = T;
+                break;
+            }
+        bool want_coarse = false;
+        if (kern == KGWAS_KERNEL_COARSE) {
+            if (!finite || !coarse_T) throw Error(KGWAS_ERR_ARG, "coarse filter needs finite phenotype values and <= 5120 accessions");
+            want_coarse = true;
+            kern = KGWAS_KERNEL_AUTO;
+        } else if (kern == KGWAS_KERNEL_AUTO && finite && coarse_T) {
+            // any number of columns: even a single column (one mostly empty 16-column tile) runs twice as fast behind
+            // the filter as through the exact VALU scorer (12.5 vs 27 ms per 100 M-row pass)
+            want_coarse = true;
+        }
+        if (kern == KGWAS_KERNEL_AUTO) kern = (s->n_pheno >= 4 && finite && mfma_fits) ? KGWAS_KERNEL_MFMA : KGWAS_KERNEL_VALU;
+        if (kern == KGWAS_KERNEL_MFMA && !mfma_fits)
+            throw Error(KGWAS_ERR_ARG, "MFMA scorer: phenotype tile does not fit LDS for this many accessions");
+        if (kern == KGWAS_KERNEL_MFMA && !finite)
+            throw Error(KGWAS_ERR_ARG, "MFMA scorer needs finite phenotype values (0*inf); use the VALU scorer");
+        if (kern != KGWAS_KERNEL_MFMA && kern != KGWAS_KERNEL_VALU) throw Error(KGWAS_ERR_ARG, "unknown kernel id");
+        s->kernel_used = kern;
+        s->coarse = want_coarse;
+        s->coarse_T = coarse_T;
+        s->n_kgroups = n_kgroups;
+        // One to four columns under AUTO: the narrow filter (FP4 x FP8 block-scaled MFMA, three slices per column)
+        // instead of the int8 one, whose 16-column tiles would be mostly padding (KGWAS_NARROW=0: keep the int8 filter).
+        s->narrow = want_coarse && p->kernel == KGWAS_KERNEL_AUTO && s->n_pheno <= NARROW_MAX_COLS &&
+                    narrow_lds_bytes(n_kgroups) <= 64u * 1024u && !(getenv("KGWAS_NARROW") && atoi(getenv("KGWAS_NARROW")) == 0);
+
+        // (narrow filter on rows read in place: chunks of up to 32 M rows - with one column a chunk's fixed costs, sort,
+        // re-score, threshold update, weigh more than the candidates a staler threshold lets through)
+        s->chunk_max = p->chunk_rows ? p->chunk_rows : ((s->narrow && s->direct) ? (32ull << 20) : (8ull << 20));
+        s->chunk_max = std::max<uint64_t>(128, (s->chunk_max + 127) / 128 * 128);
+        if (s->coarse) {  // survivor keys are (column << row_bits | row) in 32 bits, the 0xFFFFFFFF fill included
+            uint32_t pbits = 1;
+            while ((1ull << pbits) < s->n_pheno + 1) pbits++;
+            if (pbits > 22) throw Error(KGWAS_ERR_ARG, "coarse filter: too many phenotype columns for 32-bit survivor keys");
+            s->chunk_max = std::max<uint64_t>(128, std::min<uint64_t>(s->chunk_max, 1ull << (32 - pbits)));
+        }
+        if (s->coarse && !s->narrow) {  // the coarse kernel addresses a chunk's rows with 32-bit byte offsets
+            const uint64_t stride_dw = 2 * (1 + std::max<uint64_t>(s->W_f, s->W_m));
+            const uint64_t lim = ((1ull << 32) - (1ull << 20)) / (4 * stride_dw) / 128 * 128;
+            s->chunk_max = std::max<uint64_t>(128, std::min<uint64_t>(s->chunk_max, lim));
+        }
+        s->dense_rows = std::min<uint64_t>(16384, s->chunk_max);
+        // Dense chunks of a feed: enough rows to fill the largest heap with a margin for the MAC filter (more
+        // dense chunks follow while a heap is still short); everything after goes through the sparse path.
+        s->dense_chunk = std::min<uint64_t>(s->dense_rows, std::max<uint64_t>(1024, (s->max_topn + s->max_topn / 8 + 512 + 127) / 128 * 128));
+        if (getenv("KGWAS_MODE_K")) s->mode_k = atof(getenv("KGWAS_MODE_K"));  // experiments
+        const uint64_t budget = getenv("KGWAS_CAP_BUDGET") ? strtoull(getenv("KGWAS_CAP_BUDGET"), nullptr, 10) : (4ull << 20);  // candidate records per slot
+        // (few columns: longer lists, so that the ramp takes ~6 chunks instead of ~13 - a chunk's fixed costs, not its
+        // rows, are what a one-column scan pays for)
+        const uint64_t cap_mult = getenv("KGWAS_CAP_MULT") ? strtoull(getenv("KGWAS_CAP_MULT"), nullptr, 10) : (s->narrow ? 16 : 2);  // experiments
+        uint64_t cap = std::min<uint64_t>(cap_mult * s->max_topn + 4096, std::max<uint64_t>(budget / s->n_pheno, 1024));
+        s->cap = (uint32_t)std::min<uint64_t>(cap, 0x7FFFFFFFull);
+
+        KGWAS_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+        KGWAS_HIP(hipEventCreate(&s->ev_user));
+        KGWAS_HIP(hipEventCreate(&s->ev_ds));
+        KGWAS_HIP(hipEventCreate(&s->ev_d0));
+        KGWAS_HIP(hipEventCreate(&s->ev_d1));
+
+        // ---- constant device data --------------------------------------------------------
+        const uint64_t S = s->S, L = s->L, W_m = s->W_m, P = s->n_pheno;
+        std::vector<uint32_t> dmask(2 * W_m, 0), colmap(L, 0xFFFFFFFFu);
+        for (uint64_t d = 0; d < 2 * W_m; d++) {
+            if (!s->direct)
+                dmask[d] = 0xFFFFFFFFu;
+            else if (32 * d + 32 <= S)
+                dmask[d] = 0xFFFFFFFFu;
+            else if (32 * d < S)
+                dmask[d] = (1u << (S - 32 * d)) - 1u;
+        }
+        for (uint64_t i = 0; i < S; i++) colmap[i] = (uint32_t)s->col[i];
+        const uint64_t P4 = (P + 3) / 4 * 4, nct = (P + 15) / 16;
+        std::vector<float> Yperm(P4 * L, 0.0f), Ymfma(nct * L * 16, 0.0f), sums(P, 0.0f);
+        std::vector<float> V(L);
+        for (uint64_t j = 0; j < P; j++) {
+            std::fill(V.begin(), V.end(), 0.0f);
+            for (uint64_t i = 0; i < S; i++) V[i] = s->Y[j * S + i];
+            float* R = &Yperm[j * L];
+            // permute_scores (src/kmer_general.cpp:155-167): R[128b+4s+l] = V[128b+32l+31-s]
+            for (uint64_t b = 0; b < L / 128; b++)
+                for (uint64_t sx = 0; sx < 32; sx++)
+                    for (uint64_t l = 0; l < 4; l++) R[128 * b + 4 * sx + l] = V[128 * b + 32 * l + 31 - sx];
+            // update_scores_and_sum (src/kmers_multiple_databases.cpp:288-295): sequential float32 sum
+            volatile float sum = 0.0f;
+            for (uint64_t i = 0; i < L; i++) sum = sum + R[i];
+            sums[j] = sum;
+            // MFMA layout (see score_mfma.hip): [ct][(((b*4+l)*2 + t/4)*64 + kk*16+n)*4 + t%4], s = 4t+kk
+            const uint64_t ct = j / 16, n = j % 16;
+            for (uint64_t b = 0; b < L / 128; b++)
+                for (uint64_t l = 0; l < 4; l++)
+                    for (uint64_t sx = 0; sx < 32; sx++)
+                    {
+                        // chain step sx = 4t + kk; lane = kk*16 + n; four consecutive t sit together
+                        const uint64_t t = sx / 4, kk = sx % 4;
+                        Ymfma[ct * L * 16 + (((b * 4 + l) * 2 + t / 4) * 64 + kk * 16 + n) * 4 + t % 4] =
+                            V[128 * b + 32 * l + 31 - sx];
+                    }
+        }
+        {
+            const uint64_t avail = s->direct ? 2 * s->W_f : 2 * W_m;
+            uint32_t nb = 0;
+            while (nb < W_m / 2 && 4ull * nb + 3 < avail && dmask[4 * nb] == 0xFFFFFFFFu &&
+                   dmask[4 * nb + 1] == 0xFFFFFFFFu && dmask[4 * nb + 2] == 0xFFFFFFFFu && dmask[4 * nb + 3] == 0xFFFFFFFFu)
+                nb++;
+            s->nb_full = nb;
+        }
+        s->d_dmask.alloc(dmask.size());
+        s->d_colmap.alloc(colmap.size());
+        s->d_sums.alloc(P);
+        s->d_thr.alloc(P);
+        s->h_thr.alloc(8 * P);
+        s->d_thr_host.alloc(P);
+        s->d_thr_redo.alloc(P);
+        s->h_thr_redo.alloc(P);
+        s->d_hist.alloc(P * (size_t)HIST_BINS);
+        s->d_hist_base.alloc(P);
+        s->h_hist_base.alloc(P);
+        s->d_pat_cnt.alloc(1);
+        KGWAS_HIP(hipMemset(s->d_pat_cnt.p, 0, 8));
+        KGWAS_HIP(hipMemset(s->d_thr.p, 0, P * sizeof(double)));  // 0 = "nothing is filtered" until the heaps say otherwise
+        KGWAS_HIP(hipMemset(s->d_thr_host.p, 0, P * sizeof(double)));
+        s->d_topn.alloc(P);
+        s->d_sel.alloc(P);
+        s->h_sel.alloc(P);
+        s->d_sel_info.alloc(2);
+        s->h_sel_info.alloc(2);
+        KGWAS_HIP(hipMemcpy(s->d_topn.p, s->topn.data(), P * 8, hipMemcpyHostToDevice));
+        KGWAS_HIP(hipMemcpy(s->d_dmask.p, dmask.data(), dmask.size() * 4, hipMemcpyHostToDevice));
+        KGWAS_HIP(hipMemcpy(s->d_colmap.p, colmap.data(), colmap.size() * 4, hipMemcpyHostToDevice));
+        KGWAS_HIP(hipMemcpy(s->d_sums.p, sums.data(), P * 4, hipMemcpyHostToDevice));
+        if (kern == KGWAS_KERNEL_MFMA) {
+            s->d_Ymfma.alloc(Ymfma.size());
+            KGWAS_HIP(hipMemcpy(s->d_Ymfma.p, Ymfma.data(), Ymfma.size() * 4, hipMemcpyHostToDevice));
+        }
+        if (kern != KGWAS_KERNEL_MFMA || s->coarse) {
+            s->d_Yperm.alloc(Yperm.size());
+            KGWAS_HIP(hipMemcpy(s->d_Yperm.p, Yperm.data(), Yperm.size() * 4, hipMemcpyHostToDevice));
+        }
+        if (s->coarse) {
+            // int8 slices per column: y_i ~ c + u*(254*q0_i + q1_i) (two slices, ~15 bits) or c + u*q0_i (one),
+            // centred at c = sum/N, sum being the reference's float32 sum of the column: then
+            //   r_c = N*yc - N1*sum = N*u*Dc + N1*(N*c - sum),   |N1*(N*c - sum)| <= rho  (rounding of c only),
+            // i.e. an exact integer Dc times a constant. For every row
+            //   |yigi_ref - yc| <= Eg + |sum_{i in row} resid_i| <= Eg + min(Rall, N1 * rmax):
+            //   Eg   = gamma_{L/4+3} * sum|y_i|  float32 summation error of the reference chains (Higham, recursive sums)
+            //   Rall = max(sum of the positive resid_i, sum of the |negative resid_i|)  (a row's residuals cannot
+            //          add up to more than all residuals of one sign), rmax = max_i |resid_i|,
+            //          resid_i = y_i - c - u*(254 q0_i + q1_i)
+            // so score_ref > thr needs (N*u*|Dc| + rho + N*E)^2 >= thr*d*(1 - 2^-40), i.e.
+            //   |Dc| >= sqrt(thr)*kalpha*sqrt(d) - eg - min(rall, N1*rmax)       (units of u; score_coarse.hip)
+            // with kalpha rounded down by 2^-19 relative and the error terms rounded up and padded: the device
+            // evaluates the right-hand side in float32, and these margins dominate its rounding.
+            const double u32 = std::ldexp(1.0, -24);
+            const double nterms = (double)L / 4.0 + 3.0;
+            const double gamma = nterms * u32 / (1.0 - nterms * u32);
+            std::vector<int> q0(S), q1(S);
+            auto up = [](double x) { return std::nextafter((float)x, std::numeric_limits<float>::infinity()); };
+            struct ErrBound {
+                float eg, rall, rmax;     // phenotype units, rounded up
+                float egD, rallD, rmaxD;  // the same in units of Dc (divided by u), rounded up: what the kernel uses
+            };
+            auto quantise = [&](uint64_t j, int ns, CoarseCol& cc, ErrBound& eb) {
+                const double Nd = (double)S, sum = (double)sums[j];
+                const double c = sum / Nd;
+                double mx = 0, A = 0;
+                for (uint64_t i = 0; i < S; i++) {
+                    const double y = (double)s->Y[j * S + i];
+                    mx = std::max(mx, std::fabs(y - c));
+                    A += std::fabs(y);
+                }
+                // unit u: one slice spans +-127 u, two slices +-(127*254 + 127) u
+                const double u = mx > 0 ? (ns == 2 ? mx / (127.0 * 254.0) : mx / 127.0) : 1.0;
+                const double a0 = ns == 2 ? 254.0 * u : u;
+                double rpos = 0, rneg = 0, rmax = 0;
+                for (uint64_t i = 0; i < S; i++) {
+                    const double y = (double)s->Y[j * S + i] - c;
+                    int v0 = (int)std::lrint(y / a0);
+                    v0 = std::max(-127, std::min(127, v0));
+                    double r = y - a0 * v0;
+                    int v1 = 0;
+                    if (ns == 2) {
+                        v1 = (int)std::lrint(r / u);
+                        v1 = std::max(-127, std::min(127, v1));
+                        r -= u * v1;
+                    }
+                    q0[i] = v0;
+                    q1[i] = v1;
+                    if (r > 0) rpos += r; else rneg -= r;
+                    rmax = std::max(rmax, std::fabs(r));
+                }
+                const double rho = Nd * std::fabs(Nd * c - sum) * 2.0 + 1e-9 * (1.0 + std::fabs(sum));
+                const double Eg = gamma * A * (1.0 + 1e-6) + 1e-12 * (1.0 + A);
+                cc.kalpha = (1.0 - std::ldexp(1.0, -19)) / (Nd * u);
+                cc.iu = up(1.0 / u * (1.0 + 1e-6));
+                eb.eg = up((Eg + rho / Nd) * (1.0 + 1e-6) + 1e-30);
+                eb.rall = up(std::max(rpos, rneg) * (1.0 + 1e-6));
+                eb.rmax = up(rmax * (1.0 + 1e-6));
+                const double iu = 1.0 / u * (1.0 + 1e-6);
+                eb.egD = up((double)eb.eg * iu);
+                eb.rallD = up((double)eb.rall * iu);
+                eb.rmaxD = up((double)eb.rmax * iu);
+            };
+            // One slice halves the matrix work but widens the bound; it is offered when, for every column, the bound
+            // at N1 = S/2 stays below 15 % of the deviation of yigi a z = 4 association needs (2*sigma*sqrt(S)), so the
+            // survivors stay within a small multiple of the true candidates. KGWAS_COARSE_SLICES=1|2 forces one set.
+            bool one_ok = true;
+            for (uint64_t j = 0; j < P && one_ok; j++) {
+                CoarseCol cc;
+                ErrBound eb;
+                quantise(j, 1, cc, eb);
+                double mean = 0, var = 0;
+                for (uint64_t i = 0; i < S; i++) mean += (double)s->Y[j * S + i];
+                mean /= (double)S;
+                for (uint64_t i = 0; i < S; i++) var += ((double)s->Y[j * S + i] - mean) * ((double)s->Y[j * S + i] - mean);
+                const double sigma = std::sqrt(var / (double)S);
+                const double e_half = (double)eb.eg + std::min((double)eb.rall, 0.5 * (double)S * (double)eb.rmax);
+                if (!(e_half <= 0.15 * 2.0 * sigma * std::sqrt((double)S))) one_ok = false;
+            }
+            bool want[2] = {one_ok, true};
+            if (const char* e = getenv("KGWAS_COARSE_SLICES")) {
+                if (atoi(e) == 1) want[0] = true, want[1] = false;
+                if (atoi(e) == 2) want[0] = false, want[1] = true;
+            }
+            if (s->narrow) {
+                want[0] = want[1] = false;  // the int8 operand sets are not needed
+                // FP8 E4M3 operands of the narrow filter (score_narrow.hip): three slices of integers in [-15, 15] per
+                // column, y_i - c ~ sum_k u_k q_ki with u_0 = max|y_i - c| / 15 and u_{k+1} = u_k / 30 (a rounding
+                // residual of at most u_k / 2 fills the next slice's range exactly), and a ones row per column.
+                auto e4m3 = [](int v) -> uint8_t {
+                    if (v == 0) return 0;
+                    const int sg = v < 0 ? 0x80 : 0, av = std::abs(v);
+                    int e = 0;
+                    while ((2 << e) <= av) e++;
+                    return (uint8_t)(sg | ((e + 7) << 3) | ((av * 8) / (1 << e) - 8));
+                };
+                const uint64_t n_steps = 4ull * n_kgroups;
+                std::vector<uint8_t> Bn(n_steps * 64 * 32, 0);
+                std::vector<NarrowCol> ncols(P);
+                std::vector<int> q(S);
+                auto put_slot = [&](uint64_t slot, const std::vector<int>& v) {
+                    for (uint64_t g = 0; g < n_kgroups; g++)
+                        for (uint64_t jj = 0; jj < 4; jj++)
+                            for (uint64_t k = 0; k < 128; k++) {
+                                // FP4 side: k = 32 kb + 8 q + e' <-> bit 4 e' + jj of dword q of the lane's 16 bytes
+                                const uint64_t kbA = k / 32, e = k % 32, smp = 512 * g + 128 * kbA + 32 * (e / 8) + 4 * (e % 8) + jj;
+                                if (smp >= S) continue;
+                                // FP8 side: lane kb = (k % 64) / 16, byte (k / 64) * 16 + k % 16
+                                const uint64_t lane = slot + 16 * ((k % 64) / 16), byte = (k / 64) * 16 + k % 16;
+                                Bn[((g * 4 + jj) * 64 + lane) * 32 + byte] = e4m3(v[smp]);
+                            }
+                };
+                for (uint64_t j = 0; j < P; j++) {
+                    const double Nd = (double)S, sum = (double)sums[j];
+                    const double c = sum / Nd;
+                    double mx = 0, A = 0;
+                    std::vector<double> t(S);
+                    for (uint64_t i = 0; i < S; i++) {
+                        t[i] = (double)s->Y[j * S + i] - c;
+                        mx = std::max(mx, std::fabs(t[i]));
+                        A += std::fabs((double)s->Y[j * S + i]);
+                    }
+                    double u = mx > 0 ? mx / 15.0 : 1.0;
+                    NarrowCol& nc = ncols[j];
+                    for (int k = 0; k < NARROW_SLICES; k++) {
+                        for (uint64_t i = 0; i < S; i++) {
+                            int v = (int)std::lrint(t[i] / u);
+                            v = std::max(-15, std::min(15, v));
+                            q[i] = v;
+                            t[i] -= u * v;
+                        }
+                        put_slot(4 * j + k, q);  // operand row 4 p + k; 4 p + 3 = ones
+                        nc.w[k] = 2.0 * u;
+                        u /= 30.0;
+                    }
+                    double rpos = 0, rneg = 0, rmax = 0;
+                    for (uint64_t i = 0; i < S; i++) {
+                        if (t[i] > 0) rpos += t[i]; else rneg -= t[i];
+                        rmax = std::max(rmax, std::fabs(t[i]));
+                    }
+                    // (the slice products u_k * v and the running residual are evaluated in double: pad by their rounding)
+                    const double fuzz = 64.0 * std::ldexp(1.0, -52) * (mx + std::fabs(c));
+                    nc.t1 = Nd * c - sum;
+                    nc.eg = (gamma * A * (1.0 + 1e-6) + 1e-12 * (1.0 + A)) * (1.0 + 1e-9);
+                    nc.rall = (std::max(rpos, rneg) + Nd * fuzz) * (1.0 + 1e-9);
+                    nc.rmax = (rmax + fuzz) * (1.0 + 1e-9);
+                    // both sides evaluate N * x - N1 * sum and the slice sums in double: absolute slack of a few ulps of
+                    // the largest intermediate (N * N * max|y|)
+                    nc.pad = 256.0 * std::ldexp(1.0, -52) * Nd * Nd * (mx + std::fabs(c) + 1.0) + 1e-300;
+                    // float32 pre-screen (score_narrow.hip): |r| <= N |ycf| (1 + 2^-10) + slackf: N1 |t1|, N E and the pad
+                    // of the exact test, and the float32 roundings of the three products and sums.
+                    {
+                        const double slack = Nd * (nc.eg + std::min(nc.rall, Nd * nc.rmax)) + Nd * std::fabs(nc.t1) + nc.pad +
+                                             Nd * std::ldexp(1.0, -20) * mx * Nd;
+                        for (int k = 0; k < 3; k++) nc.wf[k] = (float)nc.w[k];
+                        nc.slackf = std::nextafter((float)(slack * 1.001), std::numeric_limits<float>::infinity());
+                    }
+                }
+                for (uint64_t j = 0; j < P; j++) put_slot(4 * j + 3, std::vector<int>(S, 1));
+                s->d_Bn.alloc(Bn.size());
+                s->d_ncols.alloc(P);
+                KGWAS_HIP(hipMemcpy(s->d_Bn.p, Bn.data(), Bn.size(), hipMemcpyHostToDevice));
+                KGWAS_HIP(hipMemcpy(s->d_ncols.p, ncols.data(), P * sizeof(NarrowCol), hipMemcpyHostToDevice));
+
+            }
+            // ---- block-scaled filter (score_mx.hip), the default: FP6 (+ FP4 / FP6) slices on the integer grids
+            //   A6 = {0..15, 16..30 step 2, 32..60 step 4} (E2M3 x 8),  A4 = {0, 1, 2, 3, 4, 6, 8, 12} (E2M1 x 2):
+            //   y_i - c ~ w * t_i,  t_i = a6_i (one slice), 8 a6_i + a4_i (FP4 second slice) or 32 a6_i + a6'_i (FP6 second
+            //   slice); the accumulator is kappa * sum_i g_i t_i, kappa = 1/16, 1/4, 1/16, so one accumulator unit is
+            //   u = w / kappa phenotype units and everything above (kalpha, the error terms in units of Dc) carries over
+            //   with that u. The ones column has t = 1 / kappa: its accumulator is N1.
+            // Which filter (KGWAS_COARSE_MX=1|0 forces one): the block-scaled one wherever its operands (1.25 bytes per
+            // sample and column with two slices) leave a row no more LDS groups to pass through than the int8 filter's single
+            // slice (1 byte) does. Measured: 1024 x 101 (one group each) 9.9 + 4.3 ms of filter + other kernels per 100 M
+            // rows against 10.4 + 4.8; 2048 x 201 (five groups of three column tiles against four groups of four int8
+            // tiles) 45.0 + 10.8 against 38.7 + 14.4 - there every row is loaded, expanded and tested once per group,
+            // and the int8 filter keeps the shape.
+            bool use_mx;
+            if (const char* e = getenv("KGWAS_COARSE_MX")) {
+                use_mx = atoi(e) != 0;
+            } else {
+                auto groups_for = [&](uint32_t tmax) {
+                    uint64_t g = 1;
+                    while (tmax && ((P + g - 1) / g + 1 + 15) / 16 > tmax) g++;
+                    return tmax ? g : ~0ull;
+                };
+                const uint32_t steps = 4u * (uint32_t)(S / 512) + (uint32_t)((S % 512 + 127) / 128);
+                uint32_t ctm = 0;
+                for (uint32_t ct = 7; ct >= 1 && !ctm; ct--)
+                    if (mx_lds_bytes(steps, ct, 2, 0) <= 160u * 1024u) ctm = ct;
+                use_mx = groups_for(ctm) <= groups_for(s->coarse_T);
+            }
+            if (use_mx && !s->narrow && getenv("KGWAS_COARSE_SLICES") == nullptr) want[0] = false;  // one FP6 slice alone: only on request
+            auto build_mx = [&](int mi) {
+                const int ns = mi + 1;
+                kgwas_scan::CoarseMode& M = s->cmode[mi];
+                std::vector<int> G6, G4;  // the signed grids, ascending
+                for (int q = 60; q >= 32; q -= 4) G6.push_back(-q);
+                for (int q = 30; q >= 16; q -= 2) G6.push_back(-q);
+                for (int q = 15; q >= -15; q--) G6.push_back(-q);
+                for (int q = 16; q <= 30; q += 2) G6.push_back(q);
+                for (int q = 32; q <= 60; q += 4) G6.push_back(q);
+                for (int h : {-12, -8, -6, -4, -3, -2, -1, 0, 1, 2, 3, 4, 6, 8, 12}) G4.push_back(h);
+                auto nearest = [](const std::vector<int>& g, double v) {  // index of the grid value closest to v
+                    size_t hi = std::lower_bound(g.begin(), g.end(), v, [](int a, double b) { return (double)a < b; }) - g.begin();
+                    if (hi == 0) return (size_t)0;
+                    if (hi == g.size()) return g.size() - 1;
+                    return (v - (double)g[hi - 1] <= (double)g[hi] - v) ? hi - 1 : hi;
+                };
+                auto e2m3 = [](int q) -> uint32_t {  // E2M3 code of q / 8
+                    const uint32_t sg = q < 0 ? 0x20u : 0u;
+                    const int a = std::abs(q);
+                    if (a < 8) return sg | (uint32_t)a;
+                    int e = 1, base = 8;
+                    while (a >= 2 * base) base *= 2, e++;
+                    return sg | ((uint32_t)e << 3) | (uint32_t)((a - base) / (base / 8));
+                };
+                auto e2m1 = [](int h) -> uint32_t {  // E2M1 code of h / 2
+                    static const int tab[8] = {0, 1, 2, 3, 4, 6, 8, 12};
+                    uint32_t i = 0;
+                    while (tab[i] != std::abs(h)) i++;
+                    return (h < 0 ? 8u : 0u) | i;
+                };
+                // whole 512-sample groups (the kernel reads all 64 bytes of those without a bounds check) + up to four quarter groups
+                const uint32_t n_full = (uint32_t)(S / 512), nq = (uint32_t)((S % 512 + 127) / 128);
+                const uint32_t n_steps = 4 * n_full + nq;
+                // column tiles per LDS group the LDS can hold, and the LDS groups that takes, for a second-slice format
+                auto ct_max = [&](uint32_t fp6) {
+                    for (uint32_t ct = 7; ct >= 1; ct--)
+                        if (mx_lds_bytes(n_steps, ct, (uint32_t)ns, fp6) <= 160u * 1024u) return ct;
+                    return 0u;
+                };
+                auto groups_for = [&](uint32_t ctm) {
+                    uint64_t g = 1;
+                    while (((P + g - 1) / g + 1 + 15) / 16 > ctm) g++;
+                    return g;
+                };
+                uint32_t s1_fp6 = 0;
+                if (ns == 2 && ct_max(1) && ct_max(0) && groups_for(ct_max(1)) == groups_for(ct_max(0))) s1_fp6 = 1;
+                if (const char* e = getenv("KGWAS_MX_S1")) s1_fp6 = atoi(e) == 6 && ct_max(1) ? 1u : 0u;  // experiments
+                const uint32_t CTmax = ct_max(s1_fp6);
+                if (!CTmax) throw Error(KGWAS_ERR_ARG, "coarse filter: too many accessions for the LDS");
+                const int sh = ns == 1 ? 0 : (s1_fp6 ? 5 : 3);                 // t = 2^sh * a6 + a1
+                const double kappa = (ns == 2 && !s1_fp6) ? 0.25 : 0.0625;     // accumulator = kappa * sum g t
+                const int t_ones = (int)(1.0 / kappa);                         // in the LAST slice (a6 = 0 with two slices)
+                const double t_max = ns == 1 ? 60.0 : (s1_fp6 ? 32.0 * 60.0 + 60.0 : 8.0 * 60.0 + 12.0);
+                const std::vector<int>& G1 = s1_fp6 ? G6 : G4;
+                std::vector<int> a0(S), a1(S);
+                auto quantise_mx = [&](uint64_t j, CoarseCol& cc, ErrBound& eb) {
+                    const double Nd = (double)S, sum = (double)sums[j];
+                    const double c = sum / Nd;
+                    double mx = 0, A = 0;
+                    for (uint64_t i = 0; i < S; i++) {
+                        const double y = (double)s->Y[j * S + i];
+                        mx = std::max(mx, std::fabs(y - c));
+                        A += std::fabs(y);
+                    }
+                    const double w = mx > 0 ? mx / t_max : 1.0;
+                    const double u = w / kappa;  // one accumulator unit in phenotype units
+                    double rpos = 0, rneg = 0, rmax = 0;
+                    for (uint64_t i = 0; i < S; i++) {
+                        const double y = (double)s->Y[j * S + i] - c;
+                        const double x = y / w;
+                        int b0 = 0, b1 = 0;
+                        if (ns == 1) {
+                            b0 = G6[nearest(G6, x)];
+                        } else {
+                            // the first slice's neighbours of x / 2^sh, each with its best second slice
+                            const double sc = (double)(1 << sh);
+                            const size_t k0 = nearest(G6, x / sc);
+                            double best = 1e300;
+                            for (size_t k = k0 ? k0 - 1 : 0; k <= std::min(k0 + 1, G6.size() - 1); k++) {
+                                const int c1 = G1[nearest(G1, x - sc * G6[k])];
+                                const double r = std::fabs(x - sc * G6[k] - c1);
+                                if (r < best) best = r, b0 = G6[k], b1 = c1;
+                            }
+                        }
+                        a0[i] = b0;
+                        a1[i] = b1;
+                        const double r = y - w * ((double)(1 << sh) * b0 + b1);
+                        if (r > 0) rpos += r; else rneg -= r;
+                        rmax = std::max(rmax, std::fabs(r));
+                    }
+                    const double rho = Nd * std::fabs(Nd * c - sum) * 2.0 + 1e-9 * (1.0 + std::fabs(sum));
+                    const double Eg = gamma * A * (1.0 + 1e-6) + 1e-12 * (1.0 + A);
+                    cc.kalpha = (1.0 - std::ldexp(1.0, -19)) / (Nd * u);
+                    cc.iu = up(1.0 / u * (1.0 + 1e-6));
+                    eb.eg = up((Eg + rho / Nd) * (1.0 + 1e-6) + 1e-30);
+                    eb.rall = up(std::max(rpos, rneg) * (1.0 + 1e-6));
+                    eb.rmax = up(rmax * (1.0 + 1e-6));
+                    const double iu = 1.0 / u * (1.0 + 1e-6);
+                    eb.egD = up((double)eb.eg * iu);
+                    eb.rallD = up((double)eb.rall * iu);
+                    eb.rmaxD = up((double)eb.rmax * iu);
+                };
+                // LDS groups: as few as hold all columns (+ a ones column each); or groups filled to the last slot and one
+                // smaller launch for the rest when that multiplies fewer tiles
+                uint64_t n_lgroups = groups_for(CTmax);
+                uint64_t cper = (P + n_lgroups - 1) / n_lgroups;
+                struct Plan {
+                    uint64_t j0, n, CT, groups, cper;
+                };
+                std::vector<Plan> plan;
+                plan.push_back(Plan{0, P, (cper + 1 + 15) / 16, n_lgroups, cper});
+                if (n_lgroups > 1) {
+                    const uint64_t cpf = (uint64_t)CTmax * 16 - 1;
+                    const uint64_t full = P / cpf, rem = P - full * cpf;
+                    const uint64_t CTr = rem ? (rem + 1 + 15) / 16 : 0;
+                    if (full >= 1 && full + (rem ? 1 : 0) <= n_lgroups && full * CTmax + CTr < n_lgroups * plan[0].CT) {
+                        plan.clear();
+                        plan.push_back(Plan{0, full * cpf, CTmax, full, cpf});
+                        if (rem) plan.push_back(Plan{full * cpf, rem, CTr, 1, rem});
+                    }
+                }
+                M.mx = true;
+                M.mx_full = n_full;
+                M.mx_quarter = nq;
+                M.mx_s1_fp6 = s1_fp6;
+                M.mx_scale0 = 0x01010101u * (uint32_t)(0x7F + (ns == 1 ? 0 : 5));
+                M.slices = (uint32_t)ns;
+                M.n_parts = (uint32_t)plan.size();
+                M.tile_slices = 0;
+                uint32_t groups_all = 0;
+                const uint32_t SB = mx_step_bytes_rt((uint32_t)ns, s1_fp6);
+                for (size_t pi = 0; pi < plan.size(); pi++) {
+                    const Plan& pl = plan[pi];
+                    kgwas_scan::CoarsePart& Pt = M.part[pi];
+                    const uint32_t CT = (uint32_t)pl.CT, slots = CT * 16;
+                    Pt.T = CT;
+                    Pt.n_lgroups = (uint32_t)pl.groups;
+                    Pt.wide = false;
+                    M.tile_slices += CT * (uint32_t)ns * (uint32_t)pl.groups;
+                    groups_all += (uint32_t)pl.groups;
+                    const size_t group_bytes = (size_t)n_steps * CT * SB;
+                    std::vector<uint8_t> Bq(pl.groups * group_bytes, 0);
+                    std::vector<CoarseCol> cols(pl.groups * slots);
+                    for (auto& cc : cols) {
+                        memset(&cc, 0, sizeof(cc));
+                        cc.pheno = -1;
+                    }
+                    // the slice values of operand column `slot` of LDS group lg: v0 on the A6 grid, v1 on the second slice's
+                    auto put = [&](uint64_t lg, uint64_t slot, const std::vector<int>& v0, const std::vector<int>& v1) {
+                        const uint64_t t = slot / 16, n = slot % 16;
+                        for (uint64_t st = 0; st < n_steps; st++) {
+                            uint8_t* blk = &Bq[lg * group_bytes + (st * CT + t) * SB];
+                            for (uint64_t kb = 0; kb < 4; kb++) {
+                                const uint64_t lane = kb * 16 + n;
+                                for (uint64_t e = 0; e < 32; e++) {
+                                    // score_mx.hip: k = 32 kb + e <-> sample
+                                    const uint64_t smp = st < 4ull * n_full ? 512 * (st / 4) + 128 * kb + 32 * (e / 8) + 4 * (e % 8) + st % 4
+                                                                            : 512ull * n_full + 128 * (st - 4ull * n_full) + 32 * kb + 4 * (e % 8) + e / 8;
+                                    if (smp >= S) continue;
+                                    auto put6 = [&](uint8_t* part, int q) {  // 6-bit field e of the lane's 6 dwords: dwords 0-3 | 4-5
+                                        const uint32_t code = e2m3(q);
+                                        for (int b = 0; b < 6; b++)
+                                            if (code & (1u << b)) {
+                                                const uint64_t bit = 6 * e + b, dw = bit / 32;
+                                                uint8_t* d = dw < 4 ? part + lane * 16 + dw * 4 : part + 1024 + lane * 8 + (dw - 4) * 4;
+                                                d[(bit % 32) / 8] |= (uint8_t)(1u << (bit % 8));
+                                            }
+                                    };
+                                    put6(blk, v0[smp]);
+                                    if (ns == 2) {
+                                        if (s1_fp6)
+                                            put6(blk + 1536, v1[smp]);
+                                        else
+                                            blk[1536 + lane * 16 + e / 2] |= (uint8_t)(e2m1(v1[smp]) << (4 * (e % 2)));
+                                    }
+                                }
+                            }
+                        }
+                    };
+                    for (uint64_t j = pl.j0; j < pl.j0 + pl.n; j++) {
+                        const uint64_t lg = (j - pl.j0) / pl.cper, slot = (j - pl.j0) % pl.cper;
+                        CoarseCol& cc = cols[lg * slots + slot];
+                        ErrBound eb;
+                        quantise_mx(j, cc, eb);
+                        M.eg_max = std::max(M.eg_max, eb.egD);
+                        M.rall_max = std::max(M.rall_max, eb.rallD);
+                        M.rmax_max = std::max(M.rmax_max, eb.rmaxD);
+                        cc.pheno = (int32_t)j;
+                        put(lg, slot, a0, a1);
+                    }
+                    {  // ones column: accumulator = N1
+                        std::vector<int> ones(S, t_ones), zeros(S, 0);
+                        for (uint64_t lg = 0; lg < pl.groups; lg++) put(lg, slots - 1, ns == 1 ? ones : zeros, ones);
+                    }
+                    Pt.d_Bq.alloc(Bq.size());
+                    Pt.d_cols.alloc(cols.size());
+                    KGWAS_HIP(hipMemcpy(Pt.d_Bq.p, Bq.data(), Bq.size(), hipMemcpyHostToDevice));
+                    KGWAS_HIP(hipMemcpy(Pt.d_cols.p, cols.data(), cols.size() * sizeof(CoarseCol), hipMemcpyHostToDevice));
+                }
+                s->st.coarse_mode_tiles[mi] = M.part[0].T;
+                s->st.coarse_mode_lgroups[mi] = groups_all;
+                s->st.coarse_mode_tile_slices[mi] = M.tile_slices;
+                s->st.coarse_mx = 1;
+                s->st.coarse_mx_s1_fp6 = s1_fp6;
+                s->st.coarse_mx_steps = n_steps;
+                M.ready = true;
+            };
+            for (int mi = 0; mi < 2; mi++) {
+                if (!want[mi]) continue;
+                if (use_mx) {
+                    build_mx(mi);
+                    continue;
+                }
+                const int ns = mi + 1;
+                kgwas_scan::CoarseMode& M = s->cmode[mi];
+                // Operand columns ("slots") per LDS group: the group's share of the phenotype columns, padding, and
+                // the ones column in the last slot (its dot product is the row's masked popcount N1).
+                uint32_t Tmax = s->coarse_T;  // largest tile count whose operands fit the LDS
+                if (ns == 2) Tmax &= ~1u;
+                uint64_t n_lgroups = 1, cper = P;
+                uint32_t T = 0;
+                for (;; n_lgroups++) {
+                    cper = (P + n_lgroups - 1) / n_lgroups;  // phenotype columns per group
+                    T = (uint32_t)(ns * ((cper + 1 + 15) / 16));
+                    if (T <= Tmax) break;
+                }
+                // plan[i] = {first column, columns, T, LDS groups, columns per group}
+                struct Plan {
+                    uint64_t j0, n, T, groups, cper;
+                    bool wide;
+                };
+                std::vector<Plan> plan;
+                plan.push_back(Plan{0, P, T, n_lgroups, cper, false});
+                if (n_lgroups > 1) {
+                    // The balanced split pads every group (201 columns, 4 tiles per group: 4 x (51 + ones) of 4 x 64
+                    // slots = 16 tiles for 13 tiles' worth of columns). Alternative: groups filled to the last slot and
+                    // ONE smaller launch for the rest - taken when it multiplies fewer tiles with no more row passes.
+                    const uint64_t cpf = (uint64_t)(Tmax / (uint32_t)ns) * 16 - 1;  // columns of a full group
+                    const uint64_t full = P / cpf, rem = P - full * cpf;
+                    const uint64_t Tr = rem ? (uint64_t)ns * ((rem + 1 + 15) / 16) : 0;
+                    static const bool no_split = getenv("KGWAS_COARSE_NOSPLIT") != nullptr;  // experiments
+                    if (full >= 1 && full + (rem ? 1 : 0) <= n_lgroups && full * Tmax + Tr < n_lgroups * T && !no_split) {
+                        plan.clear();
+                        plan.push_back(Plan{0, full * cpf, Tmax, full, cpf, false});
+                        if (rem) plan.push_back(Plan{full * cpf, rem, Tr, 1, rem, false});
+                    }
+                }
+                // One slice, more tiles than the LDS holds at once, at most 14: the wide kernel keeps every tile's
+                // accumulators in registers and streams the operands (score_wide.hip) - one group, every row expanded once.
+                {
+                    const uint32_t tiles = (uint32_t)((P + 1 + 15) / 16);
+                    // Measured at 2048 samples x 201 columns (T = 13): 34.5 ms per 75.6 M rows against 32.0 ms for
+                    // coarse_kernel's four LDS groups - the matrix pipe is busy 37 % of the time (one wave per SIMD: its
+                    // epilogue, the stage barriers and the vector instructions beside the MFMAs are all exposed) - so
+                    // it stays opt-in (KGWAS_WIDE=1) until it wins.
+                    const bool on = getenv("KGWAS_WIDE") && atoi(getenv("KGWAS_WIDE")) == 1;
+                    if (ns == 1 && n_lgroups > 1 && tiles >= 9 && tiles <= 14 && wide_lds_bytes(tiles) <= 160u * 1024u && on) {
+                        plan.clear();
+                        plan.push_back(Plan{0, P, tiles, 1, P, true});
+                    }
+                }
+                M.slices = (uint32_t)ns;
+                M.n_parts = (uint32_t)plan.size();
+                M.tile_slices = 0;
+                uint32_t groups_all = 0;
+                for (size_t pi = 0; pi < plan.size(); pi++) {
+                    const Plan& pl = plan[pi];
+                    kgwas_scan::CoarsePart& Pt = M.part[pi];
+                    const uint32_t Tp = (uint32_t)pl.T;
+                    const uint32_t PG = Tp / (uint32_t)ns, slots = PG * 16;
+                    Pt.T = Tp;
+                    Pt.n_lgroups = (uint32_t)pl.groups;
+                    Pt.wide = pl.wide;
+                    M.tile_slices += Tp * (uint32_t)pl.groups;
+                    groups_all += (uint32_t)pl.groups;
+                    std::vector<int8_t> Bq(pl.groups * n_kgroups * 8ull * Tp * 1024ull, 0);
+                    std::vector<CoarseCol> cols(pl.groups * slots);
+                    for (auto& cc : cols) {
+                        memset(&cc, 0, sizeof(cc));
+                        cc.pheno = -1;
+                    }
+                    auto put = [&](uint64_t lg, uint64_t slot, const std::vector<int>& v0, const std::vector<int>& v1) {
+                        const uint64_t pgl = slot / 16, n = slot % 16;
+                        for (uint64_t g = 0; g < n_kgroups; g++)
+                            for (uint64_t jj = 0; jj < 8; jj++)
+                                for (uint64_t kg = 0; kg < 4; kg++)
+                                    for (uint64_t e = 0; e < 16; e++) {
+                                        // k-element e of step jj <-> sample (score_coarse.hip: expand_step)
+                                        const uint64_t smp = 512 * g + 128 * kg + 32 * (e / 4) + 8 * (e % 4) + jj;
+                                        if (smp >= S) continue;
+                                        const uint64_t lane = kg * 16 + n;
+                                        const uint64_t base = (((lg * n_kgroups + g) * 8 + jj) * Tp);
+                                        if (ns == 1) {
+                                            Bq[((base + pgl) * 64 + lane) * 16 + e] = (int8_t)v0[smp];
+                                        } else {
+                                            Bq[((base + 2 * pgl) * 64 + lane) * 16 + e] = (int8_t)v0[smp];
+                                            Bq[((base + 2 * pgl + 1) * 64 + lane) * 16 + e] = (int8_t)v1[smp];
+                                        }
+                                    }
+                    };
+                    for (uint64_t j = pl.j0; j < pl.j0 + pl.n; j++) {
+                        const uint64_t lg = (j - pl.j0) / pl.cper, slot = (j - pl.j0) % pl.cper;
+                        CoarseCol& cc = cols[lg * slots + slot];
+                        ErrBound eb;
+                        quantise(j, ns, cc, eb);
+                        M.eg_max = std::max(M.eg_max, eb.egD);
+                        M.rall_max = std::max(M.rall_max, eb.rallD);
+                        M.rmax_max = std::max(M.rmax_max, eb.rmaxD);
+                        cc.pheno = (int32_t)j;
+                        put(lg, slot, q0, q1);
+                    }
+                    {  // ones column: Dc = N1 (one slice: q0 = 1; two slices: Dc = 254*D0 + D1 with q0 = 0, q1 = 1)
+                        std::vector<int> ones(S, 1), zeros(S, 0);
+                        for (uint64_t lg = 0; lg < pl.groups; lg++) put(lg, slots - 1, ns == 1 ? ones : zeros, ones);
+                    }
+                    Pt.d_Bq.alloc(Bq.size());
+                    Pt.d_cols.alloc(cols.size());
+                    KGWAS_HIP(hipMemcpy(Pt.d_Bq.p, Bq.data(), Bq.size(), hipMemcpyHostToDevice));
+                    KGWAS_HIP(hipMemcpy(Pt.d_cols.p, cols.data(), cols.size() * sizeof(CoarseCol), hipMemcpyHostToDevice));
+                }
+                s->st.coarse_mode_tiles[mi] = M.part[0].T;
+                s->st.coarse_mode_lgroups[mi] = groups_all;
+                s->st.coarse_mode_tile_slices[mi] = M.tile_slices;
+                M.ready = true;
+            }
+            s->key_slots = (uint32_t)std::min<uint64_t>((uint64_t)s->cap * P, 0x7FFFFFFFull);
+            s->d_surv_sorted.alloc(s->key_slots);
+            s->bitmap_words = (s->chunk_max + 63) / 64;
+            s->d_bitmap.alloc(P * s->bitmap_words);
+            s->d_bm_blocks.alloc(P * ((s->bitmap_words + 1023) / 1024 + 1) + 4);
+            s->d_surv_cnt.alloc(P);
+            s->d_surv_off.alloc(P);
+            s->d_key_count.alloc(1);
+            s->d_tile_pref.alloc(P + 1);
+            s->d_tile_cnt.alloc((size_t)s->key_slots / 256 + P + 2);
+            s->d_tile_off.alloc((size_t)s->key_slots / 256 + P + 2);
+            s->d_tmp_score.alloc(s->key_slots);
+            // The record copies run as blit kernels (rocprofv3 shows __amd_rocclr_copyBuffer, not SDMA transfers), and at
+            // normal priority they are only dispatched in the gaps of the compute stream: behind a 0.75 ms filter launch
+            // of a one-column scan, a chunk's 1 MB of records reached the host 1.3-2.8 ms after its counts. A high-priority
+            // queue gets them onto the chip between the running launch's workgroups. KGWAS_COPY_PRIO=0: the old behaviour.
+            {
+                int least = 0, greatest = 0;
+                KGWAS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+                const bool hi = !(getenv("KGWAS_COPY_PRIO") && atoi(getenv("KGWAS_COPY_PRIO")) == 0);
+                KGWAS_HIP(hipStreamCreateWithPriority(&s->copy_stream, hipStreamNonBlocking, hi ? greatest : least));
+            }
+            s->row_key_bits = 1;
+            while (s->row_key_bits < 32 && (1ull << s->row_key_bits) < s->chunk_max) s->row_key_bits++;
+        }
+        if (!s->direct) s->d_sq.alloc(s->chunk_max * 2 * W_m);
+
+        {
+            if (s->coarse) {
+                // device side: 20 B x key_slots of HBM per slot, up to 4 GiB in all; host side: the record ring
+                const uint64_t slot_bytes = (uint64_t)s->key_slots * 20;
+                s->n_slots = (int)std::min<uint64_t>(MAX_SLOTS, std::max<uint64_t>(4, (4ull << 30) / std::max<uint64_t>(slot_bytes, 1)));
+                s->ring_size = (size_t)std::max<uint64_t>(std::min<uint64_t>(1ull << 30, (uint64_t)s->n_slots * slot_bytes), 2 * slot_bytes + 4096);
+                // (tests: a ring barely larger than one chunk's worst case, so that it wraps and fills up)
+                if (getenv("KGWAS_RING_BYTES"))
+                    s->ring_size = (size_t)std::max<uint64_t>(strtoull(getenv("KGWAS_RING_BYTES"), nullptr, 10), slot_bytes + 4096);
+                s->ring.alloc(s->ring_size);
+            } else {
+                const uint64_t slot_bytes = (uint64_t)s->cap * P * sizeof(Cand);
+                s->n_slots = (int)std::min<uint64_t>(16, std::max<uint64_t>(4, (1ull << 30) / std::max<uint64_t>(slot_bytes, 1)));
+            }
+        }
+        for (int si = 0; si < s->n_slots + (s->coarse ? 1 : 0); si++) {
+            const bool is_redo = si == s->n_slots;
+            Slot& sl = is_redo ? s->redo : s->slot[si];
+            if (s->coarse && !is_redo) {
+                sl.d_so_score.alloc(s->key_slots);
+                sl.d_so_kmer.alloc(s->key_slots);
+                sl.d_so_row.alloc(s->key_slots);
+                sl.d_meta.alloc(2 * P + 2);
+                sl.h_meta.alloc(2 * P + 2);
+                memset(sl.h_meta.p, 0, (2 * P + 2) * sizeof(uint32_t));
+                KGWAS_HIP(hipEventCreateWithFlags(&sl.ev_counts, hipEventBlockingSync));
+            } else {
+                sl.cand.alloc((uint64_t)s->cap * P);
+                sl.d_cand = sl.cand.dev();
+            }
+            sl.d_cnt.alloc(P);
+            sl.h_cnt.alloc(P);
+            sl.d_tested.alloc(TESTED_SHARDS);
+            sl.h_tested.alloc(TESTED_SHARDS);
+            KGWAS_HIP(hipEventCreate(&sl.ev_sq0));
+            KGWAS_HIP(hipEventCreate(&sl.ev_k0));
+            KGWAS_HIP(hipEventCreate(&sl.ev_k1));
+            // (blocking wait: the control thread sleeps instead of spinning beside the replay workers)
+            KGWAS_HIP(hipEventCreateWithFlags(&sl.ev_done, hipEventBlockingSync));
+            KGWAS_HIP(hipEventCreate(&sl.ev_mid));
+        }
+        s->d_dense.alloc(P * s->dense_rows);
+        s->h_dense.alloc(P * s->dense_rows);
+        s->d_n1.alloc(s->dense_rows);
+        s->h_n1.alloc(s->dense_rows);
+        s->d_kmer.alloc(s->dense_rows);
+        s->h_kmer.alloc(s->dense_rows);
+        s->d_tested_dense.alloc(TESTED_SHARDS);
+
+        make_heaps(s.get());
+        s->hist.resize(P);
+        s->keys.resize(P);
+        s->col_ms.assign(P, 0.0);
+        s->trace = getenv("KGWAS_TRACE") != nullptr;
+        unsigned nt = p->host_threads ? p->host_threads : usable_cpus();
+        if (const char* e = getenv("KGWAS_HOST_THREADS"))
+            if (atoi(e) > 0) nt = (unsigned)atoi(e);
+        nt = (unsigned)std::min<uint64_t>(nt, P);
+        s->pool.reset(new Pool(nt, pick_replay_cpus(nt, s->device)));
+        s->st.replay_threads = nt;
+        s->ingest.producer_cpus_ = p->host_threads ? p->host_threads : usable_cpus();
+        // Column groups of the replay. Worker w owns the columns w, w + T, ... of the first floor(P / T) * T columns,
+        // in groups of at most MAX_LOCKSTEP (a group's heaps take their replacements in lockstep, and stay in their
+        // worker's cache from chunk to chunk); the P mod T columns left over float: each is a group of its own that
+        // whichever worker is furthest ahead takes, which evens out what a static map cannot (101 columns on 16
+        // workers is 5 x 7 + 11 x 6: the 7-column workers set the pace, 17 % above the mean).
+        {
+            const uint64_t T = nt, base = P / T;
+            const uint64_t MKc = (uint64_t)BestHeap::MAX_LOCKSTEP;
+            uint64_t per = base ? (base + ((base + MKc - 1) / MKc) - 1) / ((base + MKc - 1) / MKc) : 0;  // balanced split
+            if (const char* e = getenv("KGWAS_REPLAY_GROUP"))
+                if (atoi(e) > 0 && per) per = std::min<uint64_t>((uint64_t)atoi(e), MKc);
+            for (uint64_t w = 0; w < T && base; w++) {
+                std::vector<uint32_t> cur;
+                for (uint64_t i = 0; i < base; i++) {
+                    cur.push_back((uint32_t)(i * T + w));
+                    if (cur.size() == per || i + 1 == base) {
+                        s->grp_cols.push_back(cur);
+                        s->grp_home.push_back((int)w);
+                        cur.clear();
+                    }
+                }
+            }
+            for (uint64_t j = base * T; j < P; j++) {
+                s->grp_cols.push_back(std::vector<uint32_t>(1, (uint32_t)j));
+                s->grp_home.push_back(-1);
+            }
+            s->n_groups = s->grp_cols.size();
+            s->gstate.reset(new kgwas_scan::GroupState[s->n_groups]);
+            s->slot_left.reset(new std::atomic<uint32_t>[MAX_SLOTS]);
+            for (int i = 0; i < MAX_SLOTS; i++) s->slot_left[i].store(0);
+            kgwas_scan* raw = s.get();
+            s->rp_fn = [raw](size_t w) { replay_worker(raw, w); };
+        }
+        s->st.kernel_used = s->narrow ? (uint32_t)KGWAS_KERNEL_NARROW : s->coarse ? (uint32_t)KGWAS_KERNEL_COARSE : kern;
+        s->st.direct_mode = s->direct ? 1 : 0;
+        *out = s.release();
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,454 @@
+// scan_internal.h — the association-scan session's internals shared by scan_host.cpp (CPU topology, heaps), scan_gpu.cpp
+// (chunk submission: kernels, thresholds, record copies), scan_replay.cpp (streaming replay + the feed loop),
+// scan_create.cpp (session set-up: operand sets of the filters) and scan_api.cpp (the C ABI). Not a public header: the
+// boundary is include/kgwas.h.
+//
+// The association-scan session: pass 1 of associate_kmers (src/associate_kmers.cpp:99-148)
+// re-designed around the GPU.
+//
+//   reference                                    here
+//   ---------------------------------------     -------------------------------------------------
+//   load_kmers: read, MAC filter, squeeze        rows stream from HBM in file layout; MAC predicate
+//   (serial, per-bit)                            and (only if the column map is not the identity
+//                                                prefix) a squeeze kernel, per device chunk
+//   one CTPL task per phenotype column           one kernel scores every (k-mer, column) pair of a
+//   scoring the batch (SSE) into its heap        chunk; only pairs that beat a stale heap minimum
+//                                                come back; the host replays them, in row order,
+//                                                through the same std::priority_queue
+//
+// Exactness argument (SURVEY.md §7 hard part 1): once a heap is full add_association is a
+// no-op unless score > lowest_score, and lowest_score never decreases. A row whose score is
+// <= ANY earlier value of lowest_score can therefore be dropped without changing the heap's
+// history. Until every heap is full the chunks run in dense mode (all scores come back).
+#pragma once
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <deque>
+#include <limits>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <dirent.h>
+#include <immintrin.h>
+#include <pthread.h>
+#include <sched.h>
+#include <sys/mman.h>
+
+#include "common.h"
+#include "heap.h"
+#include "ingest.h"
+#include "kernels.h"
+
+namespace kgwas {
+
+// Minimal persistent worker pool: parallel_for over phenotype columns. The caller does not take part: it
+// sleeps until the workers are done, so exactly size() threads are busy (sized to the CPU quota).
+class Pool {
+   public:
+    // cpus: optional CPU to pin worker i to (empty = leave placement to the scheduler).
+    explicit Pool(unsigned n, const std::vector<std::vector<int>>& cpus = {})
+        : stop_(false), gen_(0), pending_(0), n_items_(0) {
+        if (n < 1) n = 1;
+        for (unsigned i = 0; i < n; i++) {
+            const std::vector<int> mine = i < cpus.size() ? cpus[i] : std::vector<int>();
+            th_.emplace_back([this, i, mine] {
+                if (!mine.empty()) {
+                    cpu_set_t set;
+                    CPU_ZERO(&set);
+                    for (int c : mine)
+                        if (c >= 0 && c < CPU_SETSIZE) CPU_SET(c, &set);
+                    (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+                }
+                loop(i);
+            });
+        }
+    }
+    ~Pool() {
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            stop_ = true;
+            gen_++;
+        }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    // Static assignment: item i always runs on worker i % size(), so a phenotype column's heap
+    // (~320 KB at N = 10001) stays in one core's cache from chunk to chunk.
+    void parallel_for(size_t n, const std::function<void(size_t)>& fn) {
+        if (n == 0) return;
+        start(n, fn);
+        wait();
+    }
+    // The two halves of parallel_for: start() hands the items out and returns, wait() blocks until every worker is
+    // done. Between the two the workers run on their own (the streaming replay: items are worker loops that end when
+    // told to). fn must stay alive until wait() returns; one start at a time.
+    void start(size_t n, const std::function<void(size_t)>& fn) {
+        std::unique_lock<std::mutex> lk(mu_);
+        fn_ = &fn;
+        n_items_ = n;
+        if (claimed_.size() < n) claimed_ = std::vector<std::atomic<uint8_t>>(n);
+        for (size_t i = 0; i < n; i++) claimed_[i].store(0, std::memory_order_relaxed);
+        pending_ = th_.size();
+        done_.store(0, std::memory_order_relaxed);
+        gen_.fetch_add(1, std::memory_order_release);
+        lk.unlock();
+        cv_.notify_all();
+    }
+    void wait(bool spin = true) {
+        for (int sp = 0; spin && sp < 20000; sp++) {  // replays take a few ms at most: spin before sleeping
+            if (done_.load(std::memory_order_acquire)) break;
+            __builtin_ia32_pause();
+        }
+        std::unique_lock<std::mutex> lk(mu_);
+        done_cv_.wait(lk, [this] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+    size_t size() const { return th_.size(); }
+    bool finished() const { return done_.load(std::memory_order_acquire) != 0; }  // every worker is through the started items
+
+   private:
+    // Own items first, in increasing order; then take whatever nobody has started yet, from the far end
+    // (with 101 columns on 16 workers the five workers that own a seventh column give it away to a worker
+    // that is done with its six). An item runs exactly once, on one thread.
+    void run(size_t me) {
+        const size_t T = th_.size();
+        for (size_t i = me; i < n_items_; i += T)
+            if (!claimed_[i].exchange(1, std::memory_order_acq_rel)) (*fn_)(i);
+        for (size_t i = n_items_; i-- > 0;)
+            if (!claimed_[i].load(std::memory_order_relaxed) && !claimed_[i].exchange(1, std::memory_order_acq_rel)) (*fn_)(i);
+    }
+    void loop(size_t me) {
+        uint64_t seen = 0;
+        for (;;) {
+            // Chunks arrive every few milliseconds while a scan is running: spin briefly before
+            // sleeping so the wake-up does not cost a futex round trip per worker per chunk.
+            bool got = false;
+            for (int spin = 0; spin < 4000; spin++) {
+                if (gen_.load(std::memory_order_acquire) != seen) {
+                    got = true;
+                    break;
+                }
+                __builtin_ia32_pause();
+            }
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                if (!got) cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen; });
+                seen = gen_.load(std::memory_order_acquire);
+                if (stop_) return;
+            }
+            run(me);
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                if (--pending_ == 0) {
+                    done_.store(1, std::memory_order_release);
+                    done_cv_.notify_all();
+                }
+            }
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_cv_;
+    bool stop_;
+    std::atomic<uint64_t> gen_;
+    std::atomic<int> done_{0};
+    std::vector<std::atomic<uint8_t>> claimed_;
+    size_t pending_;
+    const std::function<void(size_t)>* fn_ = nullptr;
+    size_t n_items_;
+};
+
+// scan_host.cpp: one CPU per replay worker near the GPU; the CPUs the process may really use (cgroup quota)
+std::vector<std::vector<int>> pick_replay_cpus(unsigned n, int device);
+unsigned usable_cpus();
+
+// Effective pushes of one phenotype column in row order (record_history: what a later shard contributes to the
+// cross-shard merge). An append-only log of 24-byte records written with streaming stores: 10 M records per pass go
+// straight to memory instead of through the worker's L2, where they would evict the heaps the same thread is
+// updating (recording through three std::vectors cost 12 ms per 36 ms pass). The separate arrays that
+// kgwas_scan_history hands out are made on demand.
+struct History {
+    struct Rec {
+        uint64_t kmer;
+        double score;
+        uint64_t row;
+    };
+    Rec* p = nullptr;
+    size_t n = 0, cap = 0;
+    std::vector<uint64_t> v_kmer, v_row;  // kgwas_scan_history's views
+    std::vector<double> v_score;
+    History() = default;
+    History(const History&) = delete;
+    History& operator=(const History&) = delete;
+    History(History&& o) noexcept : p(o.p), n(o.n), cap(o.cap) { o.p = nullptr; o.n = o.cap = 0; }
+    ~History() { free(p); }
+    inline void push(uint64_t kmer, double score, uint64_t row) {
+        if (n == cap) grow();
+        p[n] = Rec{kmer, score, row};
+        n++;
+    }
+    void grow() {
+        const size_t nc = cap ? cap * 2 : (1u << 14);
+        void* q = nullptr;
+        if (posix_memalign(&q, 64, nc * sizeof(Rec)) != 0) throw std::bad_alloc();
+        _mm_sfence();  // our own streaming stores must have landed before they are copied
+        if (n) memcpy(q, p, n * sizeof(Rec));
+        free(p);
+        p = static_cast<Rec*>(q);
+        cap = nc;
+    }
+    void clear() { n = 0; }
+};
+
+// Evictions a heap of N entries keeps for the cross-shard merge (record_history = 2): the entries of a shard above
+// another equally large shard's N-th score number N +- sqrt(2N); 16 of those deviations, unless KGWAS_HISTORY_RING
+// says otherwise (`forced` > 1).
+inline size_t ring_size(size_t forced, uint64_t topn) {
+    if (forced > 1) return forced;
+    const double r = 16.0 * std::sqrt(2.0 * (double)topn);
+    return (size_t)std::min<double>(std::max<double>(r, 256.0), 1048576.0);
+}
+
+constexpr int MAX_SLOTS = 48;  // upper bound on sparse chunks the GPU may run ahead of the host replay
+
+// What a worker adds up while replaying (chunk, column group) units.
+struct ReplayAcc {
+    uint64_t pushes = 0, cands = 0, busy_ns = 0, units = 0;
+};
+
+struct Slot {
+    PinBuf<Cand> cand;  // written by the GPU straight into mapped host memory
+    Cand* d_cand = nullptr;
+    DevBuf<uint32_t> d_cnt;
+    PinBuf<uint32_t> h_cnt;
+    bool copies_ordered = false;  // coarse chunks: the record copies are on the copy stream (ev_done follows them)
+    // coarse filter: the chunk's candidates compacted in (column, row) order - in HBM (d_so_*), and the host copy the
+    // control thread orders on the copy stream once the counts are known (exactly `total` records per array);
+    // h_meta: [0, P) candidates per column, [P, 2P) their offsets, [2P] total, [2P + 1] survivor keys emitted
+    double* so_score = nullptr;   // host copies: a piece of the session's pinned record ring (fetch_records)
+    uint64_t* so_kmer = nullptr;
+    uint32_t* so_row = nullptr;
+    size_t ring_end = 0;          // ring offset behind this chunk's records (where the ring is free again once it is replayed)
+    DevBuf<double> d_so_score;
+    DevBuf<uint64_t> d_so_kmer;
+    DevBuf<uint32_t> d_so_row;
+    DevBuf<uint32_t> d_meta;
+    PinBuf<uint32_t> h_meta;
+    hipEvent_t ev_counts = nullptr;  // compute stream: compaction done, h_meta copied
+    DevBuf<unsigned long long> d_tested;
+    PinBuf<unsigned long long> h_tested;
+    hipEvent_t ev_sq0 = nullptr, ev_k0 = nullptr, ev_k1 = nullptr, ev_done = nullptr, ev_mid = nullptr;
+    bool used_coarse = false;
+    int coarse_mode = 0;
+    double cand_est = 0;  // candidates the chunk was planned for (sum of topn x rows / rows before it)
+    const uint64_t* rows = nullptr;
+    uint64_t first_row = 0, n_rows = 0;
+    bool squeezed = false, busy = false;
+};
+
+}  // namespace kgwas
+
+using namespace kgwas;
+
+struct kgwas_scan {
+    int device = 0;
+    uint64_t S_f = 0, S = 0, W_f = 0, W_m = 0, L = 0, n_pheno = 0, min_count = 0;
+    std::vector<uint64_t> col, topn;
+    std::vector<float> Y;
+    bool direct = false;
+    uint32_t kernel_used = 0;
+    bool record_history = false;  // mode 1: every effective push is logged (hist)
+    size_t history_ring = 0;      // mode 2: each heap keeps its last history_ring evictions instead (heap.h)
+    uint64_t chunk_max = 0, dense_rows = 0, dense_chunk = 0;
+    uint32_t cap = 0;
+    uint64_t max_topn = 0;
+    uint32_t nb_full = 0;  // leading 128-sample blocks the MFMA scorer may read unmasked
+
+    hipStream_t stream = nullptr, copy_stream = nullptr;  // copy_stream: candidate records HBM -> host
+    hipEvent_t ev_user = nullptr, ev_ds = nullptr, ev_d0 = nullptr, ev_d1 = nullptr;  // caller sync + dense-chunk timing
+    DevBuf<uint32_t> d_dmask, d_colmap, d_sq;
+    DevBuf<float> d_Yperm, d_Ymfma, d_sums;
+    DevBuf<double> d_thr;
+    PinBuf<double> h_thr;  // two halves, alternated, so an in-flight upload is never overwritten
+    uint32_t thr_flip = 0;
+    // device-side threshold tracking (thr_update_kernel)
+    DevBuf<uint32_t> d_hist, d_hist_base;
+    PinBuf<uint32_t> h_hist_base;
+    DevBuf<uint64_t> d_topn;
+    DevBuf<double> d_thr_host, d_thr_redo;
+    PinBuf<double> h_thr_redo;
+    bool hist_ready = false;
+    uint64_t rows_submitted = 0;  // rows handed to the GPU (replayed or still in flight)
+    // coarse int8 filter (sparse phase)
+    bool coarse = false;
+    uint32_t coarse_T = 0, n_kgroups = 0;  // coarse_T: most operand tiles the LDS can hold
+    // Operand sets of the filter: mode[0] = one int8 slice per column (half the matrix work, ~2.5 survivors per
+    // candidate), mode[1] = two slices (~1). Both may be resident; each chunk picks one (pick_coarse_mode).
+    struct CoarsePart {  // one launch of the filter: n_lgroups LDS groups of T operand tiles over a range of columns
+        bool wide = false;  // score_wide.hip: all T tiles' accumulators in registers, operands streamed through LDS
+        uint32_t T = 0, n_lgroups = 0;
+        DevBuf<int8_t> d_Bq;
+        DevBuf<CoarseCol> d_cols;
+    };
+    struct CoarseMode {
+        bool ready = false;
+        // block-scaled filter (score_mx.hip): FP6 (+ FP4 / FP6) slices instead of int8 ones; part[].T = column tiles
+        bool mx = false;
+        uint32_t mx_full = 0, mx_quarter = 0, mx_s1_fp6 = 0, mx_scale0 = 0;
+        uint32_t slices = 0, n_parts = 0;
+        uint32_t tile_slices = 0;  // operand tiles a row is multiplied with, all parts and groups
+        float eg_max = 0, rall_max = 0, rmax_max = 0;  // row error term, maxima over the columns (kernels.h)
+        // Full LDS groups first; columns that would only fill part of another full-size group go into a second launch
+        // with as few tiles as they need (201 columns at 2048 samples: 3 groups x 4 tiles + 1 tile instead of 4 x 4).
+        CoarsePart part[2];
+    } cmode[2];
+    // dense start overlapped with the first sparse chunks: thresholds selected on the device (launch_dense_select)
+    DevBuf<double> d_sel;
+    PinBuf<double> h_sel;
+    DevBuf<uint32_t> d_sel_info;
+    PinBuf<uint32_t> h_sel_info;
+    bool sel_valid = false;  // h_sel holds the minima the heaps will have once the pending dense rows are pushed
+    double infl_obs[2] = {4.0, 1.1};  // survivors per candidate of the last finished chunk of each mode
+    double mode_k = 0.09;
+    std::chrono::steady_clock::time_point t_feed0;  // KGWAS_TRACE: the timeline's origin (start of the current feed)
+    double t_ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_feed0).count(); }
+    uint64_t sum_topn = 0;  // over the columns
+    // narrow filter (1-3 columns, score_narrow.hip): replaces coarse_kernel in the same pipeline
+    bool narrow = false;
+    DevBuf<uint8_t> d_Bn;
+    DevBuf<NarrowCol> d_ncols;
+    DevBuf<unsigned long long> d_bitmap;  // survivors of the chunk being filtered: [n_pheno][bitmap_words]
+    uint64_t bitmap_words = 0;
+    DevBuf<uint32_t> d_bm_blocks;
+    // survivors of the chunk being filtered: bitmap [column][64-row word], then row-ordered keys per column with each
+    // column's range; shared by all chunks (consumed by the re-score kernel in stream order)
+    DevBuf<uint32_t> d_surv_sorted, d_surv_cnt, d_surv_off, d_key_count;  // row-ordered keys per column, the columns' ranges, the total
+    DevBuf<uint32_t> d_tile_pref, d_tile_cnt, d_tile_off;  // tiles of 256 survivors (launch_rescore)
+    DevBuf<double> d_tmp_score;                            // exact score of every survivor (-inf: not a candidate)
+    uint32_t key_slots = 0;  // capacity of the key list = n_pheno * cap
+    uint32_t row_key_bits = 32;
+    // --pattern_counter
+    bool count_patterns = false;
+    DevBuf<uint64_t> d_pat;                // pattern hashes of the tested rows seen so far
+    DevBuf<unsigned long long> d_pat_cnt;  // how many
+    uint64_t pat_upper = 0;                // host-side upper bound of that count (rows fed)
+    Slot slot[MAX_SLOTS];
+    // Host copies of the coarse chunks' candidate records: ONE pinned ring, a chunk takes exactly its 20 B x candidates
+    // when its counts are known and gives them back when it is replayed (FIFO). Slots used to own worst-case buffers
+    // (cap x P records each), which capped the chunks in flight at 12 for 201 columns: with host and GPU level the GPU
+    // then idled while the host digested the ramp.
+    PinBuf<uint8_t> ring;
+    size_t ring_size = 0, ring_head = 0, ring_tail = 0;  // used: [tail, head) circularly; head == tail: empty
+    uint64_t ring_freed = 0;                              // chunks (of this feed) whose records have been given back
+    Slot redo;  // coarse mode: the only slot with exact-scorer candidate records (synchronous overflow re-runs)
+    int n_slots = MAX_SLOTS;  // as many as fit 1 GiB of mapped pinned candidate memory (at least 4)
+    // dense mode
+    DevBuf<double> d_dense;
+    DevBuf<uint32_t> d_n1;
+    DevBuf<uint64_t> d_kmer;
+    PinBuf<double> h_dense;
+    PinBuf<uint32_t> h_n1;
+    PinBuf<uint64_t> h_kmer;
+    DevBuf<unsigned long long> d_tested_dense;
+    // host / file ingest (kgwas_scan_feed_host, kgwas_scan_feed_table): three pinned pieces filled by a producer
+    // thread, two device pieces, a copy stream; piece k+1 is read and copied while piece k is scored and replayed
+    DevBuf<uint64_t> d_stage;  // kgwas_scan_scores_dense staging
+    Ingest ingest;
+
+    // all heaps' arrays in one 2 MB-aligned, MADV_HUGEPAGE arena (make_heaps); declared before the heaps: destroyed after
+    struct HugeArena {
+        void* p = nullptr;
+        size_t bytes = 0;
+        ~HugeArena() { free(p); }
+    } heap_arena;
+    std::unique_ptr<std::pmr::monotonic_buffer_resource> heap_mr;
+    std::vector<BestHeap> heaps;
+    std::vector<History> hist;
+    std::vector<uint64_t> exp_kmer, exp_row;  // scratch of kgwas_scan_history_above / kgwas_scan_heaps_export
+    std::vector<double> exp_score;
+    std::vector<std::vector<uint64_t>> keys;  // per-column sort scratch for the replay
+    bool trace = false;                       // KGWAS_TRACE=1: one stderr line per sparse chunk
+    std::vector<double> col_ms;               // trace only: replay time per column of the last chunk
+    bool all_full = false;
+    uint64_t rows_done = 0;  // rows whose replay is complete
+    std::unique_ptr<Pool> pool;
+    // Streaming replay (feed_device_impl): columns in n_groups groups, (chunk, group) work units.
+    struct alignas(64) GroupState {
+        std::atomic<uint64_t> done{0};  // chunks of this feed the group has replayed = the next one it must take
+        std::atomic<uint32_t> busy{0};  // a worker is on it
+    };
+    size_t n_groups = 1;
+    std::vector<std::vector<uint32_t>> grp_cols;  // columns of group g (at most BestHeap::MAX_LOCKSTEP)
+    std::vector<int> grp_home;                    // the worker that owns group g, -1: floating (anybody takes it)
+    std::unique_ptr<GroupState[]> gstate;
+    std::unique_ptr<std::atomic<uint32_t>[]> slot_left;  // [n_slots] groups that have not replayed the slot's chunk yet
+    std::atomic<uint64_t> seq_submitted{0}, seq_published{0}, seq_replayed{0};
+    std::atomic<bool> rp_quit{false}, rp_failed{false};
+    std::atomic<int> rp_idle{0};
+    std::mutex rp_mu;
+    std::condition_variable rp_cv_work, rp_cv_done;
+    std::function<void(size_t)> rp_fn;
+    ReplayAcc rp_acc;  // sums over the workers of the current streaming replay
+    std::atomic<uint64_t> prof_scan{0}, prof_heap{0};  // KGWAS_TRACE: TSC ticks in the record scans / in the heap updates
+    uint64_t rp_max_busy_ns = 0, rp_min_busy_ns = ~0ull;
+    kgwas_scan_stats st{};
+    bool finished = false;
+    std::vector<std::vector<uint64_t>> res_kmer, res_row;
+    std::vector<std::vector<double>> res_score;
+
+    ~kgwas_scan() {
+        (void)hipSetDevice(device);
+        auto drop_events = [](Slot& s) {
+            if (s.ev_sq0) (void)hipEventDestroy(s.ev_sq0);
+            if (s.ev_k0) (void)hipEventDestroy(s.ev_k0);
+            if (s.ev_k1) (void)hipEventDestroy(s.ev_k1);
+            if (s.ev_done) (void)hipEventDestroy(s.ev_done);
+            if (s.ev_mid) (void)hipEventDestroy(s.ev_mid);
+            if (s.ev_counts) (void)hipEventDestroy(s.ev_counts);
+        };
+        for (auto& s : slot) drop_events(s);
+        drop_events(redo);
+        if (ev_user) (void)hipEventDestroy(ev_user);
+        if (ev_ds) (void)hipEventDestroy(ev_ds);
+        if (ev_d0) (void)hipEventDestroy(ev_d0);
+        if (ev_d1) (void)hipEventDestroy(ev_d1);
+        if (stream) (void)hipStreamDestroy(stream);
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
+    }
+};
+
+namespace kgwas {
+// ---- scan_host.cpp
+void check_device(int device);
+void make_heaps(kgwas_scan* s);
+// ---- scan_gpu.cpp: the GPU side of a chunk
+void fill_args(kgwas_scan* s, ScoreArgs& a, const uint64_t* d_rows, uint64_t n_rows, uint64_t first_row, bool squeezed);
+void hash_patterns(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows);
+void upload_thresholds(kgwas_scan* s);
+void refresh_full(kgwas_scan* s);
+void run_dense(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, uint64_t first_row, double* scores_out, uint32_t* popcnt_out,
+               bool replay, bool select = false);
+void dense_fill(kgwas_scan* s, uint64_t n_rows, uint64_t first_row, std::chrono::steady_clock::time_point td0,
+                const std::function<void()>* meanwhile = nullptr);
+int pick_coarse_mode(const kgwas_scan* s);
+void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_rows, uint64_t first_row, bool count_hist);
+bool chunk_complete(kgwas_scan* s, Slot& sl);
+uint64_t next_sparse_chunk(const kgwas_scan* s);
+void wait_event(kgwas_scan* s, hipEvent_t ev);
+bool fetch_records(kgwas_scan* s, Slot& sl, uint64_t seq);
+// ---- scan_replay.cpp: the host side
+void replay_group(kgwas_scan* s, Slot& sl, size_t g, ReplayAcc& acc);
+void add_replay_stats(kgwas_scan* s, const ReplayAcc& a);
+void replay_worker(kgwas_scan* s, size_t w);
+void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, uint64_t first_row);
+}  // namespace kgwas

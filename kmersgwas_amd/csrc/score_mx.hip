@@ -47,13 +47,6 @@
 #ifndef KGWAS_MX_ABLATE
 #define KGWAS_MX_ABLATE 0
 #endif
-#ifndef KGWAS_MX_DEPHASE
-#define KGWAS_MX_DEPHASE 0
-#endif
-// how many units (two column tiles) the LDS operand reads run ahead of the MFMAs where a step has three or more units
-#ifndef KGWAS_MX_PFD
-#define KGWAS_MX_PFD 1
-#endif
 
 namespace kgwas {
 
@@ -154,8 +147,8 @@ __global__ void __launch_bounds__(TH) mx_kernel(MxArgs a, uint32_t rows_per_bloc
         // or the first two of the next step - are in flight, into the registers unit u - 1 freed. No MFMA waits for a read
         // issued just before it, and only four tiles' operands (40 registers) are live at a time. The order is pinned with
         // scheduling barriers; inside a unit the compiler interleaves freely.
-        constexpr int NU = (CT + 1) / 2;
-        constexpr int PFD = (NU >= 3 && KGWAS_MX_PFD >= 2) ? 2 : 1;  // units the reads run ahead of the MFMAs
+        constexpr int UT = 2;  // column tiles per unit (one: the same time, three or four: spills)
+        constexpr int NU = (CT + UT - 1) / UT;
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
         u32x4 Bx[CT], Bz[CT];  // dwords 0-3 of the first slice's operand, the second slice's
@@ -179,7 +172,7 @@ __global__ void __launch_bounds__(TH) mx_kernel(MxArgs a, uint32_t rows_per_bloc
         };
         auto read_unit = [&](int u, const StepAddr& sa) {
 #pragma unroll
-            for (int t = 2 * u; t < (2 * u + 2 < CT ? 2 * u + 2 : CT); t++) {
+            for (int t = UT * u; t < (UT * u + UT < CT ? UT * u + UT : CT); t++) {
                 if (KGWAS_MX_ABLATE & 4) {
                     Bx[t] = (u32x4){lane, (uint32_t)t, 3u, (uint32_t)u};
                     By[t] = (u32x2){5u, 6u};
@@ -197,15 +190,11 @@ __global__ void __launch_bounds__(TH) mx_kernel(MxArgs a, uint32_t rows_per_bloc
                 }
             }
         };
-#if KGWAS_MX_DEPHASE
-        if (wave >= (TH / 128)) __builtin_amdgcn_s_sleep(KGWAS_MX_DEPHASE);  // experiments: the second wave of every SIMD starts late
-#endif
         uint32_t piece[RT][4];
         set_rows(ro, wave_row0);
         if (a.n_full && wave_row0 < a.n_rows) load_group(piece, ro, 0);
         StepAddr sadr = step_addr(lds);
         read_unit(0, sadr);  // step 0 of the first pass; every pass's last step fetches it for the next
-        if (PFD == 2) read_unit(1, sadr);
         for (uint32_t ps = 0; ps * rows_per_pass < rows_per_block; ps++) {
             const uint64_t rbase = wave_row0 + (uint64_t)ps * rows_per_pass;
             if (rbase >= a.n_rows) break;  // wave-uniform
@@ -221,7 +210,7 @@ __global__ void __launch_bounds__(TH) mx_kernel(MxArgs a, uint32_t rows_per_bloc
             // (block scale sc0 on the first slice, 2^0 on the second).
             auto mfma_unit = [&](int u, const mxv8i (&A)[RT], int sa) {
 #pragma unroll
-                for (int t = 2 * u; t < (2 * u + 2 < CT ? 2 * u + 2 : CT); t++) {
+                for (int t = UT * u; t < (UT * u + UT < CT ? UT * u + UT : CT); t++) {
                     const mxv8i B0 = {(int)Bx[t].x, (int)Bx[t].y, (int)Bx[t].z, (int)Bx[t].w, (int)By[t].x, (int)By[t].y, 0, 0};
 #pragma unroll
                     for (int rt = 0; rt < RT; rt++)
@@ -263,10 +252,10 @@ __global__ void __launch_bounds__(TH) mx_kernel(MxArgs a, uint32_t rows_per_bloc
                 } else {
 #pragma unroll
                     for (int u = 0; u < NU; u++) {
-                        if (u + PFD < NU)
-                            read_unit(u + PFD, sadr);
+                        if (u + 1 < NU)
+                            read_unit(u + 1, sadr);
                         else
-                            read_unit(u + PFD - NU, nadr);
+                            read_unit(0, nadr);
                         __builtin_amdgcn_sched_barrier(0);
                         mfma_unit(u, A, sa);
                         __builtin_amdgcn_sched_barrier(0);
