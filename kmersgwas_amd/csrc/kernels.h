@@ -143,11 +143,6 @@ hipError_t launch_mx(const MxArgs& a, uint32_t CT, uint32_t rows_per_block, hipS
 // Survivors (sorted keys, per-column ranges) -> exact candidates compacted in (column, row) order into a.so_score /
 // a.so_kmer / a.so_row (HBM); meta[0..P) = candidates per column, meta[P..2P) = their offsets, meta[2P] = total,
 // meta[2P + 1] = survivor keys emitted. tile_pref [P + 1], tile_cnt / tile_off [key_cap / 256 + P + 1], tmp_score [key_cap].
-// Wide variant of the coarse filter (score_wide.hip): one int8 slice per column, ALL T operand tiles of a row tile in
-// registers (one wave per SIMD), the operand tiles streamed through LDS. Bq laid out as for launch_coarse with
-// n_lgroups = 1 and T tiles per sample-group step; same keys, same survivors.
-size_t wide_lds_bytes(uint32_t T);
-hipError_t launch_wide(const CoarseArgs& a, uint32_t T, uint32_t rows_per_block, hipStream_t st);
 hipError_t launch_rescore(const ScoreArgs& a, const uint32_t* keys, const uint32_t* surv_off, const uint32_t* surv_cnt,
                           uint32_t row_bits, uint32_t* tile_pref, uint32_t* tile_cnt, uint32_t* tile_off, double* tmp_score,
                           const uint32_t* key_count, uint32_t* meta, hipStream_t st);

@@ -529,7 +529,6 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                     const uint32_t CT = (uint32_t)pl.CT, slots = CT * 16;
                     Pt.T = CT;
                     Pt.n_lgroups = (uint32_t)pl.groups;
-                    Pt.wide = false;
                     M.tile_slices += CT * (uint32_t)ns * (uint32_t)pl.groups;
                     groups_all += (uint32_t)pl.groups;
                     const size_t group_bytes = (size_t)n_steps * CT * SB;
@@ -621,10 +620,9 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                 // plan[i] = {first column, columns, T, LDS groups, columns per group}
                 struct Plan {
                     uint64_t j0, n, T, groups, cper;
-                    bool wide;
                 };
                 std::vector<Plan> plan;
-                plan.push_back(Plan{0, P, T, n_lgroups, cper, false});
+                plan.push_back(Plan{0, P, T, n_lgroups, cper});
                 if (n_lgroups > 1) {
                     // The balanced split pads every group (201 columns, 4 tiles per group: 4 x (51 + ones) of 4 x 64
                     // slots = 16 tiles for 13 tiles' worth of columns). Alternative: groups filled to the last slot and
@@ -635,22 +633,8 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                     static const bool no_split = getenv("KGWAS_COARSE_NOSPLIT") != nullptr;  // experiments
                     if (full >= 1 && full + (rem ? 1 : 0) <= n_lgroups && full * Tmax + Tr < n_lgroups * T && !no_split) {
                         plan.clear();
-                        plan.push_back(Plan{0, full * cpf, Tmax, full, cpf, false});
-                        if (rem) plan.push_back(Plan{full * cpf, rem, Tr, 1, rem, false});
-                    }
-                }
-                // One slice, more tiles than the LDS holds at once, at most 14: the wide kernel keeps every tile's
-                // accumulators in registers and streams the operands (score_wide.hip) - one group, every row expanded once.
-                {
-                    const uint32_t tiles = (uint32_t)((P + 1 + 15) / 16);
-                    // Measured at 2048 samples x 201 columns (T = 13): 34.5 ms per 75.6 M rows against 32.0 ms for
-                    // coarse_kernel's four LDS groups - the matrix pipe is busy 37 % of the time (one wave per SIMD: its
-                    // epilogue, the stage barriers and the vector instructions beside the MFMAs are all exposed) - so
-                    // it stays opt-in (KGWAS_WIDE=1) until it wins.
-                    const bool on = getenv("KGWAS_WIDE") && atoi(getenv("KGWAS_WIDE")) == 1;
-                    if (ns == 1 && n_lgroups > 1 && tiles >= 9 && tiles <= 14 && wide_lds_bytes(tiles) <= 160u * 1024u && on) {
-                        plan.clear();
-                        plan.push_back(Plan{0, P, tiles, 1, P, true});
+                        plan.push_back(Plan{0, full * cpf, Tmax, full, cpf});
+                        if (rem) plan.push_back(Plan{full * cpf, rem, Tr, 1, rem});
                     }
                 }
                 M.slices = (uint32_t)ns;
@@ -664,7 +648,6 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                     const uint32_t PG = Tp / (uint32_t)ns, slots = PG * 16;
                     Pt.T = Tp;
                     Pt.n_lgroups = (uint32_t)pl.groups;
-                    Pt.wide = pl.wide;
                     M.tile_slices += Tp * (uint32_t)pl.groups;
                     groups_all += (uint32_t)pl.groups;
                     std::vector<int8_t> Bq(pl.groups * n_kgroups * 8ull * Tp * 1024ull, 0);

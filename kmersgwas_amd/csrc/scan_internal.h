@@ -295,7 +295,6 @@ struct kgwas_scan {
     // Operand sets of the filter: mode[0] = one int8 slice per column (half the matrix work, ~2.5 survivors per
     // candidate), mode[1] = two slices (~1). Both may be resident; each chunk picks one (pick_coarse_mode).
     struct CoarsePart {  // one launch of the filter: n_lgroups LDS groups of T operand tiles over a range of columns
-        bool wide = false;  // score_wide.hip: all T tiles' accumulators in registers, operands streamed through LDS
         uint32_t T = 0, n_lgroups = 0;
         DevBuf<int8_t> d_Bq;
         DevBuf<CoarseCol> d_cols;

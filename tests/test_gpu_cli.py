@@ -186,13 +186,21 @@ def test_bench_ranks_merge_over_torch_distributed(ranks, merge):
     env = dict(os.environ, KGWAS_DIST_BACKEND="gloo", KGWAS_BENCH_MERGE=merge, KGWAS_PIN_THREADS="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
            "--master-port", str(29500 + ranks), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "1", "--warmup", "1",
-           "--rows", "600000", "--samples", "241", "--perms", "12", "--topn", "2001", "--check-merge", "--no-cpu-baseline"]
+           "--rows", "600000", "--samples", "241", "--perms", "12", "--topn", "2001", "--check-merge"]
+    if ranks != 2:
+        cmd.append("--no-cpu-baseline")  # (with two ranks the line also carries rank 0's shard-parity check against the oracle)
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     j = json.loads(line)
     assert j["n_gpus"] == ranks and j["merge_check"] is True
     assert j["single_gpu_same_shard"]["value"] > 0
+    # every rank's own record: which rank, and which side of it (GPU kernels, host replay, merge), set the pace
+    assert [x["rank"] for x in j["ranks"]] == list(range(ranks))
+    for x in j["ranks"]:
+        assert x["step_ms"] > 0 and x["kernels_ms"] > 0 and x["replay_threads"] >= 1 and x["heap_pushes"] > 0
+    if ranks == 2:
+        assert j["parity_check"] is True
 
 
 def test_emma_kinship_kmers_gpus(tmp_path):

@@ -147,28 +147,6 @@ def test_coarse_filter_shapes(monkeypatch, mx, slices, S, P, shift):
     scan.close()
 
 
-@pytest.mark.parametrize("S,P", [(2048, 201), (1500, 150), (700, 220)])
-def test_wide_filter_variant(monkeypatch, S, P):
-    """score_wide.hip (opt-in, KGWAS_WIDE=1): the int8 filter with all 9-14 operand tiles' accumulators in registers and
-    the operands streamed through LDS by global_load_lds - same survivors, so the same heaps as the oracle's."""
-    monkeypatch.setenv("KGWAS_COARSE_MX", "0")
-    monkeypatch.setenv("KGWAS_WIDE", "1")
-    monkeypatch.setenv("KGWAS_COARSE_SLICES", "1")
-    rows = random_table(40_000, S, seed=S + P, dup_frac=0.2)
-    col = np.arange(S, dtype=np.uint64)
-    Y = phenotypes(S, P - 1, seed=P)
-    mac = onp.min_count(S, 0.05, 5)
-    exp = ob.associate(rows, S, col, Y, 257, mac, batch_size=9000, threads=4)
-    scan = kg.AssociationScan(S, col, Y, 257, mac, kernel=kg.KERNEL_COARSE, chunk_rows=8192)
-    scan.feed_host(rows)
-    scan.finish()
-    st = scan.stats()
-    assert st["coarse_mode_lgroups"][0] == 1 and st["coarse_mode_tiles"][0] == (P + 1 + 15) // 16  # the wide layout: one group
-    _check_topn(scan, exp, P)
-    assert st["rows_tested"] == exp["tested"]
-    scan.close()
-
-
 @pytest.mark.parametrize("S_f,S,P,shift,binary,reorder", [(241, 241, 1, 0.0, False, False), (241, 241, 3, 100.0, False, False),
                                                        (1024, 1024, 1, 0.0, False, False), (1024, 1024, 2, -7.5, True, False),
                                                        (1135, 1135, 1, 0.0, False, False), (2048, 2048, 3, 0.5, False, False),
@@ -713,3 +691,14 @@ def test_kinship_exact(S_f, n_rows):
     assert (Kg == K).all()
     assert kg.kinship_format(Kg, ng) == ob.kinship_text(K, n)
     kin.close()
+
+
+@pytest.mark.parametrize("N,n,levels,flavour", [(64, 4000, 9, "plain"), (33, 3000, 2, "plain"), (1000, 30000, 40, "nan"),
+                                                (1001, 30000, 2000, "negative"), (10, 500, 4, "plain")])
+def test_heap_mirror_equals_std_priority_queue_on_the_gpu_box(N, n, levels, flavour):
+    """heap.h emulates libstdc++'s push_heap / pop_heap element moves by hand; the oracle's heap is a literal
+    std::priority_queue compiled on the box it runs on. tests/test_host.py pins the two against each other in the CPU
+    suite; the same comparison here, under -m gpu, checks it against the GPU box's libstdc++ as well (tie-heavy streams,
+    NaN / negative / +inf scores: the integer-compare and the double-compare walks)."""
+    from test_host import test_heap_mirror_equals_oracle_heap_under_ties as check
+    check(N, n, levels, flavour)
