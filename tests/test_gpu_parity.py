@@ -147,6 +147,47 @@ def test_coarse_filter_shapes(monkeypatch, mx, slices, S, P, shift):
     scan.close()
 
 
+@pytest.mark.parametrize("S_f,S,P,kind,reorder", [
+    (511, 511, 20, "normal", False), (512, 512, 20, "normal", False), (513, 513, 20, "normal", False),   # 3 quarters+ / 1 group / 1 group + 1 quarter
+    (640, 640, 17, "normal", False), (896, 896, 9, "binary", False), (1023, 1023, 33, "normal", False),  # 1 + 1 / 1 + 3 / 1 + 4 quarter groups
+    (5, 5, 6, "normal", False), (64, 64, 8, "binary", False), (129, 129, 7, "normal", False),              # quarter groups only
+    (700, 650, 40, "normal", True), (300, 257, 12, "heavy", True),                                          # squeezed rows (subset, shuffled)
+    (1024, 1024, 24, "constant", False), (1135, 1135, 50, "heavy", False), (2048, 2048, 20, "binary", False)])
+def test_block_scaled_filter_edges(monkeypatch, S_f, S, P, kind, reorder):
+    """The block-scaled filter (forced: KGWAS_COARSE_MX=1) where its sample handling changes shape - whole 512-sample groups,
+    1 to 4 quarter groups, quarter groups only, rows squeezed from a shuffled subset - and on phenotypes that stress the
+    non-uniform FP6 + FP4 quantisation: binary columns (two levels), heavy tails (one value 50 sigma out: every other value
+    falls into the finest cells), a constant column beside normal ones (zero range: nothing can be a survivor, the column's
+    scores are all 0 / NaN-free), duplicated row patterns (ties). Survivors, pop order, score bytes, push and tested counts
+    equal the oracle's."""
+    monkeypatch.setenv("KGWAS_COARSE_MX", "1")
+    rows = random_table(30_000, S_f, seed=S_f * 7 + P, dup_frac=0.25)
+    rng = np.random.default_rng(S + P)
+    col = rng.permutation(S_f)[:S].astype(np.uint64) if reorder else np.arange(S, dtype=np.uint64)
+    Y = phenotypes(S, P - 1, seed=P + 11, binary=(kind == "binary"))
+    if kind == "heavy":
+        Y = Y.copy()
+        Y[:, 0] += np.float32(50.0)  # one accession far out in every column (the columns are permutations: it moves around)
+        Y[1] = (rng.standard_cauchy(S) * 3).astype(np.float32)
+    if kind == "constant":
+        Y = Y.copy()
+        Y[2] = np.float32(1.25)
+        Y[5] = np.float32(0.0)
+    mac = onp.min_count(S, 0.05, 5) if S >= 100 else 1
+    topn = 211
+    exp = ob.associate(rows, S_f, col, Y, topn, mac, batch_size=7000, threads=3)
+    scan = kg.AssociationScan(S_f, col, Y, topn, mac, kernel=kg.KERNEL_COARSE, chunk_rows=4096)
+    scan.feed_host(rows[:17_000], 0)
+    scan.feed_host(rows[17_000:], 17_000)
+    scan.finish()
+    st = scan.stats()
+    assert st["kernel_used"] == kg.KERNEL_COARSE and st["coarse_mx"] == 1 and st["coarse_launches"] > 0
+    assert st["coarse_mx_steps"] == 4 * (S // 512) + (S % 512 + 127) // 128
+    _check_topn(scan, exp, P)
+    assert st["rows_tested"] == exp["tested"]
+    scan.close()
+
+
 @pytest.mark.parametrize("S_f,S,P,shift,binary,reorder", [(241, 241, 1, 0.0, False, False), (241, 241, 3, 100.0, False, False),
                                                        (1024, 1024, 1, 0.0, False, False), (1024, 1024, 2, -7.5, True, False),
                                                        (1135, 1135, 1, 0.0, False, False), (2048, 2048, 3, 0.5, False, False),
