@@ -391,6 +391,13 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                     if (mx_lds_bytes(steps, ct, 2, 0) <= 160u * 1024u) ctm = ct;
                 use_mx = groups_for(ctm) <= groups_for(s->coarse_T);
             }
+            // Where the int8 filter keeps the shape, its TWO-slice set (the ramp: the first chunks of a scan, many
+            // candidates per row) is still the block-scaled one: at 2048 x 201 that is 13 column tiles x 2 slices x 16
+            // K = 128 steps against 28 int8 tile-slices x 32 K = 64 steps - about half the matrix work per row for the same
+            // ~1 survivor per candidate - and the chunks stay on it longer before the one-slice int8 set takes over
+            // (pick_coarse_mode prices both sets in int8 tile-slice equivalents).
+            const bool mixed = !use_mx && !s->narrow && getenv("KGWAS_COARSE_MX") == nullptr && getenv("KGWAS_COARSE_SLICES") == nullptr &&
+                               want[0] && want[1] && !(getenv("KGWAS_COARSE_MIXED") && atoi(getenv("KGWAS_COARSE_MIXED")) == 0);
             if (use_mx && !s->narrow && getenv("KGWAS_COARSE_SLICES") == nullptr) want[0] = false;  // one FP6 slice alone: only on request
             auto build_mx = [&](int mi) {
                 const int ns = mi + 1;
@@ -593,14 +600,17 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                 s->st.coarse_mode_tiles[mi] = M.part[0].T;
                 s->st.coarse_mode_lgroups[mi] = groups_all;
                 s->st.coarse_mode_tile_slices[mi] = M.tile_slices;
-                s->st.coarse_mx = 1;
+                if (use_mx) s->st.coarse_mx = 1;
                 s->st.coarse_mx_s1_fp6 = s1_fp6;
                 s->st.coarse_mx_steps = n_steps;
+                // the set's matrix work per row in int8 tile-slice equivalents (a K = 128 step is one of the 8 n_kgroups K = 64
+                // steps' worth of two; measured 30 % less efficient per MFMA with three column tiles per LDS group: 0.48 against 0.37 ms per M rows at 2048 x 201)
+                M.tile_slices_eq = (double)M.tile_slices * (double)n_steps / (8.0 * (double)n_kgroups) * (CTmax <= 3 ? 1.30 : 1.0);
                 M.ready = true;
             };
             for (int mi = 0; mi < 2; mi++) {
                 if (!want[mi]) continue;
-                if (use_mx) {
+                if (use_mx || (mixed && mi == 1)) {
                     build_mx(mi);
                     continue;
                 }

@@ -223,7 +223,8 @@ int pick_coarse_mode(const kgwas_scan* s) {
     if (!s->cmode[0].ready) return 1;
     if (!s->cmode[1].ready) return 0;
     const double cand_row = (double)s->sum_topn / (double)std::max<uint64_t>(s->rows_submitted, 1);
-    const double tiles0 = (double)s->cmode[0].tile_slices, tiles1 = (double)s->cmode[1].tile_slices;
+    auto eq = [](const kgwas_scan::CoarseMode& M) { return M.tile_slices_eq > 0 ? M.tile_slices_eq : (double)M.tile_slices; };
+    const double tiles0 = eq(s->cmode[0]), tiles1 = eq(s->cmode[1]);
     return cand_row * std::max(0.0, s->infl_obs[0] - s->infl_obs[1]) < s->mode_k * (tiles1 - tiles0) ? 0 : 1;
 }
 

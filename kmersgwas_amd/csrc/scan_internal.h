@@ -306,6 +306,7 @@ struct kgwas_scan {
         uint32_t mx_full = 0, mx_quarter = 0, mx_s1_fp6 = 0, mx_scale0 = 0;
         uint32_t slices = 0, n_parts = 0;
         uint32_t tile_slices = 0;  // operand tiles a row is multiplied with, all parts and groups
+        double tile_slices_eq = 0;  // the same in int8 tile-slice equivalents (0: tile_slices as it is): what pick_coarse_mode compares
         float eg_max = 0, rall_max = 0, rmax_max = 0;  // row error term, maxima over the columns (kernels.h)
         // Full LDS groups first; columns that would only fill part of another full-size group go into a second launch
         // with as few tiles as they need (201 columns at 2048 samples: 3 groups x 4 tiles + 1 tile instead of 4 x 4).

@@ -43,6 +43,9 @@
 #ifndef KGWAS_COARSE_ABLATE
 #define KGWAS_COARSE_ABLATE 0
 #endif
+#ifndef KGWAS_RESCORE_FMA
+#define KGWAS_RESCORE_FMA 1  // 0: the select-and-add form of rounds 1-2 (2.5 lane-ops per sample)
+#endif
 
 namespace kgwas {
 
@@ -393,6 +396,40 @@ __device__ __forceinline__ uint32_t tile_column(const uint32_t* tile_pref, uint3
 typedef __attribute__((address_space(4))) const float* kconst_f32p;
 __device__ __forceinline__ void rescore_block(const uint32_t (&w)[4], const float* yb, float (&acc)[4]) {
     kconst_f32p yc = (kconst_f32p)yb;
+#if KGWAS_RESCORE_FMA
+    // acc + (bit ? y : +0) == fma((float)bit, y, acc) for finite y (the filters only run on finite phenotypes): the bits of a
+    // dword become bytes 0 / 1 eight at a time ((w >> j) & 0x01010101: two lane-ops per four bits), v_cvt_f32_ubyteK makes
+    // 0.0f / 1.0f of one, and v_pk_fma_f32 advances two chains: 2.0 lane-ops per sample instead of 2.5.
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    uint32_t e[4][8];
+#pragma unroll
+    for (int l = 0; l < 4; l++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) e[l][j] = (w[l] >> j) & 0x01010101u;
+    f32x2 a01 = {acc[0], acc[1]}, a23 = {acc[2], acc[3]};
+#pragma unroll
+    for (int s = 0; s < 32; s++) {
+        const int b = 31 - s, j = b & 7, k = b >> 3;
+        const f32x2 y01 = {yc[4 * s], yc[4 * s + 1]}, y23 = {yc[4 * s + 2], yc[4 * s + 3]};
+        auto byte_f32 = [&](uint32_t x) {  // v_cvt_f32_ubyteK (the compiler shifts first and converts byte 0: two more ops per bit)
+            float f;
+            if (k == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(f) : "v"(x));
+            if (k == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(f) : "v"(x));
+            if (k == 2) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(f) : "v"(x));
+            if (k == 3) asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(f) : "v"(x));
+            return f;
+        };
+        const f32x2 g01 = {byte_f32(e[0][j]), byte_f32(e[1][j])};
+        const f32x2 g23 = {byte_f32(e[2][j]), byte_f32(e[3][j])};
+        a01 = __builtin_elementwise_fma(g01, y01, a01);
+        a23 = __builtin_elementwise_fma(g23, y23, a23);
+    }
+    acc[0] = a01.x;
+    acc[1] = a01.y;
+    acc[2] = a23.x;
+    acc[3] = a23.y;
+    return;
+#endif
 #pragma unroll
     for (int s = 0; s < 32; s++) {
         const float yv[4] = {yc[4 * s], yc[4 * s + 1], yc[4 * s + 2], yc[4 * s + 3]};
