@@ -443,9 +443,12 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                     while (((P + g - 1) / g + 1 + 15) / 16 > ctm) g++;
                     return g;
                 };
+                // Second slice: FP4. An FP6 one (1.1 survivors per candidate instead of 1.4) costs LDS, a slower MFMA (8.25
+                // against 9.5 POP/s) and two more operand registers per tile: measured at 1135 x 101, the same 2 x 4 tiles,
+                // filter 14.4 against 13.6 ms per 100 M rows and all kernels 18.3 against 17.8. KGWAS_MX_S1=6 selects it
+                // (tests keep that kernel form covered).
                 uint32_t s1_fp6 = 0;
-                if (ns == 2 && ct_max(1) && ct_max(0) && groups_for(ct_max(1)) == groups_for(ct_max(0))) s1_fp6 = 1;
-                if (const char* e = getenv("KGWAS_MX_S1")) s1_fp6 = atoi(e) == 6 && ct_max(1) ? 1u : 0u;  // experiments
+                if (const char* e = getenv("KGWAS_MX_S1")) s1_fp6 = ns == 2 && atoi(e) == 6 && ct_max(1) ? 1u : 0u;
                 const uint32_t CTmax = ct_max(s1_fp6);
                 if (!CTmax) throw Error(KGWAS_ERR_ARG, "coarse filter: too many accessions for the LDS");
                 const int sh = ns == 1 ? 0 : (s1_fp6 ? 5 : 3);                 // t = 2^sh * a6 + a1
@@ -514,7 +517,11 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                     const uint64_t cpf = (uint64_t)CTmax * 16 - 1;
                     const uint64_t full = P / cpf, rem = P - full * cpf;
                     const uint64_t CTr = rem ? (rem + 1 + 15) / 16 : 0;
-                    if (full >= 1 && full + (rem ? 1 : 0) <= n_lgroups && full * CTmax + CTr < n_lgroups * plan[0].CT) {
+                    // (a second launch for the rest is worth about one and a half tiles of its own: its few column tiles
+                    // multiply at a fraction of the full groups' efficiency. 1135 x 101: 2 x 4 tiles in one launch 13.6 ms per
+                    // 100 M rows, 6 + 1 tiles in two 16.3; 2048 x 201: 4 x 3 + 1 against 5 x 3)
+                    const bool no_split = getenv("KGWAS_COARSE_NOSPLIT") != nullptr;  // experiments
+                    if (full >= 1 && full + (rem ? 1 : 0) <= n_lgroups && 2 * (full * CTmax + CTr) + 3 < 2 * n_lgroups * plan[0].CT && !no_split) {
                         plan.clear();
                         plan.push_back(Plan{0, full * cpf, CTmax, full, cpf});
                         if (rem) plan.push_back(Plan{full * cpf, rem, CTr, 1, rem});
