@@ -370,12 +370,12 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
             //   slice); the accumulator is kappa * sum_i g_i t_i, kappa = 1/16, 1/4, 1/16, so one accumulator unit is
             //   u = w / kappa phenotype units and everything above (kalpha, the error terms in units of Dc) carries over
             //   with that u. The ones column has t = 1 / kappa: its accumulator is N1.
-            // Which filter (KGWAS_COARSE_MX=1|0 forces one): the block-scaled one wherever its operands (1.25 bytes per
-            // sample and column with two slices) leave a row no more LDS groups to pass through than the int8 filter's single
-            // slice (1 byte) does. Measured: 1024 x 101 (one group each) 9.9 + 4.3 ms of filter + other kernels per 100 M
-            // rows against 10.4 + 4.8; 2048 x 201 (five groups of three column tiles against four groups of four int8
-            // tiles) 45.0 + 10.8 against 38.7 + 14.4 - there every row is loaded, expanded and tested once per group,
-            // and the int8 filter keeps the shape.
+            // Which filter (KGWAS_COARSE_MX=1|0 forces one): the block-scaled one unless its operands (1.25 bytes per sample
+            // and column with two slices) make a row pass through more than ONE more LDS group than the int8 filter's single
+            // slice (1 byte) does - every row is loaded, expanded and tested once per group. Measured, all kernels per 100 M
+            // rows: 1024 x 101 (one group each) 14.2 ms against 15.2; 1135 x 101 (two each) 17.6 against 21.1; 2048 x 201
+            // (five equal groups of three column tiles in one launch against four groups of four int8 tiles + the two-slice
+            // ramp) 50.1 against 52.2 (51.5 with the int8 one-slice set + a block-scaled ramp, the arrangement beyond).
             bool use_mx;
             if (const char* e = getenv("KGWAS_COARSE_MX")) {
                 use_mx = atoi(e) != 0;
@@ -389,7 +389,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                 uint32_t ctm = 0;
                 for (uint32_t ct = 7; ct >= 1 && !ctm; ct--)
                     if (mx_lds_bytes(steps, ct, 2, 0) <= 160u * 1024u) ctm = ct;
-                use_mx = groups_for(ctm) <= groups_for(s->coarse_T);
+                use_mx = groups_for(ctm) <= groups_for(s->coarse_T) + 1;
             }
             // Where the int8 filter keeps the shape, its TWO-slice set (the ramp: the first chunks of a scan, many
             // candidates per row) is still the block-scaled one: at 2048 x 201 that is 13 column tiles x 2 slices x 16
@@ -517,11 +517,11 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                     const uint64_t cpf = (uint64_t)CTmax * 16 - 1;
                     const uint64_t full = P / cpf, rem = P - full * cpf;
                     const uint64_t CTr = rem ? (rem + 1 + 15) / 16 : 0;
-                    // (a second launch for the rest is worth about one and a half tiles of its own: its few column tiles
-                    // multiply at a fraction of the full groups' efficiency. 1135 x 101: 2 x 4 tiles in one launch 13.6 ms per
-                    // 100 M rows, 6 + 1 tiles in two 16.3; 2048 x 201: 4 x 3 + 1 against 5 x 3)
+                    // (a second launch for the rest is worth two and a half tiles of its own: its few column tiles multiply at
+                    // a fraction of the full groups' efficiency. 1135 x 101: 2 x 4 tiles in one launch 13.6 ms per 100 M rows,
+                    // 6 + 1 tiles in two 16.3; 2048 x 201: 5 x 3 tiles in one launch 39.2, 4 x 3 + 1 in two 40.2)
                     const bool no_split = getenv("KGWAS_COARSE_NOSPLIT") != nullptr;  // experiments
-                    if (full >= 1 && full + (rem ? 1 : 0) <= n_lgroups && 2 * (full * CTmax + CTr) + 3 < 2 * n_lgroups * plan[0].CT && !no_split) {
+                    if (full >= 1 && full + (rem ? 1 : 0) <= n_lgroups && 2 * (full * CTmax + CTr) + 5 < 2 * n_lgroups * plan[0].CT && !no_split) {
                         plan.clear();
                         plan.push_back(Plan{0, full * cpf, CTmax, full, cpf});
                         if (rem) plan.push_back(Plan{full * cpf, rem, CTr, 1, rem});

@@ -148,12 +148,13 @@ def test_coarse_filter_shapes(monkeypatch, mx, slices, S, P, shift):
 
 
 def test_mixed_filter_sets_int8_steady_state_block_scaled_ramp():
-    """2048 samples x 201 columns with nothing forced (BASELINE configs[3]'s shape): the block-scaled operands would need more
-    LDS groups than the int8 filter's single slice, so the int8 one-slice set keeps the steady state - and the two-slice set
-    of the scan's first chunks (many candidates per row) is the block-scaled one. Both sets run in one scan (a small top-N
-    makes the session switch inside 70 k rows), chunk by chunk; heaps equal the oracle's."""
-    S, P = 2048, 201
-    rows = random_table(70_000, S, seed=77, dup_frac=0.2)
+    """4096 samples x 100 columns with nothing forced: the block-scaled operands (one column tile per LDS group: seven groups)
+    would make a row pass through more than one more LDS group than the int8 filter's single slice (four groups of two tiles),
+    so the int8 one-slice set keeps the steady state - and the two-slice set of the scan's first chunks (many candidates per
+    row) is the block-scaled one. Both sets run in one scan (a small top-N makes the session switch inside 50 k rows), chunk
+    by chunk; heaps equal the oracle's."""
+    S, P = 4096, 100
+    rows = random_table(50_000, S, seed=77, dup_frac=0.2)
     col = np.arange(S, dtype=np.uint64)
     Y = phenotypes(S, P - 1, seed=5)
     mac = onp.min_count(S, 0.05, 5)
@@ -163,7 +164,7 @@ def test_mixed_filter_sets_int8_steady_state_block_scaled_ramp():
     scan.feed_host(rows)
     scan.finish()
     st = scan.stats()
-    assert st["kernel_used"] == kg.KERNEL_COARSE and st["coarse_mx"] == 0 and st["coarse_mx_steps"] == 16
+    assert st["kernel_used"] == kg.KERNEL_COARSE and st["coarse_mx"] == 0 and st["coarse_mx_steps"] == 32
     assert st["coarse_mode_launches"][0] > 0 and st["coarse_mode_launches"][1] > 0, st["coarse_mode_launches"]
     _check_topn(scan, exp, P)
     assert st["rows_tested"] == exp["tested"]
