@@ -212,6 +212,15 @@ int kgwas_scan_heaps_export(kgwas_scan* s, uint64_t n_cols, const uint64_t* cols
                             const double** score, const uint64_t** row);
 int kgwas_scan_heaps_import(kgwas_scan* s, uint64_t n_cols, const uint64_t* cols, const uint64_t* sizes, const uint64_t* kmer,
                             const double* score, const uint64_t* row);
+/* The same two exports as MESSAGES written straight into caller memory (the pinned staging buffer of an all-to-all):
+ * message m covers the columns msg_col0[m] .. msg_col0[m] + msg_ncols[m] - 1 and is laid out as 64-bit words
+ *   [words that follow][counts or sizes: msg_ncols[m]][kmer: T][score bit patterns: T][row: T],  T = sum of the counts
+ * (msg_ncols[m] = 0: the one word 0). Messages follow each other in `out`; msg_words[m] receives message m's length.
+ * Nothing is written unless the messages fit cap_words (the caller grows the buffer and calls again). */
+int kgwas_scan_history_above_msgs(kgwas_scan* s, const double* thr, uint64_t n_msgs, const uint64_t* msg_col0,
+                                  const uint64_t* msg_ncols, uint64_t* out, uint64_t cap_words, uint64_t* msg_words);
+int kgwas_scan_heaps_export_msgs(kgwas_scan* s, uint64_t n_msgs, const uint64_t* msg_col0, const uint64_t* msg_ncols,
+                                 uint64_t* out, uint64_t cap_words, uint64_t* msg_words);
 
 /* ------------------------------------------------------------------------------------
  * The same scan over several GPUs of one node, inside one process (the reference's caller, kmers_gwas.py:133-148, runs

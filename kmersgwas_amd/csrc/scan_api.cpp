@@ -3,6 +3,28 @@
 // shard merge through the C ABI.
 #include "scan_internal.h"
 
+// Layout of merge messages (include/kgwas.h: kgwas_scan_*_msgs).
+namespace {
+struct MsgPlan {
+    std::vector<uint64_t> start;  // word offset of message m in the buffer (n_msgs + 1)
+    uint64_t total() const { return start.back(); }
+};
+// cnt(j) = entries of column j. Fills msg_words and returns the layout.
+template <class Cnt>
+MsgPlan plan_msgs(const kgwas_scan* s, uint64_t n_msgs, const uint64_t* col0, const uint64_t* ncols, uint64_t* msg_words, Cnt cnt, const char* who) {
+    MsgPlan p;
+    p.start.assign(n_msgs + 1, 0);
+    for (uint64_t m = 0; m < n_msgs; m++) {
+        if (ncols[m] && (col0[m] >= s->n_pheno || ncols[m] > s->n_pheno - col0[m])) throw Error(KGWAS_ERR_ARG, std::string(who) + ": columns out of range");
+        uint64_t T = 0;
+        for (uint64_t c = 0; c < ncols[m]; c++) T += cnt(col0[m] + c);
+        msg_words[m] = 1 + ncols[m] + 3 * T;
+        p.start[m + 1] = p.start[m] + msg_words[m];
+    }
+    return p;
+}
+}  // namespace
+
 extern "C" {
 
 uint32_t kgwas_host_cpu_quota(void) { return usable_cpus(); }
@@ -263,6 +285,109 @@ int kgwas_scan_heaps_import(kgwas_scan* s, uint64_t n_cols, const uint64_t* cols
         KGWAS_HIP(hipSetDevice(s->device));
         s->hist_ready = false;
         upload_thresholds(s);
+    });
+}
+
+// ---- merge messages (include/kgwas.h): [words that follow][counts: n][kmer: T][score bits: T][row: T] --------------
+int kgwas_scan_history_above_msgs(kgwas_scan* s, const double* thr, uint64_t n_msgs, const uint64_t* msg_col0,
+                                  const uint64_t* msg_ncols, uint64_t* out, uint64_t cap_words, uint64_t* msg_words) {
+    return guarded([&] {
+        if (!s || !thr || (n_msgs && (!msg_col0 || !msg_ncols || !msg_words))) throw Error(KGWAS_ERR_ARG, "kgwas_scan_history_above_msgs: null argument");
+        if (!s->record_history && !s->history_ring) throw Error(KGWAS_ERR_STATE, "scan was created without record_history");
+        const uint64_t P = s->n_pheno;
+        std::vector<char> wanted(P, 0);
+        for (uint64_t m = 0; m < n_msgs; m++)
+            for (uint64_t c = 0; c < msg_ncols[m] && msg_col0[m] + c < P; c++) wanted[msg_col0[m] + c] = 1;
+        const double ninf = -std::numeric_limits<double>::infinity();
+        auto keep = [&](uint64_t j, double sc) { return thr[j] == ninf || sc > thr[j]; };
+        std::vector<std::vector<BestHeap::Rec>> recs(s->history_ring ? P : 0);
+        std::vector<uint64_t> counts(P, 0);
+        std::vector<char> ok(P, 1);
+        if (!s->history_ring) _mm_sfence();
+        s->pool->parallel_for(P, [&](size_t j) {
+            if (!wanted[j]) return;
+            if (s->history_ring) {  // mode 2: the heap's entries and its last evictions above thr, put in row order
+                ok[j] = s->heaps[j].pushes_above(thr[j], recs[j]) ? 1 : 0;
+                counts[j] = recs[j].size();
+            } else {
+                const History& h = s->hist[j];
+                uint64_t c = 0;
+                for (size_t i = 0; i < h.n; i++) c += keep(j, h.p[i].score) ? 1 : 0;
+                counts[j] = c;
+            }
+        });
+        for (uint64_t j = 0; j < P; j++)
+            if (!ok[j])
+                throw Error(KGWAS_ERR_STATE, "record_history = 2: column " + std::to_string(j) + " needs evictions that left its ring of " +
+                                                 std::to_string(ring_size(s->history_ring, s->topn[j])) + " (raise KGWAS_HISTORY_RING, or use record_history = 1)");
+        const MsgPlan plan = plan_msgs(s, n_msgs, msg_col0, msg_ncols, msg_words, [&](uint64_t j) { return counts[j]; }, "kgwas_scan_history_above_msgs");
+        if (!out || cap_words < plan.total()) return;
+        struct Job {
+            uint64_t j, ok, os, orw;  // column, word offsets of its kmer / score / row runs
+        };
+        std::vector<Job> jobs;
+        for (uint64_t m = 0; m < n_msgs; m++) {
+            uint64_t* msg = out + plan.start[m];
+            msg[0] = msg_words[m] - 1;
+            uint64_t T = 0;
+            for (uint64_t c = 0; c < msg_ncols[m]; c++) T += (msg[1 + c] = counts[msg_col0[m] + c]);
+            uint64_t o = plan.start[m] + 1 + msg_ncols[m];
+            for (uint64_t c = 0; c < msg_ncols[m]; c++) {
+                const uint64_t j = msg_col0[m] + c;
+                jobs.push_back(Job{j, o, o + T, o + 2 * T});
+                o += counts[j];
+            }
+        }
+        s->pool->parallel_for(jobs.size(), [&](size_t i) {
+            const Job& b = jobs[i];
+            uint64_t* k = out + b.ok;
+            uint64_t* sc = out + b.os;
+            uint64_t* rw = out + b.orw;
+            uint64_t o = 0;
+            auto put = [&](uint64_t kmer, double score, uint64_t row) {
+                k[o] = kmer;
+                std::memcpy(&sc[o], &score, 8);
+                rw[o] = row;
+                o++;
+            };
+            if (s->history_ring) {
+                for (const BestHeap::Rec& r : recs[b.j]) put(r.kmer, r.score, r.row);
+            } else {
+                const History& h = s->hist[b.j];
+                for (size_t e = 0; e < h.n; e++)
+                    if (keep(b.j, h.p[e].score)) put(h.p[e].kmer, h.p[e].score, h.p[e].row);
+            }
+        });
+    });
+}
+
+int kgwas_scan_heaps_export_msgs(kgwas_scan* s, uint64_t n_msgs, const uint64_t* msg_col0, const uint64_t* msg_ncols,
+                                 uint64_t* out, uint64_t cap_words, uint64_t* msg_words) {
+    return guarded([&] {
+        if (!s || (n_msgs && (!msg_col0 || !msg_ncols || !msg_words))) throw Error(KGWAS_ERR_ARG, "kgwas_scan_heaps_export_msgs: null argument");
+        const MsgPlan plan = plan_msgs(s, n_msgs, msg_col0, msg_ncols, msg_words, [&](uint64_t j) { return (uint64_t)s->heaps[j].size(); }, "kgwas_scan_heaps_export_msgs");
+        if (!out || cap_words < plan.total()) return;
+        struct Job {
+            uint64_t j, ok, os, orw;
+        };
+        std::vector<Job> jobs;
+        for (uint64_t m = 0; m < n_msgs; m++) {
+            uint64_t* msg = out + plan.start[m];
+            msg[0] = msg_words[m] - 1;
+            uint64_t T = 0;
+            for (uint64_t c = 0; c < msg_ncols[m]; c++) T += (msg[1 + c] = s->heaps[msg_col0[m] + c].size());
+            uint64_t o = plan.start[m] + 1 + msg_ncols[m];
+            for (uint64_t c = 0; c < msg_ncols[m]; c++) {
+                const uint64_t j = msg_col0[m] + c;
+                jobs.push_back(Job{j, o, o + T, o + 2 * T});
+                o += s->heaps[j].size();
+            }
+        }
+        static_assert(sizeof(double) == sizeof(uint64_t), "score bit patterns travel as 64-bit words");
+        s->pool->parallel_for(jobs.size(), [&](size_t i) {
+            const Job& b = jobs[i];
+            s->heaps[b.j].export_state(out + b.ok, reinterpret_cast<double*>(out + b.os), out + b.orw);
+        });
     });
 }
 

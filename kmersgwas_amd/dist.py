@@ -9,9 +9,10 @@ shard with no data-path collective, and one small exchange closes the job:
                 filtered by  score > max(final heap minima of the full heaps of shards < g)  — anything
                 else is rejected by add_association whenever it arrives, since the global minimum at
                 that point is at least that large: about top-N entries per column instead of
-                N*(1+ln(rows/N)). merge_by_column finishes column j on rank j mod G (rank 0's heap state for
-                it travels there, layout included; shards 1, 2, ... are replayed in order; the final states
-                return to rank 0): one all_to_all each way, work per rank P/G columns x G shards.
+                N*(1+ln(rows/N)). merge_by_column finishes the d-th block of columns on rank d (rank 0's heap
+                states for it travel there, layout included; shards 1, 2, ... are replayed in order; the final
+                states return to rank 0): one all_to_all each way, work per rank P/G columns x G shards; the
+                messages are written by the library straight into pinned staging buffers.
                 merge_to_root replays everything on rank 0 (one exchange, no heap state travels: cheaper for
                 few ranks); merge_shards picks between the two. merge_on_root is the first, simple variant.
   kinship     : integer Hamming partials + used-row counts are all-reduced (sum).
@@ -114,56 +115,127 @@ def exchange_minima(low: np.ndarray, full: np.ndarray):
     return a[:, :P], a[:, P:] > 0.5
 
 
-def _all_to_all_i64(send_parts):
-    """send_parts[d] = 1-D int64 numpy array for rank d. Returns the list of arrays received from every rank."""
+# ---- merge messages -----------------------------------------------------------------------------------------
+# A message is a run of 64-bit words: [words that follow][counts: n_cols][kmer: T][score bit patterns: T][row: T]
+# (T = sum of the counts; "no columns" is the one word 0). The scan session writes its messages straight into a
+# pinned staging buffer (AssociationScan.history_above_msgs / heaps_export_msgs: kgwas_scan_*_msgs), the buffer goes to
+# the device in one asynchronous copy, one all_to_all_single moves every rank's messages, and the received words come
+# back into a second pinned buffer whose slices the session reads in place (heaps_import / absorb_flat): no host copy
+# of the payload on either side.
+_STAGE = {}
+
+
+def _staging(name: str, n_words: int) -> torch.Tensor:
+    """Grow-only int64 staging tensor (pinned when the exchange runs over RCCL)."""
+    t = _STAGE.get(name)
+    if t is None or t.numel() < n_words:
+        pin = _dev().type == "cuda"
+        t = torch.empty(int(n_words) + int(n_words) // 4 + 1024, dtype=torch.int64, pin_memory=pin)
+        _STAGE[name] = t
+    return t
+
+
+def _column_blocks(P: int, world: int) -> np.ndarray:
+    """Columns of owner d: blocks[d] .. blocks[d + 1] - 1 (contiguous, so a message is one run of the flat exports)."""
+    return np.asarray([(P * d) // world for d in range(world + 1)], np.uint64)
+
+
+def _pack_msgs_numpy(col0, ncols, counts, kmer, score, row, out):
+    """The message writer for scan objects that only offer the flat exports (the pure-Python stand-in of the CPU
+    tests): counts[j] entries of column j, flat by column. Returns the lengths; writes if `out` is large enough."""
+    counts = np.asarray(counts, np.uint64)
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    words = np.asarray([1 + int(n) + 3 * int(counts[int(c):int(c) + int(n)].sum()) for c, n in zip(col0, ncols)], np.uint64)
+    if out is None or int(words.sum()) > len(out):
+        return words
+    o = 0
+    for c, n, w in zip(col0, ncols, words):
+        c, n, w = int(c), int(n), int(w)
+        lo, hi = int(off[c]), int(off[c + n])
+        msg = np.concatenate([np.asarray([w - 1], np.int64), counts[c:c + n].view(np.int64), np.asarray(kmer[lo:hi], np.uint64).view(np.int64),
+                              np.asarray(score[lo:hi], np.float64).view(np.int64), np.asarray(row[lo:hi], np.uint64).view(np.int64)])
+        out[o:o + w] = msg
+        o += w
+    return words
+
+
+def _write_msgs(name: str, writer, guess_words: int):
+    """Run writer(out) -> message lengths against the staging buffer `name`, growing it once if needed."""
+    buf = _staging(name, guess_words)
+    words = writer(buf.numpy())
+    if int(words.sum()) > buf.numel():
+        buf = _staging(name, int(words.sum()))
+        words = writer(buf.numpy())
+        assert int(words.sum()) <= buf.numel()
+    return buf, [int(w) for w in words]
+
+
+def _history_msgs(scan, thr, col0, ncols, name="send"):
+    guess = _STAGE[name].numel() if name in _STAGE else 0
+    if hasattr(scan, "history_above_msgs"):
+        return _write_msgs(name, lambda out: scan.history_above_msgs(thr, col0, ncols, out), guess)
+    flat = scan.history_above(thr)
+    return _write_msgs(name, lambda out: _pack_msgs_numpy(col0, ncols, *flat, out), guess)
+
+
+def _heaps_msgs(scan, col0, ncols, name="send"):
+    guess = _STAGE[name].numel() if name in _STAGE else 0
+    if hasattr(scan, "heaps_export_msgs"):
+        return _write_msgs(name, lambda out: scan.heaps_export_msgs(col0, ncols, out), guess)
+    P = scan.n_pheno
+    sizes, k, s, r = scan.heaps_export(np.arange(P, dtype=np.uint64))
+    return _write_msgs(name, lambda out: _pack_msgs_numpy(col0, ncols, sizes, k, s, r, out), guess)
+
+
+def _exchange_msgs(send: torch.Tensor, words, name="recv"):
+    """send holds this rank's world messages back to back (words[d] words for rank d, each at least the length word).
+    Returns the messages received from every rank as views of the staging buffer `name`."""
     world = dist.get_world_size()
     dev = _dev()
-    # every message carries its length in front: no zero-sized sends or receives reach the backend
-    send_parts = [np.concatenate([np.asarray([len(a)], np.int64), np.asarray(a, np.int64)]) for a in send_parts]
-    ins = [int(len(a)) for a in send_parts]
+    ins = [int(w) for w in words]
+    assert len(ins) == world and min(ins) >= 1
     t_in = torch.tensor(ins, dtype=torch.int64, device=dev)
     all_ins = [torch.zeros(world, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(all_ins, t_in)
     rank = dist.get_rank()
-    outs = [int(all_ins[src][rank]) for src in range(world)]
-    flat = np.concatenate(send_parts)
-    inp = torch.from_numpy(np.ascontiguousarray(flat, np.int64)).to(dev)
-    out = torch.zeros(sum(outs), dtype=torch.int64, device=dev)
+    sizes = torch.stack(all_ins).cpu().numpy()
+    outs = [int(sizes[src][rank]) for src in range(world)]
+    inp = send[:sum(ins)].to(dev, non_blocking=True)
+    out = torch.empty(sum(outs), dtype=torch.int64, device=dev)
     dist.all_to_all_single(out, inp, outs, ins)
-    out = out.cpu().numpy()
+    recv = _staging(name, sum(outs))
+    recv[:sum(outs)].copy_(out)  # device -> pinned (synchronises the stream the exchange ran behind)
+    a = recv.numpy()
     off = np.concatenate([[0], np.cumsum(outs)]).astype(np.int64)
-    msgs = [out[off[i]:off[i + 1]] for i in range(world)]
+    msgs = [a[off[i]:off[i + 1]] for i in range(world)]
     assert all(int(m[0]) == len(m) - 1 for m in msgs)
-    return [m[1:] for m in msgs]
+    return msgs
 
 
-def _pack(counts, kmer, score, row):
-    """One int64 message: [counts..., kmer..., score bits..., row...]."""
-    return np.concatenate([np.asarray(counts, np.uint64).view(np.int64), np.asarray(kmer, np.uint64).view(np.int64),
-                           np.asarray(score, np.float64).view(np.int64), np.asarray(row, np.uint64).view(np.int64)])
-
-
-def _unpack(msg, n_counts):
-    counts = msg[:n_counts].view(np.uint64)
+def _parse_msg(msg, n_cols: int):
+    """(counts, kmer, score, row) views of a message of n_cols columns; an empty message reads as no entries."""
+    if len(msg) == 1:
+        return np.zeros(n_cols, np.uint64), np.zeros(0, np.uint64), np.zeros(0, np.float64), np.zeros(0, np.uint64)
+    counts = msg[1:1 + n_cols].view(np.uint64)
     n = int(counts.sum())
-    body = msg[n_counts:]
+    body = msg[1 + n_cols:]
     assert len(body) == 3 * n, (len(body), n)
     return counts, body[:n].view(np.uint64), body[n:2 * n].view(np.float64), body[2 * n:].view(np.uint64)
 
 
 def merge_by_column(scan, dst: int = 0):
     """Column-distributed merge of the shard scans (every rank scanned its contiguous row range; ranks >= 1 with
-    record_history=True). Column j is finished on rank j mod G: rank 0 ships that heap's state there (layout
-    included), every later rank ships the part of its history that can still matter (score above the larger of
-    the earlier shards' final minima), the owner replays shards 1, 2, ... in order - exactly what a single heap
+    record_history). Rank d finishes the columns of block d (_column_blocks): rank 0 ships those heaps' states there
+    (layout included), every later rank ships the part of its history that can still matter (score above the larger
+    of the earlier shards' final minima), the owner replays shards 1, 2, ... in order - exactly what a single heap
     would have seen - and the final heap states return to rank 0, whose session then holds the global result
     (scan.result(j) after this call). One all_to_all each way; per rank the work is P/G columns x G shards, so
     the merge shrinks with G instead of piling up on rank 0. Returns the total tested-k-mers count.
-    `scan` needs: n_pheno, stats(), lowest(), history_above(), heaps_export(), heaps_import(), absorb_flat(),
-    finish()."""
+    `scan` needs: n_pheno, stats(), lowest(), heaps_import(), absorb_flat(), finish() and either the message writers
+    history_above_msgs() / heaps_export_msgs() or the flat exports history_above() / heaps_export()."""
     assert dst == 0, "rank 0 holds the heaps of the first shard"
     import os, time
-    trace = bool(os.environ.get("KGWAS_TRACE"))
+    trace = bool(os.environ.get("KGWAS_TRACE") or os.environ.get("KGWAS_TRACE_MERGE"))
     marks = [("start", time.perf_counter())]
     mark = (lambda name: marks.append((name, time.perf_counter()))) if trace else (lambda name: None)
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -173,56 +245,49 @@ def merge_by_column(scan, dst: int = 0):
     low, full = scan.lowest()
     lows, fulls = exchange_minima(low, full)
     thr = prefix_thresholds(lows, fulls)
-    owned = [np.arange(d, P, world, dtype=np.uint64) for d in range(world)]
+    blocks = _column_blocks(P, world)
+    col0, ncols = blocks[:-1].copy(), (blocks[1:] - blocks[:-1]).astype(np.uint64)
     mark("minima")
 
-    # way out: heap states (from rank 0) / filtered histories (from ranks >= 1), split by owner
-    parts = []
+    # way out: heap states (from rank 0, not to itself) / filtered histories (from ranks >= 1), one message per owner
     if rank == 0:
-        for d in range(world):
-            if d == 0 or len(owned[d]) == 0:
-                parts.append(np.zeros(0, np.int64))
-            else:
-                parts.append(_pack(*scan.heaps_export(owned[d])))
+        out_n = ncols.copy()
+        out_n[0] = 0
+        send, words = _heaps_msgs(scan, col0, out_n)
     else:
-        counts, k, s, r = scan.history_above(thr[rank])
-        off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
-        for d in range(world):
-            cols = owned[d].astype(np.int64)
-            if len(cols) == 0:
-                parts.append(np.zeros(0, np.int64))
-                continue
-            cat = lambda a: np.concatenate([a[off[j]:off[j + 1]] for j in cols])
-            parts.append(_pack(counts[cols], cat(k), cat(s), cat(r)))
+        send, words = _history_msgs(scan, thr[rank], col0, ncols)
     mark("export")
-    recv = _all_to_all_i64(parts)
+    recv = _exchange_msgs(send, words)
     mark("all_to_all")
 
-    mine = owned[rank]
+    mine = np.arange(int(blocks[rank]), int(blocks[rank + 1]), dtype=np.uint64)
     if len(mine):
         if rank != 0:
-            sizes, k, s, r = _unpack(recv[0], len(mine))
-            scan.heaps_import(mine, sizes, k, s, r)
+            scan.heaps_import(mine, *_parse_msg(recv[0], len(mine)))
+            mark("import")
         if world > 1:
             counts = np.zeros((world - 1, P), np.uint64)
             ks, ss, rs = [], [], []
             for g in range(1, world):
-                c, k, s, r = _unpack(recv[g], len(mine))
-                counts[g - 1, mine.astype(np.int64)] = c
+                c, k, s, r = _parse_msg(recv[g], len(mine))
+                counts[g - 1, int(mine[0]):int(mine[0]) + len(mine)] = c
                 ks.append(k); ss.append(s); rs.append(r)
             scan.absorb_flat(counts, ks, ss, rs)  # entries are ordered by column, as counts says
     mark("absorb")
 
     # way back: final heap states of the owned columns to rank 0
-    back = [np.zeros(0, np.int64) for _ in range(world)]
-    if rank != 0 and len(mine):
-        back[0] = _pack(*scan.heaps_export(mine))
-    recv = _all_to_all_i64(back)
+    back_n = np.zeros(world, np.uint64)
+    if rank != 0:
+        back_n[0] = len(mine)
+    send, words = _heaps_msgs(scan, np.full(world, int(blocks[rank]), np.uint64), back_n, name="send_back")
+    mark("export_back")
+    recv = _exchange_msgs(send, words, name="recv_back")
+    mark("all_to_all_back")
     if rank == 0:
         for g in range(1, world):
-            if len(owned[g]):
-                sizes, k, s, r = _unpack(recv[g], len(owned[g]))
-                scan.heaps_import(owned[g], sizes, k, s, r)
+            n = int(ncols[g])
+            if n:
+                scan.heaps_import(np.arange(int(col0[g]), int(col0[g]) + n, dtype=np.uint64), *_parse_msg(recv[g], n))
         mark("collect")
         scan.finish()
         mark("finish")
@@ -235,12 +300,12 @@ def merge_by_column(scan, dst: int = 0):
 
 def merge_to_root(scan, dst: int = 0):
     """The same result as merge_by_column with every column finished on rank 0: ranks >= 1 send the part of their
-    history that can still matter (score above the larger of the earlier shards' final minima; filtered and laid out
-    flat by the library), rank 0 replays shards 1, 2, ... in order into its own heaps. One exchange, no heap state
-    travels; rank 0 does P x N x ln(G) pushes (about a fifth of its own scan's at G = 8), so this is the cheaper
+    history that can still matter (score above the larger of the earlier shards' final minima; filtered and written
+    as one message by the library), rank 0 replays shards 1, 2, ... in order into its own heaps. One exchange, no heap
+    state travels; rank 0 does P x N x ln(G) pushes (about a fifth of its own scan's at G = 8), so this is the cheaper
     variant for few ranks, merge_by_column (work per rank P/G columns, but two exchanges of the heap states) for
-    many. Returns the total tested-k-mers count. `scan` needs: n_pheno, stats(), lowest(), history_above(),
-    absorb_flat(), finish()."""
+    many. Returns the total tested-k-mers count. `scan` needs: n_pheno, stats(), lowest(), absorb_flat(), finish()
+    and history_above_msgs() or history_above()."""
     assert dst == 0, "rank 0 holds the heaps of the first shard"
     rank, world = dist.get_rank(), dist.get_world_size()
     P = scan.n_pheno
@@ -249,16 +314,21 @@ def merge_to_root(scan, dst: int = 0):
     low, full = scan.lowest()
     lows, fulls = exchange_minima(low, full)
     thr = prefix_thresholds(lows, fulls)
-    parts = [np.zeros(0, np.int64) for _ in range(world)]
+    col0 = np.zeros(world, np.uint64)
+    ncols = np.zeros(world, np.uint64)
     if rank != 0:
-        parts[0] = _pack(*scan.history_above(thr[rank]))
-    recv = _all_to_all_i64(parts)
+        ncols[0] = P
+        send, words = _history_msgs(scan, thr[rank], col0, ncols)
+    else:
+        send, words = _staging("send", world), [1] * world
+        send[:world] = 0
+    recv = _exchange_msgs(send, words)
     if rank == 0:
         if world > 1:
             counts = np.zeros((world - 1, P), np.uint64)
             ks, ss, rs = [], [], []
             for g in range(1, world):
-                c, k, s, r = _unpack(recv[g], P)
+                c, k, s, r = _parse_msg(recv[g], P)
                 counts[g - 1] = c
                 ks.append(k); ss.append(s); rs.append(r)
             scan.absorb_flat(counts, ks, ss, rs)

@@ -250,6 +250,33 @@ class AssociationScan:
         check(lib.kgwas_scan_heaps_export(self._h, len(cols), ptr(cols), ptr(sizes), C.byref(k), C.byref(s), C.byref(r)))
         return (sizes,) + self._flat3(int(sizes.sum()), k, s, r)
 
+    @staticmethod
+    def _msg_args(col0, ncols, out):
+        col0 = np.ascontiguousarray(col0, np.uint64)
+        ncols = np.ascontiguousarray(ncols, np.uint64)
+        assert len(col0) == len(ncols)
+        words = np.zeros(len(col0), np.uint64)
+        if out is None:
+            return col0, ncols, words, None, 0
+        assert out.dtype.itemsize == 8 and out.ndim == 1 and out.flags["C_CONTIGUOUS"] and out.flags["WRITEABLE"]
+        return col0, ncols, words, C.c_void_p(out.ctypes.data), len(out)
+
+    def history_above_msgs(self, thr: np.ndarray, col0, ncols, out):
+        """history_above() as messages written into `out` (a 1-D array of 64-bit words, e.g. a view of a pinned staging
+        buffer; include/kgwas.h describes the layout): message m = the columns col0[m] .. col0[m] + ncols[m] - 1.
+        Returns the messages' lengths in words; nothing was written if their sum exceeds len(out)."""
+        thr = np.ascontiguousarray(thr, np.float64)
+        assert len(thr) == self.n_pheno
+        col0, ncols, words, p_out, cap = self._msg_args(col0, ncols, out)
+        check(lib.kgwas_scan_history_above_msgs(self._h, ptr(thr), len(col0), ptr(col0), ptr(ncols), p_out, cap, ptr(words)))
+        return words
+
+    def heaps_export_msgs(self, col0, ncols, out):
+        """heaps_export() as messages written into `out` (see history_above_msgs)."""
+        col0, ncols, words, p_out, cap = self._msg_args(col0, ncols, out)
+        check(lib.kgwas_scan_heaps_export_msgs(self._h, len(col0), ptr(col0), ptr(ncols), p_out, cap, ptr(words)))
+        return words
+
     def heaps_import(self, cols, sizes, kmer, score, row):
         """Re-create exported heap states (layout included) in this session. Call finish() again afterwards."""
         cols = np.ascontiguousarray(cols, np.uint64)

@@ -397,6 +397,46 @@ def test_eviction_ring_history_equals_full_log(monkeypatch):
     tiny.close()
 
 
+def test_merge_messages_equal_flat_exports():
+    """kgwas_scan_history_above_msgs / kgwas_scan_heaps_export_msgs (what the N > 1 merge sends) against the flat exports:
+    any split of the columns into messages, empty messages, both history modes; a buffer that is too small is left
+    untouched and the lengths still come back."""
+    from kmersgwas_amd import dist as kdist
+    S_f, S, P, topn = 130, 130, 7, 300
+    rows = random_table(30_000, S_f, seed=5, dup_frac=0.4)
+    col = np.arange(S, dtype=np.uint64)
+    Y = phenotypes(S, P - 1, seed=4, binary=True)
+    mac = onp.min_count(S, 0.05, 5)
+    for mode in (1, 2):
+        sc = kg.AssociationScan(S_f, col, Y, topn, mac, chunk_rows=4096, record_history=mode)
+        sc.feed_host(rows, 0)
+        thr = sc.lowest()[0] * 0.99
+        flat = [np.array(x) for x in sc.history_above(thr)]
+        heaps = [np.array(x) for x in sc.heaps_export(np.arange(P, dtype=np.uint64))]
+        for col0, ncols in (([0, 2, 2, 5], [2, 0, 3, 2]), ([0], [P]), ([3, 0], [4, 3]), ([6, 0, 0], [1, 0, 0])):
+            for ref, writer in ((flat, lambda o: sc.history_above_msgs(thr, col0, ncols, o)), (heaps, lambda o: sc.heaps_export_msgs(col0, ncols, o))):
+                words = writer(None)
+                exp = kdist._pack_msgs_numpy(col0, ncols, *ref, None)
+                assert [int(w) for w in words] == [int(w) for w in exp]
+                small = np.full(int(words.sum()) - 1, -7, np.int64)
+                assert [int(w) for w in writer(small)] == [int(w) for w in exp] and (small == -7).all()
+                out = np.full(int(words.sum()) + 3, -7, np.int64)
+                writer(out)
+                want = np.full(len(out), -7, np.int64)
+                kdist._pack_msgs_numpy(col0, ncols, *ref, want)
+                assert out.tobytes() == want.tobytes()
+                o = 0
+                off = np.concatenate([[0], np.cumsum(ref[0])]).astype(np.int64)
+                for c, n, w in zip(col0, ncols, words):
+                    cnt, k, s_, r = kdist._parse_msg(out[o:o + int(w)], n)
+                    lo, hi = int(off[c]), int(off[c + n])
+                    assert (cnt == ref[0][c:c + n]).all() and (k == ref[1][lo:hi]).all() and s_.tobytes() == ref[2][lo:hi].tobytes() and (r == ref[3][lo:hi]).all()
+                    o += int(w)
+        with pytest.raises(kg.KgwasError):
+            sc.heaps_export_msgs([5], [3], None)  # columns 5..7 of 7
+        sc.close()
+
+
 def kg_other_minima(rows, S_f, col, Y, topn, mac):
     """Final heap minima of a scan over the same rows in reverse k-mer order (a stand-in for another shard)."""
     sc = kg.AssociationScan(S_f, col, Y, topn, mac, chunk_rows=4096)
