@@ -207,7 +207,7 @@ int kgwas_scan_history_above(kgwas_scan* s, const double* thr, uint64_t* counts,
                              const double** score, const uint64_t** row);
 /* Column-distributed merge: the state of heaps cols[0..n_cols) in heap-array order (sizes[c] entries each, flat),
  * and its exact re-creation in another scan session of the same shape - layout included, so the heap goes on
- * there exactly as it would have here (column j of a multi-GPU job is merged on rank j mod G). */
+ * there exactly as it would have here (a block of columns of a multi-GPU job is merged on one rank). */
 int kgwas_scan_heaps_export(kgwas_scan* s, uint64_t n_cols, const uint64_t* cols, uint64_t* sizes, const uint64_t** kmer,
                             const double** score, const uint64_t** row);
 int kgwas_scan_heaps_import(kgwas_scan* s, uint64_t n_cols, const uint64_t* cols, const uint64_t* sizes, const uint64_t* kmer,
