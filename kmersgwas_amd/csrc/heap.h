@@ -84,9 +84,9 @@ class alignas(128) BestHeap {
             pay_.push_back(Pay{kmer, (uint64_t)row});
             v_.push_back(Ent{score, slot});
             if (ints_ok_)
-                std::push_heap(v_.begin(), v_.end(), GreaterInt());  // (same answers, hence the same moves)
+                push_up<true>(v_.data(), (ptrdiff_t)v_.size() - 1, Ent{score, slot});  // (same answers, hence the same moves)
             else
-                std::push_heap(v_.begin(), v_.end(), Greater());
+                push_up<false>(v_.data(), (ptrdiff_t)v_.size() - 1, Ent{score, slot});
             pushes_++;
             lowest_ = v_.front().score;
             return true;
@@ -105,6 +105,46 @@ class alignas(128) BestHeap {
             return true;
         }
         return false;
+    }
+
+    // std::push_heap's moves for the element x that was just appended at a[hole] (libstdc++'s __push_heap: x climbs
+    // while its parent compares greater, parents move down, a tie stops the climb). While a heap fills this runs once per
+    // row and column (1 M times per scan at 101 columns, on the scan's serial start), and how far x climbs is a coin flip
+    // per level for the branch predictor: the first three levels are taken without branches (three independent loads,
+    // selects, three stores that rewrite what is already there when x stays below), the rest - one push in eight - by
+    // the plain loop. 31 -> 17 ns per push (tests/test_host.py drives it against a literal std::priority_queue).
+    template <bool INT>
+    static inline void push_up(Ent* a, ptrdiff_t hole, Ent x) {
+        if (hole >= 16) {
+            const ptrdiff_t p1 = (hole - 1) >> 1, p2 = (p1 - 1) >> 1, p3 = (p2 - 1) >> 1;
+            const Ent e1 = a[p1], e2 = a[p2], e3 = a[p3];
+            const bool u1 = gt<INT>(e1, x), u2 = u1 & gt<INT>(e2, x), u3 = u2 & gt<INT>(e3, x);
+            a[hole] = sel(u1, e1, x);
+            a[p1] = sel(u2, e2, sel(u1, x, e1));
+            a[p2] = sel(u3, e3, sel(u2, x, e2));
+            if (__builtin_expect(!u3, 1)) return;
+            hole = p3;
+        }
+        ptrdiff_t parent = (hole - 1) / 2;
+        while (hole > 0 && gt<INT>(a[parent], x)) {
+            a[hole] = a[parent];
+            hole = parent;
+            parent = (hole - 1) / 2;
+        }
+        a[hole] = x;
+    }
+    static inline Ent sel(bool c, const Ent& t, const Ent& f) {  // c ? t : f on the two 64-bit halves (selects, not a branch)
+        uint64_t t0, t1, f0, f1;
+        memcpy(&t0, &t.score, 8);
+        memcpy(&f0, &f.score, 8);
+        t1 = t.slot;
+        f1 = f.slot;
+        const uint64_t m = (uint64_t)0 - (uint64_t)c;
+        const uint64_t r0 = (t0 & m) | (f0 & ~m);
+        Ent r;
+        memcpy(&r.score, &r0, 8);
+        r.slot = (uint32_t)((t1 & m) | (f1 & ~m));
+        return r;
     }
 
     // pop() followed by push(x) on a full heap a[0..n), written out: the element moves are exactly those of
