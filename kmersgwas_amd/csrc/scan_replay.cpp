@@ -293,6 +293,7 @@ void replay_worker(kgwas_scan* s, size_t w) {
         s->rp_failed.store(true, std::memory_order_release);
     }
     std::lock_guard<std::mutex> lk(s->rp_mu);
+    if (s->trace) fprintf(stderr, "[kgwas t=%.3f] worker %zu (cpu %d) done: busy %.2f ms, %llu units, %llu pushes\n", s->t_ms(), w, sched_getcpu(), (double)acc.busy_ns * 1e-6, (unsigned long long)acc.units, (unsigned long long)acc.pushes);
     s->rp_acc.pushes += acc.pushes;
     s->rp_acc.cands += acc.cands;
     s->rp_acc.busy_ns += acc.busy_ns;
@@ -413,7 +414,8 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
                         while (!s->pool->finished() && cpy < sub) {
                             Slot& sl = s->slot[(size_t)(cpy % (uint64_t)s->n_slots)];
                             if (sl.used_coarse && hipEventQuery(sl.ev_counts) != hipSuccess) {
-                                for (int i = 0; i < 64; i++) __builtin_ia32_pause();
+                                // (sleeping, not spinning: this thread is not pinned and may share a CPU with a pinned worker)
+                                std::this_thread::sleep_for(std::chrono::microseconds(20));
                                 continue;
                             }
                             if (!fetch_records(s, sl, cpy)) break;  // the record ring is full: the main loop deals with it
