@@ -58,6 +58,13 @@ constexpr uint32_t MX_PART0 = 1536u;  // FP6 slice of one (step, column tile): 6
 }
 
 // S1F: format of the second slice (4 = FP4 E2M1, 2 = FP6 E2M3); NS = 1: first slice only.
+#ifndef KGWAS_MX_PRIO
+#define KGWAS_MX_PRIO 0
+#endif
+#ifndef KGWAS_MX_PRIO_EPI
+#define KGWAS_MX_PRIO_EPI 3  // the epilogue runs at raised wave priority (see there); 0: off
+#endif
+
 template <int NS, int S1F>
 __host__ __device__ constexpr uint32_t mx_step_bytes() {
     return NS == 1 ? MX_PART0 : (S1F == 4 ? MX_PART0 + 1024u : 2u * MX_PART0);
@@ -267,6 +274,9 @@ __global__ void __launch_bounds__(TH) mx_kernel(MxArgs a, uint32_t rows_per_bloc
             // full 512-sample groups: four steps over this lane's 16 bytes of each of its RT rows. The pieces of the NEXT
             // group - the next one of this pass or, from the last one, group 0 of the wave's next rows - are requested as
             // soon as step 3 has expanded the current ones: a whole step (and, across passes, the epilogue) ahead.
+#if KGWAS_MX_PRIO || KGWAS_MX_PRIO_EPI
+            __builtin_amdgcn_s_setprio(KGWAS_MX_PRIO);
+#endif
             for (uint32_t g = 0; g < a.n_full; g++) {
                 const char* bg = lds + (size_t)g * 4u * CT * SB;
                 const bool last_g = g + 1u == a.n_full;
@@ -316,6 +326,12 @@ __global__ void __launch_bounds__(TH) mx_kernel(MxArgs a, uint32_t rows_per_bloc
                 run_step(A, x + 1u == a.n_quarter ? lds : bs + CT * SB, 0x7F7F7F7F);
             }
 
+#if KGWAS_MX_PRIO || KGWAS_MX_PRIO_EPI
+            // The pass's epilogue at raised priority, the main loop at the default one: a wave in its epilogue issues vector
+            // instructions only, and the sooner it is through them the sooner the SIMD has two MFMA streams again
+            // (-1.8 % in alternating runs, tools/mx_ab.sh; raising the MAIN loop's priority instead: +-0).
+            __builtin_amdgcn_s_setprio(KGWAS_MX_PRIO_EPI);
+#endif
             // Per-row terms (as in score_coarse.hip). Lane (kb, m) holds accumulator registers of the rows kb*4 + jj of
             // its RT row tiles ("row slot" i = rt*4 + jj); the 16 m-lanes of a kb share them. N1 comes from the ones column
             // (slot 15 of the last column tile: lane (kb, 15) holds it for all its slots); through a wave-private LDS
