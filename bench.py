@@ -602,6 +602,7 @@ def main():
                                                "mean": sum(s["replay_cpu_ms"] for s in stats) / args.steps / max(int(stats[-1].get("replay_threads", 1)), 1),
                                                "min": sum(s["replay_min_ms"] for s in stats) / args.steps},
                      "replay_wall_ms_per_step": sum(s["replay_wall_ms"] for s in stats) / args.steps,
+                     "replay_group_splits_per_step": sum(s["replay_splits"] for s in stats) / args.steps,
                      "candidates_per_step": sum(s["candidates"] for s in stats) // args.steps,
                      "heap_pushes_per_step": sum(s["heap_pushes"] for s in stats) // args.steps,
                      "chunks_per_step": sum(s["chunks"] for s in stats) // args.steps,

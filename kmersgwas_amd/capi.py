@@ -76,6 +76,7 @@ class ScanStats(C.Structure):
         ("coarse_mx", C.c_uint32), ("coarse_mx_s1_fp6", C.c_uint32), ("coarse_mx_steps", C.c_uint32),
         ("replay_threads", C.c_uint32),
         ("replay_min_ms", C.c_double), ("replay_wall_ms", C.c_double),
+        ("replay_splits", C.c_uint64),
     ]
 
     def as_dict(self):

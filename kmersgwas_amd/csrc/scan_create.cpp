@@ -831,8 +831,22 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                 s->grp_cols.push_back(std::vector<uint32_t>(1, (uint32_t)j));
                 s->grp_home.push_back(-1);
             }
-            s->n_groups = s->grp_cols.size();
-            s->gstate.reset(new kgwas_scan::GroupState[s->n_groups]);
+            s->n_groups0 = s->grp_cols.size();
+            s->n_groups.store(s->n_groups0);
+            s->grp_cols0 = s->grp_cols;
+            const size_t cap = s->n_groups0 + (size_t)P;  // room for every column as a group of its own (split_group)
+            s->grp_cols.resize(cap);
+            s->gstate.reset(new kgwas_scan::GroupState[cap]);
+            s->grp_owner.reset(new std::atomic<int>[cap]);
+            for (size_t g = 0; g < cap; g++) s->grp_owner[g].store(g < s->n_groups0 ? s->grp_home[g] : -1);
+            if (const char* e = getenv("KGWAS_SPLIT_LAGGING")) s->split_lagging = atoi(e) != 0;
+            if (const char* e = getenv("KGWAS_DEBUG_SLOW_WORKER")) {
+                int w = -1, pct = 100;
+                if (sscanf(e, "%d:%d", &w, &pct) >= 1) {
+                    s->dbg_slow_worker = w;
+                    s->dbg_slow_pct = pct;
+                }
+            }
             s->slot_left.reset(new std::atomic<uint32_t>[MAX_SLOTS]);
             for (int i = 0; i < MAX_SLOTS; i++) s->slot_left[i].store(0);
             kgwas_scan* raw = s.get();

@@ -387,11 +387,22 @@ struct kgwas_scan {
         std::atomic<uint64_t> done{0};  // chunks of this feed the group has replayed = the next one it must take
         std::atomic<uint32_t> busy{0};  // a worker is on it
     };
-    size_t n_groups = 1;
-    std::vector<std::vector<uint32_t>> grp_cols;  // columns of group g (at most BestHeap::MAX_LOCKSTEP)
-    std::vector<int> grp_home;                    // the worker that owns group g, -1: floating (anybody takes it)
+    // The session's own groups are restored at every feed; during a feed a group that has fallen behind while other
+    // workers have nothing left to do is SPLIT by the worker that holds it into single-column groups that anybody
+    // takes (split_group, scan_replay.cpp), so n_groups grows and the arrays below have room for one group per column more.
+    std::atomic<size_t> n_groups{1};
+    size_t n_groups0 = 1;
+    std::vector<std::vector<uint32_t>> grp_cols;   // columns of group g (at most BestHeap::MAX_LOCKSTEP)
+    std::vector<std::vector<uint32_t>> grp_cols0;  // as the session was created
+    std::vector<int> grp_home;                     // the worker that owns group g at the start of a feed, -1: floating (anybody takes it)
+    std::unique_ptr<std::atomic<int>[]> grp_owner; // ... and now
     std::unique_ptr<GroupState[]> gstate;
-    std::unique_ptr<std::atomic<uint32_t>[]> slot_left;  // [n_slots] groups that have not replayed the slot's chunk yet
+    std::unique_ptr<std::atomic<uint32_t>[]> slot_left;  // [n_slots] COLUMNS that have not replayed the slot's chunk yet
+    std::atomic<int> rp_hungry{0};                 // workers that found no unit to take the last time they looked
+    std::mutex split_mu;
+    bool split_lagging = true;                     // KGWAS_SPLIT_LAGGING=0: groups stay whole
+    int dbg_slow_worker = -1, dbg_slow_pct = 0;    // KGWAS_DEBUG_SLOW_WORKER=w:pct - worker w idles pct % of every unit's time on top (a busy co-tenant on its CPU)
+    std::atomic<uint64_t> n_splits{0};
     std::atomic<uint64_t> seq_submitted{0}, seq_published{0}, seq_replayed{0};
     std::atomic<bool> rp_quit{false}, rp_failed{false};
     std::atomic<int> rp_idle{0};

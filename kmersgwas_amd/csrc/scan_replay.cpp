@@ -191,8 +191,9 @@ bool reap_sparse(kgwas_scan* s, Slot& sl) {
     }
     if (!chunk_complete(s, sl)) return false;
     auto t0 = std::chrono::steady_clock::now();
-    std::vector<ReplayAcc> accs(s->n_groups);
-    s->pool->parallel_for(s->n_groups, [&](size_t g) { replay_group(s, sl, g, accs[g]); });
+    const size_t NG = s->n_groups.load(std::memory_order_acquire);
+    std::vector<ReplayAcc> accs(NG);
+    s->pool->parallel_for(NG, [&](size_t g) { replay_group(s, sl, g, accs[g]); });
     for (const ReplayAcc& a : accs) add_replay_stats(s, a);
     s->st.replay_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     s->rows_done += sl.n_rows;
@@ -224,13 +225,35 @@ void process_range_sync(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_
 // slowest group does not hold the others up (the per-chunk barrier cost 17 % of the replay at 101 columns on 16
 // workers), and the pool is woken once per feed instead of once per chunk. A slot is reused when all groups have
 // replayed its chunk (seq_replayed counts such chunks; they complete in order).
+// A group that has fallen behind while other workers have run out of work (a co-tenant on its worker's CPU: the pool's
+// threads are pinned, and a group's chunks can only be replayed one after the other) is cut into single-column groups
+// that anybody takes: its backlog then runs on as many CPUs as it has columns instead of on the one slow CPU. Called by
+// the worker that holds the group (busy), between two units; `done` = chunks the group has replayed.
+static void split_group(kgwas_scan* s, size_t g, uint64_t done) {
+    std::vector<uint32_t>& cols = s->grp_cols[g];
+    if (cols.size() < 2) return;
+    std::lock_guard<std::mutex> lk(s->split_mu);
+    size_t n = s->n_groups.load(std::memory_order_relaxed);
+    for (size_t i = 1; i < cols.size(); i++, n++) {
+        s->grp_cols[n].assign(1, cols[i]);
+        s->gstate[n].done.store(done, std::memory_order_relaxed);
+        s->gstate[n].busy.store(0u, std::memory_order_relaxed);
+        s->grp_owner[n].store(-1, std::memory_order_relaxed);
+    }
+    cols.resize(1);
+    s->grp_owner[g].store(-1, std::memory_order_relaxed);
+    s->n_groups.store(n, std::memory_order_release);  // (readers take n_groups with acquire: the entries above are complete)
+    s->n_splits.fetch_add(1, std::memory_order_relaxed);
+}
+
 void replay_worker(kgwas_scan* s, size_t w) {
     ReplayAcc acc;
-    const size_t NG = s->n_groups;
     int idle_spins = 0;
+    bool hungry = false;  // counted in rp_hungry
     try {
         for (;;) {
             if (s->rp_quit.load(std::memory_order_acquire)) break;
+            const size_t NG = s->n_groups.load(std::memory_order_acquire);
             const uint64_t pub = s->seq_published.load(std::memory_order_acquire);
             // The group furthest behind among this worker's own groups and the floating ones; another worker's group
             // only when that worker has fallen two published chunks behind (a heap that changes cores drags its
@@ -239,7 +262,7 @@ void replay_worker(kgwas_scan* s, size_t w) {
             uint64_t best_done = ~0ull;
             for (int pass = 0; pass < 2 && best == (size_t)-1; pass++)
                 for (size_t g = 0; g < NG; g++) {
-                    const int home = s->grp_home[g];
+                    const int home = s->grp_owner[g].load(std::memory_order_relaxed);
                     const bool mine = home < 0 || (size_t)home == w;
                     if (mine != (pass == 0)) continue;
                     kgwas_scan::GroupState& G = s->gstate[g];
@@ -260,15 +283,33 @@ void replay_worker(kgwas_scan* s, size_t w) {
                     G.busy.store(0u, std::memory_order_release);
                     continue;
                 }
+                if (hungry) {
+                    hungry = false;
+                    s->rp_hungry.fetch_sub(1, std::memory_order_relaxed);
+                }
                 const size_t si = (size_t)(d % (uint64_t)s->n_slots);
                 const double tr0 = s->trace ? s->t_ms() : 0.0;
+                const uint32_t ncols = (uint32_t)s->grp_cols[best].size();  // (before a split below makes it 1)
+                const auto tu0 = std::chrono::steady_clock::now();
                 replay_group(s, s->slot[si], best, acc);
-                if (s->trace && (s->n_groups <= 4 || best == 0))
+                if ((int)w == s->dbg_slow_worker) {  // experiments: this worker's CPU is shared with somebody else
+                    const auto dur = std::chrono::steady_clock::now() - tu0;
+                    const auto until = std::chrono::steady_clock::now() + dur * s->dbg_slow_pct / 100;
+                    while (std::chrono::steady_clock::now() < until) __builtin_ia32_pause();
+                }
+                if (s->trace && (NG <= 4 || best == 0))
                     fprintf(stderr, "[kgwas t=%.3f] worker %zu replayed chunk %llu group %zu in %.3f ms\n", s->t_ms(), w, (unsigned long long)d, best, s->t_ms() - tr0);
                 G.done.store(d + 1, std::memory_order_release);
+                // somebody has nothing to do and this group still owes two published chunks or more: cut it up
+                if (s->split_lagging && ncols > 1 && s->rp_hungry.load(std::memory_order_relaxed) > 0 &&
+                    s->seq_published.load(std::memory_order_acquire) >= d + 3) {
+                    split_group(s, best, d + 1);
+                    if (s->trace) fprintf(stderr, "[kgwas t=%.3f] worker %zu split group %zu (%u columns) after chunk %llu\n", s->t_ms(), w, best, ncols, (unsigned long long)d);
+                    s->rp_cv_work.notify_all();
+                }
                 G.busy.store(0u, std::memory_order_release);
                 idle_spins = 0;
-                if (s->slot_left[si].fetch_sub(1u, std::memory_order_acq_rel) == 1u) {  // the chunk's last group
+                if (s->slot_left[si].fetch_sub(ncols, std::memory_order_acq_rel) == ncols) {  // the chunk's last columns
                     {
                         std::lock_guard<std::mutex> lk(s->rp_mu);
                         s->seq_replayed.fetch_add(1, std::memory_order_release);
@@ -279,6 +320,10 @@ void replay_worker(kgwas_scan* s, size_t w) {
                 continue;
             }
             // nothing to do: the GPU is behind (or other workers hold the groups that have work)
+            if (!hungry) {
+                hungry = true;
+                s->rp_hungry.fetch_add(1, std::memory_order_relaxed);
+            }
             if (++idle_spins < 64) {
                 for (int i = 0; i < 32; i++) __builtin_ia32_pause();
                 continue;
@@ -292,6 +337,7 @@ void replay_worker(kgwas_scan* s, size_t w) {
     } catch (...) {
         s->rp_failed.store(true, std::memory_order_release);
     }
+    if (hungry) s->rp_hungry.fetch_sub(1, std::memory_order_relaxed);
     std::lock_guard<std::mutex> lk(s->rp_mu);
     if (s->trace) fprintf(stderr, "[kgwas t=%.3f] worker %zu (cpu %d) done: busy %.2f ms, %llu units, %llu pushes\n", s->t_ms(), w, sched_getcpu(), (double)acc.busy_ns * 1e-6, (unsigned long long)acc.units, (unsigned long long)acc.pushes);
     s->rp_acc.pushes += acc.pushes;
@@ -349,6 +395,7 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
         s->st.replay_ms += (double)s->rp_max_busy_ns * 1e-6;
         if (s->rp_min_busy_ns != ~0ull) s->st.replay_min_ms += (double)s->rp_min_busy_ns * 1e-6;
         s->st.replay_wall_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+        s->st.replay_splits += s->n_splits.exchange(0);
         if (s->trace)
             fprintf(stderr, "[kgwas] replay ticks: scanning records %.1f M, heap updates %.1f M (TSC, all workers)\n",
                     (double)s->prof_scan.exchange(0) * 1e-6, (double)s->prof_heap.exchange(0) * 1e-6);
@@ -365,10 +412,18 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
     s->seq_replayed.store(0);
     s->ring_head = s->ring_tail = 0;
     s->ring_freed = 0;
-    for (size_t g = 0; g < s->n_groups; g++) {
+    // the session's own column groups (a feed may have split some, split_group)
+    for (size_t g = 0; g < s->n_groups0 + (size_t)s->n_pheno; g++) {
+        if (g < s->n_groups0)
+            s->grp_cols[g] = s->grp_cols0[g];
+        else
+            s->grp_cols[g].clear();
+        s->grp_owner[g].store(g < s->n_groups0 ? s->grp_home[g] : -1);
         s->gstate[g].done.store(0);
         s->gstate[g].busy.store(0);
     }
+    s->n_groups.store(s->n_groups0);
+    s->rp_hungry.store(0);
     try {
         for (;;) {
             if (pos < n_rows && !s->all_full) {  // dense phase: until every heap is full
@@ -399,7 +454,7 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
                         while (pos < n_rows && sub < std::min<uint64_t>(depth, 12) && (sub < 2 || !s->pool->finished())) {
                             const uint64_t cs = std::min<uint64_t>(next_sparse_chunk(s), n_rows - pos);
                             const size_t si = (size_t)(sub % (uint64_t)s->n_slots);
-                            s->slot_left[si].store((uint32_t)s->n_groups, std::memory_order_release);
+                            s->slot_left[si].store((uint32_t)s->n_pheno, std::memory_order_release);  // (columns: groups may be split)
                             submit_sparse(s, s->slot[si], d_rows + pos * stride, cs, first_row + pos, /*count_hist=*/true);
                             s->rows_submitted += cs;
                             sub++;
@@ -444,7 +499,7 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
                 start_async();
                 const uint64_t c = std::min<uint64_t>(next_sparse_chunk(s), n_rows - pos);
                 const size_t si = (size_t)(sub % (uint64_t)s->n_slots);  // its previous chunk was replayed n_slots chunks ago
-                s->slot_left[si].store((uint32_t)s->n_groups, std::memory_order_release);
+                s->slot_left[si].store((uint32_t)s->n_pheno, std::memory_order_release);  // (columns: groups may be split)
                 submit_sparse(s, s->slot[si], d_rows + pos * stride, c, first_row + pos, /*count_hist=*/true);
                 if (s->trace) fprintf(stderr, "[kgwas t=%.3f] submit chunk %llu (%llu rows)\n", s->t_ms(), (unsigned long long)sub, (unsigned long long)c);
                 s->rows_submitted += c;
@@ -494,7 +549,7 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
                     KGWAS_HIP(hipStreamSynchronize(s->stream));
                     process_range_sync(s, sl, sl.rows, sl.n_rows, sl.first_row);
                     pub++;
-                    for (size_t g = 0; g < s->n_groups; g++) s->gstate[g].done.store(pub, std::memory_order_release);
+                    for (size_t g = 0; g < s->n_groups.load(); g++) s->gstate[g].done.store(pub, std::memory_order_release);
                     s->seq_replayed.store(pub, std::memory_order_release);
                     s->seq_published.store(pub, std::memory_order_release);
                     if (pub < sub || pos < n_rows) start_async();

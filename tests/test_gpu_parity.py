@@ -114,6 +114,44 @@ def test_topn_identities_with_ties(kernel, binary, dup):
     scan.close()
 
 
+def test_lagging_column_group_is_split_and_results_stay_exact(monkeypatch):
+    """A replay worker that is much slower than the others (KGWAS_DEBUG_SLOW_WORKER: a stand-in for a co-tenant on its
+    pinned CPU) gets its column group cut into single-column groups that the idle workers take over (scan_replay.cpp,
+    split_group): more (chunk, group) units, the same heaps - tie-heavy rows, several feeds (the groups are restored at
+    every feed), compared with the oracle."""
+    S_f, S, P = 241, 241, 24  # (every accession phenotyped, in file order: the direct layout, where chunks are in flight 16 deep)
+    rows = random_table(200_000, S_f, seed=91, dup_frac=0.4)
+    col = np.arange(S, dtype=np.uint64)
+    Y = phenotypes(S, P - 1, seed=8, binary=True)
+    mac = onp.min_count(S, 0.05, 5)
+    topn = 300
+    exp = ob.associate(rows, S_f, col, Y, topn, mac, batch_size=9000, threads=4)
+    import torch
+    monkeypatch.setenv("KGWAS_DEBUG_SLOW_WORKER", "1:50000")
+    t = torch.from_numpy(rows.view(np.int64).reshape(-1)).cuda()  # device-resident rows: one feed = many chunks in flight
+    stride = rows.shape[1]
+    st_ = torch.cuda.current_stream().cuda_stream
+    splits = 0
+    for feeds in ([0, 200_000], [0, 70_000, 140_001, 200_000]):
+        scan = kg.AssociationScan(S_f, col, Y, topn, mac, chunk_rows=2048, host_threads=4)  # 4 workers x 6 columns, ~100 chunks
+        for lo, hi in zip(feeds[:-1], feeds[1:]):
+            scan.feed_device(t.data_ptr() + lo * stride * 8, hi - lo, lo, st_)
+        scan.finish()
+        _check_topn(scan, exp, P)
+        st = scan.stats()
+        assert st["rows_tested"] == exp["tested"] and st["rows_fed"] == len(rows)
+        splits += st["replay_splits"]
+        scan.close()
+    assert splits > 0
+    monkeypatch.setenv("KGWAS_SPLIT_LAGGING", "0")
+    scan = kg.AssociationScan(S_f, col, Y, topn, mac, chunk_rows=2048, host_threads=4)
+    scan.feed_device(t.data_ptr(), len(rows), 0, st_)
+    scan.finish()
+    _check_topn(scan, exp, P)
+    assert scan.stats()["replay_splits"] == 0
+    scan.close()
+
+
 @pytest.mark.parametrize("mx", [1, 0])
 @pytest.mark.parametrize("slices", [1, 2])
 @pytest.mark.parametrize("S,P,shift", [(241, 1, 0.0), (241, 5, 0.0), (241, 40, 100.0), (1024, 101, 0.0), (1024, 130, -7.5),
