@@ -106,28 +106,44 @@ int kgwas_scan_finish(kgwas_scan* s) {
         s->res_kmer.resize(s->n_pheno);
         s->res_row.resize(s->n_pheno);
         s->res_score.resize(s->n_pheno);
-        // A worker pops its columns (w, w+T, ...) up to eight at a time in lockstep where their sizes agree.
+        // The columns are popped in batches of up to eight in lockstep where their sizes agree. A batch is one item of the
+        // pool, and there are about two per worker: a worker whose CPU is shared with somebody else keeps only the batch it
+        // has started, the pool's other workers take the rest (with one item per worker - seven columns each at 101 columns
+        // on 16 workers - finish took 3-5 ms instead of 1.8 on boxes with busy neighbours).
+        // (Batches are made of the columns w, w + T, ... whose heaps worker w replayed last and are laid out so that the
+        // pool hands worker w its own ones first: item r * T + w is worker w's r-th batch.)
         const size_t Tw = s->pool->size();
-        s->pool->parallel_for(std::min<size_t>(Tw, s->n_pheno), [&](size_t w) {
-            std::vector<size_t> mine;
-            for (size_t j = w; j < s->n_pheno; j += Tw) mine.push_back(j);
-            size_t i = 0;
-            while (i < mine.size()) {
-                size_t K = 1;
-                while (K < 8 && i + K < mine.size() && s->heaps[mine[i + K]].size() == s->heaps[mine[i]].size()) K++;
-                const BestHeap* hp[8];
-                std::vector<uint64_t>*km[8], *rw[8];
-                std::vector<double>* sc[8];
-                for (size_t k = 0; k < K; k++) {
-                    const size_t j = mine[i + k];
-                    hp[k] = &s->heaps[j];
-                    km[k] = &s->res_kmer[j];
-                    sc[k] = &s->res_score[j];
-                    rw[k] = &s->res_row[j];
-                }
-                BestHeap::pop_all_n((int)K, hp, km, sc, rw);
-                i += K;
+        const size_t per = std::min<size_t>(8, std::max<size_t>(1, (s->n_pheno + 2 * Tw - 1) / (2 * Tw)));
+        std::vector<std::vector<std::vector<size_t>>> of_worker(Tw);  // [worker][batch][column]
+        size_t rounds = 0;
+        for (size_t w = 0; w < Tw; w++) {
+            for (size_t j = w; j < s->n_pheno; j += Tw) {
+                auto& bs = of_worker[w];
+                if (bs.empty() || bs.back().size() == per || s->heaps[bs.back()[0]].size() != s->heaps[j].size()) bs.emplace_back();
+                bs.back().push_back(j);
             }
+            rounds = std::max(rounds, of_worker[w].size());
+        }
+        std::vector<const std::vector<size_t>*> batches;
+        for (size_t r = 0; r < rounds; r++)
+            for (size_t w = 0; w < Tw; w++) {
+                static const std::vector<size_t> none;
+                batches.push_back(r < of_worker[w].size() ? &of_worker[w][r] : &none);
+            }
+        s->pool->parallel_for(batches.size(), [&](size_t b) {
+            const std::vector<size_t>& cols = *batches[b];
+            const size_t K = cols.size();
+            if (!K) return;
+            const BestHeap* hp[8];
+            std::vector<uint64_t>*km[8], *rw[8];
+            std::vector<double>* sc[8];
+            for (size_t k = 0; k < K; k++) {
+                hp[k] = &s->heaps[cols[k]];
+                km[k] = &s->res_kmer[cols[k]];
+                sc[k] = &s->res_score[cols[k]];
+                rw[k] = &s->res_row[cols[k]];
+            }
+            BestHeap::pop_all_n((int)K, hp, km, sc, rw);
         });
         if (s->count_patterns) {
             unsigned long long n_hashes = 0;
