@@ -165,8 +165,9 @@ typedef struct kgwas_scan_stats {
     uint32_t replay_threads;    /* host threads replaying heap pushes in this session */
     double replay_min_ms;       /* the LEAST busy replay worker's busy time (replay_ms: the busiest one's; replay_cpu_ms / replay_threads: the mean) */
     double replay_wall_ms;      /* wall time from the start of the streaming replay (first sparse chunk submitted) to its end */
-    uint64_t replay_splits;     /* column groups of the replay cut into single columns because they had fallen behind while
-                                   other workers had nothing left to do (a slow or shared CPU under one worker) */
+    uint64_t replay_splits;     /* column groups of the replay that left their worker because they had fallen behind (a slow or
+                                   shared CPU under it): handed whole to the workers that are ahead, or cut into single
+                                   columns once other workers had nothing left to do */
 } kgwas_scan_stats;
 
 int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out);

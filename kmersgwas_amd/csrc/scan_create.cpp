@@ -840,6 +840,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
             s->grp_owner.reset(new std::atomic<int>[cap]);
             for (size_t g = 0; g < cap; g++) s->grp_owner[g].store(g < s->n_groups0 ? s->grp_home[g] : -1);
             if (const char* e = getenv("KGWAS_SPLIT_LAGGING")) s->split_lagging = atoi(e) != 0;
+            if (const char* e = getenv("KGWAS_FLOAT_LEAD")) s->float_lead = (uint64_t)std::max(0, atoi(e));
             if (const char* e = getenv("KGWAS_DEBUG_SLOW_WORKER")) {
                 int w = -1, pct = 100;
                 if (sscanf(e, "%d:%d", &w, &pct) >= 1) {

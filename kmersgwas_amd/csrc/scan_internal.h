@@ -401,6 +401,8 @@ struct kgwas_scan {
     std::atomic<int> rp_hungry{0};                 // workers that found no unit to take the last time they looked
     std::mutex split_mu;
     bool split_lagging = true;                     // KGWAS_SPLIT_LAGGING=0: groups stay whole
+    uint64_t float_lead = 2;                       // KGWAS_FLOAT_LEAD=n: a home group n chunks behind the foremost one floats (0: never)
+    std::atomic<uint64_t> n_floated{0};
     int dbg_slow_worker = -1, dbg_slow_pct = 0;    // KGWAS_DEBUG_SLOW_WORKER=w:pct - worker w idles pct % of every unit's time on top (a busy co-tenant on its CPU)
     std::atomic<uint64_t> n_splits{0};
     std::atomic<uint64_t> seq_submitted{0}, seq_published{0}, seq_replayed{0};

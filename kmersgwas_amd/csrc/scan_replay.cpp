@@ -306,6 +306,19 @@ void replay_worker(kgwas_scan* s, size_t w) {
                     split_group(s, best, d + 1);
                     if (s->trace) fprintf(stderr, "[kgwas t=%.3f] worker %zu split group %zu (%u columns) after chunk %llu\n", s->t_ms(), w, best, ncols, (unsigned long long)d);
                     s->rp_cv_work.notify_all();
+                } else if (s->float_lead && s->grp_owner[best].load(std::memory_order_relaxed) == (int)w) {
+                    // Nobody is idle yet, but this worker's own group is float_lead chunks behind the foremost group that
+                    // is still at home: the group floats from now on - whole, so its heaps keep their lockstep - and the
+                    // workers that are ahead take its chunks in turn ("the group furthest behind first"), as this one does
+                    // at its own pace.
+                    uint64_t lead = 0;
+                    for (size_t g = 0; g < s->n_groups0; g++)
+                        if (s->grp_owner[g].load(std::memory_order_relaxed) >= 0) lead = std::max(lead, s->gstate[g].done.load(std::memory_order_relaxed));
+                    if (lead >= d + 1 + s->float_lead) {
+                        s->grp_owner[best].store(-1, std::memory_order_relaxed);
+                        s->n_floated.fetch_add(1, std::memory_order_relaxed);
+                        if (s->trace) fprintf(stderr, "[kgwas t=%.3f] worker %zu lets group %zu float after chunk %llu (%llu behind)\n", s->t_ms(), w, best, (unsigned long long)d, (unsigned long long)(lead - d - 1));
+                    }
                 }
                 G.busy.store(0u, std::memory_order_release);
                 idle_spins = 0;
@@ -395,7 +408,7 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
         s->st.replay_ms += (double)s->rp_max_busy_ns * 1e-6;
         if (s->rp_min_busy_ns != ~0ull) s->st.replay_min_ms += (double)s->rp_min_busy_ns * 1e-6;
         s->st.replay_wall_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
-        s->st.replay_splits += s->n_splits.exchange(0);
+        s->st.replay_splits += s->n_splits.exchange(0) + s->n_floated.exchange(0);
         if (s->trace)
             fprintf(stderr, "[kgwas] replay ticks: scanning records %.1f M, heap updates %.1f M (TSC, all workers)\n",
                     (double)s->prof_scan.exchange(0) * 1e-6, (double)s->prof_heap.exchange(0) * 1e-6);

@@ -132,7 +132,9 @@ def test_lagging_column_group_is_split_and_results_stay_exact(monkeypatch):
     stride = rows.shape[1]
     st_ = torch.cuda.current_stream().cuda_stream
     splits = 0
-    for feeds in ([0, 200_000], [0, 70_000, 140_001, 200_000]):
+    for feeds, float_lead in (([0, 200_000], "2"), ([0, 70_000, 140_001, 200_000], "2"), ([0, 200_000], "0")):
+        # (float_lead 2, the default: a lagging group first floats whole, mid-scan; 0: only the cut into single columns at the tail)
+        monkeypatch.setenv("KGWAS_FLOAT_LEAD", float_lead)
         scan = kg.AssociationScan(S_f, col, Y, topn, mac, chunk_rows=2048, host_threads=4)  # 4 workers x 6 columns, ~100 chunks
         for lo, hi in zip(feeds[:-1], feeds[1:]):
             scan.feed_device(t.data_ptr() + lo * stride * 8, hi - lo, lo, st_)
@@ -140,6 +142,7 @@ def test_lagging_column_group_is_split_and_results_stay_exact(monkeypatch):
         _check_topn(scan, exp, P)
         st = scan.stats()
         assert st["rows_tested"] == exp["tested"] and st["rows_fed"] == len(rows)
+        assert st["replay_splits"] > 0
         splits += st["replay_splits"]
         scan.close()
     assert splits > 0
