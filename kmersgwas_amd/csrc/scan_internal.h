@@ -399,6 +399,7 @@ struct kgwas_scan {
     std::unique_ptr<GroupState[]> gstate;
     std::unique_ptr<std::atomic<uint32_t>[]> slot_left;  // [n_slots] COLUMNS that have not replayed the slot's chunk yet
     std::atomic<int> rp_hungry{0};                 // workers that found no unit to take the last time they looked
+    std::atomic<bool> rp_all_published{false};     // the feed's last chunk is published: whoever is idle now stays idle
     std::mutex split_mu;
     bool split_lagging = true;                     // KGWAS_SPLIT_LAGGING=0: groups stay whole
     uint64_t float_lead = 2;                       // KGWAS_FLOAT_LEAD=n: a home group n chunks behind the foremost one floats (0: never)

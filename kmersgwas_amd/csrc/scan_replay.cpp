@@ -301,8 +301,11 @@ void replay_worker(kgwas_scan* s, size_t w) {
                     fprintf(stderr, "[kgwas t=%.3f] worker %zu replayed chunk %llu group %zu in %.3f ms\n", s->t_ms(), w, (unsigned long long)d, best, s->t_ms() - tr0);
                 G.done.store(d + 1, std::memory_order_release);
                 // somebody has nothing to do and this group still owes two published chunks or more: cut it up
-                if (s->split_lagging && ncols > 1 && s->rp_hungry.load(std::memory_order_relaxed) > 0 &&
-                    s->seq_published.load(std::memory_order_acquire) >= d + 3) {
+                // (only once the feed's last chunk is published: while the GPU still delivers, idle workers are waiting for
+                // IT, and a group cut up then replays the rest of the feed as single columns at twice the cost per push)
+                const uint64_t pub_now = s->seq_published.load(std::memory_order_acquire);
+                if (s->split_lagging && ncols > 1 && s->rp_hungry.load(std::memory_order_relaxed) > 0 && pub_now >= d + 3 &&
+                    s->rp_all_published.load(std::memory_order_acquire)) {
                     split_group(s, best, d + 1);
                     if (s->trace) fprintf(stderr, "[kgwas t=%.3f] worker %zu split group %zu (%u columns) after chunk %llu\n", s->t_ms(), w, best, ncols, (unsigned long long)d);
                     s->rp_cv_work.notify_all();
@@ -314,7 +317,8 @@ void replay_worker(kgwas_scan* s, size_t w) {
                     uint64_t lead = 0;
                     for (size_t g = 0; g < s->n_groups0; g++)
                         if (s->grp_owner[g].load(std::memory_order_relaxed) >= 0) lead = std::max(lead, s->gstate[g].done.load(std::memory_order_relaxed));
-                    if (lead >= d + 1 + s->float_lead) {
+                    // (... and the foremost group itself has chunks waiting: the host is what the scan waits for)
+                    if (lead >= d + 1 + s->float_lead && pub_now >= lead + 2) {
                         s->grp_owner[best].store(-1, std::memory_order_relaxed);
                         s->n_floated.fetch_add(1, std::memory_order_relaxed);
                         if (s->trace) fprintf(stderr, "[kgwas t=%.3f] worker %zu lets group %zu float after chunk %llu (%llu behind)\n", s->t_ms(), w, best, (unsigned long long)d, (unsigned long long)(lead - d - 1));
@@ -437,6 +441,7 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
     }
     s->n_groups.store(s->n_groups0);
     s->rp_hungry.store(0);
+    s->rp_all_published.store(false);
     try {
         for (;;) {
             if (pos < n_rows && !s->all_full) {  // dense phase: until every heap is full
@@ -545,6 +550,7 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
                 if (chunk_complete(s, sl)) {
                     if (s->trace) fprintf(stderr, "[kgwas t=%.3f] publish chunk %llu\n", s->t_ms(), (unsigned long long)pub);
                     pub++;
+                    if (pos >= n_rows && pub == sub) s->rp_all_published.store(true, std::memory_order_release);  // the feed's last chunk
                     {
                         std::lock_guard<std::mutex> lk(s->rp_mu);
                         s->seq_published.store(pub, std::memory_order_release);

@@ -1,9 +1,9 @@
 #!/bin/bash
 # One replay worker slowed down (KGWAS_DEBUG_SLOW_WORKER=w:pct, a stand-in for a co-tenant on its pinned CPU) against the
-# policy for column groups that fall behind: none / cut up once other workers have run out of work.
+# policies for column groups that fall behind: none / cut up at the tail once other workers have run out of work / also floated whole in mid-scan.
 cd "$GRAFT_REPO_ROOT"
 for slow in "" "KGWAS_DEBUG_SLOW_WORKER=5:30" "KGWAS_DEBUG_SLOW_WORKER=5:100"; do
-for pol in "KGWAS_SPLIT_LAGGING=0" "KGWAS_SPLIT_LAGGING=1" "KGWAS_FLOAT_LEAD=2" "KGWAS_FLOAT_LEAD=3"; do
+for pol in "KGWAS_SPLIT_LAGGING=0 KGWAS_FLOAT_LEAD=0" "KGWAS_SPLIT_LAGGING=1 KGWAS_FLOAT_LEAD=0" "KGWAS_SPLIT_LAGGING=1 KGWAS_FLOAT_LEAD=2"; do
   v="$slow $pol"
   env $v python bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-subrecords $AB_ARGS 2>/dev/null | python3 -c "
 import json,sys
