@@ -394,8 +394,19 @@ __device__ __forceinline__ uint32_t tile_column(const uint32_t* tile_pref, uint3
 // loads into SGPRs (yb is wave-uniform). As vector loads - 32 x 16 bytes per lane and block, every lane the same
 // address - they kept the CU's 64 B/clk vector-memory return path busier than the lane-ops kept the SIMDs.
 typedef __attribute__((address_space(4))) const float* kconst_f32p;
+// YLDS: yb points into LDS (the tile's column staged there by rescore_kernel): one broadcast ds_read_b128 per sample brings
+// the four chains' values. The scalar loads this replaces return out of order, so every use waits for ALL of them
+// (s_waitcnt lgkmcnt(0), six times per block) and the K$ misses on 201 columns x 8 KB: the waves were parked 61 % of their
+// cycles with the vector ALUs 58 % busy (SQ_WAIT_ANY / SQ_ACTIVE_INST_VALU); LDS reads return in order. Re-score + the small
+// kernels 4.06 -> 3.75 ms per 100 M rows at 1024 x 101, all kernels 49.9 -> 49.1 at 2048 x 201. (Also tried on top: the fma's
+// 0.0f / 1.0f factors from a bank-conflict-free table in LDS instead of byte expansion + v_cvt_f32_ubyteK - a third of the
+// vector instructions - measured +-0: the lane-ops are not what this kernel waits for either.)
+template <bool YLDS>
 __device__ __forceinline__ void rescore_block(const uint32_t (&w)[4], const float* yb, float (&acc)[4]) {
     kconst_f32p yc = (kconst_f32p)yb;
+    const float4* yl = reinterpret_cast<const float4*>(yb);
+    (void)yc;
+    (void)yl;
 #if KGWAS_RESCORE_FMA
     // acc + (bit ? y : +0) == fma((float)bit, y, acc) for finite y (the filters only run on finite phenotypes): the bits of a
     // dword become bytes 0 / 1 eight at a time ((w >> j) & 0x01010101: two lane-ops per four bits), v_cvt_f32_ubyteK makes
@@ -410,7 +421,15 @@ __device__ __forceinline__ void rescore_block(const uint32_t (&w)[4], const floa
 #pragma unroll
     for (int s = 0; s < 32; s++) {
         const int b = 31 - s, j = b & 7, k = b >> 3;
-        const f32x2 y01 = {yc[4 * s], yc[4 * s + 1]}, y23 = {yc[4 * s + 2], yc[4 * s + 3]};
+        f32x2 y01, y23;
+        if (YLDS) {
+            const float4 yv = yl[s];
+            y01 = (f32x2){yv.x, yv.y};
+            y23 = (f32x2){yv.z, yv.w};
+        } else {
+            y01 = (f32x2){yc[4 * s], yc[4 * s + 1]};
+            y23 = (f32x2){yc[4 * s + 2], yc[4 * s + 3]};
+        }
         auto byte_f32 = [&](uint32_t x) {  // v_cvt_f32_ubyteK (the compiler shifts first and converts byte 0: two more ops per bit)
             float f;
             if (k == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(f) : "v"(x));
@@ -432,7 +451,8 @@ __device__ __forceinline__ void rescore_block(const uint32_t (&w)[4], const floa
 #endif
 #pragma unroll
     for (int s = 0; s < 32; s++) {
-        const float yv[4] = {yc[4 * s], yc[4 * s + 1], yc[4 * s + 2], yc[4 * s + 3]};
+        const float yv[4] = {YLDS ? yb[4 * s] : yc[4 * s], YLDS ? yb[4 * s + 1] : yc[4 * s + 1], YLDS ? yb[4 * s + 2] : yc[4 * s + 2],
+                             YLDS ? yb[4 * s + 3] : yc[4 * s + 3]};
 #pragma unroll
         for (int l = 0; l < 4; l++) {
             // bit 31 - s as 0 / -1 in one v_bfe_i32, kept from the optimiser, which turns bfe & y (like a shift pair)
@@ -461,10 +481,13 @@ __device__ __forceinline__ void rescore_finish(const ScoreArgs& a, uint32_t p, b
 
 // Rows are read in place by their own lane, 8 bytes x 2 per 128-sample block. (Staging a wave's 64 rows through LDS with
 // coalesced copies - every line fetched once - measured 30-50 % SLOWER: the gathers are not what this kernel waits for.)
+template <bool YLDS>
 __global__ void __launch_bounds__(256) rescore_kernel(ScoreArgs a, const uint32_t* keys, const uint32_t* surv_off,
                                                       const uint32_t* surv_cnt, const uint32_t* tile_pref, uint32_t row_mask,
                                                       double* tmp_score, uint32_t* tile_cnt) {
     __shared__ uint32_t wcnt[4];
+    extern __shared__ float4 ytile[];  // YLDS: the tile's column, 64 * W_m floats
+
     const uint32_t n_tiles = tile_pref[a.n_pheno];
     const uint32_t L = 64u * a.W_m;
     const uint32_t nblk = a.W_m / 2u;
@@ -477,6 +500,11 @@ __global__ void __launch_bounds__(256) rescore_kernel(ScoreArgs a, const uint32_
         const uint32_t* rp = a.src.base + r * a.src.stride_dw + a.src.off_dw;
         float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         uint32_t n1 = 0;
+        if (YLDS) {  // (the previous tile's readers are past rescore_finish's barriers)
+            const float4* ysrc = reinterpret_cast<const float4*>(a.Yperm + (size_t)p * L);
+            for (uint32_t k = threadIdx.x; k < L / 4u; k += 256u) ytile[k] = ysrc[k];
+            __syncthreads();
+        }
         // the row's words for block b + 1 are asked for before block b's 320 lane-ops start
         uint2 nx[2];
         auto fetch = [&](uint32_t b) {
@@ -496,7 +524,10 @@ __global__ void __launch_bounds__(256) rescore_kernel(ScoreArgs a, const uint32_
             }
             if (b + 1u < nblk) fetch(b + 1u);
             n1 += __popc(w[0]) + __popc(w[1]) + __popc(w[2]) + __popc(w[3]);
-            rescore_block(w, a.Yperm + (size_t)p * L + 128u * b, acc);
+            if (YLDS)
+                rescore_block<true>(w, reinterpret_cast<const float*>(ytile) + 128u * b, acc);
+            else
+                rescore_block<false>(w, a.Yperm + (size_t)p * L + 128u * b, acc);
         }
         rescore_finish(a, p, valid, gi, acc, n1, tmp_score, tile_cnt, t, wcnt);
     }
@@ -663,8 +694,15 @@ hipError_t launch_rescore(const ScoreArgs& a, const uint32_t* keys, const uint32
     if (a.n_pheno == 0) return hipSuccess;
     const uint32_t row_mask = row_bits >= 32 ? 0xFFFFFFFFu : ((1u << row_bits) - 1u);
     // fixed grid, tiles handed out round-robin: 8 blocks of 256 per CU (the tile count is only known on the device)
-    hipLaunchKernelGGL(rescore_kernel, dim3(2048), dim3(256), 0, st, a, keys, surv_off, surv_cnt, tile_pref, row_mask, tmp_score,
-                       tile_cnt);
+    // the tile's column goes through LDS while it fits beside eight blocks per CU (16 KB: 4096 samples); beyond, scalar loads
+    const size_t ybytes = 64u * (size_t)a.W_m * sizeof(float);
+    static const bool ylds_ok = getenv("KGWAS_RESCORE_YLDS") ? atoi(getenv("KGWAS_RESCORE_YLDS")) != 0 : true;  // experiments
+    if (ylds_ok && ybytes <= 16384u)
+        hipLaunchKernelGGL(rescore_kernel<true>, dim3(2048), dim3(256), ybytes, st, a, keys, surv_off, surv_cnt, tile_pref, row_mask,
+                           tmp_score, tile_cnt);
+    else
+        hipLaunchKernelGGL(rescore_kernel<false>, dim3(2048), dim3(256), 0, st, a, keys, surv_off, surv_cnt, tile_pref, row_mask,
+                           tmp_score, tile_cnt);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, tile_cnt, tile_pref, a.n_pheno, key_count, tile_off, meta);
     hipLaunchKernelGGL(compact_kernel, dim3(2048), dim3(256), 0, st, a, keys, surv_off, surv_cnt, tile_pref, row_mask, tmp_score,
                        tile_off);

@@ -2,7 +2,7 @@
 # configs[3] per-GPU shape (2048 samples x 201 columns): mixed operand sets (block-scaled two-slice ramp + int8 one-slice
 # steady state, the default) against the int8 sets alone, one gpurun call
 mkdir -p gpurun_out/c3
-for v in "A=1" "KGWAS_COARSE_MIXED=0" "A=1" "KGWAS_COARSE_MIXED=0"; do
+for v in ${C3_VARIANTS:-"A=1" "KGWAS_COARSE_MIXED=0" "A=1" "KGWAS_COARSE_MIXED=0"}; do
   env $v timeout 600 python bench.py --samples 2048 --perms 200 --rows ${C3_ROWS:-100000000} --steps 5 --warmup 2 --no-cpu-baseline --no-subrecords > gpurun_out/c3/line.json 2> gpurun_out/c3/err.txt
   python - "$v" gpurun_out/c3/line.json <<'PY'
 import json,sys
