@@ -400,7 +400,7 @@ typedef __attribute__((address_space(4))) const float* kconst_f32p;
 // cycles with the vector ALUs 58 % busy (SQ_WAIT_ANY / SQ_ACTIVE_INST_VALU); LDS reads return in order. Re-score + the small
 // kernels 4.06 -> 3.75 ms per 100 M rows at 1024 x 101, all kernels 49.9 -> 49.1 at 2048 x 201. (Also tried on top: the fma's
 // 0.0f / 1.0f factors from a bank-conflict-free table in LDS instead of byte expansion + v_cvt_f32_ubyteK - a third of the
-// vector instructions - measured +-0: the lane-ops are not what this kernel waits for either.)
+// vector instructions - measured +-0: twice the LDS reads then saturate the LDS pipe)
 template <bool YLDS>
 __device__ __forceinline__ void rescore_block(const uint32_t (&w)[4], const float* yb, float (&acc)[4]) {
     kconst_f32p yc = (kconst_f32p)yb;
