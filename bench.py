@@ -360,6 +360,8 @@ def main():
     def one_step(merge=True):
         scan = session
         scan.reset()
+        if world == 1 or not merge:
+            scan.expect_finish()  # the one feed of the pass is its last: idle replay workers start on finish()'s pops at its tail
         scan.feed_device(table.data_ptr(), M, first_row, stream)
         if world == 1 or not merge:
             scan.finish()  # with several ranks the merge finishes rank 0's session once, at its end
@@ -603,6 +605,7 @@ def main():
                                                "min": sum(s["replay_min_ms"] for s in stats) / args.steps},
                      "replay_wall_ms_per_step": sum(s["replay_wall_ms"] for s in stats) / args.steps,
                      "replay_group_splits_per_step": sum(s["replay_splits"] for s in stats) / args.steps,
+                     "columns_popped_ahead_per_step": sum(s["columns_popped_ahead"] for s in stats) / args.steps,
                      "candidates_per_step": sum(s["candidates"] for s in stats) // args.steps,
                      "heap_pushes_per_step": sum(s["heap_pushes"] for s in stats) // args.steps,
                      "chunks_per_step": sum(s["chunks"] for s in stats) // args.steps,

@@ -168,9 +168,18 @@ typedef struct kgwas_scan_stats {
     uint64_t replay_splits;     /* column groups of the replay that left their worker because they had fallen behind (a slow or
                                    shared CPU under it): handed whole to the workers that are ahead, or cut into single
                                    columns once other workers had nothing left to do */
+    uint64_t columns_popped_ahead; /* columns whose result lists were made by idle replay workers at the end of the last feed
+                                      (kgwas_scan_expect_finish) instead of by kgwas_scan_finish */
 } kgwas_scan_stats;
 
 int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out);
+/* A hint, never needed for correctness: the NEXT feed is the last one before kgwas_scan_finish (the tools know it: they
+ * feed a whole table). kgwas_scan_finish pops every heap into its result lists (output_to_file_with_scores' order,
+ * src/best_associations_heap.cpp:82-92) - 10 001 pops per column; with the hint, replay workers that run out of records
+ * near the end of that feed pop the columns that are complete while the slowest worker is still replaying, and finish
+ * only does what is left. Anything that changes a heap afterwards (another feed, kgwas_scan_absorb,
+ * kgwas_scan_heaps_import) discards those lists. */
+int kgwas_scan_expect_finish(kgwas_scan* s);
 /* Rows already resident in HBM (file layout, 8-byte aligned). hip_stream may be NULL. */
 int kgwas_scan_feed_device(kgwas_scan* s, const void* d_rows, uint64_t n_rows, uint64_t first_row, void* hip_stream);
 /* Rows in host memory (file layout). Chunked, double-buffered: a producer thread stages 128 MiB pieces into pinned

@@ -30,7 +30,7 @@ SYMBOLS = [
     "kgwas_heap_new", "kgwas_heap_add_many", "kgwas_heap_size", "kgwas_heap_pop_all", "kgwas_heap_output_list",
     "kgwas_heap_free",
     "kgwas_scan_create", "kgwas_scan_feed_device", "kgwas_scan_feed_host", "kgwas_scan_feed_table", "kgwas_scan_finish", "kgwas_scan_result",
-    "kgwas_scan_history", "kgwas_scan_get_stats", "kgwas_scan_reset", "kgwas_scan_lowest", "kgwas_scan_absorb", "kgwas_scan_history_above", "kgwas_scan_heaps_export", "kgwas_scan_heaps_import", "kgwas_scan_history_above_msgs", "kgwas_scan_heaps_export_msgs", "kgwas_scan_destroy", "kgwas_scan_scores_dense",
+    "kgwas_scan_history", "kgwas_scan_get_stats", "kgwas_scan_reset", "kgwas_scan_lowest", "kgwas_scan_absorb", "kgwas_scan_history_above", "kgwas_scan_heaps_export", "kgwas_scan_heaps_import", "kgwas_scan_expect_finish", "kgwas_scan_history_above_msgs", "kgwas_scan_heaps_export_msgs", "kgwas_scan_destroy", "kgwas_scan_scores_dense",
     "kgwas_merge_shards",
     "kgwas_multiscan_create", "kgwas_multiscan_run_table", "kgwas_multiscan_run_device", "kgwas_multiscan_finish",
     "kgwas_multiscan_result", "kgwas_multiscan_get_stats", "kgwas_multiscan_destroy", "kgwas_kinship_table_multi",
@@ -77,6 +77,7 @@ class ScanStats(C.Structure):
         ("replay_threads", C.c_uint32),
         ("replay_min_ms", C.c_double), ("replay_wall_ms", C.c_double),
         ("replay_splits", C.c_uint64),
+        ("columns_popped_ahead", C.c_uint64),
     ]
 
     def as_dict(self):
@@ -163,6 +164,7 @@ lib.kgwas_scan_feed_device.argtypes = [_vp, _vp, _u64, _u64, _vp]
 lib.kgwas_scan_feed_host.argtypes = [_vp, _vp, _u64, _u64]
 lib.kgwas_scan_feed_table.argtypes = [_vp, _vp, _u64, _u64]
 lib.kgwas_scan_finish.argtypes = [_vp]
+lib.kgwas_scan_expect_finish.argtypes = [_vp]
 lib.kgwas_scan_result.argtypes = [_vp, _u64, _pu64, C.POINTER(_pu64), C.POINTER(_pdbl), C.POINTER(_pu64)]
 lib.kgwas_scan_history.argtypes = [_vp, _u64, _pu64, C.POINTER(_pu64), C.POINTER(_pdbl), C.POINTER(_pu64)]
 lib.kgwas_scan_get_stats.argtypes = [_vp, C.POINTER(ScanStats)]

@@ -181,8 +181,10 @@ int main(int argc, char* argv[]) {
             t0 = now_s();
             if (mscan)
                 ck(kgwas_multiscan_run_table(mscan, tbl, row0, n));
-            else
+            else {
+                if (row0 + n == n_rows) ck(kgwas_scan_expect_finish(scan));  // the last batch: finish's pops may start at its tail
                 ck(kgwas_scan_feed_table(scan, tbl, row0, n));
+            }
             for (uint64_t j = 0; j < phenotypes_n; j++) cerr << ".";
             t1 = now_s();
             cerr << "Associations [" << batch_index << "]\t" << (t1 - t0) / 60. << "min" << endl;

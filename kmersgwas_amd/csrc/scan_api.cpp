@@ -59,8 +59,11 @@ void ingest_run(kgwas_scan* s, uint64_t n_rows, uint64_t first_row, const Ingest
         feed_device_impl(s, nullptr, 0, first_row);
         return;
     }
+    const bool expect_finish = s->final_feed_next;  // kgwas_scan_expect_finish: it is the LAST piece's feed that is the last one
+    s->final_feed_next = false;
     s->ingest.run(1 + s->W_f, n_rows, s->chunk_max, s->stream, fill,
                   [&](const uint64_t* d_rows, uint64_t row_off, uint64_t cnt) {
+                      if (row_off + cnt == n_rows) s->final_feed_next = expect_finish;
                       feed_device_impl(s, d_rows, cnt, first_row + row_off);  // returns with the stream idle
                   });
 }
@@ -97,6 +100,13 @@ int kgwas_scan_feed_table(kgwas_scan* s, kgwas_table* t, uint64_t row0, uint64_t
     });
 }
 
+int kgwas_scan_expect_finish(kgwas_scan* s) {
+    return guarded([&] {
+        if (!s) throw Error(KGWAS_ERR_ARG, "kgwas_scan_expect_finish: null");
+        s->final_feed_next = true;
+    });
+}
+
 int kgwas_scan_finish(kgwas_scan* s) {
     return guarded([&] {
         if (!s) throw Error(KGWAS_ERR_ARG, "kgwas_scan_finish: null");
@@ -118,6 +128,7 @@ int kgwas_scan_finish(kgwas_scan* s) {
         size_t rounds = 0;
         for (size_t w = 0; w < Tw; w++) {
             for (size_t j = w; j < s->n_pheno; j += Tw) {
+                if (s->col_popped[j].load(std::memory_order_acquire) == 2) continue;  // popped at the end of the last feed (kgwas_scan_expect_finish)
                 auto& bs = of_worker[w];
                 if (bs.empty() || bs.back().size() == per || s->heaps[bs.back()[0]].size() != s->heaps[j].size()) bs.emplace_back();
                 bs.back().push_back(j);
@@ -294,6 +305,7 @@ int kgwas_scan_heaps_import(kgwas_scan* s, uint64_t n_cols, const uint64_t* cols
             s->heaps[cols[c]].import_state((size_t)sizes[c], kmer + off[c], score + off[c], row + off[c]);
         });
         s->finished = false;
+        for (uint64_t j = 0; j < s->n_pheno; j++) s->col_popped[j].store(0);
         refresh_full(s);
         // The device's thresholds and score histograms describe the rows behind the heaps that were just replaced:
         // start them again from the imported minima before anything else is fed (the next sparse chunk re-bases the
@@ -442,6 +454,7 @@ int kgwas_scan_absorb(kgwas_scan* s, uint64_t n_shards, const uint64_t* counts, 
         });
         s->st.heap_pushes += pushes.load();
         s->finished = false;
+        for (uint64_t j = 0; j < s->n_pheno; j++) s->col_popped[j].store(0);
         refresh_full(s);
         // feeding may go on after an absorb: the device thresholds follow the heaps (see kgwas_scan_heaps_import)
         KGWAS_HIP(hipSetDevice(s->device));
@@ -456,6 +469,8 @@ int kgwas_scan_reset(kgwas_scan* s) {
         KGWAS_HIP(hipSetDevice(s->device));
         KGWAS_HIP(hipStreamSynchronize(s->stream));
         make_heaps(s);
+        for (uint64_t j = 0; j < s->n_pheno; j++) s->col_popped[j].store(0);
+        s->final_feed_next = false;
         for (auto& h : s->hist) h.clear();
         s->all_full = false;
         s->hist_ready = false;

@@ -838,6 +838,11 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
             s->grp_cols.resize(cap);
             s->gstate.reset(new kgwas_scan::GroupState[cap]);
             s->grp_owner.reset(new std::atomic<int>[cap]);
+            s->col_popped.reset(new std::atomic<uint8_t>[(size_t)P]);
+            for (uint64_t j = 0; j < P; j++) s->col_popped[j].store(0);
+            s->res_kmer.resize(P);
+            s->res_row.resize(P);
+            s->res_score.resize(P);
             for (size_t g = 0; g < cap; g++) s->grp_owner[g].store(g < s->n_groups0 ? s->grp_home[g] : -1);
             if (const char* e = getenv("KGWAS_SPLIT_LAGGING")) s->split_lagging = atoi(e) != 0;
             if (const char* e = getenv("KGWAS_FLOAT_LEAD")) s->float_lead = (uint64_t)std::max(0, atoi(e));

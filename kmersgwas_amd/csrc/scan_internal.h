@@ -400,6 +400,11 @@ struct kgwas_scan {
     std::unique_ptr<std::atomic<uint32_t>[]> slot_left;  // [n_slots] COLUMNS that have not replayed the slot's chunk yet
     std::atomic<int> rp_hungry{0};                 // workers that found no unit to take the last time they looked
     std::atomic<bool> rp_all_published{false};     // the feed's last chunk is published: whoever is idle now stays idle
+    // kgwas_scan_expect_finish: idle workers pop complete columns at the end of the (last) feed (scan_replay.cpp, pop_ahead)
+    std::atomic<bool> final_feed{false};
+    bool final_feed_next = false;                  // set by the hint, taken by the next feed
+    std::unique_ptr<std::atomic<uint8_t>[]> col_popped;  // [n_pheno] 2: res_* of the column are those of its heap as it stands (1: being made)
+    std::atomic<uint64_t> n_popped_ahead{0};
     std::mutex split_mu;
     bool split_lagging = true;                     // KGWAS_SPLIT_LAGGING=0: groups stay whole
     uint64_t float_lead = 2;                       // KGWAS_FLOAT_LEAD=n: a home group n chunks behind the foremost one floats (0: never)

@@ -246,6 +246,28 @@ static void split_group(kgwas_scan* s, size_t g, uint64_t done) {
     s->n_splits.fetch_add(1, std::memory_order_relaxed);
 }
 
+// kgwas_scan_expect_finish: a worker with nothing left to replay pops ONE column whose group has replayed every chunk of
+// the feed (no push can follow) into its result lists, as kgwas_scan_finish would. One column per turn, claimed through
+// col_popped (0 -> 1 in progress -> 2 done): the columns of the group that finishes last are then popped by as many idle
+// workers as it has columns, instead of by its own worker alone after everybody else has long finished. Returns false
+// if there is nothing left to claim.
+static bool pop_ahead(kgwas_scan* s, size_t NG, uint64_t pub) {
+    for (size_t g = 0; g < NG; g++) {
+        if (s->gstate[g].done.load(std::memory_order_acquire) != pub) continue;
+        for (const uint32_t j : s->grp_cols[g]) {
+            uint8_t expect = 0;
+            if (s->col_popped[j].load(std::memory_order_relaxed) != 0 ||
+                !s->col_popped[j].compare_exchange_strong(expect, 1, std::memory_order_acq_rel))
+                continue;
+            s->heaps[j].pop_all(s->res_kmer[j], s->res_score[j], s->res_row[j]);
+            s->col_popped[j].store(2, std::memory_order_release);
+            s->n_popped_ahead.fetch_add(1, std::memory_order_relaxed);
+            return true;
+        }
+    }
+    return false;
+}
+
 void replay_worker(kgwas_scan* s, size_t w) {
     ReplayAcc acc;
     int idle_spins = 0;
@@ -341,6 +363,9 @@ void replay_worker(kgwas_scan* s, size_t w) {
                 hungry = true;
                 s->rp_hungry.fetch_add(1, std::memory_order_relaxed);
             }
+            if (s->final_feed.load(std::memory_order_relaxed) && s->rp_all_published.load(std::memory_order_acquire) &&
+                pop_ahead(s, NG, s->seq_published.load(std::memory_order_acquire)))
+                continue;
             if (++idle_spins < 64) {
                 for (int i = 0; i < 32; i++) __builtin_ia32_pause();
                 continue;
@@ -413,6 +438,7 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
         if (s->rp_min_busy_ns != ~0ull) s->st.replay_min_ms += (double)s->rp_min_busy_ns * 1e-6;
         s->st.replay_wall_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
         s->st.replay_splits += s->n_splits.exchange(0) + s->n_floated.exchange(0);
+        s->st.columns_popped_ahead += s->n_popped_ahead.exchange(0);
         if (s->trace)
             fprintf(stderr, "[kgwas] replay ticks: scanning records %.1f M, heap updates %.1f M (TSC, all workers)\n",
                     (double)s->prof_scan.exchange(0) * 1e-6, (double)s->prof_heap.exchange(0) * 1e-6);
@@ -442,6 +468,10 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
     s->n_groups.store(s->n_groups0);
     s->rp_hungry.store(0);
     s->rp_all_published.store(false);
+    // rows are about to reach the heaps: result lists popped ahead of an earlier finish are history
+    for (uint64_t j = 0; j < s->n_pheno; j++) s->col_popped[j].store(0, std::memory_order_relaxed);
+    s->final_feed.store(s->final_feed_next, std::memory_order_release);
+    s->final_feed_next = false;
     try {
         for (;;) {
             if (pos < n_rows && !s->all_full) {  // dense phase: until every heap is full

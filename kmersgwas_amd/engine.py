@@ -175,6 +175,11 @@ class AssociationScan:
         check(lib.kgwas_scan_feed_table(self._h, table._h, row0, n_rows))
 
     # device pointer to rows already resident in HBM (e.g. torch tensor .data_ptr())
+    def expect_finish(self):
+        """Hint: the next feed is the last one before finish(); the replay workers that run out of records near its end
+        then pop complete columns into the result lists while the slowest worker is still replaying (results unchanged)."""
+        check(lib.kgwas_scan_expect_finish(self._h))
+
     def feed_device(self, d_ptr: int, n_rows: int, first_row: int = 0, stream: int = 0):
         check(lib.kgwas_scan_feed_device(self._h, C.c_void_p(d_ptr), n_rows, first_row, C.c_void_p(stream)))
 

@@ -137,12 +137,13 @@ def test_lagging_column_group_is_split_and_results_stay_exact(monkeypatch):
         monkeypatch.setenv("KGWAS_FLOAT_LEAD", float_lead)
         scan = kg.AssociationScan(S_f, col, Y, topn, mac, chunk_rows=2048, host_threads=4)  # 4 workers x 6 columns, ~100 chunks
         for lo, hi in zip(feeds[:-1], feeds[1:]):
+            scan.expect_finish()  # also before feeds that are NOT the last: lists popped ahead must be dropped by the next feed
             scan.feed_device(t.data_ptr() + lo * stride * 8, hi - lo, lo, st_)
         scan.finish()
         _check_topn(scan, exp, P)
         st = scan.stats()
         assert st["rows_tested"] == exp["tested"] and st["rows_fed"] == len(rows)
-        assert st["replay_splits"] > 0
+        assert st["replay_splits"] > 0 and st["columns_popped_ahead"] > 0  # (the idle workers pop while worker 1 crawls)
         splits += st["replay_splits"]
         scan.close()
     assert splits > 0

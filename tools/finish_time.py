@@ -15,6 +15,8 @@ torch.cuda.synchronize()
 scan = kg.AssociationScan(S, np.arange(S, dtype=np.uint64), Y, 10001, mac, device=0)
 for i in range(8):
     t0 = time.perf_counter(); scan.reset(); t1 = time.perf_counter()
+    if os.environ.get("EXPECT_FINISH", "1") != "0":
+        scan.expect_finish()
     scan.feed_device(table.data_ptr(), M, 0, stream); t2 = time.perf_counter()
     scan.finish(); t3 = time.perf_counter()
-    print("reset %.2f ms  feed %.2f ms  finish %.2f ms  total %.2f" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t3 - t0) * 1e3))
+    print("reset %.2f ms  feed %.2f ms  finish %.2f ms  total %.2f  popped ahead %d" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t3 - t0) * 1e3, scan.stats()["columns_popped_ahead"]))
