@@ -16,7 +16,7 @@ scan = kg.AssociationScan(S, np.arange(S, dtype=np.uint64), Y, 10001, mac, devic
 keys = ("chunks", "candidates", "heap_pushes", "gpu_wait_ms", "replay_tail_ms", "dense_ms", "replay_ms", "replay_min_ms", "replay_cpu_ms", "replay_wall_ms", "replay_splits", "score_kernel_ms")
 for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
     th0 = cgroup_throttle()
-    t0 = time.perf_counter(); scan.reset()
+    t0 = time.perf_counter(); scan.reset(); scan.expect_finish()
     scan.feed_device(table.data_ptr(), M, 0, stream); t2 = time.perf_counter()
     scan.finish(); t3 = time.perf_counter()
     st = scan.stats()
