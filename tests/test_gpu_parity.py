@@ -737,10 +737,12 @@ def test_double_buffered_ingest_from_file_and_host(monkeypatch, tmp_path, piece)
         if mode == "table":
             scan.feed_table(tbl, 0, 20_000)
             scan.feed_table(tbl, 20_000, 0)
+            scan.expect_finish()  # (the hint belongs to the last PIECE of the feed that follows; results must not change)
             scan.feed_table(tbl, 20_000, 27_001)
             with pytest.raises(kg.KgwasError):
                 scan.feed_table(tbl, 40_000, 10_000)  # beyond the table
         else:
+            scan.expect_finish()  # a wrong hint: another feed follows, what was popped ahead is dropped
             scan.feed_host(rows[:33_333], 0)
             scan.feed_host(rows[33_333:], 33_333)
         scan.finish()
