@@ -125,15 +125,17 @@ int main(int argc, char* argv[]) {
         sp.chunk_rows = 0;
         // --parallel: the reference's pool of scoring tasks (src/associate_kmers.cpp:104-148), 4 by default and 1 from the
         // pipeline (src/py/pipeline_parser.py:31). Here the host threads replay heap pushes beside the GPU(s), and fewer
-        // than the CPUs this process may use only makes the scan host-bound: a smaller --parallel is raised to the CPU
-        // quota (KGWAS_STRICT_PARALLEL=1 keeps it as given); a larger one is honoured.
+        // than the CPUs this process may use only makes the scan host-bound: when the option is absent or is the
+        // pipeline's 1 the pool takes the CPUs the process may use (cgroup quota, affinity mask); an explicit N > 1 is the
+        // user's cap, as in the reference, and is kept (KGWAS_STRICT_PARALLEL=1 keeps a 1 too).
         uint64_t replay_threads = threads ? threads : 1;
         {
             const uint64_t quota = kgwas_host_cpu_quota();
             const char* strict = getenv("KGWAS_STRICT_PARALLEL");
-            if (!(strict && atoi(strict) != 0) && replay_threads < quota) {
-                cerr << "[kgwas] --parallel " << threads << " is below the " << quota << " CPUs this process may use: " << quota
-                     << " replay threads (KGWAS_STRICT_PARALLEL=1 keeps --parallel)" << endl;
+            const bool is_default = !vm.count("parallel") || threads <= 1;
+            if (!(strict && atoi(strict) != 0) && is_default && replay_threads < quota) {
+                cerr << "[kgwas] --parallel " << threads << (vm.count("parallel") ? "" : " (default)") << " is below the " << quota
+                     << " CPUs this process may use: " << quota << " replay threads (KGWAS_STRICT_PARALLEL=1 keeps --parallel)" << endl;
                 replay_threads = quota;
             }
         }

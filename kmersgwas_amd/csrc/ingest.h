@@ -64,7 +64,7 @@ public:
     // (runs on a producer thread, up to two pieces ahead of the consumer).
     using Fill = std::function<void(uint64_t*, uint64_t, uint64_t)>;
     // consume(d_rows, row_off, cnt): work on a device piece; `stream` already waits for its copy. Must return with
-    // the work on the piece complete (the device buffer is reused two pieces later).
+    // the work on the piece complete (the device buffer is reused three pieces later: three device pieces are in flight).
     using Consume = std::function<void(const uint64_t*, uint64_t, uint64_t)>;
 
     ~Ingest() {

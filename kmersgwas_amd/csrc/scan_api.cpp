@@ -9,6 +9,19 @@ struct MsgPlan {
     std::vector<uint64_t> start;  // word offset of message m in the buffer (n_msgs + 1)
     uint64_t total() const { return start.back(); }
 };
+// kgwas_scan_expect_finish's hint belongs to the NEXT public feed call only, whatever becomes of that call (an argument
+// error, an empty feed, an exception half-way): it is taken here, at the call's entry, and never outlives the call.
+struct FinishHint {
+    kgwas_scan* s;
+    bool given;
+    explicit FinishHint(kgwas_scan* s_) : s(s_), given(s_ && s_->final_feed_next) {
+        if (s) s->final_feed_next = false;
+    }
+    ~FinishHint() {
+        if (s) s->final_feed_next = false;
+    }
+};
+
 // cnt(j) = entries of column j. Fills msg_words and returns the layout.
 template <class Cnt>
 MsgPlan plan_msgs(const kgwas_scan* s, uint64_t n_msgs, const uint64_t* col0, const uint64_t* ncols, uint64_t* msg_words, Cnt cnt, const char* who) {
@@ -40,9 +53,11 @@ int kgwas_device_count(int* n_devices) {
 
 int kgwas_scan_feed_device(kgwas_scan* s, const void* d_rows, uint64_t n_rows, uint64_t first_row, void* hip_stream) {
     return guarded([&] {
+        FinishHint hint(s);
         if (!s || (!d_rows && n_rows)) throw Error(KGWAS_ERR_ARG, "kgwas_scan_feed_device: null argument");
         if (s->finished) throw Error(KGWAS_ERR_STATE, "scan already finished");
         KGWAS_HIP(hipSetDevice(s->device));
+        s->final_feed_next = hint.given && n_rows > 0;
         // order our stream after whatever the caller queued on theirs (e.g. the generator kernel)
         KGWAS_HIP(hipEventRecord(s->ev_user, (hipStream_t)hip_stream));
         KGWAS_HIP(hipStreamWaitEvent(s->stream, s->ev_user, 0));
@@ -54,16 +69,15 @@ namespace {
 
 // Chunked, double-buffered ingest (ingest.h): piece k+1 is produced and copied while piece k is scored and
 // replayed; results do not depend on the piece size (rows are scored in order, thresholds only ever lag).
-void ingest_run(kgwas_scan* s, uint64_t n_rows, uint64_t first_row, const Ingest::Fill& fill) {
+void ingest_run(kgwas_scan* s, uint64_t n_rows, uint64_t first_row, const Ingest::Fill& fill, bool expect_finish) {
     if (n_rows == 0) {
         feed_device_impl(s, nullptr, 0, first_row);
         return;
     }
-    const bool expect_finish = s->final_feed_next;  // kgwas_scan_expect_finish: it is the LAST piece's feed that is the last one
-    s->final_feed_next = false;
+    // it is the LAST piece's feed that is the last one
     s->ingest.run(1 + s->W_f, n_rows, s->chunk_max, s->stream, fill,
                   [&](const uint64_t* d_rows, uint64_t row_off, uint64_t cnt) {
-                      if (row_off + cnt == n_rows) s->final_feed_next = expect_finish;
+                      s->final_feed_next = expect_finish && row_off + cnt == n_rows;
                       feed_device_impl(s, d_rows, cnt, first_row + row_off);  // returns with the stream idle
                   });
 }
@@ -72,6 +86,7 @@ void ingest_run(kgwas_scan* s, uint64_t n_rows, uint64_t first_row, const Ingest
 
 int kgwas_scan_feed_host(kgwas_scan* s, const uint64_t* rows, uint64_t n_rows, uint64_t first_row) {
     return guarded([&] {
+        FinishHint hint(s);
         if (!s || (!rows && n_rows)) throw Error(KGWAS_ERR_ARG, "kgwas_scan_feed_host: null argument");
         if (s->finished) throw Error(KGWAS_ERR_STATE, "scan already finished");
         KGWAS_HIP(hipSetDevice(s->device));
@@ -79,12 +94,13 @@ int kgwas_scan_feed_host(kgwas_scan* s, const uint64_t* rows, uint64_t n_rows, u
         s->ingest.file_feed_ = false;
         ingest_run(s, n_rows, first_row, [&](uint64_t* dst, uint64_t row_off, uint64_t cnt) {
             memcpy(dst, rows + row_off * stride, cnt * stride * 8);
-        });
+        }, hint.given);
     });
 }
 
 int kgwas_scan_feed_table(kgwas_scan* s, kgwas_table* t, uint64_t row0, uint64_t n_rows) {
     return guarded([&] {
+        FinishHint hint(s);
         if (!s || !t) throw Error(KGWAS_ERR_ARG, "kgwas_scan_feed_table: null argument");
         if (s->finished) throw Error(KGWAS_ERR_STATE, "scan already finished");
         uint64_t n_acc = 0, t_rows = 0, wpr = 0;
@@ -96,7 +112,7 @@ int kgwas_scan_feed_table(kgwas_scan* s, kgwas_table* t, uint64_t row0, uint64_t
         s->ingest.file_feed_ = true;
         ingest_run(s, n_rows, row0, [&](uint64_t* dst, uint64_t row_off, uint64_t cnt) {
             if (kgwas_table_read_rows(t, row0 + row_off, cnt, dst) != KGWAS_OK) throw Error(KGWAS_ERR_IO, kgwas_last_error());
-        });
+        }, hint.given);
     });
 }
 
@@ -324,8 +340,10 @@ int kgwas_scan_history_above_msgs(kgwas_scan* s, const double* thr, uint64_t n_m
         if (!s->record_history && !s->history_ring) throw Error(KGWAS_ERR_STATE, "scan was created without record_history");
         const uint64_t P = s->n_pheno;
         std::vector<char> wanted(P, 0);
-        for (uint64_t m = 0; m < n_msgs; m++)
-            for (uint64_t c = 0; c < msg_ncols[m] && msg_col0[m] + c < P; c++) wanted[msg_col0[m] + c] = 1;
+        for (uint64_t m = 0; m < n_msgs; m++) {  // (ranges first: nothing below loops over an unchecked count)
+            if (msg_ncols[m] && (msg_col0[m] >= P || msg_ncols[m] > P - msg_col0[m])) throw Error(KGWAS_ERR_ARG, "kgwas_scan_history_above_msgs: column range out of bounds");
+            for (uint64_t c = 0; c < msg_ncols[m]; c++) wanted[msg_col0[m] + c] = 1;
+        }
         const double ninf = -std::numeric_limits<double>::infinity();
         auto keep = [&](uint64_t j, double sc) { return thr[j] == ninf || sc > thr[j]; };
         std::vector<std::vector<BestHeap::Rec>> recs(s->history_ring ? P : 0);

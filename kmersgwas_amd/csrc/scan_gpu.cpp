@@ -197,7 +197,16 @@ void dense_fill(kgwas_scan* s, uint64_t n_rows, uint64_t first_row, std::chrono:
         pushes += local;
     };
     s->pool->start(s->n_pheno, push_column);
-    if (meanwhile) (*meanwhile)();
+    if (meanwhile) {
+        // push_column and what it captures live on this frame: whatever the callback throws (a HIP error while it submits
+        // sparse chunks), the workers are waited for before the frame unwinds
+        try {
+            (*meanwhile)();
+        } catch (...) {
+            s->pool->wait(false);
+            throw;
+        }
+    }
     if (s->trace) fprintf(stderr, "[kgwas t=%.3f] dense fill: control thread done, fill %s\n", s->t_ms(), s->pool->finished() ? "done" : "running");
     s->pool->wait();
     if (s->trace) fprintf(stderr, "[kgwas t=%.3f] dense fill done\n", s->t_ms());

@@ -1,6 +1,7 @@
 // scan_host.cpp — the host the session runs on: which CPUs the replay workers are pinned to, how many CPUs the process
 // may really use (cgroup quota), the heaps' huge-page arena.
 #include "scan_internal.h"
+#include <sched.h>
 
 namespace kgwas {
 
@@ -143,6 +144,14 @@ std::vector<std::vector<int>> pick_replay_cpus(unsigned n, int device) {
 // busy threads than the quota gets the whole process throttled for the rest of the period).
 unsigned usable_cpus() {
     unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    {  // a taskset / cpuset narrower than the machine: pinned, spinning workers beyond it would only share its CPUs
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+            const int c = CPU_COUNT(&set);
+            if (c > 0) n = std::min<unsigned>(n, (unsigned)c);
+        }
+    }
     if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota|max> <period>"
         char q[64];
         unsigned long long period = 0;

@@ -400,6 +400,7 @@ struct kgwas_scan {
     std::unique_ptr<std::atomic<uint32_t>[]> slot_left;  // [n_slots] COLUMNS that have not replayed the slot's chunk yet
     std::atomic<int> rp_hungry{0};                 // workers that found no unit to take the last time they looked
     std::atomic<bool> rp_all_published{false};     // the feed's last chunk is published: whoever is idle now stays idle
+    std::atomic<uint64_t> rp_final_pub{0};         // the feed's chunk count, stored BEFORE rp_all_published (pop_ahead's "complete")
     // kgwas_scan_expect_finish: idle workers pop complete columns at the end of the (last) feed (scan_replay.cpp, pop_ahead)
     std::atomic<bool> final_feed{false};
     bool final_feed_next = false;                  // set by the hint, taken by the next feed

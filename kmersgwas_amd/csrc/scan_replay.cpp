@@ -363,8 +363,9 @@ void replay_worker(kgwas_scan* s, size_t w) {
                 hungry = true;
                 s->rp_hungry.fetch_add(1, std::memory_order_relaxed);
             }
+            // (the feed's final chunk count, stored before the flag: never a fresh read of seq_published)
             if (s->final_feed.load(std::memory_order_relaxed) && s->rp_all_published.load(std::memory_order_acquire) &&
-                pop_ahead(s, NG, s->seq_published.load(std::memory_order_acquire)))
+                pop_ahead(s, s->n_groups.load(std::memory_order_acquire), s->rp_final_pub.load(std::memory_order_relaxed)))
                 continue;
             if (++idle_spins < 64) {
                 for (int i = 0; i < 32; i++) __builtin_ia32_pause();
@@ -580,10 +581,16 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
                 if (chunk_complete(s, sl)) {
                     if (s->trace) fprintf(stderr, "[kgwas t=%.3f] publish chunk %llu\n", s->t_ms(), (unsigned long long)pub);
                     pub++;
-                    if (pos >= n_rows && pub == sub) s->rp_all_published.store(true, std::memory_order_release);  // the feed's last chunk
                     {
                         std::lock_guard<std::mutex> lk(s->rp_mu);
                         s->seq_published.store(pub, std::memory_order_release);
+                    }
+                    // The feed's last chunk. Only AFTER seq_published holds the final count: a worker that sees the flag
+                    // (acquire) must not pair it with the count before this chunk - every caught-up group would look
+                    // complete one chunk early and pop_ahead would pop heaps this chunk's records still change.
+                    if (pos >= n_rows && pub == sub) {
+                        s->rp_final_pub.store(pub, std::memory_order_relaxed);
+                        s->rp_all_published.store(true, std::memory_order_release);
                     }
                     s->rp_cv_work.notify_all();
                     // The exact minima as far as the workers have come (racy reads of monotone values: any value a
