@@ -10,7 +10,16 @@
                        150-accession table with 40 % duplicated presence/absence patterns, a subset of
                        131 phenotyped accessions in shuffled order, one binary phenotype + 3 permutations.
 
-Run from the repo root:  python tests/golden/make_golden.py
+  exact_topn.json    : implementation-independent top-N answers at production size (tests/exact_topn.py: integer
+                       phenotypes, exact rationals rounded once, 200 k-row tables regenerated from seeds): per case
+                       and column a sha256 over (file rows, score bytes) in pop order, the 64 weakest and 64 best entries of each
+                       case's first and last column, the MAC-passing row count, and for the smallest case the number of
+                       effective heap pushes. Computed WITHOUT calling any oracle or product code. Also the kinship
+                       counts of two synthetic tables from the closed form K_ij = n - c_i - c_j + 2 c_ij (sha256).
+
+Run from the repo root:  python tests/golden/make_golden.py            (all fixtures)
+                         python tests/golden/make_golden.py --find-bumps  (columns of tests/exact_topn.py CASES whose
+                         draw has a tie across the top-N boundary, to be listed in the case's "bumps")
 """
 import json
 import os
@@ -68,6 +77,55 @@ def assoc_small():
     print("assoc_small.npz: tested", res["tested"], "kin n", n)
 
 
+KINSHIP_CASES = {"kin_s241": dict(S_f=241, n_rows=60_000, seed=31), "kin_s1135": dict(S_f=1135, n_rows=40_000, seed=32)}
+
+
+def exact_topn_fixture():
+    import hashlib
+    import exact_topn as ex
+    out = {"cases": {}, "kinship": {}}
+    for name, c in ex.CASES.items():
+        rows, Yi, mac, topn = ex.make_inputs(name)
+        exp, tested = ex.expected_topn(rows, c["S"], Yi, mac, topn)
+        e = dict(tested=tested, mac=mac, sha256=ex.digest(exp), ties_inside=int(sum((np.diff(x[2]) == 0).sum() for x in exp)))
+        for j in sorted({0, c["P"] - 1}):
+            lo, hi = slice(0, 64), slice(-64, None)  # the weakest and the best 64 entries, readable; the sha256 pins all of them
+            e["column_%d" % j] = dict(rows_lowest=[int(v) for v in exp[j][0][lo]], score_hex_lowest=[float(v).hex() for v in exp[j][2][lo]],
+                                      rows_best=[int(v) for v in exp[j][0][hi]], score_hex_best=[float(v).hex() for v in exp[j][2][hi]])
+        if name == "s241_p24":
+            e["effective_pushes"] = ex.effective_pushes(rows, c["S"], Yi, mac, topn)
+        out["cases"][name] = e
+        print("exact_topn:", name, "tested", tested, "ties inside the top-N", e["ties_inside"])
+    for name, c in KINSHIP_CASES.items():
+        rows = ex.synth_rows_numpy(0, c["n_rows"], c["S_f"], c["seed"])
+        K, n, mc = ex.kinship_closed_form(rows, c["S_f"])
+        out["kinship"][name] = dict(c, n_used=n, min_count=mc, sha256=hashlib.sha256(K.astype("<u8").tobytes()).hexdigest(),
+                                    first_row=[int(v) for v in K[0, :8]])
+        print("exact kinship:", name, "rows used", n)
+    json.dump(out, open(os.path.join(HERE, "exact_topn.json"), "w"))
+
+
+def find_bumps():
+    import exact_topn as ex
+    for name, c in ex.CASES.items():
+        rows = ex.synth_rows_numpy(0, c["n_rows"], c["S"], c["seed"])
+        mac = max(int(np.ceil(c["S"] * 0.05)), 5)
+        bumps = dict(c.get("bumps", {}))
+        for j in range(c["P"]):
+            while True:
+                Yi = ex.int_phenotypes(c["S"], c["P"], c["ymax"], c["yseed"], bumps)[j:j + 1]
+                try:
+                    ex.expected_topn(rows, c["S"], Yi, mac, c["topn"])
+                    break
+                except ex.BoundaryTie:
+                    bumps[j] = bumps.get(j, 0) + 1
+        print(name, "bumps =", bumps, flush=True)
+
+
 if __name__ == "__main__":
+    if "--find-bumps" in sys.argv:
+        find_bumps()
+        sys.exit(0)
     known_answers()
     assoc_small()
+    exact_topn_fixture()

@@ -156,6 +156,37 @@ def test_lagging_column_group_is_split_and_results_stay_exact(monkeypatch):
     scan.close()
 
 
+def test_finish_hint_with_a_small_last_chunk_and_idle_workers(monkeypatch):
+    """kgwas_scan_expect_finish lets idle replay workers pop complete columns while the feed's last chunk is still being
+    replayed by others. The flag that says "everything is published" must never be seen together with the chunk count
+    BEFORE the last chunk (a column group that had caught up would look complete one chunk early and its heaps would be
+    popped while the last chunk's records still change them). Many short scans with a tiny last chunk, one slow worker
+    and more workers than column groups (idle workers spinning exactly at that moment); every heap equals the oracle's."""
+    S, P = 241, 12
+    n = 20 * 2048 + 37  # ~20 chunks and a last one of 37 rows
+    rows = random_table(n, S, seed=123, dup_frac=0.5)
+    col = np.arange(S, dtype=np.uint64)
+    Y = phenotypes(S, P - 1, seed=21, binary=True)
+    mac = onp.min_count(S, 0.05, 5)
+    topn = 64
+    exp = ob.associate(rows, S, col, Y, topn, mac, batch_size=5000, threads=4)
+    import torch
+    t = torch.from_numpy(rows.view(np.int64).reshape(-1)).cuda()
+    st_ = torch.cuda.current_stream().cuda_stream
+    monkeypatch.setenv("KGWAS_DEBUG_SLOW_WORKER", "0:300")
+    scan = kg.AssociationScan(S, col, Y, topn, mac, chunk_rows=2048, host_threads=8)  # 8 workers, 12 columns
+    popped = 0
+    for rep in range(40):
+        scan.expect_finish()
+        scan.feed_device(t.data_ptr(), n, 0, st_)
+        scan.finish()
+        _check_topn(scan, exp, P)
+        popped += scan.stats()["columns_popped_ahead"]
+        scan.reset()
+    assert popped > 0, "the hint never popped a column ahead: the test does not reach the path it is about"
+    scan.close()
+
+
 @pytest.mark.parametrize("mx", [1, 0])
 @pytest.mark.parametrize("slices", [1, 2])
 @pytest.mark.parametrize("S,P,shift", [(241, 1, 0.0), (241, 5, 0.0), (241, 40, 100.0), (1024, 101, 0.0), (1024, 130, -7.5),
@@ -853,3 +884,168 @@ def test_heap_mirror_equals_std_priority_queue_on_the_gpu_box(N, n, levels, flav
     NaN / negative / +inf scores: the integer-compare and the double-compare walks)."""
     from test_host import test_heap_mirror_equals_oracle_heap_under_ties as check
     check(N, n, levels, flavour)
+
+
+# ---- the production kernels against implementation-independent arithmetic (no oracle in the expectation) -------------------
+_EXACT_CACHE = {}
+
+
+def _exact_case(name):
+    """(rows, Y float32, mac, topn, expected per column, tested): tests/exact_topn.py, checked against the committed digests."""
+    import json
+    import exact_topn as ex
+    if name not in _EXACT_CACHE:
+        c = ex.CASES[name]
+        fx = json.load(open(os.path.join(GOLD, "exact_topn.json")))["cases"][name]
+        rows, Yi, mac, topn = ex.make_inputs(name)
+        exp, tested = ex.expected_topn(rows, c["S"], Yi, mac, topn)
+        assert ex.digest(exp) == fx["sha256"] and tested == fx["tested"]
+        _EXACT_CACHE.clear()  # (one case at a time: a case is 30-50 MB of rows)
+        _EXACT_CACHE[name] = (rows, Yi.astype(np.float32), mac, topn, exp, tested, fx)
+    return _EXACT_CACHE[name]
+
+
+@pytest.mark.parametrize("name,mode", [
+    ("s241_p24", "mx"), ("s241_p24", "int8"), ("s241_p24", "mfma"), ("s241_p24", "valu"),
+    ("s1024_p101", "mx"), ("s1024_p101", "int8"), ("s1135_p40", "mx"), ("s1135_p40", "mx6"), ("s1135_p40", "int8"),
+    ("s2048_p64", "mx"), ("s2048_p64", "int8"),
+    ("s1024_p1", "narrow"), ("s1135_p2", "narrow"), ("s2048_p4", "narrow"), ("s2048_p4", "mx")])
+def test_exact_rational_topn_through_the_production_kernels(monkeypatch, name, mode):
+    """Top-N of 200 k-row scans against exact rational arithmetic (tests/exact_topn.py, tests/golden/exact_topn.json: integer
+    phenotypes make every float32 add of calculate_kmer_score exact, so the expected score is r^2 / d rounded once and the
+    expected heap content follows from integer comparisons - computed without the oracle or the product). Which kernels a
+    mode reaches is asserted from the session's statistics:
+      mx     mx_kernel (FP4 x FP6 + FP4 block-scaled filter) -> bitmap keys -> rescore_kernel          [KGWAS_COARSE_MX=1]
+      mx6    the same with an FP6 second slice                                                          [KGWAS_MX_S1=6]
+      int8   coarse_kernel (int8 MFMA filter, chunk-wise one or two slices) -> rescore_kernel           [KGWAS_COARSE_MX=0]
+      narrow narrow_staged_kernel / narrow_kernel (FP4 x FP8, 1-4 columns) -> rescore_kernel            [AUTO]
+      mfma / valu  the exact scorers alone (score_mfma_kernel / score_valu_kernel), dense and sparse phase
+    The dense start of every mode runs score_mfma_kernel + dense_select_kernel. Rows go in through kgwas_scan_feed_host in
+    two feeds, the second one after the finish hint."""
+    import exact_topn as ex
+    rows, Y, mac, topn, exp, tested, fx = _exact_case(name)
+    S, P = Y.shape[1], Y.shape[0]
+    kernel = {"mx": kg.KERNEL_COARSE, "mx6": kg.KERNEL_COARSE, "int8": kg.KERNEL_COARSE, "narrow": kg.KERNEL_AUTO,
+              "mfma": kg.KERNEL_MFMA, "valu": kg.KERNEL_VALU}[mode]
+    if mode in ("mx", "mx6"):
+        monkeypatch.setenv("KGWAS_COARSE_MX", "1")
+    if mode == "mx6":
+        monkeypatch.setenv("KGWAS_MX_S1", "6")
+    if mode == "int8":
+        monkeypatch.setenv("KGWAS_COARSE_MX", "0")
+    scan = kg.AssociationScan(S, np.arange(S, dtype=np.uint64), Y, topn, mac, kernel=kernel)
+    cut = 120_000
+    scan.feed_host(rows[:cut], 0)
+    scan.expect_finish()
+    scan.feed_host(rows[cut:], cut)
+    scan.finish()
+    st = scan.stats()
+    if mode in ("mx", "mx6", "int8"):
+        assert st["kernel_used"] == kg.KERNEL_COARSE and st["coarse_launches"] > 0 and st["coarse_mx"] == (0 if mode == "int8" else 1)
+        if mode != "int8":
+            assert st["coarse_mx_s1_fp6"] == (1 if mode == "mx6" else 0)
+    elif mode == "narrow":
+        assert st["kernel_used"] == kg.KERNEL_NARROW and st["coarse_launches"] > 0
+    else:
+        assert st["kernel_used"] == kernel and st["coarse_launches"] == 0
+    assert st["rows_tested"] == tested and st["rows_fed"] == len(rows)
+    for j in range(P):
+        k, s, r = scan.result(j)
+        ex.compare((r, k, s), exp[j])
+    if "effective_pushes" in fx:  # (a function of the score multiset alone: simulated with heapq for the smallest case)
+        assert st["heap_pushes"] == fx["effective_pushes"]
+    scan.close()
+
+
+@pytest.mark.parametrize("name", ["kin_s241", "kin_s1135"])
+def test_kinship_equals_closed_form_fixture(name):
+    """kin_transpose_kernel + kin_gram_kernel against K_ij = n - c_i - c_j + 2 c_ij computed with NumPy integers
+    (tests/exact_topn.py::kinship_closed_form, digest committed in tests/golden/exact_topn.json) - no oracle involved."""
+    import hashlib
+    import json
+    import exact_topn as ex
+    fx = json.load(open(os.path.join(GOLD, "exact_topn.json")))["kinship"][name]
+    rows = ex.synth_rows_numpy(0, fx["n_rows"], fx["S_f"], fx["seed"])
+    K, n, mc = ex.kinship_closed_form(rows, fx["S_f"])
+    assert hashlib.sha256(K.astype("<u8").tobytes()).hexdigest() == fx["sha256"] and n == fx["n_used"]
+    kin = kg.Kinship(fx["S_f"], mc)
+    kin.feed_host(rows[:17_001])
+    kin.feed_host(rows[17_001:])
+    Kg, ng = kin.matrix()
+    assert ng == n
+    iu = np.tril_indices(fx["S_f"], -1)
+    assert (np.asarray(Kg, np.int64)[iu] == K[iu]).all()
+    kin.close()
+
+
+# ---- numeric edges of the filters' bound (against the oracle: these values are not exactly summable) --------------------------
+def _edge_phenotypes(kind, S, P, rng):
+    Y = phenotypes(S, P - 1, seed=P + 29)
+    if kind == "subnormal":      # every magnitude below FLT_MIN: SSE keeps denormals (no FTZ/DAZ in the reference's build)
+        Y = (Y * np.float32(1e-41)).astype(np.float32)
+        assert (np.abs(Y[Y != 0]) < np.finfo(np.float32).tiny).all()
+    elif kind == "mixed_subnormal":  # normal columns beside subnormal ones, and single subnormal values inside normal columns
+        Y[1::3] = (Y[1::3] * np.float32(3e-40)).astype(np.float32)
+        Y[0, ::7] = np.float32(1e-42)
+    elif kind == "huge":         # |y| ~ 1e37: the reference's float32 chains overflow to +-inf on many rows (scores inf / NaN)
+        Y = (Y * np.float32(1e37)).astype(np.float32)
+    elif kind == "near_max":     # finite sums, squares beyond double? no: (1e34 * 1e3)^2 ~ 1e74 fits a double; stresses up((double)...)
+        Y = (Y * np.float32(3e34)).astype(np.float32)
+    elif kind == "neg_zero":     # -0.0f values: blendv selects them, +0.0f + -0.0f = +0.0f
+        Y[:, ::3] = np.float32(-0.0)
+        Y[2] = np.float32(-0.0)
+    elif kind == "one_hot":      # a column with one non-zero value (and one with one value different from a constant)
+        Y[1] = 0
+        Y[1, S // 3] = np.float32(2.5)
+        Y[3] = np.float32(-7.0)
+        Y[3, 5] = np.float32(11.0)
+    return np.ascontiguousarray(Y.astype(np.float32))
+
+
+@pytest.mark.parametrize("kernel", [kg.KERNEL_COARSE, kg.KERNEL_AUTO, kg.KERNEL_MFMA, kg.KERNEL_VALU])
+@pytest.mark.parametrize("kind", ["subnormal", "mixed_subnormal", "huge", "near_max", "neg_zero", "one_hot"])
+@pytest.mark.parametrize("S,P", [(300, 12), (1024, 3)])
+def test_numeric_edges_of_the_phenotype_values(kernel, kind, S, P):
+    """Phenotype values at the edges of float32: subnormal magnitudes (the reference's SSE code keeps denormals; whatever
+    the matrix pipe does with them, the library must route around it), values whose chains overflow to +-inf or come near
+    FLT_MAX, negative zeros, one-hot columns. Heaps, score bytes and push counts equal the oracle's for every scorer
+    (12 columns: the coarse filter, 3: the narrow one under AUTO)."""
+    if kernel == kg.KERNEL_AUTO and P > 4:
+        pytest.skip("AUTO with more than four columns is the coarse filter: covered by KERNEL_COARSE")
+    rng = np.random.default_rng(S + P)
+    rows = random_table(30_000, S, seed=S * 5 + P, dup_frac=0.2)
+    col = np.arange(S, dtype=np.uint64)
+    Y = _edge_phenotypes(kind, S, P, rng)
+    mac = onp.min_count(S, 0.05, 5)
+    topn = 150
+    exp = ob.associate(rows, S, col, Y, topn, mac, batch_size=7000, threads=3)
+    sc_exp, _ = ob.scores_dense(rows[:2000], S, col, Y, mac)
+    scan = kg.AssociationScan(S, col, Y, topn, mac, kernel=kernel, chunk_rows=4096)
+    got, _ = scan.scores_dense(rows[:2000])
+    assert got.tobytes() == sc_exp.tobytes(), "dense scores differ (%s)" % kind
+    scan.feed_host(rows[:11_000], 0)
+    scan.feed_host(rows[11_000:], 11_000)
+    scan.finish()
+    _check_topn(scan, exp, P)
+    assert scan.stats()["rows_tested"] == exp["tested"]
+    scan.close()
+
+
+@pytest.mark.parametrize("S,P", [(5121, 20), (5200, 3), (6000, 1)])
+def test_more_than_5120_samples_leave_the_filters(S, P):
+    """Beyond 5120 accessions the filters' operand sets are not built (scan_create.cpp): the session must say which scorer
+    runs instead, and the heaps still equal the oracle's."""
+    rows = random_table(6000, S, seed=S, dup_frac=0.2)
+    col = np.arange(S, dtype=np.uint64)
+    Y = phenotypes(S, P - 1, seed=P + 1)
+    mac = onp.min_count(S, 0.05, 5)
+    topn = 100
+    exp = ob.associate(rows, S, col, Y, topn, mac, batch_size=2000, threads=3)
+    scan = kg.AssociationScan(S, col, Y, topn, mac, chunk_rows=1024)
+    scan.feed_host(rows)
+    scan.finish()
+    st = scan.stats()
+    assert st["kernel_used"] in (kg.KERNEL_MFMA, kg.KERNEL_VALU) and st["coarse_launches"] == 0, st
+    _check_topn(scan, exp, P)
+    assert st["rows_tested"] == exp["tested"]
+    scan.close()

@@ -212,3 +212,51 @@ def test_golden_regression_vectors():
         assert (res["per_pheno"][j]["file_row"] == g["top_row"][j]).all()
     K, n = ob.kinship(rows, S_f, int(g["kin_min_count"]))
     assert n == int(g["kin_n"]) and (K == g["kin_K"]).all()
+
+
+# ---- the oracle against implementation-independent arithmetic at production size --------------------------------------
+def _exact_fixture():
+    return json.load(open(os.path.join(GOLD, "exact_topn.json")))
+
+
+@pytest.mark.parametrize("name", ["s241_p24", "s1024_p101", "s1135_p40", "s2048_p64", "s1024_p1", "s1135_p2", "s2048_p4"])
+def test_oracle_topn_equals_exact_rationals(name):
+    """tests/exact_topn.py: 200 k synthetic rows, integer phenotypes - every float32 add of the reference is exact, the score
+    is a rational rounded once, the top-N is decided by integer arithmetic (no oracle, no product code). The committed
+    fixture (tests/golden/exact_topn.json) pins that computation; the oracle's heaps must hold exactly those entries, with
+    those score bytes, in ascending pop order (entries of EQUAL score may pop in either order: that depends on the heap's
+    history and is pinned elsewhere, against libstdc++ itself)."""
+    import exact_topn as ex
+    c = ex.CASES[name]
+    fx = _exact_fixture()["cases"][name]
+    rows, Yi, mac, topn = ex.make_inputs(name)
+    exp, tested = ex.expected_topn(rows, c["S"], Yi, mac, topn)
+    assert ex.digest(exp) == fx["sha256"] and tested == fx["tested"] and mac == fx["mac"]  # the fixture pins the expectation
+    for j in (0, c["P"] - 1):
+        f = fx["column_%d" % j]
+        assert [int(v) for v in exp[j][0][:64]] == f["rows_lowest"] and [float(v).hex() for v in exp[j][2][-64:]] == f["score_hex_best"]
+    res = ob.associate(rows, c["S"], np.arange(c["S"], dtype=np.uint64), Yi.astype(np.float32), topn, mac, threads=4)
+    assert res["tested"] == tested
+    for j in range(c["P"]):
+        o = res["per_pheno"][j]
+        ex.compare((o["file_row"], o["kmer"], o["score"]), exp[j])
+    if "effective_pushes" in fx:
+        assert ex.effective_pushes(rows, c["S"], Yi, mac, topn) == fx["effective_pushes"] == res["pushes"]
+
+
+@pytest.mark.parametrize("name", ["kin_s241", "kin_s1135"])
+def test_oracle_kinship_equals_closed_form_fixture(name):
+    """The kinship loop (1 ^ g_i ^ g_j per pair and row) against K_ij = n - c_i - c_j + 2 c_ij from NumPy integers."""
+    import hashlib
+    import exact_topn as ex
+    fx = _exact_fixture()["kinship"][name]
+    n_rows = fx["n_rows"] if name == "kin_s241" else 6000  # (the loop is S_f^2 / 2 per row: a slice of the large case)
+    rows = ex.synth_rows_numpy(0, fx["n_rows"], fx["S_f"], fx["seed"])
+    K, n, mc = ex.kinship_closed_form(rows, fx["S_f"])
+    assert n == fx["n_used"] and mc == fx["min_count"]
+    assert hashlib.sha256(K.astype("<u8").tobytes()).hexdigest() == fx["sha256"]
+    K2, n2, _ = ex.kinship_closed_form(rows[:n_rows], fx["S_f"])
+    Ko, no = ob.kinship(rows[:n_rows], fx["S_f"], mc)
+    assert no == n2
+    iu = np.tril_indices(fx["S_f"], -1)  # the loop fills j < i; what it leaves elsewhere is the formatter's business
+    assert (np.asarray(Ko, np.int64)[iu] == K2[iu]).all()
