@@ -307,6 +307,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     multi = world > 1 or args.gpus > 1
+    # KGWAS_BENCH_FORCE_DIST=1: take the N > 1 path (process group, merge, per-rank records) even with ONE rank - the only way
+    # to run the RCCL ("nccl") branch on a one-GPU box (tests/test_gpu_rccl.py)
+    dist_on = world > 1 or os.environ.get("KGWAS_BENCH_FORCE_DIST") == "1"
     if args.samples == 0:
         args.samples = 2048 if multi else 1024
     if args.perms < 0:
@@ -315,7 +318,7 @@ def main():
         args.rows = 250_000_000 if multi else 100_000_000
     config_name = ("BASELINE.json configs[3] per GPU" if (args.samples, args.perms) == (2048, 200) else
                    "BASELINE.json configs[1]" if (args.samples, args.perms, args.rows) == (1024, 100, 100_000_000) else "custom")
-    if world > 1:
+    if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         ndev = torch.cuda.device_count()
         if ndev < int(os.environ.get("LOCAL_WORLD_SIZE", str(world))):
@@ -360,13 +363,13 @@ def main():
     def one_step(merge=True):
         scan = session
         scan.reset()
-        if world == 1 or not merge:
+        if not dist_on or not merge:
             scan.expect_finish()  # the one feed of the pass is its last: idle replay workers start on finish()'s pops at its tail
         scan.feed_device(table.data_ptr(), M, first_row, stream)
-        if world == 1 or not merge:
+        if not dist_on or not merge:
             scan.finish()  # with several ranks the merge finishes rank 0's session once, at its end
         st = scan.stats()
-        if world > 1 and merge:
+        if dist_on and merge:
             if os.environ.get("KGWAS_BENCH_MERGE_DIAG"):  # diagnostics: separate "waiting for the slowest rank" from the merge
                 dist.barrier()
             tm = time.perf_counter()
@@ -379,7 +382,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -390,7 +393,7 @@ def main():
     if args.steps <= 0:  # about 5 s of timed steps, the same count on every rank
         est = (time.perf_counter() - t_w) / max(args.warmup, 1)
         n = int(min(400, max(10, round(5.0 / max(est, 1e-3)))))
-        if world > 1:
+        if dist_on:
             tn = torch.tensor([n], dtype=torch.int64, device=kdist._dev())
             dist.broadcast(tn, 0)
             n = int(tn.item())
@@ -410,14 +413,14 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     thr1 = cgroup_throttle()
-    if world > 1:
+    if dist_on:
         tmax = torch.tensor([dt], dtype=torch.float64, device=kdist._dev())
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
     # what every rank did, side by side: a sub-linear point then says which rank, and which side (host replay, GPU, merge)
     per_rank = None
-    if world > 1:
+    if dist_on:
         mine = [float(np.mean(step_ms)), float(np.max(step_ms)),
                 sum(s_["score_kernel_ms"] for s_ in stats) / args.steps, sum(s_["coarse_kernel_ms"] for s_ in stats) / args.steps,
                 sum(s_["replay_ms"] for s_ in stats) / args.steps, sum(s_["replay_cpu_ms"] for s_ in stats) / args.steps,
@@ -435,7 +438,7 @@ def main():
 
     # the N = 1 reference of a multi-GPU run: rank 0's shard alone, no merge (other ranks wait)
     single = None
-    if world > 1:
+    if dist_on:
         if rank == 0:
             k1 = max(2, min(5, args.steps))
             one_step(merge=False)
@@ -450,7 +453,7 @@ def main():
         dist.barrier()
 
     shard_parity = None
-    if world > 1 and not args.no_cpu_baseline:
+    if dist_on and not args.no_cpu_baseline:
         if rank == 0:
             try:
                 from oracle import binding as ob
@@ -464,7 +467,7 @@ def main():
         dist.barrier()
 
     merge_check = None
-    if world > 1 and args.check_merge:
+    if dist_on and args.check_merge:
         # one more merged step (the merge consumed rank 0's session state), then the reference: everything in one session
         scan_m, _, tested_m = one_step()
         if rank == 0:
@@ -629,7 +632,7 @@ def main():
             out["single_gpu_same_shard"] = single
         if merge_check is not None:
             out["merge_check"] = bool(merge_check)
-        if world == 1 and not args.no_cpu_baseline:
+        if not dist_on and not args.no_cpu_baseline:
             rec, ores = cpu_baseline(S, Y, mac, args.topn, seed_table, min(args.cpu_sample_rows, M),
                                      threads=min(usable_cpus(), P))
             out["cpu_baseline"] = rec
@@ -639,7 +642,7 @@ def main():
             except Exception as e:  # a failed comparison must show up in the line, not kill it
                 out["parity_check"] = False
                 out["parity_check_error"] = repr(e)
-        if world == 1 and not args.no_subrecords and config_name == "BASELINE.json configs[1]":
+        if not dist_on and not args.no_subrecords and config_name == "BASELINE.json configs[1]":
             try:
                 out["p1_scan"] = p1_scan_record(kg, torch, table, stream, M, S, Y, args.topn, mac, dev, host_threads)
             except Exception as e:
@@ -662,7 +665,7 @@ def main():
         print(json.dumps(out))
     if last is not None:
         last.close()
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -50,6 +50,17 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
 
         bool finite = true;
         for (float v : s->Y) finite = finite && std::isfinite(v);
+        // The filters bound |reference yigi - exact sum| by float32 ROUNDING errors only: that needs every partial sum of
+        // the reference's four chains (and their final adds) to stay finite. sum |y_i| of a column, with the growth factor
+        // of recursive float32 summation, bounds them all; a column beyond that (|y| ~ 1e36 and up) can overflow to +-inf
+        // in the reference on rows whose exact sum is finite - such sessions keep the exact scorers, which reproduce the
+        // overflow (tests/test_gpu_parity.py::test_numeric_edges_of_the_phenotype_values[huge]).
+        bool chain_safe = finite;
+        for (uint64_t j = 0; j < s->n_pheno && chain_safe; j++) {
+            double a = 0;
+            for (uint64_t i = 0; i < s->S; i++) a += std::fabs((double)s->Y[j * s->S + i]);
+            chain_safe = a * (1.0 + (double)(s->S + 8) * 0x1p-23) < 0.99 * (double)std::numeric_limits<float>::max();
+        }
         uint32_t kern = p->kernel;
         const bool mfma_fits = mfma_lds_bytes((uint32_t)s->W_m) <= 160u * 1024u;
         // Coarse int8 filter + exact re-scoring for the sparse phase (score_coarse.hip): needs finite values,
@@ -63,10 +74,11 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
             }
         bool want_coarse = false;
         if (kern == KGWAS_KERNEL_COARSE) {
-            if (!finite || !coarse_T) throw Error(KGWAS_ERR_ARG, "coarse filter needs finite phenotype values and <= 5120 accessions");
+            if (!chain_safe || !coarse_T)
+                throw Error(KGWAS_ERR_ARG, "coarse filter needs finite phenotype values whose float32 sums cannot overflow (sum |y| < FLT_MAX per column) and <= 5120 accessions");
             want_coarse = true;
             kern = KGWAS_KERNEL_AUTO;
-        } else if (kern == KGWAS_KERNEL_AUTO && finite && coarse_T) {
+        } else if (kern == KGWAS_KERNEL_AUTO && chain_safe && coarse_T) {
             // any number of columns: even a single column (one mostly empty 16-column tile) runs twice as fast behind
             // the filter as through the exact VALU scorer (12.5 vs 27 ms per 100 M-row pass)
             want_coarse = true;

@@ -560,8 +560,10 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
             // records on the copy stream, ordered here as soon as the counts are in - before waiting for an older
             // chunk's copy if this chunk's counts are already there, so the copy engine never waits for this thread.
             const bool can_submit = pos < n_rows && sub - rep_now < depth;
-            if (cpy < sub && ((cpy == pub && !can_submit) || hipEventQuery(s->slot[(size_t)(cpy % (uint64_t)s->n_slots)].ev_counts) == hipSuccess ||
-                              !s->slot[(size_t)(cpy % (uint64_t)s->n_slots)].used_coarse)) {
+            // (exact-scorer chunks have no counts step and no ev_counts: querying a null event fails AND leaves the error
+            // for the next hipGetLastError - the next kernel launch then reports "invalid resource handle")
+            if (cpy < sub && ((cpy == pub && !can_submit) || !s->slot[(size_t)(cpy % (uint64_t)s->n_slots)].used_coarse ||
+                              hipEventQuery(s->slot[(size_t)(cpy % (uint64_t)s->n_slots)].ev_counts) == hipSuccess)) {
                 if (fetch_records(s, s->slot[(size_t)(cpy % (uint64_t)s->n_slots)], cpy)) {
                     if (s->trace) fprintf(stderr, "[kgwas t=%.3f] counts of chunk %llu in, record copy ordered\n", s->t_ms(), (unsigned long long)cpy);
                     cpy++;

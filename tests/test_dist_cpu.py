@@ -1,4 +1,4 @@
-"""world_size-2 and -5 `gloo` tests of the multi-GPU plumbing on CPU (kmersgwas_amd/dist.py).
+"""world_size-2, -5 and -8 `gloo` tests of the multi-GPU plumbing on CPU (kmersgwas_amd/dist.py).
 
 The product's scoring needs a GPU, so each rank's shard-local heap-push history and kinship partials
 are produced here by the oracle (as the checker / stand-in data source); what is under test is the
@@ -111,6 +111,12 @@ WORKER = textwrap.dedent("""
                     o += int(counts[g, j])
         def finish(self):
             pass
+    by_column_calls = []
+    _by_column = kdist.merge_by_column
+    def _spy(scan, dst=0):
+        by_column_calls.append(1)
+        return _by_column(scan, dst)
+    kdist.merge_by_column = _spy  # (merge_shards looks the name up when it is called)
     for merge in (kdist.merge_by_column, kdist.merge_to_root, kdist.merge_shards):
         ps = PyScan(hist)
         tested = merge(ps)
@@ -122,6 +128,8 @@ WORKER = textwrap.dedent("""
                 assert [e[0] for e in pops] == [int(x) for x in o["kmer"]], "column %%d" %% j
                 assert [e[2] for e in pops] == [int(x) for x in o["file_row"]]
                 assert np.asarray([e[1] for e in pops]).tobytes() == o["score"].tobytes()
+    # merge_shards picks by itself: to the root up to four ranks, by column beyond
+    assert len(by_column_calls) == (2 if world > 4 else 1), (world, by_column_calls)
     # kinship partials: integer Hamming sums + used-row counts all-reduce to the single-process answer
     mc = int(np.ceil(S_f * 0.05))
     g = onp.unpack_bits(rows[lo:hi], np.arange(S_f, dtype=np.uint64)).astype(np.int64)
@@ -141,7 +149,9 @@ WORKER = textwrap.dedent("""
 import pytest
 
 
-@pytest.mark.parametrize("world", [2, 5])  # 5 ranks > 3 columns: ranks that own no column take part with empty messages
+# 5 and 8 ranks > 3 columns: ranks that own no column take part with empty messages; 8 (the node's GPU count): merge_shards
+# takes merge_by_column by itself
+@pytest.mark.parametrize("world", [2, 5, 8])
 def test_gloo_merge_and_kinship_allreduce(tmp_path, world):
     script = tmp_path / "worker.py"
     script.write_text(WORKER % {"root": ROOT})

@@ -997,8 +997,8 @@ def _edge_phenotypes(kind, S, P, rng):
     elif kind == "one_hot":      # a column with one non-zero value (and one with one value different from a constant)
         Y[1] = 0
         Y[1, S // 3] = np.float32(2.5)
-        Y[3] = np.float32(-7.0)
-        Y[3, 5] = np.float32(11.0)
+        Y[P - 1] = np.float32(-7.0)
+        Y[P - 1, 5] = np.float32(11.0)
     return np.ascontiguousarray(Y.astype(np.float32))
 
 
@@ -1020,14 +1020,26 @@ def test_numeric_edges_of_the_phenotype_values(kernel, kind, S, P):
     topn = 150
     exp = ob.associate(rows, S, col, Y, topn, mac, batch_size=7000, threads=3)
     sc_exp, _ = ob.scores_dense(rows[:2000], S, col, Y, mac)
+    if kind == "huge":
+        # sum |y| of a column exceeds FLT_MAX: the reference's chains overflow to +-inf on rows whose exact sum is finite,
+        # which no rounding-error bound covers - the filters refuse such columns, AUTO keeps the exact scorers
+        assert np.isinf(sc_exp).any()
+        if kernel == kg.KERNEL_COARSE:
+            with pytest.raises(kg.KgwasError, match="cannot overflow"):
+                kg.AssociationScan(S, col, Y, topn, mac, kernel=kernel, chunk_rows=4096)
+            return
     scan = kg.AssociationScan(S, col, Y, topn, mac, kernel=kernel, chunk_rows=4096)
+    if kind == "huge":
+        assert scan.stats()["kernel_used"] in (kg.KERNEL_MFMA, kg.KERNEL_VALU)
     got, _ = scan.scores_dense(rows[:2000])
     assert got.tobytes() == sc_exp.tobytes(), "dense scores differ (%s)" % kind
     scan.feed_host(rows[:11_000], 0)
     scan.feed_host(rows[11_000:], 11_000)
     scan.finish()
     _check_topn(scan, exp, P)
-    assert scan.stats()["rows_tested"] == exp["tested"]
+    st = scan.stats()
+    assert st["rows_tested"] == exp["tested"]
+    assert (st["coarse_launches"] > 0) == (kind != "huge" and kernel in (kg.KERNEL_COARSE, kg.KERNEL_AUTO)), st["coarse_launches"]
     scan.close()
 
 
