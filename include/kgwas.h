@@ -313,6 +313,15 @@ uint64_t kgwas_kinship_format(uint64_t n_acc_file, const uint64_t* K, uint64_t n
 int kgwas_write_plink(const char* out_base, kgwas_table* t, const uint64_t* col, uint64_t n_acc,
                       const char* const* acc_names, const float* y, uint64_t n, const uint64_t* kmer_pop,
                       const uint64_t* row_pop);
+/* The same for ALL phenotype columns of a run in one call - what the loop of src/associate_kmers.cpp:167-195 writes from
+ * its second pass over the table: column j's files <out_bases[j]>.bed/.bim/.fam from its heap in pop order (n_win[j]
+ * entries kmer_pop[j][i], row_pop[j][i]) and its values Y[j * n_acc ..]. The union of the winners' rows is read once
+ * (sorted, neighbouring rows in one read, read-ahead requested when the file turns out to be cold), expanded once
+ * (word-wise) and written by `threads` host threads (0: the CPUs this process may use). Files are byte-identical to
+ * kgwas_write_plink's, which is this call with one column. */
+int kgwas_write_plink_many(uint64_t n_cols, const char* const* out_bases, kgwas_table* t, const uint64_t* col, uint64_t n_acc,
+                           const char* const* acc_names, const float* Y, const uint64_t* n_win, const uint64_t* const* kmer_pop,
+                           const uint64_t* const* row_pop, uint32_t threads);
 
 /* ------------------------------------------------------------------------------------
  * kmers_table_to_bed (src/kmers_table_to_bed.cpp:93-129): the whole table, MAC-filtered on the phenotyped

@@ -9,5 +9,5 @@ from . import capi  # noqa: F401  (raises ImportError if libkgwas.so is missing)
 from .capi import KgwasError, KERNEL_AUTO, KERNEL_VALU, KERNEL_MFMA, KERNEL_COARSE, KERNEL_NARROW, device_count  # noqa: F401
 from .engine import (  # noqa: F401
     AssociationScan, BestAssociationsHeap, Kinship, MultiDeviceScan, kinship_table_multi, KmersTable, Phenotypes, SnpsDataBase, kinship_format, kinship_from_partials,
-    merge_shards, min_count, synth_rows_device, synth_rows_host, table_to_bed, write_plink,
+    merge_shards, min_count, synth_rows_device, synth_rows_host, table_to_bed, write_plink, write_plink_many,
 )

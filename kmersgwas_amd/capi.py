@@ -36,7 +36,7 @@ SYMBOLS = [
     "kgwas_multiscan_result", "kgwas_multiscan_get_stats", "kgwas_multiscan_destroy", "kgwas_kinship_table_multi",
     "kgwas_kinship_create", "kgwas_kinship_feed_device", "kgwas_kinship_feed_host", "kgwas_kinship_feed_table", "kgwas_kinship_partials",
     "kgwas_kinship_from_partials", "kgwas_kinship_get_stats", "kgwas_kinship_destroy", "kgwas_kinship_format",
-    "kgwas_write_plink", "kgwas_table_to_bed",
+    "kgwas_write_plink", "kgwas_write_plink_many", "kgwas_table_to_bed",
     "kgwas_snps_open", "kgwas_snps_info", "kgwas_snps_scores", "kgwas_snps_best", "kgwas_snps_write", "kgwas_snps_close",
     "kgwas_synth_rows_device", "kgwas_synth_rows_host",
 ]
@@ -201,6 +201,7 @@ lib.kgwas_kinship_destroy.restype = None
 lib.kgwas_kinship_format.argtypes = [_u64, _vp, _u64, C.c_char_p, _u64]
 lib.kgwas_kinship_format.restype = _u64
 lib.kgwas_write_plink.argtypes = [C.c_char_p, _vp, _vp, _u64, _pstr, _vp, _u64, _vp, _vp]
+lib.kgwas_write_plink_many.argtypes = [_u64, _pstr, _vp, _vp, _u64, _pstr, _vp, _vp, _pp, _pp, _u32]
 lib.kgwas_snps_open.argtypes = [C.c_char_p, _pstr, _u64, _vp]
 lib.kgwas_snps_info.argtypes = [_vp, _vp, _vp, _vp]
 lib.kgwas_snps_scores.argtypes = [_vp, _vp, _u64, C.c_double, C.c_int, _vp]

@@ -23,6 +23,8 @@
 #include <vector>
 
 #include "../../include/kgwas.h"
+#include <cstring>
+
 #include "cli_args.h"
 
 using namespace std;
@@ -46,6 +48,7 @@ static void ck(int rc) {
 }
 
 int main(int argc, char* argv[]) {
+    const double t_main = now_s();
     CliArgs vm({
         {"phenotype_file", 'p', true, "phenotype file name", ""},
         {"base_name", 'b', true, "base name to use for all files", ""},
@@ -151,6 +154,7 @@ int main(int argc, char* argv[]) {
         }
         kgwas_scan* scan = nullptr;
         kgwas_multiscan* mscan = nullptr;
+        const double t_setup = now_s();
         if (n_gpus > 1) {
             int present = 0;
             ck(kgwas_device_count(&present));
@@ -166,6 +170,7 @@ int main(int argc, char* argv[]) {
         } else {
             ck(kgwas_scan_create(&sp, &scan));
         }
+        const double t_created = now_s();
 
         // Pass 1: stream the table through the GPU in file order. The reference loads a batch, then associates it
         // (src/associate_kmers.cpp:104-148); here a batch is read, copied and scored in overlapping 128 MiB pieces
@@ -193,6 +198,7 @@ int main(int argc, char* argv[]) {
             t0 = now_s();
             batch_index++;
         }
+        const double t_fed = now_s();
         kgwas_scan_stats st;
         double scan_ms = 0, merge_ms = 0;
         uint64_t rescans = 0;
@@ -204,7 +210,14 @@ int main(int argc, char* argv[]) {
             ck(kgwas_scan_get_stats(scan, &st));
         }
 
-        // Outputs (:150-205)
+        const double t_finished = now_s();
+        // Outputs (:150-205). The reference writes the winners' presence/absence from a second pass over the whole table
+        // (:167-195); here the rows of ALL columns' winners are fetched by file row index and written in one batched,
+        // multi-threaded call (kgwas_write_plink_many).
+        vector<string> out_names(phenotypes_n);
+        vector<const char*> out_bases(phenotypes_n);
+        vector<uint64_t> n_win(phenotypes_n);
+        vector<const uint64_t*> kmers(phenotypes_n), rows_(phenotypes_n);
         for (uint64_t j = 0; j < phenotypes_n; j++) {
             uint64_t n = 0;
             const uint64_t *kmer = nullptr, *row = nullptr;
@@ -214,16 +227,24 @@ int main(int argc, char* argv[]) {
             else
                 ck(kgwas_scan_result(scan, j, &n, &kmer, &score, &row));
             if (vm.count("k_mers_scores")) {  // output_to_file_with_scores (best_associations_heap.cpp:82-92)
-                ofstream of(fn_base + "." + to_string(j) + ".best_kmers.scores", ios::binary);
+                vector<char> rec(16 * n);
                 for (uint64_t i = 0; i < n; i++) {
-                    of.write(reinterpret_cast<const char*>(&kmer[i]), sizeof(uint64_t));
-                    of.write(reinterpret_cast<const char*>(&score[i]), sizeof(double));
+                    memcpy(&rec[16 * i], &kmer[i], sizeof(uint64_t));
+                    memcpy(&rec[16 * i + 8], &score[i], sizeof(double));
                 }
+                ofstream of(fn_base + "." + to_string(j) + ".best_kmers.scores", ios::binary);
+                of.write(rec.data(), (std::streamsize)rec.size());
             }
-            const string out = fn_base + "." + to_string(j) + "." + pname[j];
+            out_names[j] = fn_base + "." + to_string(j) + "." + pname[j];
+            out_bases[j] = out_names[j].c_str();
+            n_win[j] = n;
+            kmers[j] = kmer;
+            rows_[j] = row;
             cerr << "Save [" << j << "]" << endl;
-            ck(kgwas_write_plink(out.c_str(), tbl, col.data(), n_accessions, acc.data(), Y + j * n_accessions, n, kmer, row));
         }
+        ck(kgwas_write_plink_many(phenotypes_n, out_bases.data(), tbl, col.data(), n_accessions, acc.data(), Y, n_win.data(), kmers.data(),
+                                  rows_.data(), (uint32_t)replay_threads));
+        const double t_written = now_s();
         if (vm.count("pattern_counter")) {  // :143-144, :197-201
             cerr << "Total patterns\t" << st.patterns << endl;
             ofstream fout(fn_base + ".pattern_counter");
@@ -243,6 +264,9 @@ int main(int argc, char* argv[]) {
         cerr << "[kgwas] replay_threads=" << replay_threads << " replay_threads_per_gpu=" << std::max<uint64_t>(1, replay_threads / n_gpus) << endl;
         if (mscan)
             cerr << "[kgwas] gpus=" << n_gpus << " scan_ms=" << scan_ms << " merge_ms=" << merge_ms << " rescans=" << rescans << endl;
+        // where the wall time of the run went (bench.py's cli_e2e record reads this line)
+        cerr << "[kgwas] seconds: setup=" << (t_setup - t_main) << " session_create=" << (t_created - t_setup) << " scan=" << (t_fed - t_created)
+             << " finish=" << (t_finished - t_fed) << " output=" << (t_written - t_finished) << " total=" << (now_s() - t_main) << endl;
         if (mscan) kgwas_multiscan_destroy(mscan);
         if (scan) kgwas_scan_destroy(scan);
         kgwas_table_close(tbl);

@@ -9,6 +9,11 @@
 #include <cstring>
 #include <fstream>
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <exception>
+#include <mutex>
+#include <thread>
 #include <iostream>
 #include <memory>
 #include <sstream>
@@ -21,6 +26,7 @@ namespace kgwas {
 
 static thread_local std::string g_last_error;
 void set_error(const std::string& msg) { g_last_error = msg; }
+unsigned usable_cpus();  // scan_host.cpp: cgroup quota / affinity mask
 
 }  // namespace kgwas
 
@@ -51,15 +57,57 @@ static std::vector<std::string> read_names(const std::string& base) {
     return res;
 }
 
-static std::string bits_to_kmer(uint64_t w, size_t k) {  // bits2kmer31, src/kmer_general.cpp:77-87
-    static const char bp[4] = {'A', 'C', 'G', 'T'};
-    std::string s(k, 'X');
-    for (size_t i = 0; i < k; i++) {
-        s[k - 1 - i] = bp[w & 3u];
-        w >>= 2;
+namespace {
+
+template <class F>
+void parallel_items(unsigned threads, size_t n, const F& fn) {
+    if (n == 0) return;
+    threads = (unsigned)std::min<size_t>(std::max(1u, threads), n);
+    if (threads == 1) {
+        for (size_t i = 0; i < n; i++) fn(i);
+        return;
     }
-    return s;
+    std::atomic<size_t> next(0);
+    std::exception_ptr err;
+    std::mutex mu;
+    auto work = [&] {
+        try {
+            for (size_t i; (i = next.fetch_add(1, std::memory_order_relaxed)) < n;) fn(i);
+        } catch (...) {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!err) err = std::current_exception();
+            next.store(n);
+        }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < threads; t++) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+    if (err) std::rethrow_exception(err);
 }
+
+struct FdFile {  // unbuffered output file, written in large pieces
+    int fd = -1;
+    std::string path;
+    void create(const std::string& p) {
+        path = p;
+        fd = ::open(p.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+        if (fd < 0) throw Error(KGWAS_ERR_IO, "cannot create " + p);
+    }
+    void append(const char* d, size_t n) {
+        while (n) {
+            const ssize_t w = ::write(fd, d, n);
+            if (w <= 0) throw Error(KGWAS_ERR_IO, "write error on " + path);
+            d += w;
+            n -= (size_t)w;
+        }
+    }
+    ~FdFile() {
+        if (fd >= 0) ::close(fd);
+    }
+};
+
+}  // namespace
 
 extern "C" {
 
@@ -241,49 +289,243 @@ uint64_t kgwas_min_count(uint64_t n_acc, double maf, uint64_t mac) {
     return mc;
 }
 
+// ---- pass 2 of associate_kmers: the winners of ALL phenotype columns -> <base>.bed/.bim/.fam ------------------------------
+// The reference re-scans the whole table once per run and writes every column's files from it
+// (src/associate_kmers.cpp:167-195). Here the winners' rows are fetched by file row index:
+//   1. the union of the columns' winner rows, sorted (a row that wins in several columns is read and expanded once);
+//   2. per block of the union: the rows are read by a pool of threads - neighbouring rows in one pread, and, once the
+//      reads turn out to be slow (a cold file), with the block's read-ahead requested up front so the device sees a deep
+//      queue instead of one request at a time - and expanded to PLINK bytes word-wise (write_PA's two bits per accession:
+//      a byte of table bits -> 16 bits through a 256-entry table when the phenotyped accessions are the table's leading
+//      columns in order, a gather over precomputed (word, shift) pairs otherwise); the expansion does not depend on the
+//      phenotype column;
+//   3. per column (in parallel): its winners of the block, in row order, appended to its .bed and .bim.
+
+int kgwas_write_plink_many(uint64_t n_cols, const char* const* out_bases, kgwas_table* t, const uint64_t* col, uint64_t n_acc,
+                           const char* const* acc_names, const float* Y, const uint64_t* n_win, const uint64_t* const* kmer_pop,
+                           const uint64_t* const* row_pop, uint32_t threads) {
+    return guarded([&] {
+        if (!t || !col || !acc_names || (n_cols && (!out_bases || !Y || !n_win || !kmer_pop || !row_pop)))
+            throw Error(KGWAS_ERR_ARG, "kgwas_write_plink_many: null argument");
+        const unsigned T = threads ? threads : usable_cpus();
+        const bool trace = getenv("KGWAS_TRACE") != nullptr;
+        double ph[5] = {0, 0, 0, 0, 0};  // sort + union, read-ahead, read + expand, append, fam
+        auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        double tp = tnow();
+        auto lap = [&](int i) {
+            const double n = tnow();
+            ph[i] += n - tp;
+            tp = n;
+        };
+        const uint64_t W = t->W_f, row_bytes = 8 * (1 + W), bed_bytes = (n_acc + 3) / 4;
+        for (uint64_t i = 0; i < n_acc; i++)
+            if (col[i] >= t->n_acc) throw Error(KGWAS_ERR_ARG, "kgwas_write_plink_many: column index out of range");
+        bool direct = true;
+        for (uint64_t i = 0; i < n_acc; i++) direct = direct && col[i] == i;
+
+        // get_kmers_for_output (src/best_associations_heap.cpp:110-127): rank = queue size at pop, then sorted by row
+        struct Ent {
+            uint64_t row, kmer;
+            uint32_t rank;
+        };
+        std::vector<std::vector<Ent>> lst(n_cols);
+        parallel_items(T, n_cols, [&](size_t j) {
+            const uint64_t n = n_win[j];
+            if (n && (!kmer_pop[j] || !row_pop[j])) throw Error(KGWAS_ERR_ARG, "kgwas_write_plink_many: null winner list");
+            if (n > 0xFFFFFFFFull) throw Error(KGWAS_ERR_ARG, "kgwas_write_plink_many: too many winners");
+            lst[j].resize(n);
+            for (uint64_t i = 0; i < n; i++) {
+                if (row_pop[j][i] >= t->n_rows) throw Error(KGWAS_ERR_ARG, "kgwas_write_plink: row index out of range");
+                lst[j][i] = Ent{row_pop[j][i], kmer_pop[j][i], (uint32_t)(n - i)};
+            }
+            std::sort(lst[j].begin(), lst[j].end(), [](const Ent& a, const Ent& b) { return a.row < b.row; });
+        });
+        // the union of the winner rows: every thread takes a slice of the table's row range, collects the (sorted) columns'
+        // entries that fall into it, sorts and de-duplicates them; the slices in order are the union
+        std::vector<uint64_t> urow;
+        {
+            const size_t NB = std::max<size_t>(1, std::min<size_t>(4 * T, 256));
+            std::vector<std::vector<uint64_t>> part(NB);
+            parallel_items(T, NB, [&](size_t b) {
+                const uint64_t lo = (uint64_t)((unsigned __int128)t->n_rows * b / NB), hi = (uint64_t)((unsigned __int128)t->n_rows * (b + 1) / NB);
+                std::vector<uint64_t>& v = part[b];
+                for (auto& l : lst) {
+                    auto cmp = [](const Ent& e, uint64_t r) { return e.row < r; };
+                    auto a = std::lower_bound(l.begin(), l.end(), lo, cmp), z = std::lower_bound(l.begin(), l.end(), hi, cmp);
+                    for (; a != z; ++a) v.push_back(a->row);
+                }
+                std::sort(v.begin(), v.end());
+                v.erase(std::unique(v.begin(), v.end()), v.end());
+            });
+            size_t total = 0;
+            for (auto& v : part) total += v.size();
+            urow.reserve(total);
+            for (auto& v : part) urow.insert(urow.end(), v.begin(), v.end());
+        }
+
+        lap(0);
+        std::vector<FdFile> bed(n_cols), bim(n_cols);
+        for (uint64_t j = 0; j < n_cols; j++) {
+            if (!out_bases[j]) throw Error(KGWAS_ERR_ARG, "kgwas_write_plink_many: null output name");
+            bed[j].create(std::string(out_bases[j]) + ".bed");
+            bim[j].create(std::string(out_bases[j]) + ".bim");
+            const char magic[3] = {(char)0x6C, (char)0x1B, (char)0x01};  // BedBimFilesHandle, src/kmer_general.h:138
+            bed[j].append(magic, 3);
+        }
+
+        // write_PA's byte (src/kmers_multiple_databases.cpp:225-236): accession a of a group of four -> bits 2a, 2a + 1
+        uint16_t spread[256];
+        for (unsigned b = 0; b < 256; b++) {
+            unsigned v = 0;
+            for (unsigned k = 0; k < 8; k++)
+                if (b & (1u << k)) v |= 3u << (2 * k);
+            spread[b] = (uint16_t)v;
+        }
+        std::vector<uint32_t> g_word(direct ? 0 : n_acc);
+        std::vector<uint8_t> g_shift(direct ? 0 : n_acc);
+        for (uint64_t i = 0; i < n_acc && !direct; i++) {
+            g_word[i] = (uint32_t)(1 + col[i] / 64);
+            g_shift[i] = (uint8_t)(col[i] % 64);
+        }
+
+        const size_t BLOCK = 1u << 16;  // distinct rows per block
+        const uint64_t exp_bytes = (bed_bytes + 15) / 16 * 16 + 16;  // room for the word-wise expansion's overshoot
+        std::vector<unsigned char> pa(std::min<size_t>(BLOCK, urow.size()) * exp_bytes);
+        std::vector<size_t> cur(n_cols, 0);  // next entry of every column
+        std::atomic<int> cold(0);             // reads are slow: ask for the block's read-ahead first
+        for (size_t b0 = 0; b0 < urow.size(); b0 += BLOCK) {
+            const size_t nb = std::min(BLOCK, urow.size() - b0);
+            // -- read + expand, in pieces of 256 union rows
+            const size_t PIECE = 256, n_pieces = (nb + PIECE - 1) / PIECE;
+            if (cold.load(std::memory_order_relaxed))
+                parallel_items(T, n_pieces, [&](size_t pc) {
+                    const size_t lo = b0 + pc * PIECE, hi = std::min(b0 + nb, lo + PIECE);
+                    for (size_t u = lo; u < hi;) {
+                        size_t v = u + 1;
+                        while (v < hi && (urow[v] - urow[v - 1]) * row_bytes <= 8192) v++;
+                        (void)posix_fadvise(t->fd, (off_t)(16 + urow[u] * row_bytes), (off_t)((urow[v - 1] - urow[u] + 1) * row_bytes), POSIX_FADV_WILLNEED);
+                        u = v;
+                    }
+                });
+            lap(1);
+            parallel_items(T, n_pieces, [&](size_t pc) {
+                const size_t lo = b0 + pc * PIECE, hi = std::min(b0 + nb, lo + PIECE);
+                std::vector<uint64_t> buf;
+                double small_us = 0;  // time in reads of at most 16 KB: what tells a cold file from the page cache
+                size_t n_small = 0;
+                for (size_t u = lo; u < hi;) {
+                    // neighbouring winners (at most 8 KB of other rows between two of them) in one read
+                    size_t v = u + 1;
+                    while (v < hi && (urow[v] - urow[v - 1]) * row_bytes <= 8192 && (urow[v] - urow[u] + 1) * row_bytes <= (1u << 20)) v++;
+                    const uint64_t span_rows = urow[v - 1] - urow[u] + 1;
+                    buf.resize(span_rows * (1 + W));
+                    const size_t want = span_rows * row_bytes;
+                    size_t got = 0;
+                    const bool timed = pc < 8 && want <= 16384;
+                    const auto tr0 = timed ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
+                    while (got < want) {
+                        const ssize_t r = pread(t->fd, (char*)buf.data() + got, want - got, (off_t)(16 + urow[u] * row_bytes + got));
+                        if (r <= 0) throw Error(KGWAS_ERR_IO, "read error on " + t->base + ".table");
+                        got += (size_t)r;
+                    }
+                    if (timed) {
+                        small_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tr0).count();
+                        n_small++;
+                    }
+                    for (size_t x = u; x < v; x++) {
+                        const uint64_t* row = buf.data() + (urow[x] - urow[u]) * (1 + W);
+                        unsigned char* out = pa.data() + (x - b0) * exp_bytes;
+                        if (direct) {
+                            const uint64_t nw = (n_acc + 63) / 64;
+                            for (uint64_t w = 0; w < nw; w++) {
+                                const uint64_t bits = row[1 + w];
+                                uint16_t o16[8];
+                                for (int k = 0; k < 8; k++) o16[k] = spread[(bits >> (8 * k)) & 0xFF];
+                                memcpy(out + 16 * w, o16, 16);
+                            }
+                            if (n_acc % 4) out[bed_bytes - 1] &= (unsigned char)((1u << (2 * (n_acc % 4))) - 1u);  // accessions beyond n_acc
+                        } else {
+                            for (uint64_t a0 = 0; a0 < n_acc; a0 += 4) {
+                                unsigned b = 0;
+                                for (uint64_t k = 0; k < 4 && a0 + k < n_acc; k++)
+                                    b |= (unsigned)((row[g_word[a0 + k]] >> g_shift[a0 + k]) & 1ull) * (3u << (2 * k));
+                                out[a0 / 4] = (unsigned char)b;
+                            }
+                        }
+                    }
+                    u = v;
+                }
+                // the first pieces decide: page cache (a few microseconds per small read) or device (NVMe ~ 80, disks more)?
+                if (n_small >= 8 && small_us / (double)n_small > 40.0) cold.store(1, std::memory_order_relaxed);
+            });
+            lap(2);
+            // -- every column appends its winners of this block (row order) to its .bed and .bim
+            const uint64_t row_hi = urow[b0 + nb - 1];
+            parallel_items(T, n_cols, [&](size_t j) {
+                const std::vector<Ent>& l = lst[j];
+                size_t c = cur[j];
+                if (c >= l.size() || l[c].row > row_hi) return;
+                size_t c1 = c;
+                while (c1 < l.size() && l[c1].row <= row_hi) c1++;
+                const size_t k = t->kmer_len, line_max = 2 + k + 1 + 10 + 9;
+                std::vector<char> bedbuf((c1 - c) * bed_bytes), bimbuf((c1 - c) * line_max);
+                char* bp = bedbuf.data();
+                char* mp = bimbuf.data();
+                const uint64_t* ub = urow.data() + b0;
+                const uint64_t* ue = ub + nb;
+                const uint64_t* at = ub;
+                for (; c < c1; c++) {
+                    const Ent& e = l[c];
+                    at = std::lower_bound(at, ue, e.row);
+                    memcpy(bp, pa.data() + (size_t)(at - ub) * exp_bytes, bed_bytes);
+                    bp += bed_bytes;
+                    // "0\t<kmer>_<rank>\t0\t0\t0\t1\n" (src/kmers_multiple_databases.cpp:219, 245-247; bits2kmer31,
+                    // src/kmer_general.cpp:77-87)
+                    *mp++ = '0';
+                    *mp++ = '\t';
+                    uint64_t w = e.kmer;
+                    for (size_t i = 0; i < k; i++, w >>= 2) mp[k - 1 - i] = "ACGT"[w & 3u];
+                    mp += k;
+                    *mp++ = '_';
+                    char dig[12];
+                    int nd = 0;
+                    for (uint32_t v = e.rank; v || !nd; v /= 10) dig[nd++] = (char)('0' + v % 10);
+                    while (nd) *mp++ = dig[--nd];
+                    memcpy(mp, "\t0\t0\t0\t1\n", 9);
+                    mp += 9;
+                }
+                cur[j] = c;
+                bed[j].append(bedbuf.data(), (size_t)(bp - bedbuf.data()));
+                bim[j].append(bimbuf.data(), (size_t)(mp - bimbuf.data()));
+            });
+            lap(3);
+        }
+        // write_fam_file (src/kmer_general.cpp:207-225)
+        parallel_items(T, n_cols, [&](size_t j) {
+            std::ostringstream fam;
+            const float* y = Y + j * n_acc;
+            for (uint64_t i = 0; i < n_acc; i++) fam << acc_names[i] << " " << acc_names[i] << " 0 0 0" << " " << y[i] << "\n";
+            FdFile f;
+            f.create(std::string(out_bases[j]) + ".fam");
+            const std::string s = fam.str();
+            f.append(s.data(), s.size());
+        });
+        lap(4);
+        if (trace)
+            fprintf(stderr, "[kgwas] write_plink_many: %llu columns, %zu distinct rows, %u threads%s: sort+union %.3f s, read-ahead %.3f, read+expand %.3f, append %.3f, fam %.3f\n",
+                    (unsigned long long)n_cols, urow.size(), T, cold.load() ? " (cold file)" : "", ph[0], ph[1], ph[2], ph[3], ph[4]);
+    });
+}
+
 // Pass 2 of associate_kmers for one phenotype column.
 int kgwas_write_plink(const char* out_base, kgwas_table* t, const uint64_t* col, uint64_t n_acc,
                       const char* const* acc_names, const float* y, uint64_t n, const uint64_t* kmer_pop,
                       const uint64_t* row_pop) {
-    return guarded([&] {
-        if (!out_base || !t || !col || !acc_names || !y) throw Error(KGWAS_ERR_ARG, "kgwas_write_plink: null argument");
-        // get_kmers_for_output (src/best_associations_heap.cpp:110-127): rank = queue size at pop, sort by row
-        struct Ent {
-            uint64_t kmer, rank, row;
-        };
-        std::vector<Ent> lst(n);
-        for (uint64_t i = 0; i < n; i++) lst[i] = Ent{kmer_pop[i], n - i, row_pop[i]};
-        std::sort(lst.begin(), lst.end(), [](const Ent& a, const Ent& b) { return a.row < b.row; });
-        const std::string base(out_base);
-        std::ofstream bed(base + ".bed", std::ios::binary), bim(base + ".bim", std::ios::out);
-        if (!bed || !bim) throw Error(KGWAS_ERR_IO, "cannot create " + base + ".bed/.bim");
-        bed << (char)0x6C << (char)0x1B << (char)0x01;  // BedBimFilesHandle, src/kmer_general.h:138
-        const uint64_t row_bytes = 8 * (1 + t->W_f);
-        std::vector<uint64_t> row(1 + t->W_f);
-        std::string bytes;
-        for (const Ent& e : lst) {
-            if (e.row >= t->n_rows) throw Error(KGWAS_ERR_ARG, "kgwas_write_plink: row index out of range");
-            if (pread(t->fd, row.data(), row_bytes, (off_t)(16 + e.row * row_bytes)) != (ssize_t)row_bytes)
-                throw Error(KGWAS_ERR_IO, "read error on " + t->base + ".table");
-            // write_PA (src/kmers_multiple_databases.cpp:218-239)
-            bim << "0\t" << bits_to_kmer(e.kmer, t->kmer_len) << "_" << std::to_string(e.rank) << "\t0\t0\t0\t1\n";
-            bytes.clear();
-            for (uint64_t a0 = 0; a0 < n_acc; a0 += 4) {
-                unsigned char b = 0;
-                for (uint64_t k = 0; k < 4 && a0 + k < n_acc; k++) {
-                    const uint64_t c = col[a0 + k];
-                    if ((row[1 + c / 64] >> (c % 64)) & 1ull) b |= (unsigned char)(3u << (2 * k));
-                }
-                bytes.push_back((char)b);
-            }
-            bed.write(bytes.data(), (std::streamsize)bytes.size());
-        }
-        // write_fam_file (src/kmer_general.cpp:207-225)
-        std::ofstream fam(base + ".fam", std::ios::out);
-        if (!fam) throw Error(KGWAS_ERR_IO, "cannot create " + base + ".fam");
-        for (uint64_t i = 0; i < n_acc; i++)
-            fam << acc_names[i] << " " << acc_names[i] << " 0 0 0" << " " << y[i] << std::endl;
-    });
+    if (!out_base || !y) {
+        set_error("kgwas_write_plink: null argument");
+        return KGWAS_ERR_ARG;
+    }
+    return kgwas_write_plink_many(1, &out_base, t, col, n_acc, acc_names, y, &n, &kmer_pop, &row_pop, 0);
 }
 
 // emma_kinship_kmers' output (src/emma_kinship_kmers.cpp:95-111)

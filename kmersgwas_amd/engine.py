@@ -508,6 +508,22 @@ def write_plink(out_base: str, table: KmersTable, col, acc_names, y, kmer_pop, r
                                 ptr(kmer_pop), ptr(row_pop)))
 
 
+def write_plink_many(out_bases, table: KmersTable, col, acc_names, Y, kmer_pops, row_pops, threads: int = 0):
+    """Pass 2 for all phenotype columns at once: column j's .bed/.bim/.fam from (kmer_pops[j], row_pops[j]) in pop order."""
+    col = np.ascontiguousarray(col, np.uint64)
+    Y = np.ascontiguousarray(Y, np.float32)
+    n = len(out_bases)
+    assert Y.shape == (n, len(col)) and len(kmer_pops) == n and len(row_pops) == n
+    ks = [np.ascontiguousarray(k, np.uint64) for k in kmer_pops]
+    rs = [np.ascontiguousarray(r, np.uint64) for r in row_pops]
+    n_win = np.asarray([len(k) for k in ks], np.uint64)
+    bases = (C.c_char_p * n)(*[b.encode() for b in out_bases])
+    names = (C.c_char_p * len(acc_names))(*[a.encode() for a in acc_names])
+    kp = (C.c_void_p * n)(*[a.ctypes.data for a in ks])
+    rp = (C.c_void_p * n)(*[a.ctypes.data for a in rs])
+    check(lib.kgwas_write_plink_many(n, bases, table._h, ptr(col), len(col), names, ptr(Y), ptr(n_win), kp, rp, threads))
+
+
 def synth_rows_host(first_row: int, n_rows: int, n_acc: int, seed: int) -> np.ndarray:
     out = np.empty((n_rows, 1 + (n_acc + 63) // 64), np.uint64)
     check(lib.kgwas_synth_rows_host(ptr(out), first_row, n_rows, n_acc, seed))

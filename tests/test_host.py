@@ -215,6 +215,41 @@ def test_plink_writer_matches_oracle_bytes(tmp_path):
     assert bim[0].startswith("0\t") and re.match(r"^0\t[ACGT]{31}_\d+\t0\t0\t0\t1$", bim[0])
 
 
+@pytest.mark.parametrize("S_f,S,reorder,threads", [(150, 131, True, 3), (150, 150, False, 0), (150, 131, False, 2), (64, 64, False, 1),
+                                                   (70, 5, True, 4), (1135, 1135, False, 0)])
+def test_plink_writer_for_all_columns_matches_oracle_bytes(tmp_path, S_f, S, reorder, threads):
+    """kgwas_write_plink_many (the batched, multi-threaded pass 2 of the command-line tool) against the oracle's per-column
+    writer: shuffled subsets and leading columns (the word-wise expansion; fewer phenotyped accessions than the table has,
+    so set bits beyond them must not leak into the last byte), accession counts that are not multiples of 4, columns that
+    share winners, winners next to each other and far apart (coalesced and separate reads), an empty column, more union
+    rows than one block's pieces."""
+    n_rows = 3000
+    rows = random_table(n_rows, S_f, seed=S_f + S)
+    names = ["s%d" % i for i in range(S_f)]
+    base = str(tmp_path / "tab")
+    onp.write_table(base, names, 31, rows[:, 0], rows[:, 1:])
+    rng = np.random.default_rng(S)
+    col = rng.permutation(S_f)[:S].astype(np.uint64) if reorder else np.arange(S, dtype=np.uint64)
+    acc = [names[c] for c in col]
+    P = 7
+    Y = rng.standard_normal((P, S)).astype(np.float32)
+    Y[0, :3] = [71.6666666667, 1e-05, -0.0]
+    picks = [rng.choice(n_rows, size=n, replace=False) for n in (900, 1, 0, 2000, 300, 900, 57)]
+    picks[5] = picks[0][::-1].copy()                    # the same winners in another pop order (other ranks)
+    picks[4] = np.arange(1000, 1300)[rng.permutation(300)]  # a run of neighbouring rows
+    t = kg.KmersTable(base, 31)
+    outs = [str(tmp_path / ("prod%d" % j)) for j in range(P)]
+    kg.write_plink_many(outs, t, col, acc, Y, [rows[p, 0] for p in picks], [p.astype(np.uint64) for p in picks], threads=threads)
+    for j in range(P):
+        orc = str(tmp_path / ("orc%d" % j))
+        ob.write_plink(orc, rows, S_f, col, acc, Y[j], 31, rows[picks[j], 0], picks[j].astype(np.uint64))
+        for ext in (".bed", ".bim", ".fam"):
+            assert open(outs[j] + ext, "rb").read() == open(orc + ext, "rb").read(), (j, ext)
+    with pytest.raises(kg.KgwasError):
+        kg.write_plink_many(outs[:1], t, col, acc, Y[:1], [rows[:1, 0]], [np.asarray([n_rows], np.uint64)])  # row beyond the table
+    t.close()
+
+
 def test_kinship_text_and_from_partials():
     S = 50
     rows = random_table(300, S, seed=5)
