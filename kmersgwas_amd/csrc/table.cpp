@@ -309,7 +309,7 @@ int kgwas_write_plink_many(uint64_t n_cols, const char* const* out_bases, kgwas_
             throw Error(KGWAS_ERR_ARG, "kgwas_write_plink_many: null argument");
         const unsigned T = threads ? threads : usable_cpus();
         const bool trace = getenv("KGWAS_TRACE") != nullptr;
-        double ph[5] = {0, 0, 0, 0, 0};  // sort + union, read-ahead, read + expand, append, fam
+        double ph[6] = {0, 0, 0, 0, 0, 0};  // sort + union, read-ahead, read + expand, append, fam, output files created
         auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         double tp = tnow();
         auto lap = [&](int i) {
@@ -365,14 +365,17 @@ int kgwas_write_plink_many(uint64_t n_cols, const char* const* out_bases, kgwas_
 
         lap(0);
         std::vector<FdFile> bed(n_cols), bim(n_cols);
-        for (uint64_t j = 0; j < n_cols; j++) {
+        for (uint64_t j = 0; j < n_cols; j++)
             if (!out_bases[j]) throw Error(KGWAS_ERR_ARG, "kgwas_write_plink_many: null output name");
+        // (in parallel: creating a file costs more than a millisecond on some container file systems)
+        parallel_items(T, n_cols, [&](size_t j) {
             bed[j].create(std::string(out_bases[j]) + ".bed");
             bim[j].create(std::string(out_bases[j]) + ".bim");
             const char magic[3] = {(char)0x6C, (char)0x1B, (char)0x01};  // BedBimFilesHandle, src/kmer_general.h:138
             bed[j].append(magic, 3);
-        }
+        });
 
+        lap(5);
         // write_PA's byte (src/kmers_multiple_databases.cpp:225-236): accession a of a group of four -> bits 2a, 2a + 1
         uint16_t spread[256];
         for (unsigned b = 0; b < 256; b++) {
@@ -388,6 +391,14 @@ int kgwas_write_plink_many(uint64_t n_cols, const char* const* out_bases, kgwas_
             g_shift[i] = (uint8_t)(col[i] % 64);
         }
 
+        // Winners at most `coalesce` bytes apart are read together. What pays depends on where the file is: from the page
+        // cache a read costs a system call (1-3 us, more in sandboxed containers) plus a copy at ~10 GB/s, so skipping over
+        // 32 KB of other rows is cheaper than a second call; from a device every 4 KB page read for nothing is bandwidth
+        // lost. The first pieces run at 8 KB and time their small reads; the rest of the call uses 32 KB (page cache) or
+        // 4 KB + read-ahead hints (cold file). KGWAS_PLINK_COALESCE=bytes: fixed.
+        const bool coalesce_fixed = getenv("KGWAS_PLINK_COALESCE") != nullptr;
+        std::atomic<uint64_t> coalesce(coalesce_fixed ? strtoull(getenv("KGWAS_PLINK_COALESCE"), nullptr, 10) : 8192);
+        std::atomic<uint64_t> probe_ns(0), probe_n(0);
         const size_t BLOCK = 1u << 16;  // distinct rows per block
         const uint64_t exp_bytes = (bed_bytes + 15) / 16 * 16 + 16;  // room for the word-wise expansion's overshoot
         std::vector<unsigned char> pa(std::min<size_t>(BLOCK, urow.size()) * exp_bytes);
@@ -400,9 +411,10 @@ int kgwas_write_plink_many(uint64_t n_cols, const char* const* out_bases, kgwas_
             if (cold.load(std::memory_order_relaxed))
                 parallel_items(T, n_pieces, [&](size_t pc) {
                     const size_t lo = b0 + pc * PIECE, hi = std::min(b0 + nb, lo + PIECE);
+                    const uint64_t COALESCE = coalesce.load(std::memory_order_relaxed);
                     for (size_t u = lo; u < hi;) {
                         size_t v = u + 1;
-                        while (v < hi && (urow[v] - urow[v - 1]) * row_bytes <= 8192) v++;
+                        while (v < hi && (urow[v] - urow[v - 1]) * row_bytes <= COALESCE) v++;
                         (void)posix_fadvise(t->fd, (off_t)(16 + urow[u] * row_bytes), (off_t)((urow[v - 1] - urow[u] + 1) * row_bytes), POSIX_FADV_WILLNEED);
                         u = v;
                     }
@@ -411,17 +423,18 @@ int kgwas_write_plink_many(uint64_t n_cols, const char* const* out_bases, kgwas_
             parallel_items(T, n_pieces, [&](size_t pc) {
                 const size_t lo = b0 + pc * PIECE, hi = std::min(b0 + nb, lo + PIECE);
                 std::vector<uint64_t> buf;
+                const uint64_t COALESCE = coalesce.load(std::memory_order_relaxed);
                 double small_us = 0;  // time in reads of at most 16 KB: what tells a cold file from the page cache
                 size_t n_small = 0;
                 for (size_t u = lo; u < hi;) {
                     // neighbouring winners (at most 8 KB of other rows between two of them) in one read
                     size_t v = u + 1;
-                    while (v < hi && (urow[v] - urow[v - 1]) * row_bytes <= 8192 && (urow[v] - urow[u] + 1) * row_bytes <= (1u << 20)) v++;
+                    while (v < hi && (urow[v] - urow[v - 1]) * row_bytes <= COALESCE && (urow[v] - urow[u] + 1) * row_bytes <= (1u << 20)) v++;
                     const uint64_t span_rows = urow[v - 1] - urow[u] + 1;
                     buf.resize(span_rows * (1 + W));
                     const size_t want = span_rows * row_bytes;
                     size_t got = 0;
-                    const bool timed = pc < 8 && want <= 16384;
+                    const bool timed = b0 == 0 && pc < 8 && want <= 16384;
                     const auto tr0 = timed ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
                     while (got < want) {
                         const ssize_t r = pread(t->fd, (char*)buf.data() + got, want - got, (off_t)(16 + urow[u] * row_bytes + got));
@@ -455,10 +468,23 @@ int kgwas_write_plink_many(uint64_t n_cols, const char* const* out_bases, kgwas_
                     }
                     u = v;
                 }
-                // the first pieces decide: page cache (a few microseconds per small read) or device (NVMe ~ 80, disks more)?
-                if (n_small >= 8 && small_us / (double)n_small > 40.0) cold.store(1, std::memory_order_relaxed);
+                if (n_small) {
+                    probe_ns.fetch_add((uint64_t)(small_us * 1e3), std::memory_order_relaxed);
+                    probe_n.fetch_add(n_small, std::memory_order_relaxed);
+                }
             });
             lap(2);
+            if (b0 == 0 && !coalesce_fixed) {
+                // the first block's probe decides: page cache (a few microseconds per small read) or device (NVMe ~ 80, disks more)?
+                const uint64_t n = probe_n.load();
+                const double us = n ? (double)probe_ns.load() * 1e-3 / (double)n : 0.0;
+                if (n >= 8 && us > 40.0) {
+                    cold.store(1);
+                    coalesce.store(4096);
+                } else {
+                    coalesce.store(32768);
+                }
+            }
             // -- every column appends its winners of this block (row order) to its .bed and .bim
             const uint64_t row_hi = urow[b0 + nb - 1];
             parallel_items(T, n_cols, [&](size_t j) {
@@ -512,8 +538,8 @@ int kgwas_write_plink_many(uint64_t n_cols, const char* const* out_bases, kgwas_
         });
         lap(4);
         if (trace)
-            fprintf(stderr, "[kgwas] write_plink_many: %llu columns, %zu distinct rows, %u threads%s: sort+union %.3f s, read-ahead %.3f, read+expand %.3f, append %.3f, fam %.3f\n",
-                    (unsigned long long)n_cols, urow.size(), T, cold.load() ? " (cold file)" : "", ph[0], ph[1], ph[2], ph[3], ph[4]);
+            fprintf(stderr, "[kgwas] write_plink_many: %llu columns, %zu distinct rows, %u threads%s: sort+union %.3f s, files created %.3f, read-ahead %.3f, read+expand %.3f, append %.3f, fam %.3f\n",
+                    (unsigned long long)n_cols, urow.size(), T, cold.load() ? " (cold file)" : "", ph[0], ph[5], ph[1], ph[2], ph[3], ph[4]);
     });
 }
 
