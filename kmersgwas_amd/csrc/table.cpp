@@ -86,24 +86,36 @@ void parallel_items(unsigned threads, size_t n, const F& fn) {
     if (err) std::rethrow_exception(err);
 }
 
-struct FdFile {  // unbuffered output file, written in large pieces
-    int fd = -1;
+struct FdFile {  // output file written in large pieces; open only while a piece is written
+    // (A process that holds hundreds of descriptors at once grows its descriptor table, and in a multi-threaded process the
+    // kernel waits for an RCU grace period every time it does - 100 ms and more on a 256-CPU host, found as 0.3 s of
+    // "file creation" in the command-line tool's output stage. With a file open only for the duration of a write no more
+    // than two descriptors per thread exist at a time.)
     std::string path;
-    void create(const std::string& p) {
-        path = p;
-        fd = ::open(p.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
-        if (fd < 0) throw Error(KGWAS_ERR_IO, "cannot create " + p);
-    }
+    std::string head;  // written together with the first piece
+    bool created = false;
+    void create(const std::string& p) { path = p; }
     void append(const char* d, size_t n) {
+        std::string h;
+        if (!head.empty()) {
+            h.swap(head);
+            if (n) h.append(d, n);
+            d = h.data();
+            n = h.size();
+        }
+        const int fd = ::open(path.c_str(), created ? (O_WRONLY | O_APPEND) : (O_WRONLY | O_CREAT | O_TRUNC), 0666);
+        if (fd < 0) throw Error(KGWAS_ERR_IO, "cannot create " + path);
+        created = true;
         while (n) {
             const ssize_t w = ::write(fd, d, n);
-            if (w <= 0) throw Error(KGWAS_ERR_IO, "write error on " + path);
+            if (w <= 0) {
+                ::close(fd);
+                throw Error(KGWAS_ERR_IO, "write error on " + path);
+            }
             d += w;
             n -= (size_t)w;
         }
-    }
-    ~FdFile() {
-        if (fd >= 0) ::close(fd);
+        ::close(fd);
     }
 };
 
@@ -367,13 +379,12 @@ int kgwas_write_plink_many(uint64_t n_cols, const char* const* out_bases, kgwas_
         std::vector<FdFile> bed(n_cols), bim(n_cols);
         for (uint64_t j = 0; j < n_cols; j++)
             if (!out_bases[j]) throw Error(KGWAS_ERR_ARG, "kgwas_write_plink_many: null output name");
-        // (in parallel: creating a file costs more than a millisecond on some container file systems)
-        parallel_items(T, n_cols, [&](size_t j) {
+        for (uint64_t j = 0; j < n_cols; j++) {
             bed[j].create(std::string(out_bases[j]) + ".bed");
             bim[j].create(std::string(out_bases[j]) + ".bim");
             const char magic[3] = {(char)0x6C, (char)0x1B, (char)0x01};  // BedBimFilesHandle, src/kmer_general.h:138
-            bed[j].append(magic, 3);
-        });
+            bed[j].head.assign(magic, 3);
+        }
 
         lap(5);
         // write_PA's byte (src/kmers_multiple_databases.cpp:225-236): accession a of a group of four -> bits 2a, 2a + 1
@@ -525,6 +536,10 @@ int kgwas_write_plink_many(uint64_t n_cols, const char* const* out_bases, kgwas_
                 bim[j].append(bimbuf.data(), (size_t)(mp - bimbuf.data()));
             });
             lap(3);
+        }
+        for (uint64_t j = 0; j < n_cols; j++) {  // a column without winners: the magic alone, an empty .bim
+            if (!bed[j].created) bed[j].append(nullptr, 0);
+            if (!bim[j].created) bim[j].append(nullptr, 0);
         }
         // write_fam_file (src/kmer_general.cpp:207-225)
         parallel_items(T, n_cols, [&](size_t j) {
