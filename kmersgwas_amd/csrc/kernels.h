@@ -146,7 +146,15 @@ hipError_t launch_mx(const MxArgs& a, uint32_t CT, uint32_t rows_per_block, hipS
 hipError_t launch_rescore(const ScoreArgs& a, const uint32_t* keys, const uint32_t* surv_off, const uint32_t* surv_cnt,
                           uint32_t row_bits, uint32_t* tile_pref, uint32_t* tile_cnt, uint32_t* tile_off, double* tmp_score,
                           const uint32_t* key_count, uint32_t* meta, hipStream_t st);
-hipError_t launch_chunk_prep(uint32_t* cand_cnt, uint32_t n_pheno, unsigned long long* tested, uint32_t* key_count, hipStream_t st);
+// Scans of a few columns: every survivor's record goes straight to its place in the key order (a.so_score = exact score or
+// -inf for a survivor that is no candidate - the host's replay skips those), no tile scan, no compaction; meta was written
+// by launch_narrow_keys (records per column = survivors per column).
+hipError_t launch_rescore_direct(const ScoreArgs& a, const uint32_t* keys, const uint32_t* surv_off, const uint32_t* surv_cnt,
+                                 uint32_t row_bits, const uint32_t* tile_pref, hipStream_t st);
+// Counters of the next chunk and its survivors' bitmap (bitmap_words 64-bit words, may be 0) zeroed in one launch;
+// seg_cnt (n_seg_words, may be 0): the narrow filter's per-segment survivor counts.
+hipError_t launch_chunk_prep(uint32_t* cand_cnt, uint32_t n_pheno, unsigned long long* tested, uint32_t* key_count,
+                             unsigned long long* bitmap, uint64_t bitmap_words, uint32_t* seg_cnt, uint32_t n_seg_words, hipStream_t st);
 
 // Narrow filter (score_narrow.hip): scans with one to four phenotype columns. FP4 table bits x three FP8 slices per
 // column on v_mfma_scale_f32_16x16x128_f8f6f4; operand row 4 p + k = slice k of phenotype column p, row 4 p + 3 = ones
@@ -174,6 +182,9 @@ struct NarrowArgs {
     uint64_t words_per_col;
     unsigned long long* tested;
     uint32_t row_off;          // chunk row of this launch's first row (a launch that starts inside a chunk), a multiple of 64
+    uint32_t* seg_cnt;         // [n_pheno][n_segs] survivors per 65 536-row segment of the chunk (atomic adds; zeroed by the caller), or null
+    uint32_t n_segs;
+    uint64_t slack_rows;       // rows of the same buffer that follow the launch's rows (readable: the staged kernel may read whole KB past its last row)
 };
 // The bitmap's set bits as row-ordered keys (column << row_bits | row), column after column, with each column's range
 // (surv_off, surv_cnt) and the total (key_count; above key_cap = overflow, the ranges are then emptied). No sort: counts
@@ -182,6 +193,12 @@ struct NarrowArgs {
 hipError_t launch_bitmap_keys(const unsigned long long* bitmap, uint64_t words_per_col, uint64_t n_rows, uint32_t n_pheno, uint32_t* blk_scratch,
                               uint32_t* keys_sorted, uint32_t key_cap, uint32_t row_bits, uint32_t* surv_off, uint32_t* surv_cnt,
                               uint32_t* key_count, uint32_t* tile_pref, bool nibble_transposed, hipStream_t st);
+// The same for the narrow filter (one to four columns), whose kernels have already counted the survivors per segment
+// (NarrowArgs::seg_cnt): ONE launch instead of four - every (segment, column) block adds up the counts before it and
+// writes its keys; block (0, 0) writes the ranges, the tile table and meta (records = survivors: see launch_rescore_direct).
+hipError_t launch_narrow_keys(const unsigned long long* bitmap, uint64_t words_per_col, uint64_t n_rows, uint32_t n_pheno, const uint32_t* seg_cnt,
+                              uint32_t* keys_sorted, uint32_t key_cap, uint32_t row_bits, uint32_t* surv_off, uint32_t* surv_cnt,
+                              uint32_t* key_count, uint32_t* tile_pref, uint32_t* meta, hipStream_t st);
 size_t narrow_lds_bytes(uint32_t n_kgroups);
 hipError_t launch_narrow(const NarrowArgs& a, uint32_t rows_per_block, hipStream_t st);
 

@@ -265,10 +265,20 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
         a.thr = s->d_thr_redo.p;
     }
     const bool use_coarse = s->coarse && count_hist;
-    KGWAS_HIP(launch_chunk_prep(sl.d_cnt.p, (uint32_t)s->n_pheno, sl.d_tested.p, use_coarse ? s->d_key_count.p : nullptr, s->stream));
     KGWAS_HIP(hipEventRecord(sl.ev_sq0, s->stream));
     maybe_squeeze(s, d_rows, n_rows);
     KGWAS_HIP(hipEventRecord(sl.ev_k0, s->stream));
+    {
+        // One launch for the chunk's counters, its survivors' bitmap ([column][64-row word], which a popcount scan turns
+        // into row-ordered keys per column: no key list, no sort) and the narrow filter's per-segment counts - inside the
+        // interval the statistics count as kernel time.
+        const uint64_t n_words = (n_rows + 63) / 64;
+        const uint32_t n_segs = (uint32_t)((n_words + 1023) / 1024);
+        KGWAS_HIP(launch_chunk_prep(sl.d_cnt.p, (uint32_t)s->n_pheno, sl.d_tested.p, use_coarse ? s->d_key_count.p : nullptr,
+                                    use_coarse ? s->d_bitmap.p : nullptr, use_coarse ? s->n_pheno * n_words : 0,
+                                    (use_coarse && s->narrow) ? s->d_bm_blocks.p : nullptr, (use_coarse && s->narrow) ? (uint32_t)s->n_pheno * n_segs : 0u,
+                                    s->stream));
+    }
     sl.used_coarse = use_coarse;
     if (use_coarse) {
         CoarseArgs c;
@@ -290,10 +300,7 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
         c.thr = a.thr;
         c.tested = a.tested;
         static const uint32_t rpb_env = getenv("KGWAS_COARSE_RPB") ? (uint32_t)atoi(getenv("KGWAS_COARSE_RPB")) : 0u;  // experiments
-        // Survivors leave the filter as a bitmap [column][64-row word] of this chunk (zeroed here), which a popcount
-        // scan turns into row-ordered keys per column: no key list, no sort (launch_bitmap_keys).
         const uint64_t n_words = (n_rows + 63) / 64;
-        KGWAS_HIP(hipMemsetAsync(s->d_bitmap.p, 0, (size_t)s->n_pheno * n_words * 8, s->stream));
         if (s->narrow) {
             NarrowArgs na;
             memset(&na, 0, sizeof(na));
@@ -309,6 +316,11 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
             na.bitmap = s->d_bitmap.p;
             na.words_per_col = n_words;
             na.tested = a.tested;
+            na.seg_cnt = s->d_bm_blocks.p;
+            na.n_segs = (uint32_t)((n_words + 1023) / 1024);
+            // (rows of the same device buffer behind this chunk, when the rows are read in place: only a feed's last chunk needs
+            // the narrow filter's second, tiny launch)
+            na.slack_rows = s->direct ? s->slack_rows : 0;
             // (short blocks: three 4-wave blocks share a CU and a launch's block count is rarely a multiple of the
             // 768 block slots, so long blocks leave CUs idle at the end of every launch: 4096 rows per block measured
             // 3.4 ms per 100 M rows, 768 rows 3.0)
@@ -354,6 +366,16 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
         }
         KGWAS_HIP(hipEventRecord(sl.ev_mid, s->stream));
         a.tested = nullptr;  // counted by the filter
+        a.so_score = sl.d_so_score.p;
+        a.so_kmer = sl.d_so_kmer.p;
+        a.so_row = sl.d_so_row.p;
+        if (s->narrow) {
+            // one to four columns: keys in one launch (the filter has counted its survivors per segment), every survivor's
+            // record written in place by the re-score kernel - a chunk is five launches, not thirteen
+            KGWAS_HIP(launch_narrow_keys(s->d_bitmap.p, n_words, n_rows, (uint32_t)s->n_pheno, s->d_bm_blocks.p, s->d_surv_sorted.p, s->key_slots,
+                                         s->row_key_bits, s->d_surv_off.p, s->d_surv_cnt.p, s->d_key_count.p, s->d_tile_pref.p, sl.d_meta.p, s->stream));
+            KGWAS_HIP(launch_rescore_direct(a, s->d_surv_sorted.p, s->d_surv_off.p, s->d_surv_cnt.p, s->row_key_bits, s->d_tile_pref.p, s->stream));
+        } else {
         KGWAS_HIP(launch_bitmap_keys(s->d_bitmap.p, n_words, n_rows, (uint32_t)s->n_pheno, s->d_bm_blocks.p, s->d_surv_sorted.p, s->key_slots,
                                      s->row_key_bits, s->d_surv_off.p, s->d_surv_cnt.p, s->d_key_count.p, s->d_tile_pref.p, /*nibble_transposed=*/!s->narrow, s->stream));
         a.so_score = sl.d_so_score.p;
@@ -361,6 +383,7 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
         a.so_row = sl.d_so_row.p;
         KGWAS_HIP(launch_rescore(a, s->d_surv_sorted.p, s->d_surv_off.p, s->d_surv_cnt.p, s->row_key_bits, s->d_tile_pref.p,
                                  s->d_tile_cnt.p, s->d_tile_off.p, s->d_tmp_score.p, s->d_key_count.p, sl.d_meta.p, s->stream));
+        }
         s->st.score_launches++;
     } else {
         launch_score(s, a);

@@ -329,7 +329,8 @@ struct kgwas_scan {
     DevBuf<NarrowCol> d_ncols;
     DevBuf<unsigned long long> d_bitmap;  // survivors of the chunk being filtered: [n_pheno][bitmap_words]
     uint64_t bitmap_words = 0;
-    DevBuf<uint32_t> d_bm_blocks;
+    DevBuf<uint32_t> d_bm_blocks;                  // block counts of launch_bitmap_keys / the narrow filter's per-segment counts
+    uint64_t slack_rows = 0;                       // rows of the feed's device buffer behind the chunk being submitted
     // survivors of the chunk being filtered: bitmap [column][64-row word], then row-ordered keys per column with each
     // column's range; shared by all chunks (consumed by the re-score kernel in stream order)
     DevBuf<uint32_t> d_surv_sorted, d_surv_cnt, d_surv_off, d_key_count;  // row-ordered keys per column, the columns' ranges, the total

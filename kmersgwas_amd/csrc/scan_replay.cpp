@@ -504,7 +504,9 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
                             const uint64_t cs = std::min<uint64_t>(next_sparse_chunk(s), n_rows - pos);
                             const size_t si = (size_t)(sub % (uint64_t)s->n_slots);
                             s->slot_left[si].store((uint32_t)s->n_pheno, std::memory_order_release);  // (columns: groups may be split)
+                            s->slack_rows = n_rows - pos - cs;
                             submit_sparse(s, s->slot[si], d_rows + pos * stride, cs, first_row + pos, /*count_hist=*/true);
+                            s->slack_rows = 0;
                             s->rows_submitted += cs;
                             sub++;
                             s->seq_submitted.store(sub, std::memory_order_release);
@@ -549,7 +551,9 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
                 const uint64_t c = std::min<uint64_t>(next_sparse_chunk(s), n_rows - pos);
                 const size_t si = (size_t)(sub % (uint64_t)s->n_slots);  // its previous chunk was replayed n_slots chunks ago
                 s->slot_left[si].store((uint32_t)s->n_pheno, std::memory_order_release);  // (columns: groups may be split)
+                s->slack_rows = n_rows - pos - c;
                 submit_sparse(s, s->slot[si], d_rows + pos * stride, c, first_row + pos, /*count_hist=*/true);
+                s->slack_rows = 0;
                 if (s->trace) fprintf(stderr, "[kgwas t=%.3f] submit chunk %llu (%llu rows)\n", s->t_ms(), (unsigned long long)sub, (unsigned long long)c);
                 s->rows_submitted += c;
                 sub++;

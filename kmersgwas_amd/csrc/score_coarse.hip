@@ -481,7 +481,9 @@ __device__ __forceinline__ void rescore_finish(const ScoreArgs& a, uint32_t p, b
 
 // Rows are read in place by their own lane, 8 bytes x 2 per 128-sample block. (Staging a wave's 64 rows through LDS with
 // coalesced copies - every line fetched once - measured 30-50 % SLOWER: the gathers are not what this kernel waits for.)
-template <bool YLDS>
+// DIRECT (scans of a few columns, launch_rescore_direct): the survivor's record is written at its place in the key order -
+// score or -inf, k-mer, row - and nothing is counted or compacted afterwards.
+template <bool YLDS, bool DIRECT = false>
 __global__ void __launch_bounds__(256) rescore_kernel(ScoreArgs a, const uint32_t* keys, const uint32_t* surv_off,
                                                       const uint32_t* surv_cnt, const uint32_t* tile_pref, uint32_t row_mask,
                                                       double* tmp_score, uint32_t* tile_cnt) {
@@ -529,7 +531,20 @@ __global__ void __launch_bounds__(256) rescore_kernel(ScoreArgs a, const uint32_
             else
                 rescore_block<false>(w, a.Yperm + (size_t)p * L + 128u * b, acc);
         }
-        rescore_finish(a, p, valid, gi, acc, n1, tmp_score, tile_cnt, t, wcnt);
+        if (DIRECT) {
+            const float yf = ((acc[0] + acc[1]) + acc[2]) + acc[3];
+            double q, d, sc, out = -__builtin_huge_val();
+            score_terms(a, yf, n1, a.sums[p], q, d);
+            if (valid && mac_pass(a, n1) && candidate_score(a, p, q, d, a.thr[p], sc)) out = sc;
+            if (valid) {
+                a.so_score[gi] = out;
+                a.so_kmer[gi] = a.file_rows[r * a.file_stride_w];
+                a.so_row[gi] = (uint32_t)r;
+            }
+            if (YLDS) __syncthreads();  // the next tile's column overwrites ytile
+        } else {
+            rescore_finish(a, p, valid, gi, acc, n1, tmp_score, tile_cnt, t, wcnt);
+        }
     }
 }
 
@@ -599,17 +614,31 @@ __global__ void __launch_bounds__(256) compact_kernel(ScoreArgs a, const uint32_
     }
 }
 
-// One launch instead of a handful of small memsets per chunk: counters of the next chunk.
-__global__ void chunk_prep_kernel(uint32_t* cand_cnt, uint32_t n_pheno, unsigned long long* tested, uint32_t* key_count) {
+// One launch instead of a handful of small memsets per chunk: counters of the next chunk, its survivors' bitmap, the narrow
+// filter's per-segment counts.
+__global__ void __launch_bounds__(256) chunk_prep_kernel(uint32_t* cand_cnt, uint32_t n_pheno, unsigned long long* tested, uint32_t* key_count,
+                                                         unsigned long long* bitmap, uint64_t bitmap_words, uint32_t* seg_cnt, uint32_t n_seg_words) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_pheno) cand_cnt[i] = 0u;
     if (i < TESTED_SHARDS) tested[i] = 0ull;
     if (i == 0 && key_count) *key_count = 0u;
+    if (i < n_seg_words) seg_cnt[i] = 0u;
+    // the bitmap, two words (16 bytes) per thread and turn
+    ulonglong2* b2 = reinterpret_cast<ulonglong2*>(bitmap);
+    const uint64_t pairs = bitmap_words / 2u;
+    for (uint64_t k = i; k < pairs; k += (uint64_t)gridDim.x * blockDim.x) b2[k] = make_ulonglong2(0ull, 0ull);
+    if (i == 0 && (bitmap_words & 1u)) bitmap[bitmap_words - 1u] = 0ull;
 }
 
-hipError_t launch_chunk_prep(uint32_t* cand_cnt, uint32_t n_pheno, unsigned long long* tested, uint32_t* key_count, hipStream_t st) {
-    const uint32_t n = n_pheno > TESTED_SHARDS ? n_pheno : TESTED_SHARDS;
-    hipLaunchKernelGGL(chunk_prep_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, cand_cnt, n_pheno, tested, key_count);
+hipError_t launch_chunk_prep(uint32_t* cand_cnt, uint32_t n_pheno, unsigned long long* tested, uint32_t* key_count,
+                             unsigned long long* bitmap, uint64_t bitmap_words, uint32_t* seg_cnt, uint32_t n_seg_words, hipStream_t st) {
+    uint64_t n = n_pheno > TESTED_SHARDS ? n_pheno : TESTED_SHARDS;
+    if (n_seg_words > n) n = n_seg_words;
+    if (bitmap_words / 8u > n) n = bitmap_words / 8u;  // (four turns per thread on a large bitmap)
+    const uint64_t blocks = std::min<uint64_t>((n + 255u) / 256u, 8192u);
+    if (blocks * 256u < std::max<uint64_t>(std::max<uint64_t>(n_pheno, TESTED_SHARDS), n_seg_words)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(chunk_prep_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, cand_cnt, n_pheno, tested, key_count, bitmap, bitmap_words,
+                       seg_cnt, n_seg_words);
     return hipGetLastError();
 }
 
@@ -706,6 +735,22 @@ hipError_t launch_rescore(const ScoreArgs& a, const uint32_t* keys, const uint32
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, tile_cnt, tile_pref, a.n_pheno, key_count, tile_off, meta);
     hipLaunchKernelGGL(compact_kernel, dim3(2048), dim3(256), 0, st, a, keys, surv_off, surv_cnt, tile_pref, row_mask, tmp_score,
                        tile_off);
+    return hipGetLastError();
+}
+
+hipError_t launch_rescore_direct(const ScoreArgs& a, const uint32_t* keys, const uint32_t* surv_off, const uint32_t* surv_cnt,
+                                 uint32_t row_bits, const uint32_t* tile_pref, hipStream_t st) {
+    if (a.n_pheno == 0) return hipSuccess;
+    const uint32_t row_mask = row_bits >= 32 ? 0xFFFFFFFFu : ((1u << row_bits) - 1u);
+    const size_t ybytes = 64u * (size_t)a.W_m * sizeof(float);
+    // (a few tiles per launch: a small grid - an empty block costs its launch slot, and a scan of a few columns is made of
+    // these launches)
+    if (ybytes <= 16384u)
+        hipLaunchKernelGGL((rescore_kernel<true, true>), dim3(512), dim3(256), ybytes, st, a, keys, surv_off, surv_cnt, tile_pref, row_mask,
+                           (double*)nullptr, (uint32_t*)nullptr);
+    else
+        hipLaunchKernelGGL((rescore_kernel<false, true>), dim3(512), dim3(256), 0, st, a, keys, surv_off, surv_cnt, tile_pref, row_mask,
+                           (double*)nullptr, (uint32_t*)nullptr);
     return hipGetLastError();
 }
 

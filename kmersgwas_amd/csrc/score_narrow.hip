@@ -148,7 +148,11 @@ __device__ __forceinline__ void narrow_test(const NarrowArgs& a, const NarrowCol
                 unsigned long long w = 0;
 #pragma unroll
                 for (int rt = 0; rt < NRT; rt++) w |= ((bal[rt] >> (16u * q)) & 0xFFFFull) << (16 * rt);
-                if (w) a.bitmap[(uint64_t)q * a.words_per_col + word] = w;
+                if (w) {
+                    a.bitmap[(uint64_t)q * a.words_per_col + word] = w;
+                    // survivors per (column, 65 536-row segment): what launch_narrow_keys' blocks add up instead of a count kernel
+                    if (a.seg_cnt) atomicAdd(&a.seg_cnt[q * a.n_segs + (uint32_t)(word >> 10)], (uint32_t)__popcll(w));
+                }
             }
         }
     }
@@ -507,6 +511,109 @@ hipError_t launch_bitmap_keys(const unsigned long long* bitmap, uint64_t words_p
     return hipGetLastError();
 }
 
+// The narrow filter's keys in one launch: block (b, p) = segment b (1024 bitmap words) of column p. The survivors per
+// (column, segment) are already counted (NarrowArgs::seg_cnt), so a block's place in the key list - everything of the
+// columns before it and of its own column's earlier segments - is a sum over at most a few thousand counters that every
+// block forms for itself: no scan kernel, no inter-block dependency. Block (0, 0) also writes the columns' ranges, the
+// re-score tiles' table and meta.
+__global__ void __launch_bounds__(256) narrow_keys_kernel(const unsigned long long* bm, uint64_t words_per_col, uint32_t n_words, uint32_t n_segs,
+                                                          uint32_t n_pheno, const uint32_t* seg_cnt, uint32_t* keys, uint32_t key_cap,
+                                                          uint32_t row_bits, uint32_t* surv_off, uint32_t* surv_cnt, uint32_t* key_count,
+                                                          uint32_t* tile_pref, uint32_t* meta) {
+    __shared__ uint32_t red[4][NARROW_MAX_COLS + 1];
+    __shared__ uint32_t tot[NARROW_MAX_COLS + 1];
+    __shared__ uint32_t part[4];
+    const uint32_t p = blockIdx.y, b = blockIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // col_sum[q] = survivors of column q; mine = those of column p's segments before b
+    uint32_t cs[NARROW_MAX_COLS] = {0u, 0u, 0u, 0u}, mine = 0;
+    for (uint32_t q = 0; q < n_pheno; q++)
+        for (uint32_t k = threadIdx.x; k < n_segs; k += 256u) {
+            const uint32_t v = seg_cnt[q * n_segs + k];
+            cs[q] += v;
+            if (q == p && k < b) mine += v;
+        }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        mine += __shfl_xor(mine, d);
+#pragma unroll
+        for (int q = 0; q < (int)NARROW_MAX_COLS; q++) cs[q] += __shfl_xor(cs[q], d);
+    }
+    if (lane == 0u) {
+#pragma unroll
+        for (int q = 0; q < (int)NARROW_MAX_COLS; q++) red[wave][q] = cs[q];
+        red[wave][NARROW_MAX_COLS] = mine;
+    }
+    __syncthreads();
+    if (threadIdx.x <= NARROW_MAX_COLS) tot[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    __syncthreads();
+    uint32_t total = 0, off_p = 0;
+    for (uint32_t q = 0; q < n_pheno; q++) {
+        if (q < p) off_p += tot[q];
+        total += tot[q];
+    }
+    const bool over = total > key_cap;  // the chunk is redone in halves: nothing for the re-score kernel to walk
+    if (b == 0u && p == 0u && threadIdx.x == 0u) {
+        uint32_t o = 0, t = 0;
+        for (uint32_t q = 0; q < n_pheno; q++) {
+            const uint32_t c = over ? 0u : tot[q];
+            surv_off[q] = o;
+            surv_cnt[q] = c;
+            tile_pref[q] = t;
+            meta[q] = c;             // records of column q: its survivors (a survivor that is no candidate carries -inf)
+            meta[n_pheno + q] = o;
+            o += tot[q];
+            t += (c + 255u) / 256u;
+        }
+        tile_pref[n_pheno] = t;
+        *key_count = total;
+        meta[2u * n_pheno] = over ? 0u : total;
+        meta[2u * n_pheno + 1u] = total;
+    }
+    if (over || seg_cnt[p * n_segs + b] == 0u) return;  // block-uniform
+    const unsigned long long* w = bm + (uint64_t)p * words_per_col;
+    unsigned long long x[4];
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t idx = b * BM_WORDS + threadIdx.x * 4u + i;
+        x[i] = idx < n_words ? w[idx] : 0ull;
+        c += __popcll(x[i]);
+    }
+    uint32_t incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(incl, d);
+        if ((int)lane >= d) incl += t;
+    }
+    if (lane == 63u) part[wave] = incl;
+    __syncthreads();
+    uint32_t o = off_p + tot[NARROW_MAX_COLS] + incl - c;
+    for (uint32_t k = 0; k < wave; k++) o += part[k];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        unsigned long long v = x[i];
+        const uint32_t row0 = (b * BM_WORDS + threadIdx.x * 4u + i) * 64u;
+        while (v) {
+            const uint32_t bit = __ffsll((long long)v) - 1u;
+            v &= v - 1ull;
+            if (o < key_cap) keys[o] = (p << row_bits) | (row0 + bit);
+            o++;
+        }
+    }
+}
+
+hipError_t launch_narrow_keys(const unsigned long long* bitmap, uint64_t words_per_col, uint64_t n_rows, uint32_t n_pheno, const uint32_t* seg_cnt,
+                              uint32_t* keys_sorted, uint32_t key_cap, uint32_t row_bits, uint32_t* surv_off, uint32_t* surv_cnt,
+                              uint32_t* key_count, uint32_t* tile_pref, uint32_t* meta, hipStream_t st) {
+    if (n_pheno < 1 || n_pheno > NARROW_MAX_COLS) return hipErrorInvalidValue;
+    const uint32_t n_words = (uint32_t)((n_rows + 63) / 64);
+    const uint32_t n_segs = (n_words + BM_WORDS - 1) / BM_WORDS;
+    hipLaunchKernelGGL(narrow_keys_kernel, dim3(n_segs, n_pheno), dim3(256), 0, st, bitmap, words_per_col, n_words, n_segs, n_pheno, seg_cnt,
+                       keys_sorted, key_cap, row_bits, surv_off, surv_cnt, key_count, tile_pref, meta);
+    return hipGetLastError();
+}
+
 size_t narrow_lds_bytes(uint32_t n_kgroups) { return (size_t)n_kgroups * 4u * 2048u + 4u * sizeof(NarrowCol); }
 
 template <int NP>
@@ -536,8 +643,15 @@ hipError_t launch_narrow(const NarrowArgs& a, uint32_t rows_per_block, hipStream
     // KB's worth) go through the direct kernel in a second, tiny launch.
     uint64_t n_staged = 0;
     if (!no_stage && lds_staged <= 53u * 1024u && np <= 12 && (reinterpret_cast<uintptr_t>(a.src.base) & 15u) == 0) {
+        // All rows, if the last pass (whole or not: rows past n_rows fail narrow_test's row test) can be read in whole KB
+        // inside the buffer - a.slack_rows rows of the same buffer follow the launch's rows, which every chunk of a feed
+        // but the last has. Otherwise the passes that can, and a second launch for the rest.
+        const uint64_t readable_b = (a.n_rows + a.slack_rows) * (uint64_t)stride_b;
         const uint64_t total_b = a.n_rows * (uint64_t)stride_b, over = (uint64_t)np * 1024u - 64ull * stride_b;
-        if (total_b > over) n_staged = (total_b - over) / (64ull * stride_b) * 64ull;
+        if ((a.n_rows - 1u) / 64u * 64u * stride_b + (uint64_t)np * 1024u <= readable_b)
+            n_staged = a.n_rows;
+        else if (total_b > over)
+            n_staged = (total_b - over) / (64ull * stride_b) * 64ull;
     }
     if (n_staged) {
         NarrowArgs s1 = a;
