@@ -4,7 +4,7 @@
 //             (src/kmers_multiple_databases.cpp:125-132), only needed when the phenotyped
 //             accessions are not the table's leading columns in order
 //   kin_*   : update_emma_kinshhip_calculation (src/kmers_multiple_databases.cpp:418-438)
-#include "kernels.h"
+#include "score_common.h"
 #include "synth.h"
 
 namespace kgwas {
@@ -83,58 +83,7 @@ __global__ void __launch_bounds__(256) synth_kernel(uint64_t* rows, uint64_t fir
 __global__ void __launch_bounds__(256) thr_update_kernel(const uint32_t* hist, const uint32_t* hist_base,
                                                          uint32_t bins, const uint64_t* topn, const double* thr_host,
                                                          double* thr) {
-    __shared__ unsigned long long part[256];
-    const uint32_t p = blockIdx.x, t = threadIdx.x;
-    const uint32_t per = bins / 256u;
-    const uint32_t* h = hist + (uint64_t)p * bins;
-    unsigned long long s = 0;
-    for (uint32_t i = 0; i < per; i++) s += h[t * per + i];
-    part[t] = s;
-    __syncthreads();
-    // suffix sums over the 256 segments (Hillis-Steele from the top): above[t] = scores counted in segments > t; the
-    // segment that takes the count past N is found by its own thread (one thread walking all 256 took 30 us per launch)
-    __shared__ unsigned long long suf[256];
-    __shared__ int seg_s;
-    __shared__ unsigned long long run_s;
-    suf[t] = s;
-    if (t == 0) seg_s = -1;
-    __syncthreads();
-    for (uint32_t d = 1; d < 256u; d <<= 1) {
-        const unsigned long long x = t + d < 256u ? suf[t + d] : 0ull;
-        __syncthreads();
-        suf[t] += x;
-        __syncthreads();
-    }
-    {
-        const unsigned long long N = topn[p];
-        const unsigned long long above = suf[t] - s;  // segments t + 1 .. 255
-        if (above < N && above + s >= N) {  // exactly one t (or none: fewer than N scores counted)
-            seg_s = (int)t;
-            run_s = above;
-        }
-    }
-    __syncthreads();
-    if (t == 0) {
-        const unsigned long long N = topn[p];
-        unsigned long long run = seg_s >= 0 ? run_s : 0ull;
-        const int seg = seg_s;
-        double cur = thr[p];
-        const double th = thr_host[p];
-        if (seg >= 0) {
-            uint32_t b = seg * per + per - 1;
-            for (;; b--) {  // run = counted scores above this segment; walk down inside it
-                run += h[b];
-                if (run >= N || b == (uint32_t)seg * per) break;
-            }
-            const double v = __longlong_as_double((long long)((unsigned long long)(hist_base[p] + b) << HIST_SHIFT));
-            if (v > cur) cur = v;
-        }
-        if (th != th || cur != cur)
-            cur = __longlong_as_double(0x7FF8000000000000LL);
-        else if (th > cur)
-            cur = th;
-        thr[p] = cur;
-    }
+    thr_update_block(hist, hist_base, bins, topn, thr_host, thr, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -152,9 +152,20 @@ hipError_t launch_rescore(const ScoreArgs& a, const uint32_t* keys, const uint32
 hipError_t launch_rescore_direct(const ScoreArgs& a, const uint32_t* keys, const uint32_t* surv_off, const uint32_t* surv_cnt,
                                  uint32_t row_bits, const uint32_t* tile_pref, hipStream_t st);
 // Counters of the next chunk and its survivors' bitmap (bitmap_words 64-bit words, may be 0) zeroed in one launch;
-// seg_cnt (n_seg_words, may be 0): the narrow filter's per-segment survivor counts.
+// seg_cnt (n_seg_words, may be 0): the narrow filter's per-segment survivor counts. tu.hist != null: the kernel's first
+// blocks also raise the thresholds from the histograms (thr_update_kernel's work without a launch of its own: the chunk
+// that follows is filtered against everything counted before it).
+struct PrepThr {
+    const uint32_t* hist;
+    const uint32_t* hist_base;
+    uint32_t bins;
+    const uint64_t* topn;
+    const double* thr_host;
+    double* thr;
+};
 hipError_t launch_chunk_prep(uint32_t* cand_cnt, uint32_t n_pheno, unsigned long long* tested, uint32_t* key_count,
-                             unsigned long long* bitmap, uint64_t bitmap_words, uint32_t* seg_cnt, uint32_t n_seg_words, hipStream_t st);
+                             unsigned long long* bitmap, uint64_t bitmap_words, uint32_t* seg_cnt, uint32_t n_seg_words, const PrepThr& tu,
+                             hipStream_t st);
 
 // Narrow filter (score_narrow.hip): scans with one to four phenotype columns. FP4 table bits x three FP8 slices per
 // column on v_mfma_scale_f32_16x16x128_f8f6f4; operand row 4 p + k = slice k of phenotype column p, row 4 p + 3 = ones
@@ -198,7 +209,7 @@ hipError_t launch_bitmap_keys(const unsigned long long* bitmap, uint64_t words_p
 // writes its keys; block (0, 0) writes the ranges, the tile table and meta (records = survivors: see launch_rescore_direct).
 hipError_t launch_narrow_keys(const unsigned long long* bitmap, uint64_t words_per_col, uint64_t n_rows, uint32_t n_pheno, const uint32_t* seg_cnt,
                               uint32_t* keys_sorted, uint32_t key_cap, uint32_t row_bits, uint32_t* surv_off, uint32_t* surv_cnt,
-                              uint32_t* key_count, uint32_t* tile_pref, uint32_t* meta, hipStream_t st);
+                              uint32_t* key_count, uint32_t* tile_pref, uint32_t* meta, const unsigned long long* tested_shards, hipStream_t st);
 size_t narrow_lds_bytes(uint32_t n_kgroups);
 hipError_t launch_narrow(const NarrowArgs& a, uint32_t rows_per_block, hipStream_t st);
 

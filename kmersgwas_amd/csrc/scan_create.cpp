@@ -736,7 +736,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
             s->d_bm_blocks.alloc(P * ((s->bitmap_words + 1023) / 1024 + 1) + 4);
             s->d_surv_cnt.alloc(P);
             s->d_surv_off.alloc(P);
-            s->d_key_count.alloc(1);
+            s->d_key_count.alloc(2);  // the survivor count; the narrow re-score kernel's block counter
             s->d_tile_pref.alloc(P + 1);
             s->d_tile_cnt.alloc((size_t)s->key_slots / 256 + P + 2);
             s->d_tile_off.alloc((size_t)s->key_slots / 256 + P + 2);
@@ -778,9 +778,9 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                 sl.d_so_score.alloc(s->key_slots);
                 sl.d_so_kmer.alloc(s->key_slots);
                 sl.d_so_row.alloc(s->key_slots);
-                sl.d_meta.alloc(2 * P + 2);
-                sl.h_meta.alloc(2 * P + 2);
-                memset(sl.h_meta.p, 0, (2 * P + 2) * sizeof(uint32_t));
+                sl.d_meta.alloc(2 * P + 4);
+                sl.h_meta.alloc(2 * P + 4);
+                memset(sl.h_meta.p, 0, (2 * P + 4) * sizeof(uint32_t));
                 KGWAS_HIP(hipEventCreateWithFlags(&sl.ev_counts, hipEventBlockingSync));
             } else {
                 sl.cand.alloc((uint64_t)s->cap * P);

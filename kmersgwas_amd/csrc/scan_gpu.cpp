@@ -274,10 +274,22 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
         // interval the statistics count as kernel time.
         const uint64_t n_words = (n_rows + 63) / 64;
         const uint32_t n_segs = (uint32_t)((n_words + 1023) / 1024);
+        // (narrow scans: the thresholds are raised here, by the first blocks of this launch, from everything the chunks
+        // before this one counted - not by a launch of its own behind each chunk)
+        PrepThr tu;
+        memset(&tu, 0, sizeof(tu));
+        if (use_coarse && s->narrow && s->hist_ready) {
+            tu.hist = s->d_hist.p;
+            tu.hist_base = s->d_hist_base.p;
+            tu.bins = HIST_BINS;
+            tu.topn = s->d_topn.p;
+            tu.thr_host = s->d_thr_host.p;
+            tu.thr = s->d_thr.p;
+        }
         KGWAS_HIP(launch_chunk_prep(sl.d_cnt.p, (uint32_t)s->n_pheno, sl.d_tested.p, use_coarse ? s->d_key_count.p : nullptr,
                                     use_coarse ? s->d_bitmap.p : nullptr, use_coarse ? s->n_pheno * n_words : 0,
                                     (use_coarse && s->narrow) ? s->d_bm_blocks.p : nullptr, (use_coarse && s->narrow) ? (uint32_t)s->n_pheno * n_segs : 0u,
-                                    s->stream));
+                                    tu, s->stream));
     }
     sl.used_coarse = use_coarse;
     if (use_coarse) {
@@ -373,7 +385,7 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
             // one to four columns: keys in one launch (the filter has counted its survivors per segment), every survivor's
             // record written in place by the re-score kernel - a chunk is five launches, not thirteen
             KGWAS_HIP(launch_narrow_keys(s->d_bitmap.p, n_words, n_rows, (uint32_t)s->n_pheno, s->d_bm_blocks.p, s->d_surv_sorted.p, s->key_slots,
-                                         s->row_key_bits, s->d_surv_off.p, s->d_surv_cnt.p, s->d_key_count.p, s->d_tile_pref.p, sl.d_meta.p, s->stream));
+                                         s->row_key_bits, s->d_surv_off.p, s->d_surv_cnt.p, s->d_key_count.p, s->d_tile_pref.p, sl.d_meta.p, sl.d_tested.p, s->stream));
             KGWAS_HIP(launch_rescore_direct(a, s->d_surv_sorted.p, s->d_surv_off.p, s->d_surv_cnt.p, s->row_key_bits, s->d_tile_pref.p, s->stream));
         } else {
         KGWAS_HIP(launch_bitmap_keys(s->d_bitmap.p, n_words, n_rows, (uint32_t)s->n_pheno, s->d_bm_blocks.p, s->d_surv_sorted.p, s->key_slots,
@@ -389,14 +401,17 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
         launch_score(s, a);
     }
     KGWAS_HIP(hipEventRecord(sl.ev_k1, s->stream));
-    if (s->hist_ready)  // raise the thresholds for whatever is queued next; no host round trip
+    const bool fused_tail = use_coarse && s->narrow;  // thresholds: raised by the next chunk's prep launch; the tested count: in meta (launch_narrow_keys)
+    if (s->hist_ready && !fused_tail)  // raise the thresholds for whatever is queued next; no host round trip
         KGWAS_HIP(launch_thr_update(s->d_hist.p, s->d_hist_base.p, HIST_BINS, s->d_topn.p, s->d_thr_host.p, s->d_thr.p,
                                     (uint32_t)s->n_pheno, s->stream));
-    KGWAS_HIP(hipMemcpyAsync(sl.h_tested.p, sl.d_tested.p, TESTED_SHARDS * sizeof(unsigned long long), hipMemcpyDeviceToHost,
-                             s->stream));
+    if (!fused_tail)
+        KGWAS_HIP(hipMemcpyAsync(sl.h_tested.p, sl.d_tested.p, TESTED_SHARDS * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                                 s->stream));
+    sl.tested_in_meta = fused_tail;
     if (use_coarse) {
         // the record copies follow on the copy stream once the control thread has read the counts (fetch_records)
-        KGWAS_HIP(hipMemcpyAsync(sl.h_meta.p, sl.d_meta.p, (2 * s->n_pheno + 2) * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+        KGWAS_HIP(hipMemcpyAsync(sl.h_meta.p, sl.d_meta.p, (2 * s->n_pheno + 4) * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
         KGWAS_HIP(hipEventRecord(sl.ev_counts, s->stream));
     } else {
         KGWAS_HIP(hipMemcpyAsync(sl.h_cnt.p, sl.d_cnt.p, s->n_pheno * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
@@ -449,7 +464,10 @@ bool chunk_complete(kgwas_scan* s, Slot& sl) {
                 over ? " OVERFLOW" : "");
     }
     if (over) return false;
-    for (uint32_t i = 0; i < TESTED_SHARDS; i++) s->st.rows_tested += sl.h_tested.p[i];
+    if (sl.tested_in_meta)
+        s->st.rows_tested += (uint64_t)sl.h_meta.p[2 * s->n_pheno + 2] | ((uint64_t)sl.h_meta.p[2 * s->n_pheno + 3] << 32);
+    else
+        for (uint32_t i = 0; i < TESTED_SHARDS; i++) s->st.rows_tested += sl.h_tested.p[i];
     return true;
 }
 

@@ -234,7 +234,8 @@ struct Slot {
     bool copies_ordered = false;  // coarse chunks: the record copies are on the copy stream (ev_done follows them)
     // coarse filter: the chunk's candidates compacted in (column, row) order - in HBM (d_so_*), and the host copy the
     // control thread orders on the copy stream once the counts are known (exactly `total` records per array);
-    // h_meta: [0, P) candidates per column, [P, 2P) their offsets, [2P] total, [2P + 1] survivor keys emitted
+    // h_meta: [0, P) candidates per column, [P, 2P) their offsets, [2P] total, [2P + 1] survivor keys emitted,
+    // [2P + 2, 2P + 3] narrow scans: the chunk's MAC-passing rows (64 bits; instead of a copy of h_tested)
     double* so_score = nullptr;   // host copies: a piece of the session's pinned record ring (fetch_records)
     uint64_t* so_kmer = nullptr;
     uint32_t* so_row = nullptr;
@@ -244,6 +245,7 @@ struct Slot {
     DevBuf<uint32_t> d_so_row;
     DevBuf<uint32_t> d_meta;
     PinBuf<uint32_t> h_meta;
+    bool tested_in_meta = false;     // the chunk's MAC-passing rows came in h_meta (narrow scans), not in h_tested
     hipEvent_t ev_counts = nullptr;  // compute stream: compaction done, h_meta copied
     DevBuf<unsigned long long> d_tested;
     PinBuf<unsigned long long> h_tested;

@@ -617,7 +617,8 @@ __global__ void __launch_bounds__(256) compact_kernel(ScoreArgs a, const uint32_
 // One launch instead of a handful of small memsets per chunk: counters of the next chunk, its survivors' bitmap, the narrow
 // filter's per-segment counts.
 __global__ void __launch_bounds__(256) chunk_prep_kernel(uint32_t* cand_cnt, uint32_t n_pheno, unsigned long long* tested, uint32_t* key_count,
-                                                         unsigned long long* bitmap, uint64_t bitmap_words, uint32_t* seg_cnt, uint32_t n_seg_words) {
+                                                         unsigned long long* bitmap, uint64_t bitmap_words, uint32_t* seg_cnt, uint32_t n_seg_words,
+                                                         PrepThr tu) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_pheno) cand_cnt[i] = 0u;
     if (i < TESTED_SHARDS) tested[i] = 0ull;
@@ -628,17 +629,22 @@ __global__ void __launch_bounds__(256) chunk_prep_kernel(uint32_t* cand_cnt, uin
     const uint64_t pairs = bitmap_words / 2u;
     for (uint64_t k = i; k < pairs; k += (uint64_t)gridDim.x * blockDim.x) b2[k] = make_ulonglong2(0ull, 0ull);
     if (i == 0 && (bitmap_words & 1u)) bitmap[bitmap_words - 1u] = 0ull;
+    // the thresholds the chunk is filtered against, raised from the histograms of everything counted so far
+    if (tu.hist)
+        for (uint32_t p = blockIdx.x; p < n_pheno; p += gridDim.x) thr_update_block(tu.hist, tu.hist_base, tu.bins, tu.topn, tu.thr_host, tu.thr, p);
 }
 
 hipError_t launch_chunk_prep(uint32_t* cand_cnt, uint32_t n_pheno, unsigned long long* tested, uint32_t* key_count,
-                             unsigned long long* bitmap, uint64_t bitmap_words, uint32_t* seg_cnt, uint32_t n_seg_words, hipStream_t st) {
+                             unsigned long long* bitmap, uint64_t bitmap_words, uint32_t* seg_cnt, uint32_t n_seg_words, const PrepThr& tu,
+                             hipStream_t st) {
     uint64_t n = n_pheno > TESTED_SHARDS ? n_pheno : TESTED_SHARDS;
     if (n_seg_words > n) n = n_seg_words;
     if (bitmap_words / 8u > n) n = bitmap_words / 8u;  // (four turns per thread on a large bitmap)
     const uint64_t blocks = std::min<uint64_t>((n + 255u) / 256u, 8192u);
     if (blocks * 256u < std::max<uint64_t>(std::max<uint64_t>(n_pheno, TESTED_SHARDS), n_seg_words)) return hipErrorInvalidValue;
+    if (tu.hist && (tu.bins % 1024u || tu.bins / 256u > 64u)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(chunk_prep_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, cand_cnt, n_pheno, tested, key_count, bitmap, bitmap_words,
-                       seg_cnt, n_seg_words);
+                       seg_cnt, n_seg_words, tu);
     return hipGetLastError();
 }
 

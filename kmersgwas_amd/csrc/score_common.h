@@ -72,4 +72,76 @@ __device__ __forceinline__ void finish_pair(const ScoreArgs& a, uint64_t r, uint
     }
 }
 
+// ---- device-side threshold tracking (aux_kernels.hip describes it) -----------------------------------------------------
+// One 256-thread block raises thr[p] (thr_update_kernel's body: one block per column there; the narrow scans run it in the
+// first blocks of the NEXT chunk's prep kernel instead of a launch of its own). Ends with a block barrier.
+// Thread t owns the segment of bins [t * per, (t + 1) * per); suffix sums over the 256 segments (Hillis-Steele from the
+// top) find the segment that takes the count past N, and wave 0 then looks at that segment's bins side by side (one thread
+// walking them was a chain of dependent loads: most of the 12 us this used to take).
+__device__ __forceinline__ void thr_update_block(const uint32_t* hist, const uint32_t* hist_base, uint32_t bins, const uint64_t* topn,
+                                                 const double* thr_host, double* thr, uint32_t p) {
+    __shared__ unsigned long long suf[256];
+    __shared__ int seg_s;
+    __shared__ unsigned long long run_s;
+    const uint32_t t = threadIdx.x;
+    const uint32_t per = bins / 256u;  // 64 with HIST_BINS = 16384 (any multiple of 4 up to 64 works below)
+    const uint32_t* h = hist + (uint64_t)p * bins;
+    unsigned long long s = 0;
+    {
+        const uint4* h4 = reinterpret_cast<const uint4*>(h + (size_t)t * per);
+        for (uint32_t i = 0; i < per / 4u; i++) {
+            const uint4 v = h4[i];
+            s += (unsigned long long)v.x + v.y + v.z + v.w;
+        }
+    }
+    suf[t] = s;
+    if (t == 0) seg_s = -1;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256u; d <<= 1) {
+        const unsigned long long x = t + d < 256u ? suf[t + d] : 0ull;
+        __syncthreads();
+        suf[t] += x;
+        __syncthreads();
+    }
+    const unsigned long long N = topn[p];
+    {
+        const unsigned long long above = suf[t] - s;  // segments t + 1 .. 255
+        if (above < N && above + s >= N) {  // exactly one t (or none: fewer than N scores counted)
+            seg_s = (int)t;
+            run_s = above;
+        }
+    }
+    __syncthreads();
+    if (t < 64u) {  // wave 0
+        const int seg = seg_s;
+        double cur = thr[p];
+        const double th = thr_host[p];
+        if (seg >= 0) {
+            // lane l looks at bin b = seg * per + per - 1 - l (from the top down): incl = scores counted in the bins above the
+            // segment and in the segment's bins b and higher; the first lane with incl >= N holds the boundary (the last
+            // bin of the segment if none: cannot happen, above + s >= N)
+            const uint32_t l = t;
+            const uint32_t b = (uint32_t)seg * per + per - 1u - (l < per ? l : per - 1u);
+            unsigned long long incl = l < per ? h[b] : 0ull;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const unsigned long long x = __shfl_up(incl, d);
+                if ((int)l >= d) incl += x;
+            }
+            incl += run_s;
+            const unsigned long long m = __ballot(l < per && incl >= N);
+            const uint32_t first = m ? (uint32_t)__ffsll((long long)m) - 1u : per - 1u;
+            const uint32_t bb = (uint32_t)seg * per + per - 1u - first;
+            const double v = __longlong_as_double((long long)((unsigned long long)(hist_base[p] + bb) << HIST_SHIFT));
+            if (v > cur) cur = v;
+        }
+        if (th != th || cur != cur)
+            cur = __longlong_as_double(0x7FF8000000000000LL);
+        else if (th > cur)
+            cur = th;
+        if (t == 0) thr[p] = cur;
+    }
+    __syncthreads();
+}
+
 }  // namespace kgwas

@@ -519,7 +519,7 @@ hipError_t launch_bitmap_keys(const unsigned long long* bitmap, uint64_t words_p
 __global__ void __launch_bounds__(256) narrow_keys_kernel(const unsigned long long* bm, uint64_t words_per_col, uint32_t n_words, uint32_t n_segs,
                                                           uint32_t n_pheno, const uint32_t* seg_cnt, uint32_t* keys, uint32_t key_cap,
                                                           uint32_t row_bits, uint32_t* surv_off, uint32_t* surv_cnt, uint32_t* key_count,
-                                                          uint32_t* tile_pref, uint32_t* meta) {
+                                                          uint32_t* tile_pref, uint32_t* meta, const unsigned long long* tested_shards) {
     __shared__ uint32_t red[4][NARROW_MAX_COLS + 1];
     __shared__ uint32_t tot[NARROW_MAX_COLS + 1];
     __shared__ uint32_t part[4];
@@ -553,6 +553,19 @@ __global__ void __launch_bounds__(256) narrow_keys_kernel(const unsigned long lo
         total += tot[q];
     }
     const bool over = total > key_cap;  // the chunk is redone in halves: nothing for the re-score kernel to walk
+    if (b == 0u && p == 0u) {  // the filter's MAC-passing-row counters -> meta[2 P + 2 .. 3]: one copy closes the chunk
+        __shared__ unsigned long long tsum[4];
+        unsigned long long v = tested_shards[threadIdx.x];  // TESTED_SHARDS == 256 == blockDim.x
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d);
+        if (lane == 0u) tsum[wave] = v;
+        __syncthreads();
+        if (threadIdx.x == 0u) {
+            const unsigned long long tt = tsum[0] + tsum[1] + tsum[2] + tsum[3];
+            meta[2u * n_pheno + 2u] = (uint32_t)tt;
+            meta[2u * n_pheno + 3u] = (uint32_t)(tt >> 32);
+        }
+    }
     if (b == 0u && p == 0u && threadIdx.x == 0u) {
         uint32_t o = 0, t = 0;
         for (uint32_t q = 0; q < n_pheno; q++) {
@@ -605,12 +618,13 @@ __global__ void __launch_bounds__(256) narrow_keys_kernel(const unsigned long lo
 
 hipError_t launch_narrow_keys(const unsigned long long* bitmap, uint64_t words_per_col, uint64_t n_rows, uint32_t n_pheno, const uint32_t* seg_cnt,
                               uint32_t* keys_sorted, uint32_t key_cap, uint32_t row_bits, uint32_t* surv_off, uint32_t* surv_cnt,
-                              uint32_t* key_count, uint32_t* tile_pref, uint32_t* meta, hipStream_t st) {
+                              uint32_t* key_count, uint32_t* tile_pref, uint32_t* meta, const unsigned long long* tested_shards, hipStream_t st) {
+    static_assert(TESTED_SHARDS == 256, "block (0, 0) sums one counter per thread");
     if (n_pheno < 1 || n_pheno > NARROW_MAX_COLS) return hipErrorInvalidValue;
     const uint32_t n_words = (uint32_t)((n_rows + 63) / 64);
     const uint32_t n_segs = (n_words + BM_WORDS - 1) / BM_WORDS;
     hipLaunchKernelGGL(narrow_keys_kernel, dim3(n_segs, n_pheno), dim3(256), 0, st, bitmap, words_per_col, n_words, n_segs, n_pheno, seg_cnt,
-                       keys_sorted, key_cap, row_bits, surv_off, surv_cnt, key_count, tile_pref, meta);
+                       keys_sorted, key_cap, row_bits, surv_off, surv_cnt, key_count, tile_pref, meta, tested_shards);
     return hipGetLastError();
 }
 
