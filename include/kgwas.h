@@ -170,6 +170,8 @@ typedef struct kgwas_scan_stats {
                                    columns once other workers had nothing left to do */
     uint64_t columns_popped_ahead; /* columns whose result lists were made by idle replay workers at the end of the last feed
                                       (kgwas_scan_expect_finish) instead of by kgwas_scan_finish */
+    uint32_t coarse_mx32;       /* block-scaled filter in its v_mfma_scale_f32_32x32x64_f8f6f4 form (score_mx32.hip) */
+    uint32_t reserved0;
 } kgwas_scan_stats;
 
 int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out);

@@ -516,6 +516,124 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                     eb.rallD = up((double)eb.rall * iu);
                     eb.rmaxD = up((double)eb.rmax * iu);
                 };
+                // ---- the 32 x 32 x 64 form (score_mx32.hip): tiles of 32 columns + one combined tile for a remainder of up to 16.
+                // Taken when it multiplies no more 16-column tile equivalents, in no more LDS groups, than the 16 x 16 x 128
+                // plan below would (KGWAS_MX32=0: never; =1: whenever its operands fit).
+                {
+                    const char* e32 = getenv("KGWAS_MX32");
+                    const int want32 = e32 ? atoi(e32) : 0;
+                    const uint32_t nf32 = (uint32_t)(S / 256), nq32 = (uint32_t)((S % 256 + 63) / 64), steps32 = 4 * nf32 + nq32;
+                    auto tiles_for = [](uint64_t cols, uint32_t& ct32, uint32_t& comb) {
+                        ct32 = (uint32_t)(cols / 32);
+                        comb = 0;
+                        const uint64_t rem = cols % 32;
+                        if (rem && rem <= 16)
+                            comb = 1;
+                        else if (rem)
+                            ct32++;
+                    };
+                    uint64_t g32 = 0;
+                    uint32_t ct32 = 0, comb = 0;
+                    for (uint64_t g = 1; g <= P && !g32 && want32 && ns == 2 && !s1_fp6 && !s->narrow; g++) {
+                        tiles_for((P + g - 1) / g + 1, ct32, comb);
+                        if (ct32 <= 3 && mx32_lds_bytes(steps32, ct32, comb) <= 160u * 1024u) g32 = g;
+                    }
+                    if (g32) {
+                        const uint64_t g16 = groups_for(CTmax), ct16 = ((P + g16 - 1) / g16 + 1 + 15) / 16;
+                        if (want32 < 2 && (g32 > g16 || g32 * (2 * ct32 + comb) > g16 * ct16)) g32 = 0;  // (KGWAS_MX32=2: wherever it fits)
+                    }
+                    if (g32) {
+                        const uint64_t cper = (P + g32 - 1) / g32;
+                        const uint32_t NT = ct32 + comb, slots = NT * 32;
+                        const uint32_t SB32 = ct32 * 2560u + comb * 1536u;
+                        const size_t group_bytes = (size_t)steps32 * SB32;
+                        std::vector<uint8_t> Bq(g32 * group_bytes, 0);
+                        std::vector<CoarseCol> cols(g32 * slots);
+                        for (auto& cc : cols) {
+                            memset(&cc, 0, sizeof(cc));
+                            cc.pheno = -1;
+                        }
+                        // k = 32 kblk + e of step st <-> sample (score_mx32.hip)
+                        auto sample_of = [&](uint64_t st, uint64_t kblk, uint64_t e) -> uint64_t {
+                            return st < 4ull * nf32 ? 256 * (st / 4) + 128 * kblk + 32 * (e / 8) + 4 * (e % 8) + st % 4
+                                                    : 256ull * nf32 + 64 * (st - 4ull * nf32) + 32 * kblk + 4 * (e % 8) + e / 8;
+                        };
+                        auto put6 = [&](uint8_t* part, uint64_t lane, uint64_t e, int q) {  // 6-bit field e of the lane's 6 dwords: dwords 0-3 | 4-5
+                            const uint32_t code = e2m3(q);
+                            for (int b = 0; b < 6; b++)
+                                if (code & (1u << b)) {
+                                    const uint64_t bit = 6 * e + b, dw = bit / 32;
+                                    uint8_t* d = dw < 4 ? part + lane * 16 + dw * 4 : part + 1024 + lane * 8 + (dw - 4) * 4;
+                                    d[(bit % 32) / 8] |= (uint8_t)(1u << (bit % 8));
+                                }
+                        };
+                        // column `c` of LDS group lg (c < ct32 * 32: a full tile's slot; beyond: slot c - ct32 * 32 < 16 of the combined tile)
+                        auto put32 = [&](uint64_t lg, uint64_t c, const std::vector<int>& v0, const std::vector<int>& v1) {
+                            const uint64_t t = c / 32, n = c % 32;
+                            for (uint64_t st = 0; st < steps32; st++) {
+                                uint8_t* blk = &Bq[lg * group_bytes + st * SB32 + t * 2560u];
+                                for (uint64_t kblk = 0; kblk < 2; kblk++)
+                                    for (uint64_t e = 0; e < 32; e++) {
+                                        const uint64_t smp = sample_of(st, kblk, e);
+                                        if (smp >= S) continue;
+                                        if (t < ct32) {
+                                            const uint64_t lane = kblk * 32 + n;
+                                            put6(blk, lane, e, v0[smp]);
+                                            blk[1536 + lane * 16 + e / 2] |= (uint8_t)(e2m1(v1[smp]) << (4 * (e % 2)));
+                                        } else {  // both slices as FP6 codes: slice 0 in lane n, slice 1 (a1 / 2 = 4 a1 / 8) in lane n + 16
+                                            put6(blk, kblk * 32 + n, e, v0[smp]);
+                                            put6(blk, kblk * 32 + n + 16, e, 4 * v1[smp]);
+                                        }
+                                    }
+                            }
+                        };
+                        for (uint64_t j = 0; j < P; j++) {
+                            const uint64_t lg = j / cper, c = j % cper;
+                            CoarseCol& cc = cols[lg * slots + c];
+                            ErrBound eb;
+                            quantise_mx(j, cc, eb);
+                            M.eg_max = std::max(M.eg_max, eb.egD);
+                            M.rall_max = std::max(M.rall_max, eb.rallD);
+                            M.rmax_max = std::max(M.rmax_max, eb.rmaxD);
+                            cc.pheno = (int32_t)j;
+                            put32(lg, c, a0, a1);
+                        }
+                        {  // ones column: accumulator = N1; the last column slot of the last tile (slot 31 / slot 15 of the combined tile)
+                            std::vector<int> ones(S, t_ones), zeros(S, 0);
+                            const uint64_t c_ones = comb ? (uint64_t)ct32 * 32 + 15 : (uint64_t)ct32 * 32 - 1;
+                            if (cper > c_ones) throw Error(KGWAS_ERR_ARG, "mx32 plan: no slot left for the ones column");
+                            for (uint64_t lg = 0; lg < g32; lg++) put32(lg, c_ones, zeros, ones);
+                        }
+                        kgwas_scan::CoarsePart& Pt = M.part[0];
+                        Pt.T = 2 * ct32 + comb;
+                        Pt.ct32 = ct32;
+                        Pt.comb = comb;
+                        Pt.n_lgroups = (uint32_t)g32;
+                        Pt.d_Bq.alloc(Bq.size());
+                        Pt.d_cols.alloc(cols.size());
+                        KGWAS_HIP(hipMemcpy(Pt.d_Bq.p, Bq.data(), Bq.size(), hipMemcpyHostToDevice));
+                        KGWAS_HIP(hipMemcpy(Pt.d_cols.p, cols.data(), cols.size() * sizeof(CoarseCol), hipMemcpyHostToDevice));
+                        M.mx = true;
+                        M.mx32 = true;
+                        M.mx_full = nf32;
+                        M.mx_quarter = nq32;
+                        M.mx_s1_fp6 = 0;
+                        M.mx_scale0 = 0x01010101u * (uint32_t)(0x7F + 5);
+                        M.slices = 2;
+                        M.n_parts = 1;
+                        M.tile_slices = Pt.T * 2 * (uint32_t)g32;
+                        s->st.coarse_mode_tiles[mi] = Pt.T;
+                        s->st.coarse_mode_lgroups[mi] = (uint32_t)g32;
+                        s->st.coarse_mode_tile_slices[mi] = M.tile_slices;
+                        if (use_mx) s->st.coarse_mx = 1;
+                        s->st.coarse_mx_s1_fp6 = 0;
+                        s->st.coarse_mx_steps = n_steps;  // (in K = 128 steps' worth, as for the 16 x 16 x 128 form)
+                        s->st.coarse_mx32 = 1;
+                        M.tile_slices_eq = (double)M.tile_slices * (double)steps32 / (16.0 * (double)n_kgroups) * (Pt.T <= 3 ? 1.30 : 1.0);
+                        M.ready = true;
+                        return;
+                    }
+                }
                 // LDS groups: as few as hold all columns (+ a ones column each); or groups filled to the last slot and one
                 // smaller launch for the rest when that multiplies fewer tiles
                 uint64_t n_lgroups = groups_for(CTmax);

@@ -371,6 +371,9 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
                     x.eg_max = c.eg_max;
                     x.rall_max = c.rall_max;
                     x.rmax_max = c.rmax_max;
+                    if (M.mx32)
+                        KGWAS_HIP(launch_mx32(x, Pt.ct32, Pt.comb, rpb_env ? rpb_env : (n_rows >= (1u << 22) ? 4096u : n_rows >= (1u << 20) ? 2048u : 512u), s->stream));
+                    else
                     KGWAS_HIP(launch_mx(x, Pt.T, rpb_env ? rpb_env : (n_rows >= (1u << 22) ? 4096u : n_rows >= (1u << 20) ? 2048u : 512u), s->stream));
                 } else
                     KGWAS_HIP(launch_coarse(c, Pt.T, rpb_env ? rpb_env : (n_rows >= (1u << 22) ? 4096u : n_rows >= (1u << 20) ? 2048u : 512u), s->stream));
@@ -389,7 +392,7 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
             KGWAS_HIP(launch_rescore_direct(a, s->d_surv_sorted.p, s->d_surv_off.p, s->d_surv_cnt.p, s->row_key_bits, s->d_tile_pref.p, s->stream));
         } else {
         KGWAS_HIP(launch_bitmap_keys(s->d_bitmap.p, n_words, n_rows, (uint32_t)s->n_pheno, s->d_bm_blocks.p, s->d_surv_sorted.p, s->key_slots,
-                                     s->row_key_bits, s->d_surv_off.p, s->d_surv_cnt.p, s->d_key_count.p, s->d_tile_pref.p, /*nibble_transposed=*/!s->narrow, s->stream));
+                                     s->row_key_bits, s->d_surv_off.p, s->d_surv_cnt.p, s->d_key_count.p, s->d_tile_pref.p, /*nibble_transposed=*/!s->narrow && !s->cmode[sl.coarse_mode].mx32, s->stream));
         a.so_score = sl.d_so_score.p;
         a.so_kmer = sl.d_so_kmer.p;
         a.so_row = sl.d_so_row.p;
