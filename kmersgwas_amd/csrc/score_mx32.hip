@@ -28,6 +28,12 @@
 
 #include "score_common.h"
 
+// Timing experiments only (wrong results). Bits: 1 the tests are replaced by an XOR over all accumulators (every MFMA stays
+// alive), 2 no cross-lane add for the combined tile, 4 accumulators not zeroed per pass, 8 no row loads.
+#ifndef KGWAS_MX32_ABLATE
+#define KGWAS_MX32_ABLATE 0
+#endif
+
 namespace kgwas {
 
 typedef int m32v8i __attribute__((ext_vector_type(8)));
@@ -110,7 +116,7 @@ __global__ void __launch_bounds__(TH) mx32_kernel(MxArgs a, uint32_t rows_per_bl
             for (int rt = 0; rt < 2; rt++) {
                 uint32_t off = o[rt] + b0;
                 asm volatile("" : "+v"(off));  // a 32-bit offset on the scalar base, made here: not a hoisted (and spilled) 64-bit pointer
-                const U4 v = *reinterpret_cast<const U4*>(rows_base + off);
+                const U4 v = (KGWAS_MX32_ABLATE & 8) ? U4{off, lane * 2654435761u, lane, b0} : *reinterpret_cast<const U4*>(rows_base + off);
                 pc[rt][0] = v.x;
                 pc[rt][1] = v.y;
                 pc[rt][2] = v.z;
@@ -119,11 +125,16 @@ __global__ void __launch_bounds__(TH) mx32_kernel(MxArgs a, uint32_t rows_per_bl
         };
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-        // B operands of the tiles, read one tile ahead of their MFMAs: tile 0 of a step has a register set of its own (it
-        // is fetched while the LAST tile of the step before multiplies), tiles 1, 2, .. alternate between two more
-        u32x4 Bx[3], Bz[3];
+        // B operands, read one UNIT ahead of their MFMAs. A unit is one slice of one tile (two MFMAs: the two row tiles); a step
+        // runs the first slices of all its tiles, then the second slices: the two instructions that add into the same
+        // accumulator are a whole phase (2 NT instructions) apart, not two (with the second slice right behind the first -
+        // a dependent 16-pass instruction two issue slots later - the main loop measured 13 % slower than the 16 x 16 x 128
+        // kernel's). Unit 0 of a step has a register set of its own (it is fetched while the LAST unit of the step before
+        // multiplies), the others alternate between two more.
+        constexpr int NU = NT + CT32;
+        u32x4 Bx[3];
         u32x2 By[3];
-        auto set_of = [](int t) { return t == 0 ? 2 : ((t - 1) & 1); };
+        auto set_of = [](int u) { return u == 0 ? 2 : ((u - 1) & 1); };
         struct StepAddr {
             uint32_t o16, o8;
         };
@@ -134,60 +145,62 @@ __global__ void __launch_bounds__(TH) mx32_kernel(MxArgs a, uint32_t rows_per_bl
             asm volatile("" : "+v"(sa.o16), "+v"(sa.o8));
             return sa;
         };
-        auto read_tile = [&](int t, int set, const StepAddr& sa) {
-            const char* p16 = lds + sa.o16 + t * M32_FULL;
-            const char* p8 = lds + sa.o8 + t * M32_FULL;
-            Bx[set] = *reinterpret_cast<const u32x4*>(p16);
-            By[set] = *reinterpret_cast<const u32x2*>(p8);
-            if (t < CT32) Bz[set] = *reinterpret_cast<const u32x4*>(p16 + 1536);
+        auto read_unit = [&](int u, int set, const StepAddr& sa) {
+            if (u < NT) {  // first slice of tile u: FP6, dwords 0-3 | 4-5
+                Bx[set] = *reinterpret_cast<const u32x4*>(lds + sa.o16 + u * M32_FULL);
+                By[set] = *reinterpret_cast<const u32x2*>(lds + sa.o8 + u * M32_FULL);
+            } else {  // second slice of tile u - NT: FP4, dwords 0-3
+                Bx[set] = *reinterpret_cast<const u32x4*>(lds + sa.o16 + (u - NT) * M32_FULL + 1536);
+            }
         };
         uint32_t piece[2][4];
         set_rows(ro, wave_row0);
         if (a.n_full && wave_row0 < a.n_rows) load_group(piece, ro, 0);
         StepAddr sadr = step_addr(lds);
-        read_tile(0, 2, sadr);  // step 0 of the first pass; every pass's last step fetches it for the next
+        read_unit(0, 2, sadr);  // step 0 of the first pass; every pass's last step fetches it for the next
         for (uint32_t ps = 0; ps * rows_per_pass < rows_per_block; ps++) {
             const uint64_t rbase = wave_row0 + (uint64_t)ps * rows_per_pass;
             if (rbase >= a.n_rows) break;  // wave-uniform
             uint32_t ro_next[2];
             set_rows(ro_next, rbase + rows_per_pass);
             m32v16f acc[2][NT];
+            if (!(KGWAS_MX32_ABLATE & 4) || ps == 0) {
 #pragma unroll
-            for (int rt = 0; rt < 2; rt++)
+                for (int rt = 0; rt < 2; rt++)
 #pragma unroll
-                for (int t = 0; t < NT; t++)
+                    for (int t = 0; t < NT; t++)
 #pragma unroll
-                    for (int r = 0; r < 16; r++) acc[rt][t][r] = 0.0f;
+                        for (int r = 0; r < 16; r++) acc[rt][t][r] = 0.0f;
+            }
 
-            // one step: [read tile 1 | MFMAs of tile 0 | read tile 2 | MFMAs of tile 1 | ... | read the next step's tile 0 | MFMAs of the last tile]
+            // one step: [read unit 1 | MFMAs of unit 0 | read unit 2 | MFMAs of unit 1 | ... | read the next step's unit 0 | MFMAs of the last unit]
             auto run_step = [&](const m32v8i (&A)[2], const char* bs_next, int sa) {
                 const StepAddr nadr = step_addr(bs_next);
 #pragma unroll
-                for (int t = 0; t < NT; t++) {
-                    const int set = set_of(t);
-                    if (t + 1 < NT)
-                        read_tile(t + 1, set_of(t + 1), sadr);
+                for (int u = 0; u < NU; u++) {
+                    const int set = set_of(u);
+                    if (u + 1 < NU)
+                        read_unit(u + 1, set_of(u + 1), sadr);
                     else
-                        read_tile(0, NT == 1 ? 0 : 2, nadr);  // (a single tile per step: its own set is still being multiplied with - moved over below)
+                        read_unit(0, NU == 1 ? 0 : 2, nadr);  // (a single unit per step: its own set is still being multiplied with - moved over below)
                     __builtin_amdgcn_sched_barrier(0);
-                    const m32v8i B0 = {(int)Bx[set].x, (int)Bx[set].y, (int)Bx[set].z, (int)Bx[set].w, (int)By[set].x, (int)By[set].y, 0, 0};
-                    if (t < CT32) {
-                        const m32v8i B1 = {(int)Bz[set].x, (int)Bz[set].y, (int)Bz[set].z, (int)Bz[set].w, 0, 0, 0, 0};
+                    if (u < NT) {
+                        const m32v8i B0 = {(int)Bx[set].x, (int)Bx[set].y, (int)Bx[set].z, (int)Bx[set].w, (int)By[set].x, (int)By[set].y, 0, 0};
+                        const int sb = (COMB && u == NT - 1) ? sc_comb : sc0;
 #pragma unroll
-                        for (int rt = 0; rt < 2; rt++) acc[rt][t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[rt], B0, acc[rt][t], 4, 2, 0, sa, 0, sc0);
-#pragma unroll
-                        for (int rt = 0; rt < 2; rt++)
-                            acc[rt][t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[rt], B1, acc[rt][t], 4, 4, 0, sa, 0, 0x7F7F7F7F);
+                        for (int rt = 0; rt < 2; rt++) acc[rt][u] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[rt], B0, acc[rt][u], 4, 2, 0, sa, 0, sb);
                     } else {
+                        const m32v8i B1 = {(int)Bx[set].x, (int)Bx[set].y, (int)Bx[set].z, (int)Bx[set].w, 0, 0, 0, 0};
 #pragma unroll
                         for (int rt = 0; rt < 2; rt++)
-                            acc[rt][t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[rt], B0, acc[rt][t], 4, 2, 0, sa, 0, sc_comb);
+                            acc[rt][u - NT] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[rt], B1, acc[rt][u - NT], 4, 4, 0, sa, 0, 0x7F7F7F7F);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (NT == 1) Bx[2] = Bx[0], By[2] = By[0], Bz[2] = Bz[0];
+                if (NU == 1) Bx[2] = Bx[0], By[2] = By[0];
                 sadr = nadr;
             };
+
             __builtin_amdgcn_s_setprio(0);
             for (uint32_t g = 0; g < a.n_full; g++) {
                 const char* bg = lds + (size_t)g * 4u * SB;
@@ -234,7 +247,7 @@ __global__ void __launch_bounds__(TH) mx32_kernel(MxArgs a, uint32_t rows_per_bl
 
             // ---- epilogue -----------------------------------------------------------------------------------------
             // the combined tile: a column's two partial sums sit 16 lanes apart
-            if (COMB) {
+            if (COMB && !(KGWAS_MX32_ABLATE & 2)) {
 #pragma unroll
                 for (int rt = 0; rt < 2; rt++)
 #pragma unroll
@@ -301,10 +314,22 @@ __global__ void __launch_bounds__(TH) mx32_kernel(MxArgs a, uint32_t rows_per_bl
                     for (int r = 0; r < 16; r++) mx[r] = fmaxf(mx[r], fabsf(acc[rt][t][r]));
                 uint64_t hit[16];
                 uint64_t hit_any = 0;
+                if (KGWAS_MX32_ABLATE & 1) {
+                    int x = 0;
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+#pragma unroll
+                        for (int t = 0; t < NT; t++) x ^= __float_as_int(acc[rt][t][r]);
+#pragma unroll
+                    for (int r = 0; r < 16; r++) hit[r] = 0;
+                    hit[0] = __ballot(x == 0x7fffffff);
+                    hit_any = hit[0];
+                } else {
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     hit[r] = __ballot(fmaf(-al_min, sqd[r], mx[r]) + er[r] >= 0.0f);
                     hit_any |= hit[r];
+                }
                 }
                 if (hit_any) {  // wave-uniform
                     uint32_t mb[NT];

@@ -19,6 +19,6 @@ for f in sorted(glob.glob('gpurun_out/pmc_mx/p*/*/*counter_collection.csv')):
             acc[r['Counter_Name']].append(float(r['Counter_Value']))
     for k, v in sorted(acc.items()): print("%-36s %16.0f  (%d launches)" % (k, sum(v) / len(v), len(v)))
 for f in sorted(glob.glob('gpurun_out/pmc_mx/p*/*/*kernel_trace.csv')):
-    d = [ (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) for r in csv.DictReader(open(f)) if K in r['Kernel_Name'] and int(r['Grid_Size']) == G ]
+    d = [ (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) for r in csv.DictReader(open(f)) if K in r['Kernel_Name'] and int(r.get('Grid_Size', r.get('Grid_Size_X'))) == G ]
     if d: print("%s: %d launches, avg duration %.1f us" % (f.split('/')[2], len(d), sum(d) / len(d) / 1e3))
 PY
