@@ -384,6 +384,16 @@ def cli_e2e_record(d, base, S, Y, topn, rows, table_gb, lib_tested, lib_col0):
     return best
 
 
+def kernel_source_sha16(src_file):
+    """sha256 over a kernel's source file AND the headers it is compiled from (kernels.h, score_common.h): what a committed
+    PMC profile must have been taken of to be quoted for the kernel that runs now."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in (src_file, "kernels.h", "score_common.h"):
+        h.update(open(os.path.join(ROOT, "kmersgwas_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def cgroup_throttle():
     """(nr_throttled, throttled_usec) of this container's CPU controller, (0, 0) if unreadable."""
     try:
@@ -656,7 +666,7 @@ def main():
         # The profile names the kernel and carries the hash of the kernel source it was taken of: a profile of another
         # kernel, or of an older version of this one, is not used (traffic: null, traffic_stale_profile: true).
         traffic, traffic_src, traffic_stale = None, None, False
-        cands = (["r03_mx_pmc_hbm_traffic.json"] if mx else ["r02_coarse_pmc_hbm_traffic.json", "r01b_coarse_pmc_hbm_traffic.json"]) \
+        cands = (["r04_mx_pmc_hbm_traffic.json", "r03_mx_pmc_hbm_traffic.json"] if mx else ["r02_coarse_pmc_hbm_traffic.json", "r01b_coarse_pmc_hbm_traffic.json"]) \
             if ku == 3 else ["r01a_exactmfma_pmc_hbm_traffic.json"]
         src_file = {"mx_kernel": "score_mx.hip", "coarse_kernel": "score_coarse.hip", "score_mfma_kernel": "score_mfma.hip"}.get(kernel_name)
         for cand in cands:
@@ -667,8 +677,7 @@ def main():
                     if kernel_name not in str(j.get("kernel", kernel_name)):
                         continue
                     if "kernel_source_sha16" in j and src_file:
-                        import hashlib
-                        cur = hashlib.sha256(open(os.path.join(ROOT, "kmersgwas_amd", "csrc", src_file), "rb").read()).hexdigest()[:16]
+                        cur = kernel_source_sha16(src_file)
                         if cur != j["kernel_source_sha16"]:
                             traffic_stale = True
                             continue
@@ -735,6 +744,17 @@ def main():
                      "cores": usable_cpus(), "replay_threads_per_rank": int(stats[-1].get("replay_threads", host_threads)), "logical_cpus": os.cpu_count(),
                      "step_ms": [round(x, 2) for x in (step_ms if len(step_ms) <= 40 else step_ms[:20] + step_ms[-20:])],
                      "step_ms_median": float(np.median(step_ms)), "step_ms_max": float(np.max(step_ms)),
+                     # the steps that took 12 % longer than the median, with what was different in them: the busiest / least
+                     # busy replay worker (a co-tenant on one worker's pinned CPU shows as busiest >> least), the replay's tail
+                     # after the GPU had finished, the dense start, group hand-overs and throttling belong to the host;
+                     # kernels_ms to the GPU
+                     "outlier_steps": [
+                         {"step": i, "ms": round(step_ms[i], 2), "replay_busiest_ms": round(stats[i]["replay_ms"], 2),
+                          "replay_least_busy_ms": round(stats[i]["replay_min_ms"], 2), "replay_tail_ms": round(stats[i]["replay_tail_ms"], 2),
+                          "dense_ms": round(stats[i]["dense_ms"], 2), "gpu_wait_ms": round(stats[i]["gpu_wait_ms"], 2),
+                          "kernels_ms": round(stats[i]["score_kernel_ms"], 2), "group_handovers": int(stats[i]["replay_splits"]),
+                          "columns_popped_ahead": int(stats[i]["columns_popped_ahead"])}
+                         for i in range(len(step_ms)) if step_ms[i] > 1.12 * float(np.median(step_ms))][:12],
                      # cross-shard merge on rank 0's clock (includes waiting for the slowest rank's scan)
                      "merge_ms": [round(x, 2) for x in merge_ms[n_merge_warm:][:40]],
                      "merge_ms_mean": float(np.mean(merge_ms[n_merge_warm:])) if merge_ms[n_merge_warm:] else None,

@@ -78,9 +78,19 @@ uint64_t kgwas_min_count(uint64_t n_acc, double maf, uint64_t mac);
 
 /* ------------------------------------------------------------------------------------
  * BestAssociationsHeap (src/best_associations_heap.h:32-54, .cpp:26-127): bounded min-heap
- * with the reference's strict-'>' replacement, backed by the same std::priority_queue type
- * so that ties resolve identically. Used by the scan for its host-side replay and exposed
- * for cross-shard merges.
+ * with the reference's strict-'>' replacement. NOT a std::priority_queue: csrc/heap.h performs,
+ * by hand, the element moves libstdc++'s std::push_heap / std::pop_heap (__push_heap, __adjust_heap)
+ * make for the reference's comparator (a.score > b.score, src/kmer_general.h:113-128) - on 16-byte
+ * (score, slot) entries, several heaps in lockstep, integer compares where all scores are >= +0 -
+ * so that ties resolve identically: which equal-score entry survives at the boundary and the order
+ * equal scores pop in. The emulation is pinned against a literal std::priority_queue over the
+ * reference's tuple type (oracle/oracle.cpp) on tie-heavy, NaN, negative and +inf streams, in the
+ * CPU suite (tests/test_host.py::test_heap_mirror_equals_oracle_heap_under_ties) and again on the
+ * GPU box (tests/test_gpu_parity.py::test_heap_mirror_equals_std_priority_queue_on_the_gpu_box);
+ * checked against libstdc++ of GCC 11.4 (GLIBCXX_3.4.30), the toolchain of this image and of the
+ * test boxes. A libstdc++ whose heap algorithms move elements differently would fail those tests;
+ * the reference itself would then produce different tie orders with it.
+ * Used by the scan for its host-side replay and exposed for cross-shard merges.
  * ---------------------------------------------------------------------------------- */
 typedef struct kgwas_heap kgwas_heap;
 int kgwas_heap_new(uint64_t max_results, kgwas_heap** out);

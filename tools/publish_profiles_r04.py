@@ -1,0 +1,112 @@
+"""Copy the rocprofv3 summaries tools/collect_profiles_r04.sh left under gpurun_out/prof_r04/ into profiles/ (the
+tracked, judged copies): kernel statistics of the bench workload, the one-column scan and the kinship accumulation, the
+PMC passes of the block-scaled filter's steady launches (HBM traffic, SQ counters, clock) and the bench lines.
+Usage: python tools/publish_profiles_r04.py"""
+import collections, csv, glob, hashlib, json, os
+
+src = "gpurun_out/prof_r04"
+os.makedirs("profiles", exist_ok=True)
+KNAME, GRID, ROWS = "mx_kernel", 2048 * 512, 8388608  # steady launches: 8 388 608 rows, 2048 blocks of 512 threads
+
+
+def one(pattern):
+    return max(glob.glob(os.path.join(src, pattern)), key=os.path.getmtime)
+
+
+def strip_stats(path, out, keep=25):
+    rows = list(csv.DictReader(open(path)))
+    with open(out, "w") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+        for r in rows[:keep]:
+            n = r["Name"]
+            if len(n) > 160:
+                n = n[:60] + " ... " + n[-60:]
+            w.writerow([n, r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
+
+
+strip_stats(one("stats/*/*_kernel_stats.csv"), "profiles/r04_bench_kernel_stats.csv")
+strip_stats(one("p1_stats/*/*_kernel_stats.csv"), "profiles/r04_p1scan_kernel_stats.csv")
+strip_stats(one("kin_stats/*/*_kernel_stats.csv"), "profiles/r04_kinship_kernel_stats.csv")
+for name in ("bench_line", "config4_line", "shard250M_line"):
+    line = [l for l in open(os.path.join(src, name + ".json")) if l.startswith("{")][-1]
+    open("profiles/r04_%s.json" % name, "w").write(line)
+
+
+def counters(path, kname, grid):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if kname in r["Kernel_Name"] and (grid is None or int(r["Grid_Size"]) == grid):
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+
+
+def durations(path, kname, grid):
+    d = []
+    for r in csv.DictReader(open(path)):
+        g = r.get("Grid_Size", r.get("Grid_Size_X"))
+        if kname in r["Kernel_Name"] and (g is None or int(g) == grid):
+            d.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    return d
+
+
+f = counters(one("pmc_fetch/*/*_counter_collection.csv"), KNAME, GRID)["FETCH_SIZE"]
+w = counters(one("pmc_write/*/*_counter_collection.csv"), KNAME, GRID)["WRITE_SIZE"]
+t = 2.0 * f[0] * 1024.0 + w[0] * 1024.0
+import sys
+sys.path.insert(0, ".")
+from bench import kernel_source_sha16
+sha = kernel_source_sha16("score_mx.hip")
+j = {"kernel": KNAME, "kernel_source_sha16": sha,
+     "fetch": {"counter": "FETCH_SIZE", "launches_averaged": f[1], "value_KiB_per_launch": f[0]},
+     "write": {"counter": "WRITE_SIZE", "launches_averaged": w[1], "value_KiB_per_launch": w[0]},
+     "rows_per_launch": ROWS, "algorithmic_bytes_per_launch": ROWS * 136, "traffic_bytes_per_launch": t,
+     "traffic_bytes_per_row": t / ROWS, "traffic_over_algorithmic": t / (ROWS * 136),
+     "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/collect_profiles_r04.sh); counter values "
+             "are KiB; on gfx950 FETCH_SIZE tallies 128-B read requests at 64 B, so HBM-side read bytes = 2 * FETCH_SIZE * 1024 "
+             "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE is taken as is. kernel_source_sha16 = sha256(score_mx.hip + kernels.h + score_common.h)[:16] when the "
+             "profile was taken: bench.py does not use it for another version of the kernel."}
+json.dump(j, open("profiles/r04_mx_pmc_hbm_traffic.json", "w"), indent=1)
+print("traffic / algorithmic = %.3f" % j["traffic_over_algorithmic"])
+
+# the same at 2048 samples x 201 columns (the per-GPU shape of BASELINE configs[3]): the largest launches of the pass
+def largest(path, counter):
+    v = [(float(r["Counter_Value"]), int(r["Grid_Size"])) for r in csv.DictReader(open(path)) if KNAME in r["Kernel_Name"] and r["Counter_Name"] == counter]
+    g = max(x[1] for x in v)
+    big = [x[0] for x in v if x[1] == g]
+    return sum(big) / len(big), len(big), g
+
+
+f3, nf3, g3 = largest(one("pmc_c3_fetch/*/*_counter_collection.csv"), "FETCH_SIZE")
+w3, nw3, _ = largest(one("pmc_c3_write/*/*_counter_collection.csv"), "WRITE_SIZE")
+# rows of those launches: the grid is (row blocks of 4096 rows rounded up to 8) x 5 LDS groups x 768 threads
+rows3 = g3 // 768 // 5 * 4096
+t3 = 2.0 * f3 * 1024.0 + w3 * 1024.0
+json.dump({"kernel": KNAME, "kernel_source_sha16": sha, "shape": "2048 samples x 201 columns (five LDS groups of three column tiles per row block)",
+           "fetch": {"counter": "FETCH_SIZE", "launches_averaged": nf3, "value_KiB_per_launch": f3},
+           "write": {"counter": "WRITE_SIZE", "launches_averaged": nw3, "value_KiB_per_launch": w3},
+           "grid_threads": g3, "rows_per_launch_upper_bound": rows3, "algorithmic_bytes_per_launch_upper_bound": rows3 * 264,
+           "traffic_bytes_per_launch": t3, "traffic_over_algorithmic_lower_bound": t3 / (rows3 * 264),
+           "note": "as r04_mx_pmc_hbm_traffic.json; rows per launch from the grid (row blocks are rounded up to a multiple of 8 per LDS group, so "
+                   "the row count is an upper bound and the ratio a lower bound by less than 0.5 %)"},
+          open("profiles/r04_mx_pmc_hbm_traffic_2048x201.json", "w"), indent=1)
+print("2048 x 201: traffic / algorithmic >= %.3f" % (t3 / (rows3 * 264)))
+
+with open("profiles/r04_mx_pmc_sq_summary.txt", "w") as out:
+    out.write("SQ counters of the steady mx_kernel<7,4,2,4,512> launches (8 388 608 rows, grid 2048 x 512), averages per launch;\n"
+              "ACTIVE_* / WAIT_* / *_CYCLES of the SQ count quad-cycles (4 clocks) per wave or SIMD; SQ_VALU_MFMA_BUSY_CYCLES counts\n"
+              "clocks per SIMD; GRBM_GUI_ACTIVE is summed over the 8 XCDs; two passes, tools/collect_profiles_r04.sh\n")
+    vals = {}
+    for p in ("pmc_sq1", "pmc_sq2"):
+        for k, (v, n) in sorted(counters(one(p + "/*/*_counter_collection.csv"), KNAME, GRID).items()):
+            out.write("%-32s %16.0f  (%d launches)\n" % (k, v, n))
+            vals[k] = v
+    d = durations(one("pmc_sq2/*/*_kernel_trace.csv"), KNAME, GRID)
+    if d and "GRBM_GUI_ACTIVE" in vals:
+        us = sum(d) / len(d) / 1e3
+        clk = vals["GRBM_GUI_ACTIVE"] / 8.0 / us  # MHz
+        out.write("average launch %.1f us under the profiler -> shader clock %.0f MHz (GRBM_GUI_ACTIVE / 8 XCDs / duration)\n" % (us, clk))
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in vals:
+            out.write("matrix pipe busy: %.3f of the SIMD-cycles of the launch (1024 SIMDs x GRBM_GUI_ACTIVE / 8)\n"
+                      % (vals["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * vals["GRBM_GUI_ACTIVE"] / 8.0)))
+print(open("profiles/r04_mx_pmc_sq_summary.txt").read())
