@@ -18,7 +18,11 @@
 //   * the heap is libstdc++'s own std::priority_queue over the same tuple and
 //     comparator types the reference declares (src/kmer_general.h:113-128),
 //     cross-checked against a pure-Python restatement of push_heap/pop_heap;
-//   * hand-derived known answers in tests/golden/known_answers.json.
+//   * hand-derived known answers in tests/golden/known_answers.json;
+//   * implementation-independent top-N answers at production size (tests/exact_topn.py,
+//     tests/golden/exact_topn.json: integer phenotypes, exact rationals rounded once, heap
+//     content decided by integer comparisons) and the kinship closed form, which
+//     tests/test_oracle.py holds this file against.
 //
 // All citations are relative to /root/reference/.
 
