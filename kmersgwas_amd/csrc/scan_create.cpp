@@ -98,9 +98,11 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         s->narrow = want_coarse && p->kernel == KGWAS_KERNEL_AUTO && s->n_pheno <= NARROW_MAX_COLS &&
                     narrow_lds_bytes(n_kgroups) <= 64u * 1024u && !(getenv("KGWAS_NARROW") && atoi(getenv("KGWAS_NARROW")) == 0);
 
-        // (narrow filter on rows read in place: chunks of up to 32 M rows - with one column a chunk's fixed costs, sort,
-        // re-score, threshold update, weigh more than the candidates a staler threshold lets through)
-        s->chunk_max = p->chunk_rows ? p->chunk_rows : ((s->narrow && s->direct) ? (32ull << 20) : (8ull << 20));
+        // (narrow filter on rows read in place: chunks of up to 128 M rows - with one column a chunk's fixed costs, five
+        // launches and a copy with the gaps between them, ~40 us, weigh more than the candidates a staler threshold lets
+        // through. 1.2 G rows x 1024 samples, one column: cap 32 M rows 49 chunks 30.8 ms, 64 M 33 / 30.0, 128 M 25 / 29.8,
+        // 256 M 21 / 29.7 - identical heaps, tools/p1_large_chunks.py)
+        s->chunk_max = p->chunk_rows ? p->chunk_rows : ((s->narrow && s->direct) ? (128ull << 20) : (8ull << 20));
         s->chunk_max = std::max<uint64_t>(128, (s->chunk_max + 127) / 128 * 128);
         if (s->coarse) {  // survivor keys are (column << row_bits | row) in 32 bits, the 0xFFFFFFFF fill included
             uint32_t pbits = 1;

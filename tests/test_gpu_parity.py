@@ -1006,6 +1006,44 @@ def test_exact_rational_topn_through_the_production_kernels(monkeypatch, name, m
     scan.close()
 
 
+@pytest.mark.parametrize("name,path", [("s241_p24", "file"), ("s241_p24", "shards"), ("s1135_p2", "file"), ("s1135_p40", "shards")])
+def test_exact_rational_topn_through_file_ingest_and_row_shards(monkeypatch, tmp_path, name, path):
+    """The same implementation-independent expectations through the callers either side of the scan: the .table file streamed
+    by kgwas_scan_feed_table in small pinned pieces (three feeds, a ragged last piece), and kgwas_multiscan_* - the table cut
+    into three / five contiguous row shards inside one process, each with its own session, merged by replaying the later
+    shards' filtered push histories (what `associate_kmers --gpus N` runs)."""
+    import exact_topn as ex
+    rows, Y, mac, topn, exp, tested, fx = _exact_case(name)
+    S, P = Y.shape[1], Y.shape[0]
+    base = str(tmp_path / "t")
+    onp.write_table(base, ["a%d" % i for i in range(S)], 31, rows[:, 0], rows[:, 1:])
+    tbl = kg.KmersTable(base, 31)
+    col = np.arange(S, dtype=np.uint64)
+    if path == "file":
+        monkeypatch.setenv("KGWAS_INGEST_PIECE_ROWS", "30011")
+        scan = kg.AssociationScan(S, col, Y, topn, mac)
+        scan.feed_table(tbl, 0, 70_000)
+        scan.feed_table(tbl, 70_000, 1)
+        scan.expect_finish()
+        scan.feed_table(tbl, 70_001, len(rows) - 70_001)
+        scan.finish()
+        st = scan.stats()
+        assert st["rows_tested"] == tested and st["coarse_launches"] > 0
+        res = [scan.result(j) for j in range(P)]
+        scan.close()
+    else:
+        ms = kg.MultiDeviceScan(S, col, Y, topn, mac, devices=[0] * (3 if P > 30 else 5), chunk_rows=16384)
+        ms.run_table(tbl, 0, len(rows))
+        ms.finish()
+        assert ms.stats()["rows_tested"] == tested
+        res = [ms.result(j) for j in range(P)]
+        ms.close()
+    for j in range(P):
+        k, s, r = res[j]
+        ex.compare((r, k, s), exp[j])
+    tbl.close()
+
+
 @pytest.mark.parametrize("name", ["kin_s241", "kin_s1135"])
 def test_kinship_equals_closed_form_fixture(name):
     """kin_transpose_kernel + kin_gram_kernel against K_ij = n - c_i - c_j + 2 c_ij computed with NumPy integers
