@@ -1,6 +1,7 @@
 // scan_create.cpp — kgwas_scan_create: validation, the constant device data of a session (phenotype layouts of the exact
 // scorers, the operand sets and error bounds of the filters: block-scaled FP4 x FP6/FP4, int8, narrow), buffers and slots.
 #include "scan_internal.h"
+#include <chrono>
 
 extern "C" {
 
@@ -127,7 +128,14 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         uint64_t cap = std::min<uint64_t>(cap_mult * s->max_topn + 4096, std::max<uint64_t>(budget / s->n_pheno, 1024));
         s->cap = (uint32_t)std::min<uint64_t>(cap, 0x7FFFFFFFull);
 
+        const bool trace_create = getenv("KGWAS_TRACE") != nullptr;
+        const auto tc0 = std::chrono::steady_clock::now();
+        auto tcreate = [&](const char* what) {
+            if (trace_create)
+                fprintf(stderr, "[kgwas] scan_create +%.1f ms: %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count(), what);
+        };
         KGWAS_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+        tcreate("stream created (HIP context up)");
         KGWAS_HIP(hipEventCreate(&s->ev_user));
         KGWAS_HIP(hipEventCreate(&s->ev_ds));
         KGWAS_HIP(hipEventCreate(&s->ev_d0));
@@ -849,6 +857,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                 s->st.coarse_mode_tile_slices[mi] = M.tile_slices;
                 M.ready = true;
             }
+            tcreate("operand sets built and uploaded");
             s->key_slots = (uint32_t)std::min<uint64_t>((uint64_t)s->cap * P, 0x7FFFFFFFull);
             s->d_surv_sorted.alloc(s->key_slots);
             s->bitmap_words = (s->chunk_max + 63) / 64;
@@ -881,11 +890,20 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                 // device side: 20 B x key_slots of HBM per slot, up to 4 GiB in all; host side: the record ring
                 const uint64_t slot_bytes = (uint64_t)s->key_slots * 20;
                 s->n_slots = (int)std::min<uint64_t>(MAX_SLOTS, std::max<uint64_t>(4, (4ull << 30) / std::max<uint64_t>(slot_bytes, 1)));
-                s->ring_size = (size_t)std::max<uint64_t>(std::min<uint64_t>(1ull << 30, (uint64_t)s->n_slots * slot_bytes), 2 * slot_bytes + 4096);
+                // Pinning memory is slow - 1 GiB takes 0.21-0.25 s, two thirds of a session's creation (KGWAS_TRACE), and every
+                // other allocation of the process queues behind it, so a thread of its own does not hide it: the ring is sized
+                // for what the scan plans to have in flight instead of the cap. A chunk is planned to fill 40 % of the key list
+                // (next_sparse_chunk) and the GPU runs up to ~16 chunks ahead of the replay: 20 planned chunks' records
+                // (8 x a slot's worst case), at least 64 MiB and two worst-case chunks, at most 1 GiB - 390 MB at 101 columns
+                // (top-10001), 775 MB at 201. A ring that fills up only makes the GPU wait for the replay (fetch_records).
+                s->ring_size = (size_t)std::max<uint64_t>(std::min<uint64_t>(1ull << 30, std::min<uint64_t>((uint64_t)s->n_slots * slot_bytes, std::max<uint64_t>(64ull << 20, 8 * slot_bytes))),
+                                                          2 * slot_bytes + 4096);
                 // (tests: a ring barely larger than one chunk's worst case, so that it wraps and fills up)
                 if (getenv("KGWAS_RING_BYTES"))
                     s->ring_size = (size_t)std::max<uint64_t>(strtoull(getenv("KGWAS_RING_BYTES"), nullptr, 10), slot_bytes + 4096);
+                tcreate("device buffers and slots allocated");
                 s->ring.alloc(s->ring_size);
+                tcreate("pinned record ring allocated");
             } else {
                 const uint64_t slot_bytes = (uint64_t)s->cap * P * sizeof(Cand);
                 s->n_slots = (int)std::min<uint64_t>(16, std::max<uint64_t>(4, (1ull << 30) / std::max<uint64_t>(slot_bytes, 1)));
@@ -929,6 +947,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         s->hist.resize(P);
         s->keys.resize(P);
         s->col_ms.assign(P, 0.0);
+        tcreate("buffers done");
         s->trace = getenv("KGWAS_TRACE") != nullptr;
         unsigned nt = p->host_threads ? p->host_threads : usable_cpus();
         if (const char* e = getenv("KGWAS_HOST_THREADS"))
@@ -992,6 +1011,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         }
         s->st.kernel_used = s->narrow ? (uint32_t)KGWAS_KERNEL_NARROW : s->coarse ? (uint32_t)KGWAS_KERNEL_COARSE : kern;
         s->st.direct_mode = s->direct ? 1 : 0;
+        tcreate("pool, heaps and arena ready");
         *out = s.release();
     });
 }

@@ -40,7 +40,7 @@ try:
         wall = time.perf_counter() - t0
         print("run %d: rc %d wall %.3f s" % (rep, r.returncode, wall))
         for l in r.stderr.splitlines():
-            if "seconds:" in l or "write_plink_many" in l:
+            if "seconds:" in l or "write_plink_many" in l or "scan_create" in l:
                 print("   ", l)
 finally:
     shutil.rmtree(d, ignore_errors=True)
