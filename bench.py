@@ -346,7 +346,6 @@ def cli_e2e_record(d, base, S, Y, topn, rows, table_gb, lib_tested, lib_col0):
     streamed through the GPU), finish (heaps popped) and output (all columns' .bed/.bim/.fam by kgwas_write_plink_many).
     Checked: .tested_kmers and column 0's .bim (k-mers and ranks, in row order) against the library scan of the same file."""
     import subprocess
-    from oracle import binding as ob
     P = Y.shape[0]
     pheno = os.path.join(d, "p.pheno")
     with open(pheno, "w") as f:
@@ -374,7 +373,9 @@ def cli_e2e_record(d, base, S, Y, topn, rows, table_gb, lib_tested, lib_col0):
     k, sc, rw = lib_col0
     n = len(k)
     order = np.argsort(rw, kind="stable")
-    want = ["%s_%d" % (ob.bits2kmer(int(k[i]), 31), n - int(i)) for i in order]
+    def kmer_text(w, klen=31):  # bits2kmer31 (src/kmer_general.cpp:77-87): two bits per base, most significant first
+        return "".join("ACGT"[(w >> (2 * (klen - 1 - i))) & 3] for i in range(klen))
+    want = ["%s_%d" % (kmer_text(int(k[i])), n - int(i)) for i in order]
     got = [l.split("\t")[1] for l in open(os.path.join(outdir, "run.0.perm0.bim")).read().splitlines()]
     bed_ok = all(os.path.getsize(os.path.join(outdir, "run.%d.perm%d.bed" % (j, j))) == 3 + topn * ((S + 3) // 4) for j in range(P))
     best.update({"command": "associate_kmers -p <101 columns> -n %d --parallel 1 --kmers_table <%dM x %d .table, page cache> --maf 0.05 --mac 5" % (topn, rows // 1_000_000, S),
