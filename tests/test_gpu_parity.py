@@ -1148,3 +1148,14 @@ def test_more_than_5120_samples_leave_the_filters(S, P):
     _check_topn(scan, exp, P)
     assert st["rows_tested"] == exp["tested"]
     scan.close()
+
+
+def test_random_scans_equal_the_oracle():
+    """tools/fuzz_parity.py for half a minute with a fixed seed: random shapes, heap sizes, chunk sizes, feeds, column subsets,
+    tie densities, phenotype kinds (subnormal, near the chain-overflow gate, one-hot ...) and filter forms, each scan compared
+    with the oracle (identities, score bytes, push and tested counts). Longer runs: python tools/fuzz_parity.py <seconds> <seed>."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "30", "20240601"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "random scans equal the oracle's" in r.stdout

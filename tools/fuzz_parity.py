@@ -22,7 +22,7 @@ while time.time() < t_end:
     topn = int(rng.choice([1, 2, 7, 64, 301, 1000, 5000]))
     chunk = int(rng.choice([0, 128, 1024, 4096, 8192, 65536]))
     dup = float(rng.choice([0.0, 0.0, 0.2, 0.6]))
-    kind = str(rng.choice(["normal", "binary", "shifted", "heavy", "tiny", "ints"]))
+    kind = str(rng.choice(["normal", "binary", "shifted", "heavy", "tiny", "ints", "subnormal", "near_overflow", "onehot"]))
     kernel = int(rng.choice([kg.KERNEL_AUTO, kg.KERNEL_AUTO, kg.KERNEL_COARSE, kg.KERNEL_MFMA, kg.KERNEL_VALU]))
     env = {"KGWAS_COARSE_MX": str(rng.choice(["", "0", "1"])), "KGWAS_MX32": str(rng.choice(["0", "0", "2"])),
            "KGWAS_COARSE_SLICES": str(rng.choice(["", "", "1", "2"]))}
@@ -36,6 +36,13 @@ while time.time() < t_end:
     if kind == "heavy": Y = Y.copy(); Y[:, 0] += np.float32(50.0)
     if kind == "tiny": Y = (Y * np.float32(1e-30)).astype(np.float32)
     if kind == "ints": Y = np.round(Y * 20).astype(np.float32)
+    if kind == "subnormal": Y = (Y * np.float32(rng.choice([1e-38, 1e-41, 1e-44]))).astype(np.float32)
+    if kind == "near_overflow":  # sum |y| of a column between 0.3 and 3 x FLT_MAX: on both sides of the filters' gate
+        a = np.abs(Y.astype(np.float64)).sum(axis=1).max()
+        Y = (Y.astype(np.float64) * (float(rng.uniform(0.3, 3.0)) * 3.4e38 / max(a, 1e-30))).astype(np.float32)
+        Y[~np.isfinite(Y)] = np.float32(3e38)
+    if kind == "onehot":
+        Y = Y.copy(); Y[0] = 0; Y[0, int(rng.integers(S))] = np.float32(2.5)
     Y = np.ascontiguousarray(Y, np.float32)
     mac = onp.min_count(S, 0.05, 5) if S >= 100 else 1
     desc = dict(S_f=S_f, S=S, P=P, n_rows=n_rows, topn=topn, chunk=chunk, dup=dup, kind=kind, kernel=kernel, env=env, reorder=bool(reorder))
