@@ -265,7 +265,7 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
         a.thr = s->d_thr_redo.p;
     }
     const bool use_coarse = s->coarse && count_hist;
-    KGWAS_HIP(hipEventRecord(sl.ev_sq0, s->stream));
+    if (!s->direct) KGWAS_HIP(hipEventRecord(sl.ev_sq0, s->stream));  // (only read when rows are squeezed: an event costs the stream ~5 us)
     maybe_squeeze(s, d_rows, n_rows);
     KGWAS_HIP(hipEventRecord(sl.ev_k0, s->stream));
     {
