@@ -361,7 +361,65 @@ class alignas(128) BestHeap {
     inline void note_rejected(uint64_t n = 1) { inserted_ += n; }
 
     // output_to_file_with_scores order (:82-92): ascending pops from a copy.
+    // The pop sequence WITHOUT popping, where the scores alone decide it: if every score is +0 .. +inf (ints_ok_) and no
+    // two entries share one, N pops yield the entries in ascending score order whatever the array's layout - a heap's pop
+    // order can only depend on the layout among EQUAL scores. The entries' bit patterns are radix-sorted (11-bit digits,
+    // digits in which all keys agree skipped: the top-N of a scan share sign, exponent and often the leading mantissa
+    // bits) and neighbours compared; on the first equal pair the function gives up (false, outputs untouched) and the
+    // caller pops for real. 10 001 entries: ~0.1 ms against 0.5 ms of pops alone, 0.27 in 8-way lockstep.
+    bool pop_all_sorted(std::vector<uint64_t>& kmer, std::vector<double>& score, std::vector<uint64_t>& row) const {
+        if (!ints_ok_) return false;
+        const size_t n = v_.size();
+        struct Key {
+            uint64_t bits;
+            uint32_t slot;
+        };
+        // (scratch kept per thread: two fresh 160 KB vectors per call are two mmaps' worth of page faults, a third of the call)
+        static thread_local std::vector<Key> a, b;
+        if (a.size() < n) a.resize(n), b.resize(n);
+        uint64_t all_or = 0, all_and = ~0ull;
+        for (size_t i = 0; i < n; i++) {
+            uint64_t x;
+            memcpy(&x, &v_[i].score, 8);
+            a[i] = Key{x, v_[i].slot};
+            all_or |= x;
+            all_and &= x;
+        }
+        const uint64_t varying = all_or ^ all_and;  // bits in which at least two keys differ
+        Key* src = a.data();
+        Key* dst = b.data();
+        for (int shift = 0; shift < 64; shift += 11) {
+            if (((varying >> shift) & 0x7FFull) == 0) continue;
+            uint32_t cnt[2048] = {0};
+            for (size_t i = 0; i < n; i++) cnt[(src[i].bits >> shift) & 0x7FFu]++;
+            uint32_t run = 0;
+            for (int d = 0; d < 2048; d++) {
+                const uint32_t c = cnt[d];
+                cnt[d] = run;
+                run += c;
+            }
+            for (size_t i = 0; i < n; i++) dst[cnt[(src[i].bits >> shift) & 0x7FFu]++] = src[i];
+            std::swap(src, dst);
+        }
+        for (size_t i = 1; i < n; i++)
+            if (src[i].bits == src[i - 1].bits) return false;  // a tie: its pop order is the layout's business
+        kmer.resize(n);
+        score.resize(n);
+        row.resize(n);
+        for (size_t i = 0; i < n; i++) {
+            memcpy(&score[i], &src[i].bits, 8);
+            kmer[i] = pay_[src[i].slot].kmer;
+            row[i] = pay_[src[i].slot].row;
+        }
+        return true;
+    }
+
     void pop_all(std::vector<uint64_t>& kmer, std::vector<double>& score, std::vector<uint64_t>& row) const {
+        if (pop_all_sorted(kmer, score, row)) return;
+        pop_all_classic(kmer, score, row);
+    }
+    // N pops on a copy of the array, with std::pop_heap's moves
+    void pop_all_classic(std::vector<uint64_t>& kmer, std::vector<double>& score, std::vector<uint64_t>& row) const {
         std::vector<Ent> tmp(v_.begin(), v_.end());
         const size_t n = tmp.size();
         kmer.resize(n);
@@ -409,10 +467,34 @@ class alignas(128) BestHeap {
     // K heaps of equal size() (1 <= K <= 8): pop_all of each, in lockstep; integer compares if all of them allow it
     static void pop_all_n(int K, const BestHeap* const* hp, std::vector<uint64_t>* const* kmer, std::vector<double>* const* score,
                           std::vector<uint64_t>* const* row) {
+        {  // heaps whose scores decide the order are sorted, not popped; the rest (ties, NaN, negative scores) go on in lockstep
+            const BestHeap* rest_h[8];
+            std::vector<uint64_t>* rest_k[8];
+            std::vector<double>* rest_s[8];
+            std::vector<uint64_t>* rest_r[8];
+            int R = 0;
+            for (int k = 0; k < K; k++)
+                if (!hp[k]->pop_all_sorted(*kmer[k], *score[k], *row[k])) {
+                    rest_h[R] = hp[k];
+                    rest_k[R] = kmer[k];
+                    rest_s[R] = score[k];
+                    rest_r[R] = row[k];
+                    R++;
+                }
+            if (R == 0) return;
+            if (R < K) {
+                pop_all_lockstep(R, rest_h, rest_k, rest_s, rest_r);
+                return;
+            }
+        }
+        pop_all_lockstep(K, hp, kmer, score, row);
+    }
+    static void pop_all_lockstep(int K, const BestHeap* const* hp, std::vector<uint64_t>* const* kmer, std::vector<double>* const* score,
+                                 std::vector<uint64_t>* const* row) {
         bool ints = true;
         for (int k = 0; k < K; k++) ints = ints && hp[k]->ints_ok_;
         if (K == 1) {
-            hp[0]->pop_all(*kmer[0], *score[0], *row[0]);
+            hp[0]->pop_all_classic(*kmer[0], *score[0], *row[0]);
             return;
         }
 #define KGWAS_POP_CASE(N)                                                                       \

@@ -130,13 +130,19 @@ def test_min_count_matches_the_reference_rule():
 
 @pytest.mark.parametrize("N,n,levels", [(1, 60, 3), (2, 100, 3), (3, 200, 2), (10, 500, 4), (64, 4000, 9), (200, 150, 5), (33, 3000, 2),
                                         (1000, 30000, 40), (1001, 30000, 2000)])
-@pytest.mark.parametrize("flavour", ["nan", "plain", "negative"])
+@pytest.mark.parametrize("flavour", ["nan", "plain", "negative", "distinct", "one_tie"])
 def test_heap_mirror_equals_oracle_heap_under_ties(N, n, levels, flavour):
     """(plain: scores in +0 .. +inf, the heap compares their bit patterns as integers; nan / negative: it must notice
-    and compare as doubles)"""
+    and compare as doubles; distinct: no two scores equal - the pop sequence is then produced by sorting, not popping;
+    one_tie: distinct but for ONE pair of equal scores among the largest - sorting must give up and pop for real)"""
     rng = np.random.default_rng(N * 31 + n)
     k = np.arange(n, dtype=np.uint64) + 7
     s = rng.integers(0, levels, size=n).astype(np.float64) / 8.0
+    if flavour in ("distinct", "one_tie"):
+        s = rng.permutation(n).astype(np.float64) * 0.37 + rng.random(n) * 0.1  # all different
+        if flavour == "one_tie" and n >= 4:
+            top = np.argsort(s)[-min(N, n):]
+            s[top[0]] = s[top[-1]]  # the weakest entry that stays gets the best one's score
     if flavour == "nan":
         s[rng.random(n) < 0.01] = np.nan
     elif flavour == "negative":
