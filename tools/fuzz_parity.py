@@ -1,6 +1,7 @@
 """Randomised parity runs of the scan against the oracle (diagnostics; the fixed cases live in tests/): random accession
 counts, column counts, heap sizes, chunk sizes, feeds, column subsets / orders, tie densities, phenotype kinds, filter forms.
-   python tools/fuzz_parity.py [seconds=240] [seed=1]      (needs a GPU)"""
+   python tools/fuzz_parity.py [seconds=240] [seed=1] [big]     (needs a GPU)
+"big": tables of 0.3-3 M rows (many chunks in flight, record-ring wrap, group splits, popping ahead) instead of 200-60 000."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -11,6 +12,7 @@ from helpers import random_table, phenotypes
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+BIG = len(sys.argv) > 3 and sys.argv[3] == "big"
 t_end = time.time() + budget
 n_ok = 0
 while time.time() < t_end:
@@ -21,6 +23,13 @@ while time.time() < t_end:
     n_rows = int(rng.integers(200, 60_000))
     topn = int(rng.choice([1, 2, 7, 64, 301, 1000, 5000]))
     chunk = int(rng.choice([0, 128, 1024, 4096, 8192, 65536]))
+    if BIG:
+        S_f = int(rng.choice([241, 512, 1024, 1135, 2048]))
+        S = S_f if not reorder else int(rng.integers(S_f // 2, S_f + 1))
+        P = int(rng.choice([1, 3, 4, 16, 40, 101]))
+        n_rows = int(rng.integers(300_000, 3_000_000) * (1.0 if P <= 16 else 0.4))
+        topn = int(rng.choice([301, 5000, 10001]))
+        chunk = int(rng.choice([0, 0, 65536, 262144]))
     dup = float(rng.choice([0.0, 0.0, 0.2, 0.6]))
     kind = str(rng.choice(["normal", "binary", "shifted", "heavy", "tiny", "ints", "subnormal", "near_overflow", "onehot"]))
     kernel = int(rng.choice([kg.KERNEL_AUTO, kg.KERNEL_AUTO, kg.KERNEL_COARSE, kg.KERNEL_MFMA, kg.KERNEL_VALU]))
@@ -48,7 +57,7 @@ while time.time() < t_end:
     desc = dict(S_f=S_f, S=S, P=P, n_rows=n_rows, topn=topn, chunk=chunk, dup=dup, kind=kind, kernel=kernel, env=env, reorder=bool(reorder))
     try:
         if kernel == kg.KERNEL_MFMA and S > 2600: kernel = kg.KERNEL_AUTO
-        exp = ob.associate(rows, S_f, col, Y, topn, mac, batch_size=int(rng.integers(100, 20000)), threads=4)
+        exp = ob.associate(rows, S_f, col, Y, topn, mac, batch_size=int(rng.integers(100, 20000)), threads=16 if BIG else 4)
         scan = kg.AssociationScan(S_f, col, Y, topn, mac, kernel=kernel, chunk_rows=chunk, host_threads=int(rng.choice([0, 1, 3, 8])))
         cuts = sorted(set([0, n_rows] + [int(x) for x in rng.integers(0, n_rows + 1, size=int(rng.integers(0, 3)))]))
         for lo, hi in zip(cuts[:-1], cuts[1:]):
