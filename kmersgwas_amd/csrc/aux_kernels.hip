@@ -178,6 +178,31 @@ hipError_t launch_dense_select(const double* dense, const uint32_t* n1, uint32_t
     return hipGetLastError();
 }
 
+// A chunk's records (three arrays) from their slot in HBM to their place in the pinned, mapped record ring, written by
+// the GPU itself in ONE launch (three hipMemcpyAsync calls: three blits or SDMA transfers, and beside a streamed feed's
+// 128 MiB host -> device pieces their completion came 2 ms late, scan_gpu.cpp fetch_records).
+__global__ void __launch_bounds__(256) records_to_host_kernel(const unsigned long long* __restrict__ sc, const unsigned long long* __restrict__ km,
+                                                              const uint32_t* __restrict__ rw, uint32_t n, unsigned long long* __restrict__ h_sc,
+                                                              unsigned long long* __restrict__ h_km, uint32_t* __restrict__ h_rw) {
+    const uint32_t step = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+        h_sc[i] = sc[i];
+        h_km[i] = km[i];
+        h_rw[i] = rw[i];
+    }
+}
+
+hipError_t launch_records_to_host(const double* sc, const uint64_t* km, const uint32_t* rw, uint32_t n, double* h_sc, uint64_t* h_km, uint32_t* h_rw,
+                                  hipStream_t st) {
+    if (!n) return hipSuccess;
+    static const uint32_t max_blocks = getenv("KGWAS_RECORD_BLOCKS") ? (uint32_t)atoi(getenv("KGWAS_RECORD_BLOCKS")) : 64u;  // experiments (8 to 512 blocks: the same rates; few blocks leave the CUs to the filter)
+    const uint32_t blocks = std::min<uint32_t>((n + 255u) / 256u, std::max(1u, max_blocks));
+    hipLaunchKernelGGL(records_to_host_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const unsigned long long*>(sc),
+                       reinterpret_cast<const unsigned long long*>(km), rw, n, reinterpret_cast<unsigned long long*>(h_sc),
+                       reinterpret_cast<unsigned long long*>(h_km), h_rw);
+    return hipGetLastError();
+}
+
 hipError_t launch_thr_update(const uint32_t* hist, const uint32_t* hist_base, uint32_t bins, const uint64_t* topn,
                              const double* thr_host, double* thr, uint32_t n_pheno, hipStream_t st) {
     if (n_pheno == 0 || bins % 256u) return hipErrorInvalidValue;

@@ -2,13 +2,22 @@
 // (replaces the reference's load-a-batch-then-compute loops,
 // src/associate_kmers.cpp:104-148 and src/emma_kinship_kmers.cpp:86-99).
 //
-// Three pinned pieces are filled by producer threads, three device pieces receive them on a copy stream, and the
-// consumer works on piece k while pieces k+1 and k+2 are copied / queued for copying and produced: the consumer's
-// call is synchronous (a piece's scan + replay), and with only two device pieces the copy of piece k+2 could not be
-// queued before it returned - the link idled for the consumer's fixed costs of every piece (43 -> ~50 GB/s). The
-// consumer sees the rows in order, so results do not depend on the piece size.
+// A ring of pinned pieces is filled by producer threads, a ring of device pieces receives them on a copy stream (queued
+// by a copier thread as soon as a piece is filled and a device piece is free), and the consumer works on piece k while
+// the pieces behind it are copied: its call is synchronous (a piece's scan + replay), and the copies must not wait for
+// it (two device pieces: 43 GB/s; three, queued between the consumer's calls: 48; ten and the copier: see run()). A PINNED piece
+// is free again when its copy has completed, not when the consumer is through with the rows: the producers run up to
+// pinned_pieces_ ahead of the last copy that was queued and wait for the copy event of the piece they overwrite (with
+// three pinned pieces tied to the consumer's progress, they could only ever work on ONE piece, and every piece ended
+// with most of them idle behind its last sub-piece). The consumer sees the rows in order, so results do not depend
+// on any of these sizes.
 #pragma once
+#include <pthread.h>
+#include <sched.h>
+
+#include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <functional>
 #include <mutex>
@@ -64,11 +73,13 @@ public:
     // (runs on a producer thread, up to two pieces ahead of the consumer).
     using Fill = std::function<void(uint64_t*, uint64_t, uint64_t)>;
     // consume(d_rows, row_off, cnt): work on a device piece; `stream` already waits for its copy. Must return with
-    // the work on the piece complete (the device buffer is reused three pieces later: three device pieces are in flight).
+    // the work on the piece complete (the device buffer is reused device_pieces_ pieces later).
     using Consume = std::function<void(const uint64_t*, uint64_t, uint64_t)>;
 
     ~Ingest() {
         for (auto& e : ev_)
+            if (e) (void)hipEventDestroy(e);
+        for (auto& e : ev_h_)
             if (e) (void)hipEventDestroy(e);
         if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
     }
@@ -83,7 +94,17 @@ public:
                 if (atoll(e) > 0) pr = (uint64_t)atoll(e);
             pr = std::max<uint64_t>(128, std::min<uint64_t>(pr, max_piece_rows) / 128 * 128);
             piece_rows_ = pr;
+            if (const char* e = getenv("KGWAS_INGEST_PINNED"))
+                if (atoi(e) >= 2 && atoi(e) <= 16) pinned_pieces_ = (unsigned)atoi(e);
+            h_.resize(pinned_pieces_);
+            ev_h_.assign(pinned_pieces_, nullptr);
             for (auto& h : h_) h.alloc(pr * stride);
+            // (blocking: a producer that has to wait for a copy sleeps; the replay workers share its CPU)
+            for (auto& e : ev_h_) KGWAS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync));
+            if (const char* e = getenv("KGWAS_INGEST_DEVICE"))
+                if (atoi(e) >= 2 && atoi(e) <= 64) device_pieces_ = (unsigned)atoi(e);
+            d_.resize(device_pieces_);
+            ev_.assign(device_pieces_, nullptr);
             for (auto& d : d_) d.alloc(pr * stride);
             KGWAS_HIP(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
             for (auto& e : ev_) KGWAS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -97,29 +118,45 @@ public:
         // A piece is filled in SUB-PIECES of 16 MiB by several producer threads at once (a single thread tops out near
         // 15 GB/s reading the page cache and 28 GB/s copying memory; one thread per 128 MiB piece, the first version, kept
         // at most three of them busy and delivered 27 / 42 GB/s). Items are handed out in order; a piece may be started
-        // while it is less than three pieces ahead of the consumer (three pinned buffers).
-        const uint64_t sub_rows = std::max<uint64_t>(128, std::min<uint64_t>(piece, ((16ull << 20) / (8 * stride)) / 128 * 128));
+        // once the copy of the piece whose pinned buffer it takes has been queued (its producers then wait for that copy).
+        static const uint64_t sub_mib = getenv("KGWAS_INGEST_SUB_MIB") && atoi(getenv("KGWAS_INGEST_SUB_MIB")) > 0 ? (uint64_t)atoi(getenv("KGWAS_INGEST_SUB_MIB")) : 4u;
+        const uint64_t sub_rows = std::max<uint64_t>(128, std::min<uint64_t>(piece, ((sub_mib << 20) / (8 * stride)) / 128 * 128));
+        const uint64_t NH = pinned_pieces_;
         auto subs_of = [&](uint64_t k) { return (count_of(k) + sub_rows - 1) / sub_rows; };
-        uint64_t next_piece = 0, next_sub = 0, consumed = 0;  // next item to produce / pieces whose buffers may be overwritten
+        uint64_t next_piece = 0, next_sub = 0, queued = 0;  // next item to produce / copies queued
         std::vector<uint32_t> left(n_pieces);  // sub-pieces of a piece still to be filled
         for (uint64_t k = 0; k < n_pieces; k++) left[k] = (uint32_t)subs_of(k);
         std::vector<char> done(n_pieces, 0);
         bool stop = false;
-        std::string producer_error;
+        std::string producer_error, copier_error;
+        uint64_t consumed = 0;  // pieces the consumer has returned from
         auto producer_main = [&] {
+            {
+                // The producers share their CPUs with the consumer's pinned replay workers, which wake up for a fraction of a
+                // millisecond per piece and must not wait out a copying thread's time slice: SCHED_IDLE gives way at once.
+                static const int pol = getenv("KGWAS_INGEST_SCHED") ? atoi(getenv("KGWAS_INGEST_SCHED")) : 1;  // experiments: 0 = leave as is
+                if (pol) {
+                    struct sched_param sp;
+                    sp.sched_priority = 0;
+                    (void)pthread_setschedparam(pthread_self(), SCHED_IDLE, &sp);
+                }
+            }
             try {
                 for (;;) {
                     uint64_t k, j;
                     {
                         std::unique_lock<std::mutex> lk(mu);
-                        cv.wait(lk, [&] { return stop || next_piece >= n_pieces || next_piece < consumed + 3; });
+                        cv.wait(lk, [&] { return stop || next_piece >= n_pieces || next_piece < queued + NH; });
                         if (stop || next_piece >= n_pieces) return;
                         k = next_piece;
                         j = next_sub++;
                         if (next_sub >= subs_of(k)) next_piece++, next_sub = 0;
                     }
+                    // the copy of piece k - NH out of this pinned buffer (queued: see the wait above; the event is recorded
+                    // again only for piece k itself, after every one of its sub-pieces is in)
+                    if (k >= NH) KGWAS_HIP(hipEventSynchronize(ev_h_[k % NH]));
                     const uint64_t r0 = j * sub_rows, cnt = std::min<uint64_t>(sub_rows, count_of(k) - r0);
-                    fill(h_[k % 3].p + r0 * stride, k * piece + r0, cnt);
+                    fill(h_[k % NH].p + r0 * stride, k * piece + r0, cnt);
                     bool last;
                     {
                         std::unique_lock<std::mutex> lk(mu);
@@ -152,12 +189,13 @@ public:
             }
         } joiner{producers, mu, cv, stop};
         {
-            // producer threads: a share of the CPUs this process may use (the replay workers of the consumer need the
-            // rest; a streamed scan is bound by the producers and the link, not by the replay)
-            // (measured on 16 quota CPUs, 40 M rows x 1135 samples from the page cache: 5 producers 41.8 GB/s, 8 35.6, 12 31.7)
-            // reading the page cache (the kernel's copy, ~8 GB/s per thread) takes more threads than copying memory:
-            // half of the CPUs for a file feed (8 of 16: 40.8 GB/s; 5: 35 GB/s), a third for a memory feed
-            uint64_t nt = file_feed_ ? std::max(3u, std::min(8u, producer_cpus_ / 2)) : std::max(3u, std::min(6u, producer_cpus_ / 3));
+            // producer threads: a third of the CPUs this process may use (the replay workers of the consumer need the rest; a
+            // streamed scan is bound by the link once the producers deliver ~57 GB/s). Round 4, 16 quota CPUs, 40 M rows x
+            // 1024 samples: memory feeds 100 ms with anything from 4 to 12 threads; page-cache feeds (the kernel's copy,
+            // ~10 GB/s a thread) 102-105 ms with 5 threads, 101-122 with 8, 117-119 with 10 or 16 - more copying threads only
+            // get in each other's and the replay's way. (Round 3 measured 8 threads best for files: the bound then was the
+            // record copies' late completion, see scan_gpu.cpp fetch_records, not the producers.)
+            uint64_t nt = std::max(3u, std::min(6u, producer_cpus_ / 3));
             if (const char* e = getenv("KGWAS_INGEST_THREADS"))
                 if (atoi(e) > 0) nt = (uint64_t)atoi(e);
             uint64_t items = 0;
@@ -165,40 +203,87 @@ public:
             for (uint64_t i = 0; i < std::min<uint64_t>(nt, items); i++) producers.emplace_back(producer_main);
         }
 
-        auto compute = [&](uint64_t k) {
-            KGWAS_HIP(hipStreamWaitEvent(stream, ev_[k % 3], 0));
-            consume(d_[k % 3].p, k * piece, count_of(k));
+        // The copier: queues piece k's copy as soon as the producers are through with it and device piece k % ND is free (the
+        // consumer has returned from piece k - ND). A thread of its own, because the consumer's call is synchronous and the
+        // FIRST piece's takes 15 ms at 101 columns (the heaps fill, and most of a scan's pushes belong to its first rows):
+        // with the copies queued between the consumer's calls, the link stood still for 14 of those 15 ms - an eighth of a
+        // 40 M-row feed. Device pieces are cheap (128 MiB of 288 GB each), so there are enough of them to copy through it.
+        const uint64_t ND = d_.size();
+        int dev = 0;
+        KGWAS_HIP(hipGetDevice(&dev));
+        auto copier_main = [&] {
+            try {
+                KGWAS_HIP(hipSetDevice(dev));
+                for (uint64_t k = 0; k < n_pieces; k++) {
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return stop || (done[k] && k < consumed + ND); });
+                        if (stop) return;
+                    }
+                    KGWAS_HIP(hipMemcpyAsync(d_[k % ND].p, h_[k % NH].p, count_of(k) * stride * 8, hipMemcpyHostToDevice, copy_stream_));
+                    KGWAS_HIP(hipEventRecord(ev_[k % ND], copy_stream_));
+                    KGWAS_HIP(hipEventRecord(ev_h_[k % NH], copy_stream_));
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        queued = k + 1;
+                    }
+                    cv.notify_all();
+                }
+            } catch (const std::exception& e) {
+                std::unique_lock<std::mutex> lk(mu);
+                copier_error = e.what();
+                stop = true;
+                cv.notify_all();
+            }
+        };
+        producers.emplace_back(copier_main);  // (joined with the producers, whatever happens)
+
+        static const bool trace = getenv("KGWAS_INGEST_TRACE") != nullptr;  // where the caller's thread spends a run
+        double t_wait = 0, t_copy = 0, t_consume = 0;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto ms_since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(now() - t0).count(); };
+        for (uint64_t k = 0; k < n_pieces; k++) {
+            {
+                const auto t0 = now();
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || queued > k; });
+                t_wait += ms_since(t0);
+                if (queued <= k)
+                    throw Error(KGWAS_ERR_IO, !producer_error.empty() ? producer_error : !copier_error.empty() ? copier_error : "ingest stopped");
+            }
+            KGWAS_HIP(hipStreamWaitEvent(stream, ev_[k % ND], 0));
+            if (trace) {
+                const auto t0 = now();
+                KGWAS_HIP(hipEventSynchronize(ev_[k % ND]));
+                t_copy += ms_since(t0);
+            }
+            const auto t0 = now();
+            consume(d_[k % ND].p, k * piece, count_of(k));
+            t_consume += ms_since(t0);
             {
                 std::unique_lock<std::mutex> lk(mu);
                 consumed = k + 1;
             }
             cv.notify_all();
-        };
-        for (uint64_t k = 0; k < n_pieces; k++) {
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return stop || done[k]; });
-                if (!done[k]) throw Error(KGWAS_ERR_IO, producer_error.empty() ? "ingest stopped" : producer_error);
-            }
-            // device piece k % 3 is free: compute(k - 3) returned two turns ago
-            KGWAS_HIP(hipMemcpyAsync(d_[k % 3].p, h_[k % 3].p, count_of(k) * stride * 8, hipMemcpyHostToDevice, copy_stream_));
-            KGWAS_HIP(hipEventRecord(ev_[k % 3], copy_stream_));
-            if (k >= 2) compute(k - 2);
         }
-        if (n_pieces >= 2) compute(n_pieces - 2);
-        compute(n_pieces - 1);
+        if (trace)
+            fprintf(stderr, "[kgwas ingest] %llu pieces of %llu rows: caller waited %.1f ms for a piece to be queued, %.1f ms for copies, %.1f ms in the consumer\n",
+                    (unsigned long long)n_pieces, (unsigned long long)piece, t_wait, t_copy, t_consume);
     }
 
 private:
-    PinBuf<uint64_t> h_[3];
-    DevBuf<uint64_t> d_[3];
+    std::vector<PinBuf<uint64_t>> h_;
+    std::vector<hipEvent_t> ev_h_;  // per pinned piece: its copy to the device has completed
+    std::vector<DevBuf<uint64_t>> d_;
     hipStream_t copy_stream_ = nullptr;
-    hipEvent_t ev_[3] = {nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> ev_;  // per device piece: its copy has completed
     uint64_t piece_rows_ = 0;
 
 public:
     unsigned producer_cpus_ = 16;  // CPUs the process may use (the owner sets it: cgroup quota / GPUs sharing the host)
     bool file_feed_ = false;       // the next run's fill reads a file (set by the owner before run())
+    unsigned pinned_pieces_ = 3;   // pinned pieces the producers fill ahead of the copies
+    unsigned device_pieces_ = 10;  // device pieces: copies queued ahead of the consumer
 };
 
 }  // namespace kgwas

@@ -68,6 +68,9 @@ constexpr int HIST_SHIFT = 44;          // 8 mantissa bits per bin: 0.4 % score 
 constexpr uint32_t HIST_BINS = 16384;   // 64 binades above the threshold at sparse start
 
 // thr[p] = max(thr[p], thr_host[p], largest bin boundary with >= topn[p] counted scores at or above it).
+// device pointers of the (mapped) pinned destination
+hipError_t launch_records_to_host(const double* sc, const uint64_t* km, const uint32_t* rw, uint32_t n, double* h_sc, uint64_t* h_km, uint32_t* h_rw,
+                                  hipStream_t st);
 hipError_t launch_thr_update(const uint32_t* hist, const uint32_t* hist_base, uint32_t bins, const uint64_t* topn,
                              const double* thr_host, double* thr, uint32_t n_pheno, hipStream_t st);
 

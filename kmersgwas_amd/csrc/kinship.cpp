@@ -30,7 +30,7 @@ struct kgwas_kinship {
     void* d_part = nullptr;  // partial tiles of a chunk's row slices (kin_gram_scratch_bytes)
     size_t part_bytes = 0;
     unsigned long long* d_n = nullptr;
-    Ingest ingest;  // host / file feeds: three pinned pieces, two device pieces, a copy stream
+    Ingest ingest;  // host / file feeds: pinned and device piece rings, a copy stream (ingest.h)
     double kernel_ms = 0;
     uint64_t launches = 0, rows_fed = 0;
     ~kgwas_kinship() {

@@ -903,6 +903,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                     s->ring_size = (size_t)std::max<uint64_t>(strtoull(getenv("KGWAS_RING_BYTES"), nullptr, 10), slot_bytes + 4096);
                 tcreate("device buffers and slots allocated");
                 s->ring.alloc(s->ring_size);
+                s->ring_dev = s->ring.dev();
                 tcreate("pinned record ring allocated");
             } else {
                 const uint64_t slot_bytes = (uint64_t)s->cap * P * sizeof(Cand);

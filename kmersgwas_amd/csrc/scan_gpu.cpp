@@ -566,7 +566,12 @@ bool fetch_records(kgwas_scan* s, Slot& sl, uint64_t seq) {
         s->infl_obs[sl.coarse_mode] = std::min(256.0, std::max(s->infl_obs[sl.coarse_mode], 1.25 * (double)n_surv / std::max(sl.cand_est, 1.0)));
     else if (!s->narrow && n >= 1024)
         s->infl_obs[sl.coarse_mode] = std::min(64.0, std::max(1.0, (double)n_surv / (double)n));
-    if (copy) {
+    static const bool by_memcpy = getenv("KGWAS_RECORD_MEMCPY") != nullptr;  // experiments: three hipMemcpyAsync calls, as before
+    if (copy && !by_memcpy) {
+        uint8_t* dev_at = s->ring_dev + (reinterpret_cast<uint8_t*>(sl.so_score) - s->ring.p);
+        KGWAS_HIP(launch_records_to_host(sl.d_so_score.p, sl.d_so_kmer.p, sl.d_so_row.p, n, reinterpret_cast<double*>(dev_at),
+                                         reinterpret_cast<uint64_t*>(dev_at + (size_t)n * 8), reinterpret_cast<uint32_t*>(dev_at + (size_t)n * 16), s->copy_stream));
+    } else if (copy) {
         KGWAS_HIP(hipMemcpyAsync(sl.so_score, sl.d_so_score.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s->copy_stream));
         KGWAS_HIP(hipMemcpyAsync(sl.so_row, sl.d_so_row.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, s->copy_stream));
         KGWAS_HIP(hipMemcpyAsync(sl.so_kmer, sl.d_so_kmer.p, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost, s->copy_stream));

@@ -353,6 +353,7 @@ struct kgwas_scan {
     // (cap x P records each), which capped the chunks in flight at 12 for 201 columns: with host and GPU level the GPU
     // then idled while the host digested the ramp.
     PinBuf<uint8_t> ring;
+    uint8_t* ring_dev = nullptr;  // the ring's address on the device (mapped)
     size_t ring_size = 0, ring_head = 0, ring_tail = 0;  // used: [tail, head) circularly; head == tail: empty
     uint64_t ring_freed = 0;                              // chunks (of this feed) whose records have been given back
     Slot redo;  // coarse mode: the only slot with exact-scorer candidate records (synchronous overflow re-runs)
