@@ -232,4 +232,31 @@ hipError_t launch_synth(uint64_t* rows, uint64_t first_row, uint64_t n_rows, uin
     return hipGetLastError();
 }
 
+// Plain device -> mapped-host copy by the GPU itself (bytes a multiple of 4; both 16-byte aligned). The first SDMA
+// device -> host transfer of a process blocked its hipMemcpyAsync call for 58 ms (the dense chunk's 9.5 MB of scores in
+// a fresh `associate_kmers`), and later ones complete late beside host -> device pieces (launch_records_to_host).
+__global__ void __launch_bounds__(256) copy_to_host_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16, uint32_t tail_words) {
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += step) dst[i] = src[i];
+    if (blockIdx.x == 0 && threadIdx.x < tail_words)
+        reinterpret_cast<uint32_t*>(dst + n16)[threadIdx.x] = reinterpret_cast<const uint32_t*>(src + n16)[threadIdx.x];
+}
+
+hipError_t launch_copy_to_host(const void* src, void* dst_dev, size_t bytes, hipStream_t st) {
+    if (!bytes) return hipSuccess;
+    if (bytes % 4 || ((uintptr_t)src | (uintptr_t)dst_dev) % 16) return hipErrorInvalidValue;
+    const size_t n16 = bytes / 16;
+    const uint32_t blocks = (uint32_t)std::min<size_t>(std::max<size_t>((n16 + 255) / 256, 1), 256);
+    hipLaunchKernelGGL(copy_to_host_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const uint4*>(src), reinterpret_cast<uint4*>(dst_dev), n16,
+                       (uint32_t)((bytes % 16) / 4));
+    return hipGetLastError();
+}
+
+// Loads this file's code object (HIP does it at the first use of any of its kernels: tens of milliseconds for the whole
+// library in a fresh process - kgwas_scan_create does it on a thread of its own, beside the pinning of the record ring).
+hipError_t warm_aux_kernels() {
+    hipFuncAttributes at;
+    return hipFuncGetAttributes(&at, reinterpret_cast<const void*>(thr_update_kernel));
+}
+
 }  // namespace kgwas

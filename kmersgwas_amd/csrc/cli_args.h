@@ -2,6 +2,11 @@
 // cxxopts, an empty submodule in its tree). Accepts "--name value", "--name=value", "-x value"
 // and boolean flags, like the invocations kmers_gwas.py builds (kmers_gwas.py:133-148).
 #pragma once
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
 #include <map>
 #include <stdexcept>
 #include <string>
@@ -104,3 +109,14 @@ class CliArgs {
     std::vector<CliOption> opts_;
     std::map<std::string, std::string> vals_;
 };
+
+// Every output of the tool is written and closed: leave without unpinning gigabytes of host memory, freeing device
+// buffers and tearing the HIP runtime down one object at a time - the kernel reclaims all of it at process exit, and
+// for `associate_kmers` on a 40 M-row table the orderly way was 0.35 s of a 0.88 s run (0.19 s in the session's
+// destructors, the rest in the runtime's exit handlers). KGWAS_CLI_FULL_TEARDOWN=1 returns instead (leak checkers).
+inline void cli_finish() {
+    std::cout.flush();
+    std::cerr.flush();
+    fflush(nullptr);
+    if (!getenv("KGWAS_CLI_FULL_TEARDOWN")) _exit(0);
+}

@@ -24,6 +24,7 @@
 
 #include "../../include/kgwas.h"
 #include <cstring>
+#include <unistd.h>
 
 #include "cli_args.h"
 
@@ -267,10 +268,13 @@ int main(int argc, char* argv[]) {
         // where the wall time of the run went (bench.py's cli_e2e record reads this line)
         cerr << "[kgwas] seconds: setup=" << (t_setup - t_main) << " session_create=" << (t_created - t_setup) << " scan=" << (t_fed - t_created)
              << " finish=" << (t_finished - t_fed) << " output=" << (t_written - t_finished) << " total=" << (now_s() - t_main) << endl;
+        const double t_down = now_s();
+        cli_finish();  // (returns only with KGWAS_CLI_FULL_TEARDOWN=1)
         if (mscan) kgwas_multiscan_destroy(mscan);
         if (scan) kgwas_scan_destroy(scan);
         kgwas_table_close(tbl);
         kgwas_pheno_free(ph);
+        cerr << "[kgwas] teardown_s=" << (now_s() - t_down) << endl;
     } catch (const std::invalid_argument& e) {
         cerr << "error parsing options: " << e.what() << endl;
         cerr << vm.help("associate_kmers", desc) << endl;

@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 
+#include "cli_args.h"
 #include "../../include/kgwas.h"
 
 using namespace std;
@@ -64,6 +65,7 @@ int main(int argc, char* argv[]) {
     vector<const char*> bases_c;
     for (auto& b : bases) bases_c.push_back(b.c_str());
     ck(kgwas_snps_write(snps, phenotype_n, bases_c.data(), counts.data(), indices.data(), n_best_snps_to_save));
+    cli_finish();
     kgwas_snps_close(snps);
     kgwas_pheno_free(ph);
     return 0;

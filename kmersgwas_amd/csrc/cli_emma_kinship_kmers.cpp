@@ -101,7 +101,7 @@ int main(int argc, char* argv[]) {
                 cerr.flush();
             }
             ck(kgwas_kinship_partials(kin, H.data(), &n_snps));
-            kgwas_kinship_destroy(kin);
+            if (getenv("KGWAS_CLI_FULL_TEARDOWN")) kgwas_kinship_destroy(kin);  // (otherwise left to the process exit, cli_finish)
         }
         ck(kgwas_kinship_from_partials(n_acc, H.data(), n_snps, K.data()));
         cerr << "#" << n_snps << endl;
@@ -109,6 +109,7 @@ int main(int argc, char* argv[]) {
         string text(need, '\0');
         kgwas_kinship_format(n_acc, K.data(), n_snps, &text[0], need);
         cout << text;
+        cli_finish();
         kgwas_table_close(tbl);
     } catch (const std::invalid_argument& e) {
         cerr << "error parsing options: " << e.what() << endl;

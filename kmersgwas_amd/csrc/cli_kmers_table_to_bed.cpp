@@ -105,6 +105,7 @@ int main(int argc, char* argv[]) {
         ck(kgwas_table_to_bed(tbl, col.data(), n_accessions, acc.data(), Y, min_count, max_batch_size, unique_patterns ? 1 : 0,
                               output_base.c_str(), (int)result.u64("device", 0), &n_batches, &n_written));
         for (uint64_t b = 0; b < n_batches; b++) cerr << "Batch:\t" << b + 1 << endl;
+        cli_finish();
         kgwas_table_close(tbl);
         kgwas_pheno_free(ph);
     } catch (const std::invalid_argument& e) {

@@ -14,11 +14,14 @@
 #pragma once
 #include <pthread.h>
 #include <sched.h>
+#include <sys/mman.h>
 
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
+#include <cstdint>
 #include <functional>
 #include <mutex>
 #include <string>
@@ -45,13 +48,75 @@ struct DevBuf {
     }
     ~DevBuf() { release(); }
 };
+// Pinned, device-mapped host memory. hipHostMalloc costs 0.16 s per GiB (it faults and zeroes 4 KiB pages one by one; a
+// fresh `associate_kmers` spent 0.17 of its 0.52 s there): large buffers are mapped with MADV_HUGEPAGE, touched by a few
+// threads and registered instead - 5 ms per 512 MiB where transparent huge pages are available (16x), ~45 ms where they
+// are not - and fall back to hipHostMalloc if any step fails (KGWAS_PIN_PLAIN=1 forces that).
+struct PinRegion {
+    void* p = nullptr;       // what the caller uses
+    void* map = nullptr;     // the mapping it lies in (registered memory), nullptr: hipHostMalloc
+    size_t map_bytes = 0;
+    static constexpr size_t HUGE = 2u << 20;
+    void alloc(size_t bytes) {
+        release();
+        if (!bytes) return;
+        static const bool plain = getenv("KGWAS_PIN_PLAIN") != nullptr;
+        if (!plain && bytes >= (8u << 20)) {
+            const size_t len = (bytes + HUGE - 1) / HUGE * HUGE;
+            void* m = mmap(nullptr, len + HUGE, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+            if (m != MAP_FAILED) {
+                char* al = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(m) + HUGE - 1) & ~(uintptr_t)(HUGE - 1));
+                (void)madvise(al, len, MADV_HUGEPAGE);
+                {
+                    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+                    const size_t nt = std::min<size_t>(std::min<size_t>(8, hw), std::max<size_t>(1, len / (32u << 20)));
+                    std::vector<std::thread> th;
+                    for (size_t i = 0; i < nt; i++)
+                        th.emplace_back([=] {
+                            const size_t a = len / nt / HUGE * HUGE * i, b = i + 1 == nt ? len : len / nt / HUGE * HUGE * (i + 1);
+                            for (size_t o = a; o < b; o += 4096) al[o] = 0;
+                        });
+                    for (auto& t : th) t.join();
+                }
+                if (hipHostRegister(al, len, hipHostRegisterMapped) == hipSuccess) {
+                    p = al;
+                    map = m;
+                    map_bytes = len + HUGE;
+                    return;
+                }
+                (void)hipGetLastError();  // (not sticky: the plain allocation below is the answer)
+                munmap(m, len + HUGE);
+            }
+        }
+        KGWAS_HIP(hipHostMalloc(&p, bytes, hipHostMallocMapped));
+    }
+    void release() {
+        if (map) {
+            (void)hipHostUnregister(p);
+            munmap(map, map_bytes);
+        } else if (p)
+            (void)hipHostFree(p);
+        p = map = nullptr;
+        map_bytes = 0;
+    }
+};
 template <class T>
 struct PinBuf {
     T* p = nullptr;
     size_t n = 0;
+    PinRegion r;
+    PinBuf() = default;
+    PinBuf(const PinBuf&) = delete;
+    PinBuf& operator=(const PinBuf&) = delete;
+    PinBuf(PinBuf&& o) noexcept : p(o.p), n(o.n), r(o.r) {
+        o.p = nullptr;
+        o.n = 0;
+        o.r = PinRegion();
+    }
     void alloc(size_t count) {
         release();
-        if (count) KGWAS_HIP(hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocMapped));
+        r.alloc(count * sizeof(T));
+        p = static_cast<T*>(r.p);
         n = count;
     }
     T* dev() const {
@@ -60,7 +125,7 @@ struct PinBuf {
         return d;
     }
     void release() {
-        if (p) (void)hipHostFree(p);
+        r.release();
         p = nullptr;
         n = 0;
     }
@@ -130,7 +195,10 @@ public:
         bool stop = false;
         std::string producer_error, copier_error;
         uint64_t consumed = 0;  // pieces the consumer has returned from
+        int dev = 0;
+        KGWAS_HIP(hipGetDevice(&dev));
         auto producer_main = [&] {
+            (void)hipSetDevice(dev);
             {
                 // The producers share their CPUs with the consumer's pinned replay workers, which wake up for a fraction of a
                 // millisecond per piece and must not wait out a copying thread's time slice: SCHED_IDLE gives way at once.
@@ -209,8 +277,6 @@ public:
         // with the copies queued between the consumer's calls, the link stood still for 14 of those 15 ms - an eighth of a
         // 40 M-row feed. Device pieces are cheap (128 MiB of 288 GB each), so there are enough of them to copy through it.
         const uint64_t ND = d_.size();
-        int dev = 0;
-        KGWAS_HIP(hipGetDevice(&dev));
         auto copier_main = [&] {
             try {
                 KGWAS_HIP(hipSetDevice(dev));

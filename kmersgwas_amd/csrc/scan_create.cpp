@@ -136,6 +136,71 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         };
         KGWAS_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
         tcreate("stream created (HIP context up)");
+        // The library's code objects, loaded beside everything below (a fresh process spent 58 ms on them inside its first
+        // dense chunk). Errors are left to the launches that would have hit them.
+        const int warm_dev = s->device;
+        const hipStream_t warm_stream = s->stream;
+        std::thread warm([warm_dev, warm_stream, trace_create, tc0] {
+            if (getenv("KGWAS_NO_WARM")) return;  // experiments
+            (void)hipSetDevice(warm_dev);
+            (void)warm_aux_kernels();
+            {
+                // ... and the compute stream's first fill, launch and device-to-host copy (its hardware queue, the copy path)
+                void *d = nullptr, *h = nullptr;
+                hipEvent_t w0 = nullptr, w1 = nullptr;  // (timed events too: the dense chunk brackets its kernels with them)
+                (void)hipEventCreate(&w0);
+                (void)hipEventCreate(&w1);
+                if (hipMalloc(&d, 1 << 20) == hipSuccess && hipHostMalloc(&h, 1 << 20, hipHostMallocMapped) == hipSuccess) {
+                    (void)hipMemsetAsync(d, 0, 4096, warm_stream);
+                    if (w0) (void)hipEventRecord(w0, warm_stream);
+                    void* hd = nullptr;
+                    if (hipHostGetDevicePointer(&hd, h, 0) == hipSuccess)
+                        (void)launch_records_to_host((const double*)d, (const uint64_t*)d + 64, (const uint32_t*)d + 256, 8, (double*)hd, (uint64_t*)hd + 64,
+                                                     (uint32_t*)hd + 256, warm_stream);
+                    (void)launch_copy_to_host(d, hd ? hd : d, 2048, warm_stream);
+                    (void)hipMemcpyAsync(h, d, 2048, hipMemcpyDeviceToHost, warm_stream);
+                    // (a transfer large enough for the DMA engines: a fresh process's first one took ~20 ms host -> device - the
+                    // streamed feed's first piece - and 58 ms device -> host)
+                    (void)hipMemcpyAsync(h, d, 1 << 20, hipMemcpyDeviceToHost, warm_stream);
+                    // ... and the streamed feed's pattern: a transfer on ANOTHER stream, the compute stream's kernels behind its
+                    // event (the first piece's kernels started 18 ms after its copy had landed)
+                    hipStream_t s2 = nullptr;
+                    hipEvent_t w2 = nullptr;
+                    if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&w2, hipEventDisableTiming) == hipSuccess) {
+                        (void)hipMemcpyAsync(d, h, 1 << 20, hipMemcpyHostToDevice, s2);
+                        (void)hipEventRecord(w2, s2);
+                        (void)hipStreamWaitEvent(warm_stream, w2, 0);
+                        (void)launch_copy_to_host(d, hd ? hd : d, 2048, warm_stream);
+                        (void)hipStreamSynchronize(warm_stream);
+                    }
+                    if (w2) (void)hipEventDestroy(w2);
+                    if (s2) (void)hipStreamDestroy(s2);
+                    if (w1) (void)hipEventRecord(w1, warm_stream);
+                    (void)hipStreamSynchronize(warm_stream);
+                    float ms = 0;
+                    if (w0 && w1) (void)hipEventElapsedTime(&ms, w0, w1);
+                }
+                if (w0) (void)hipEventDestroy(w0);
+                if (w1) (void)hipEventDestroy(w1);
+                if (d) (void)hipFree(d);
+                if (h) (void)hipHostFree(h);
+                if (trace_create)
+                    fprintf(stderr, "[kgwas] scan_create +%.1f ms: compute stream warmed (side thread)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count());
+            }
+            (void)warm_score_mfma();
+            (void)warm_score_coarse();
+            (void)warm_score_mx();
+            (void)warm_score_narrow();
+            (void)warm_score_valu();
+            if (trace_create)
+                fprintf(stderr, "[kgwas] scan_create +%.1f ms: code objects loaded (side thread)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count());
+        });
+        struct WarmJoin {
+            std::thread& t;
+            ~WarmJoin() {
+                if (t.joinable()) t.join();
+            }
+        } warm_join{warm};
         KGWAS_HIP(hipEventCreate(&s->ev_user));
         KGWAS_HIP(hipEventCreate(&s->ev_ds));
         KGWAS_HIP(hipEventCreate(&s->ev_d0));
@@ -942,6 +1007,9 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         s->h_n1.alloc(s->dense_rows);
         s->d_kmer.alloc(s->dense_rows);
         s->h_kmer.alloc(s->dense_rows);
+        s->h_dense_dev = s->h_dense.dev();
+        s->h_n1_dev = s->h_n1.dev();
+        s->h_kmer_dev = s->h_kmer.dev();
         s->d_tested_dense.alloc(TESTED_SHARDS);
 
         make_heaps(s.get());

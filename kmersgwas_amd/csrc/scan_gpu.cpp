@@ -135,11 +135,22 @@ void run_dense(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, uint64_t 
     a.n1_out = s->d_n1.p;
     a.kmer_out = s->d_kmer.p;
     a.tested = s->d_tested_dense.p;
+    double lap_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // KGWAS_TRACE: host time of the calls below (a fresh process: first uses)
+    int lap_i = 0;
+    auto lap_t = std::chrono::steady_clock::now();
+    auto lap = [&] {
+        const auto n = std::chrono::steady_clock::now();
+        if (lap_i < 8) lap_ms[lap_i++] = std::chrono::duration<double, std::milli>(n - lap_t).count();
+        lap_t = n;
+    };
     KGWAS_HIP(hipMemsetAsync(s->d_tested_dense.p, 0, TESTED_SHARDS * sizeof(unsigned long long), s->stream));
     KGWAS_HIP(hipEventRecord(es, s->stream));
+    lap();  // 0: fill + event
     maybe_squeeze(s, d_rows, n_rows);
+    lap();  // 1: squeeze
     KGWAS_HIP(hipEventRecord(e0, s->stream));
     launch_score(s, a);
+    lap();  // 2: scorer
     KGWAS_HIP(hipEventRecord(e1, s->stream));
     if (select) {
         KGWAS_HIP(launch_dense_select(s->d_dense.p, s->d_n1.p, (uint32_t)n_rows, (uint32_t)s->n_pheno, (uint32_t)s->S,
@@ -148,14 +159,25 @@ void run_dense(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, uint64_t 
         KGWAS_HIP(hipMemcpyAsync(s->h_sel.p, s->d_sel.p, s->n_pheno * sizeof(double), hipMemcpyDeviceToHost, s->stream));
         KGWAS_HIP(hipMemcpyAsync(s->h_sel_info.p, s->d_sel_info.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     }
-    KGWAS_HIP(hipMemcpyAsync(s->h_dense.p, s->d_dense.p, s->n_pheno * n_rows * sizeof(double), hipMemcpyDeviceToHost,
-                             s->stream));
-    KGWAS_HIP(hipMemcpyAsync(s->h_n1.p, s->d_n1.p, n_rows * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
-    KGWAS_HIP(hipMemcpyAsync(s->h_kmer.p, s->d_kmer.p, n_rows * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream));
+    lap();  // 3: select + its copies
+    // (by kernels into the mapped buffers: no SDMA device -> host transfer anywhere in a scan, kernels.h launch_copy_to_host)
+    KGWAS_HIP(launch_copy_to_host(s->d_dense.p, s->h_dense_dev, s->n_pheno * n_rows * sizeof(double), s->stream));
+    lap();  // 4: scores' copy
+    KGWAS_HIP(launch_copy_to_host(s->d_n1.p, s->h_n1_dev, n_rows * sizeof(uint32_t), s->stream));
+    KGWAS_HIP(launch_copy_to_host(s->d_kmer.p, s->h_kmer_dev, n_rows * sizeof(uint64_t), s->stream));
+    lap();  // 5: n1 + kmer copies
+    const auto td1 = std::chrono::steady_clock::now();
     KGWAS_HIP(hipStreamSynchronize(s->stream));
     float ms = 0;
     KGWAS_HIP(hipEventElapsedTime(&ms, e0, e1));
     s->st.score_kernel_ms += ms;
+    if (s->trace) {
+        float pre = 0;
+        KGWAS_HIP(hipEventElapsedTime(&pre, es, e0));
+        fprintf(stderr, "[kgwas] dense chunk on the device: %.3f ms to queue it, %.3f ms until the stream was idle; squeeze %.3f ms, scorer %.3f ms; host calls: fill %.2f squeeze %.2f scorer %.2f select %.2f scores' copy %.2f n1/kmer copies %.2f ms\n",
+                std::chrono::duration<double, std::milli>(td1 - td0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - td1).count(), pre, ms,
+                lap_ms[0], lap_ms[1], lap_ms[2], lap_ms[3], lap_ms[4], lap_ms[5]);
+    }
     if (!s->direct) {
         KGWAS_HIP(hipEventElapsedTime(&ms, es, e0));
         s->st.squeeze_kernel_ms += ms;

@@ -354,6 +354,9 @@ struct kgwas_scan {
     // then idled while the host digested the ramp.
     PinBuf<uint8_t> ring;
     uint8_t* ring_dev = nullptr;  // the ring's address on the device (mapped)
+    double* h_dense_dev = nullptr;  // device addresses of h_dense / h_n1 / h_kmer (mapped)
+    uint32_t* h_n1_dev = nullptr;
+    uint64_t* h_kmer_dev = nullptr;
     size_t ring_size = 0, ring_head = 0, ring_tail = 0;  // used: [tail, head) circularly; head == tail: empty
     uint64_t ring_freed = 0;                              // chunks (of this feed) whose records have been given back
     Slot redo;  // coarse mode: the only slot with exact-scorer candidate records (synchronous overflow re-runs)

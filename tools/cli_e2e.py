@@ -35,12 +35,13 @@ try:
         out = os.path.join(os.environ.get("OUT_ROOT", d), "out%d_%d" % (os.getpid(), rep))
         os.makedirs(out)
         t0 = time.perf_counter()
-        r = subprocess.run([exe, "-p", pheno, "-b", "run", "-o", out, "-n", str(N), "--parallel", "1", "--kmers_table", base, "--kmer_len", "31",
+        wrap = os.environ.get("CLI_WRAP", "").split()  # e.g. a profiler in front of the binary
+        r = subprocess.run(wrap + [exe, "-p", pheno, "-b", "run", "-o", out, "-n", str(N), "--parallel", "1", "--kmers_table", base, "--kmer_len", "31",
                             "--maf", "0.050000", "--mac", "5"], capture_output=True, text=True)
         wall = time.perf_counter() - t0
         print("run %d: rc %d wall %.3f s" % (rep, r.returncode, wall))
         for l in r.stderr.splitlines():
-            if "seconds:" in l or "write_plink_many" in l or "scan_create" in l:
+            if "seconds:" in l or "teardown" in l or "write_plink_many" in l or "scan_create" in l:
                 print("   ", l)
 finally:
     shutil.rmtree(d, ignore_errors=True)
