@@ -74,6 +74,11 @@ void ingest_run(kgwas_scan* s, uint64_t n_rows, uint64_t first_row, const Ingest
         feed_device_impl(s, nullptr, 0, first_row);
         return;
     }
+    struct Streamed {  // (fetch_records picks the records' way to the host by it)
+        kgwas_scan* s;
+        explicit Streamed(kgwas_scan* s_) : s(s_) { s->streamed_feed = true; }
+        ~Streamed() { s->streamed_feed = false; }
+    } streamed(s);
     // it is the LAST piece's feed that is the last one
     s->ingest.run(1 + s->W_f, n_rows, s->chunk_max, s->stream, fill,
                   [&](const uint64_t* d_rows, uint64_t row_off, uint64_t cnt) {

@@ -588,7 +588,13 @@ bool fetch_records(kgwas_scan* s, Slot& sl, uint64_t seq) {
         s->infl_obs[sl.coarse_mode] = std::min(256.0, std::max(s->infl_obs[sl.coarse_mode], 1.25 * (double)n_surv / std::max(sl.cand_est, 1.0)));
     else if (!s->narrow && n >= 1024)
         s->infl_obs[sl.coarse_mode] = std::min(64.0, std::max(1.0, (double)n_surv / (double)n));
-    static const bool by_memcpy = getenv("KGWAS_RECORD_MEMCPY") != nullptr;  // experiments: three hipMemcpyAsync calls, as before
+    // Two ways to the host. Beside a streamed feed's 128 MiB host -> device pieces, hipMemcpyAsync device -> host transfers
+    // complete ~2 ms late (every piece's consumer call took 3 ms instead of 0.55): there the GPU writes the records into the
+    // mapped ring itself, one launch. Over a table resident in HBM the transfers are punctual and cost the compute units
+    // nothing, while the copying kernel's waves - parked on PCIe stores - slow the filter beside them (10.2 -> 12.7 ms per
+    // 100 M rows x 101 columns): there the three transfers stay. KGWAS_RECORD_COPY=kernel|memcpy forces one (experiments).
+    static const char* rc_env = getenv("KGWAS_RECORD_COPY");
+    const bool by_memcpy = rc_env ? strcmp(rc_env, "memcpy") == 0 : !s->streamed_feed;
     if (copy && !by_memcpy) {
         uint8_t* dev_at = s->ring_dev + (reinterpret_cast<uint8_t*>(sl.so_score) - s->ring.p);
         KGWAS_HIP(launch_records_to_host(sl.d_so_score.p, sl.d_so_kmer.p, sl.d_so_row.p, n, reinterpret_cast<double*>(dev_at),

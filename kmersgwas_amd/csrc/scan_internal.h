@@ -354,6 +354,7 @@ struct kgwas_scan {
     // then idled while the host digested the ramp.
     PinBuf<uint8_t> ring;
     uint8_t* ring_dev = nullptr;  // the ring's address on the device (mapped)
+    bool streamed_feed = false;   // the rows of the current feed arrive over PCIe while it runs (ingest_run): fetch_records
     double* h_dense_dev = nullptr;  // device addresses of h_dense / h_n1 / h_kmer (mapped)
     uint32_t* h_n1_dev = nullptr;
     uint64_t* h_kmer_dev = nullptr;
