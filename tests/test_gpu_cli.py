@@ -66,6 +66,32 @@ def test_associate_kmers_ecoli_shaped_config(tmp_path):
                      "pheno.pattern_counter", "pheno.tested_kmers"]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"KGWAS_PIN_PLAIN": "1", "KGWAS_CLI_FULL_TEARDOWN": "1"}, {"KGWAS_RECORD_COPY": "memcpy", "KGWAS_NO_WARM": "1"},
+                                 {"KGWAS_RECORD_COPY": "kernel", "KGWAS_INGEST_DEVICE": "2", "KGWAS_INGEST_PINNED": "2", "KGWAS_INGEST_PIECE_ROWS": "4096"}])
+def test_associate_kmers_process_switches_change_nothing(tmp_path, env):
+    """The start-up / teardown / transfer switches of the tool (hipHostMalloc instead of registered huge-page mappings, an orderly
+    teardown instead of _exit, the records' two ways to the host, no warm-up thread, a minimal ingest ring with tiny pieces):
+    the same files as the default run, byte for byte."""
+    names, acc, Y = onp.load_phenotypes(os.path.join(GOLD, "resistence.pheno"))
+    S_f = 241
+    rows = random_table(120_000, S_f, seed=77, dup_frac=0.3)
+    base = str(tmp_path / "kmers_table")
+    onp.write_table(base, list(acc), 31, rows[:, 0], rows[:, 1:])
+    outs = []
+    for tag, e in (("default", {}), ("switched", env)):
+        out = tmp_path / tag
+        out.mkdir()
+        cmd = [os.path.join(BIN, "associate_kmers"), "-p", os.path.join(GOLD, "resistence.pheno"), "-b", "pheno", "-o", str(out), "-n", "1001",
+               "--kmers_table", base, "--kmer_len", "31", "--maf", "0.050000", "--mac", "5"]
+        r = subprocess.run(cmd, capture_output=True, text=True, env={**os.environ, **e})
+        assert r.returncode == 0, r.stderr[-2000:]
+        if e.get("KGWAS_CLI_FULL_TEARDOWN"):
+            assert "[kgwas] teardown_s=" in r.stderr
+        outs.append(str(out))
+    assert len(_compare_dirs(outs[0], outs[1])) == 4
+
+
 @pytest.mark.parametrize("kernel", ["1", "2", "3"])
 def test_associate_kmers_permutations_subset_scores(tmp_path, kernel):
     """Several phenotype columns (value + permutations), phenotyped subset in shuffled order,
