@@ -1,6 +1,7 @@
 // emma_kinship_kmers — drop-in for the reference tool of the same name
 // (src/emma_kinship_kmers.cpp): same options (-t/--kmers_table, -k/--kmers_len, --maf, all
 // required), matrix on stdout, progress on stderr; the accumulation runs on the GPU.
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <fstream>
@@ -28,6 +29,8 @@ static void ck(int rc) {
     exit(rc == KGWAS_ERR_DEVICE ? 3 : 1);
 }
 
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 int main(int argc, char* argv[]) {
     CliArgs result({
         {"kmers_table", 't', true, "k-mers table path", ""},
@@ -38,6 +41,7 @@ int main(int argc, char* argv[]) {
         {"help", 0, false, "print help", ""},
     });
     const string desc = "Calculate a kinship matrix from the k-mers table (output to stdout)";
+    const double t_main = now_s();
     try {
         result.parse(argc, argv);
         if (result.count("help")) {
@@ -77,6 +81,8 @@ int main(int argc, char* argv[]) {
         }
         vector<uint64_t> H(n_acc * n_acc), K(n_acc * n_acc);
         uint64_t n_snps = 0;
+        const double t_setup = now_s();
+        double t_created = t_setup;
         cerr << "loading..." << endl;
         if (n_gpus > 1) {
             // contiguous row shards, one session + thread per GPU, integer partials added (kgwas_kinship_table_multi)
@@ -92,23 +98,37 @@ int main(int argc, char* argv[]) {
         } else {
             kgwas_kinship* kin = nullptr;
             ck(kgwas_kinship_create((int32_t)result.u64("device", 0), n_acc, min_count, &kin));
-            // the reference loads 2^20 rows, then accumulates them (:89-99); here the file read, the copy and the
-            // kernels of consecutive pieces overlap (kgwas_kinship_feed_table)
-            const uint64_t batch = 1ull << 24;
+            t_created = now_s();
+            // the reference loads 2^20 rows, then accumulates them and prints a dot (:89-93); here the file read, the copy and
+            // the kernels of consecutive pieces overlap (kgwas_kinship_feed_table), in feeds of 2^26 rows (a feed ends with
+            // the pipeline drained), and the dots - one per 2^20 rows, as there - follow each feed
+            const uint64_t batch = 1ull << 26;
             for (uint64_t row0 = 0; row0 < n_rows; row0 += batch) {
-                ck(kgwas_kinship_feed_table(kin, tbl, row0, std::min<uint64_t>(batch, n_rows - row0)));
-                cerr << ".";
+                const uint64_t n = std::min<uint64_t>(batch, n_rows - row0);
+                ck(kgwas_kinship_feed_table(kin, tbl, row0, n));
+                for (uint64_t d = 0; d < (n + (1ull << 20) - 1) >> 20; d++) cerr << ".";
                 cerr.flush();
             }
             ck(kgwas_kinship_partials(kin, H.data(), &n_snps));
             if (getenv("KGWAS_CLI_FULL_TEARDOWN")) kgwas_kinship_destroy(kin);  // (otherwise left to the process exit, cli_finish)
         }
+        const double t_fed = now_s();
         ck(kgwas_kinship_from_partials(n_acc, H.data(), n_snps, K.data()));
         cerr << "#" << n_snps << endl;
-        const uint64_t need = kgwas_kinship_format(n_acc, K.data(), n_snps, nullptr, 0);
-        string text(need, '\0');
-        kgwas_kinship_format(n_acc, K.data(), n_snps, &text[0], need);
+        // (one call: a cell is at most 12 characters - six significant digits, a point or an exponent - and a separator)
+        string text(n_acc * n_acc * 16 + 16, '\0');
+        const uint64_t need = kgwas_kinship_format(n_acc, K.data(), n_snps, &text[0], text.size());
+        if (need > text.size()) {
+            text.assign(need, '\0');
+            kgwas_kinship_format(n_acc, K.data(), n_snps, &text[0], need);
+        } else
+            text.resize(need);
+        const double t_text = now_s();
         cout << text;
+        cout.flush();
+        // where the wall time of the run went (as associate_kmers' last line)
+        cerr << "[kgwas] seconds: setup=" << (t_setup - t_main) << " session_create=" << (t_created - t_setup) << " accumulate=" << (t_fed - t_created)
+             << " matrix_text=" << (t_text - t_fed) << " stdout=" << (now_s() - t_text) << " total=" << (now_s() - t_main) << endl;
         cli_finish();
         kgwas_table_close(tbl);
     } catch (const std::invalid_argument& e) {

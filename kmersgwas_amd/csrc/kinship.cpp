@@ -176,8 +176,13 @@ int kgwas_kinship_partials(kgwas_kinship* k, uint64_t* hamming, uint64_t* n_used
         if (!k || !hamming || !n_used) throw Error(KGWAS_ERR_ARG, "kgwas_kinship_partials: null argument");
         KGWAS_HIP(hipSetDevice(k->device));
         KGWAS_HIP(hipStreamSynchronize(k->stream));
-        std::vector<unsigned long long> H((size_t)k->S_pad * k->S_pad);
-        KGWAS_HIP(hipMemcpy(H.data(), k->d_H, H.size() * 8, hipMemcpyDeviceToHost));
+        // (written into pinned, mapped memory by the GPU: a process's first SDMA device -> host transfer blocks its call for
+        // ~60 ms - a fifth of an `emma_kinship_kmers` run on 40 M rows -, and the copy into pageable memory is staged anyway)
+        PinBuf<unsigned long long> Hp;
+        Hp.alloc((size_t)k->S_pad * k->S_pad);
+        KGWAS_HIP(launch_copy_to_host(k->d_H, Hp.dev(), Hp.n * 8, k->stream));
+        KGWAS_HIP(hipStreamSynchronize(k->stream));
+        const unsigned long long* H = Hp.p;
         unsigned long long n = 0, shards[TESTED_SHARDS];
         KGWAS_HIP(hipMemcpy(shards, k->d_n, sizeof(shards), hipMemcpyDeviceToHost));
         for (unsigned long long v : shards) n += v;

@@ -269,6 +269,25 @@ def test_kinship_text_and_from_partials():
     assert kg.kinship_format(K2, n) == ob.kinship_text(K, n)
 
 
+def test_kinship_text_covers_the_formats_of_ostream_double():
+    """`os << double` (src/emma_kinship_kmers.cpp:104-109) is %g with six digits: fixed and exponent forms, trailing zeros
+    dropped, rounding at the sixth digit - the library formats with std::to_chars on several threads; the oracle with an
+    ostream. Ratios k / n from every decade down to 1e-12, around the 1e-5 switch to exponents, and round ones."""
+    S = 160  # several threads' row blocks
+    rng = np.random.default_rng(12)
+    n = 10 ** 12 + 7
+    vals = np.concatenate([rng.integers(0, n, 4000), 10 ** rng.integers(0, 12, 4000) * rng.integers(1, 1000, 4000),
+                           np.array([0, 1, 2, 9, 10, 99999, 100000, 100001, 9999994, 9999995, 9999996, n // 2, n - 1, n, 10 ** 7, 10 ** 7 + 3, 12345649999, 12345650000])])
+    K = np.zeros((S, S), np.uint64)
+    iu = np.tril_indices(S, -1)
+    K[iu] = rng.choice(vals, len(iu[0])).astype(np.uint64)
+    K = K + K.T
+    text = kg.kinship_format(K, n)
+    assert text == ob.kinship_text(K, n)
+    cells = text.decode().split("\n")[1].split("\t")
+    assert cells[1] == "1" and cells[0] == "%g" % (int(K[1, 0]) / n)
+
+
 def test_synth_host_twin_matches_numpy_statement():
     for n_acc in (1, 63, 64, 65, 241, 1024, 1135):
         a = kg.synth_rows_host(999, 500, n_acc, 20240601)

@@ -43,5 +43,13 @@ try:
         for l in r.stderr.splitlines():
             if "seconds:" in l or "teardown" in l or "write_plink_many" in l or "scan_create" in l:
                 print("   ", l)
+    if os.environ.get("KIN"):  # the kinship tool on the same table
+        kexe = os.path.join(ROOT, "kmersgwas_amd", "bin", "emma_kinship_kmers")
+        for rep in range(3):
+            t0 = time.perf_counter()
+            r = subprocess.run([kexe, "-t", base, "-k", "31", "--maf", "0.05"], capture_output=True)
+            wall = time.perf_counter() - t0
+            print("emma_kinship_kmers run %d: rc %d wall %.3f s (%.1f GB/s of table), stdout %d bytes" % (rep, r.returncode, wall, rows * (1 + (S + 63) // 64) * 8 / wall / 1e9, len(r.stdout)))
+            print("   ", [l for l in r.stderr.decode().splitlines() if "seconds:" in l][-1:])
 finally:
     shutil.rmtree(d, ignore_errors=True)
