@@ -213,6 +213,7 @@ struct NarrowArgs {
     uint32_t* seg_cnt;         // [n_pheno][n_segs] survivors per 65 536-row segment of the chunk (atomic adds; zeroed by the caller), or null
     uint32_t n_segs;
     uint64_t slack_rows;       // rows of the same buffer that follow the launch's rows (readable: the staged kernel may read whole KB past its last row)
+    uint32_t pack1;            // one column whose operand rows are replicated in all four column slots: lane (r, kb) tests row 16 kb + r of the pass
 };
 // The bitmap's set bits as row-ordered keys (column << row_bits | row), column after column, with each column's range
 // (surv_off, surv_cnt) and the total (key_count; above key_cap = overflow, the ranges are then emptied). No sort: counts

@@ -383,6 +383,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                     return (uint8_t)(sg | ((e + 7) << 3) | ((av * 8) / (1 << e) - 8));
                 };
                 const uint64_t n_steps = 4ull * n_kgroups;
+                s->narrow_pack1 = P == 1 && !(getenv("KGWAS_NARROW_PACK") && atoi(getenv("KGWAS_NARROW_PACK")) == 0);  // (experiments: 0)
                 std::vector<uint8_t> Bn(n_steps * 64 * 32, 0);
                 std::vector<NarrowCol> ncols(P);
                 std::vector<int> q(S);
@@ -418,6 +419,8 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                             t[i] -= u * v;
                         }
                         put_slot(4 * j + k, q);  // operand row 4 p + k; 4 p + 3 = ones
+                        if (s->narrow_pack1)    // (one column: the same rows in the other three column slots, kernels.h NarrowArgs::pack1)
+                            for (uint64_t t = 1; t < 4; t++) put_slot(4 * t + k, q);
                         nc.w[k] = 2.0 * u;
                         u /= 30.0;
                     }
@@ -444,7 +447,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                         nc.slackf = std::nextafter((float)(slack * 1.001), std::numeric_limits<float>::infinity());
                     }
                 }
-                for (uint64_t j = 0; j < P; j++) put_slot(4 * j + 3, std::vector<int>(S, 1));
+                for (uint64_t j = 0; j < (s->narrow_pack1 ? 4 : P); j++) put_slot(4 * j + 3, std::vector<int>(S, 1));
                 s->d_Bn.alloc(Bn.size());
                 s->d_ncols.alloc(P);
                 KGWAS_HIP(hipMemcpy(s->d_Bn.p, Bn.data(), Bn.size(), hipMemcpyHostToDevice));

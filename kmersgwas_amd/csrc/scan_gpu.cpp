@@ -350,6 +350,7 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
             na.bitmap = s->d_bitmap.p;
             na.words_per_col = n_words;
             na.tested = a.tested;
+            na.pack1 = s->narrow_pack1 ? 1u : 0u;
             na.seg_cnt = s->d_bm_blocks.p;
             na.n_segs = (uint32_t)((n_words + 1023) / 1024);
             // (rows of the same device buffer behind this chunk, when the rows are read in place: only a feed's last chunk needs
@@ -357,8 +358,9 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
             na.slack_rows = s->direct ? s->slack_rows : 0;
             // (short blocks: three 4-wave blocks share a CU and a launch's block count is rarely a multiple of the
             // 768 block slots, so long blocks leave CUs idle at the end of every launch: 4096 rows per block measured
-            // 3.4 ms per 100 M rows, 768 rows 3.0)
-            KGWAS_HIP(launch_narrow(na, rpb_env ? rpb_env : (n_rows >= (1u << 18) ? 768u : 256u), s->stream));
+            // 3.4 ms per 100 M rows, 768 rows 3.0; the large chunks of a table that fills the HBM - 48-128 M rows - take
+            // 1280: 26.3 ms per 1.2 G rows against 27.1 with 768, 26.5 with 1024 or 1536)
+            KGWAS_HIP(launch_narrow(na, rpb_env ? rpb_env : (n_rows >= (1u << 24) ? 1280u : n_rows >= (1u << 18) ? 768u : 256u), s->stream));
         } else {
             c.bitmap = s->d_bitmap.p;
             c.words_per_col = n_words;

@@ -329,6 +329,7 @@ struct kgwas_scan {
     uint64_t sum_topn = 0;  // over the columns
     // narrow filter (1-3 columns, score_narrow.hip): replaces coarse_kernel in the same pipeline
     bool narrow = false;
+    bool narrow_pack1 = false;  // one column, replicated in the operand's four column slots (NarrowArgs::pack1)
     DevBuf<uint8_t> d_Bn;
     DevBuf<NarrowCol> d_ncols;
     DevBuf<unsigned long long> d_bitmap;  // survivors of the chunk being filtered: [n_pheno][bitmap_words]

@@ -103,6 +103,44 @@ __device__ __forceinline__ void narrow_test(const NarrowArgs& a, const NarrowCol
     const uint64_t left = a.n_rows - rbase;
     const uint32_t rows_here = left < 64u ? (uint32_t)left : 64u;
     const float Nf = (float)a.S;
+    if (a.pack1) {
+        // ONE column, its slices in all four column slots of the operand: the four lane groups hold the same numbers for
+        // every row tile, so lane (r, kb) takes row tile kb's - the wave tests its 64 rows in one go instead of four
+        // (a quarter of the pre-screen's instructions: 1.2 of the 26 ms a pass over 1.2 G rows takes), and a ballot IS
+        // the pass's bitmap word (bit = lane = row).
+        const uint32_t kb = p;
+        const float d0 = kb == 0u ? acc[0][0] : kb == 1u ? acc[1][0] : kb == 2u ? acc[2][0] : acc[3][0];
+        const float d1 = kb == 0u ? acc[0][1] : kb == 1u ? acc[1][1] : kb == 2u ? acc[2][1] : acc[3][1];
+        const float d2 = kb == 0u ? acc[0][2] : kb == 1u ? acc[1][2] : kb == 2u ? acc[2][2] : acc[3][2];
+        const float on = kb == 0u ? acc[0][3] : kb == 1u ? acc[1][3] : kb == 2u ? acc[2][3] : acc[3][3];
+        const uint32_t n1 = (uint32_t)(2.0f * on);
+        const bool ok = mac_any && (lane < rows_here) && ((n1 - a.min_count) <= span);
+        tested_local += ok ? 1u : 0u;
+        const float ycf = L.wf0 * d0 + L.wf1 * d1 + L.wf2 * d2;
+        const float lf = (fabsf(Nf * ycf) + L.slackf) * 1.001f;
+        const float f1 = (float)n1;
+        const bool maybe1 = ok && !(lf * lf < L.thrf * (f1 * (Nf - f1)) * 0.998f);
+        if (__ballot(maybe1)) {
+            bool hit = false;
+            if (maybe1) {
+                const NarrowCol& cc = cols[0];
+                const double Nd = (double)a.S, thr = a.thr[0];
+                const double N1 = (double)(2.0f * on);
+                const double yc = cc.w[0] * (double)d0 + cc.w[1] * (double)d1 + cc.w[2] * (double)d2;
+                const double rc = Nd * yc + N1 * cc.t1;
+                const double e = cc.eg + fmin(cc.rall, N1 * cc.rmax);
+                const double lhs = (fabs(rc) + Nd * e) * (1.0 + 0x1p-30) + cc.pad;
+                hit = lhs * lhs >= thr * (N1 * (Nd - N1)) * (1.0 - 0x1p-30);  // NaN threshold: never
+            }
+            const unsigned long long w = __ballot(hit);
+            if (w && lane == 0u) {
+                const uint64_t word = (a.row_off + rbase) >> 6;
+                a.bitmap[word] = w;
+                if (a.seg_cnt) atomicAdd(&a.seg_cnt[(uint32_t)(word >> 10)], (uint32_t)__popcll(w));
+            }
+        }
+        return;
+    }
     uint32_t maybe = 0;  // bit rt: this lane's pair of row tile rt may pass
 #pragma unroll
     for (int rt = 0; rt < NRT; rt++) {
@@ -160,7 +198,7 @@ __device__ __forceinline__ void narrow_test(const NarrowArgs& a, const NarrowCol
 
 __device__ __forceinline__ NarrowLane narrow_lane_constants(const NarrowArgs& a, const NarrowCol* cols, uint32_t lane) {
     NarrowLane L;
-    const uint32_t p = lane >> 4;
+    const uint32_t p = a.pack1 ? 0u : lane >> 4;  // (pack1: every lane group tests column 0, narrow_test)
     L.live = p < a.n_pheno;
     const NarrowCol& cc = cols[L.live ? p : 0u];
     L.wf0 = cc.wf[0];
@@ -242,6 +280,25 @@ __global__ void __launch_bounds__(256) narrow_kernel(NarrowArgs a, uint32_t rows
 // in registers while the previous 64 rows are processed, written to the wave's own LDS area and read back from there
 // as the 16-byte pieces the MFMA lanes need. NP = 16-byte pieces per lane = ceil(64 * stride / 1024). The launcher
 // guarantees that every pass that exists can be read in whole KB without leaving the launch's rows.
+// A row is read ONCE per scan: non-temporal loads (`global_load_dwordx4 ... nt`) keep the stream out of the L2's and the
+// MALL's retention policy, and the memory system then delivers 7.1 TB/s to a pure read kernel instead of 6.0-6.3
+// (tools/probe_hbm_read.hip: 8 KB per wave, lane-linear, as here). KGWAS_NARROW_NT=0 at compile time: plain loads.
+// (Persistent blocks - a grid of what the chip holds, each block walking row blocks b, b + grid, ... so that the operands
+// are loaded once per block - measured SLOWER than one block per 1280 rows handed out by the hardware: 26.8-27.6 ms per
+// 1.2 G rows against 26.3 at every grid size from 512 to 4096.)
+#ifndef KGWAS_NARROW_NT
+#define KGWAS_NARROW_NT 1
+#endif
+__device__ __forceinline__ uint4 load_row_piece(const char* p) {
+#if KGWAS_NARROW_NT
+    typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
+    const v4u_t v = __builtin_nontemporal_load(reinterpret_cast<const v4u_t*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *reinterpret_cast<const uint4*>(p);
+#endif
+}
+
 template <int NP>
 __global__ void __launch_bounds__(256) narrow_staged_kernel(NarrowArgs a, uint32_t rows_per_block, uint32_t stage_bytes) {
     extern __shared__ uint4 nlds[];  // slice operands [n_steps][64][2], column constants, then per wave stage_bytes of rows
@@ -273,7 +330,7 @@ __global__ void __launch_bounds__(256) narrow_staged_kernel(NarrowArgs a, uint32
     // loop-carried uint4 array in scratch memory)
     uint4 R0, R1, R2, R3, R4, R5, R6, R7, R8, R9, R10, R11;
 #define NARROW_EACH(X) X(0, R0) X(1, R1) X(2, R2) X(3, R3) X(4, R4) X(5, R5) X(6, R6) X(7, R7) X(8, R8) X(9, R9) X(10, R10) X(11, R11)
-#define NARROW_LOAD(i, r) if (NP > i) r = (KGWAS_NARROW_ABLATE & 32) ? make_uint4(lane, i, (uint32_t)fb, 7u) : *reinterpret_cast<const uint4*>(fetch_ptr + 1024 * i);
+#define NARROW_LOAD(i, r) if (NP > i) r = (KGWAS_NARROW_ABLATE & 32) ? make_uint4(lane, i, (uint32_t)fb, 7u) : load_row_piece(fetch_ptr + 1024 * i);
 #define NARROW_PUT(i, r) if (NP > i) *reinterpret_cast<uint4*>(stage + 16u * (64u * i + lane)) = r;
     {
         const uint64_t fb = pass_row0(0u) * stride_b;
