@@ -289,6 +289,11 @@ __global__ void __launch_bounds__(256) narrow_kernel(NarrowArgs a, uint32_t rows
 #ifndef KGWAS_NARROW_NT
 #define KGWAS_NARROW_NT 1
 #endif
+// KGWAS_NARROW_DEPTH: passes of rows in flight per wave. 1: the next pass. 2: the next two in a second register set -
+// 176 registers with it, two waves per SIMD instead of three, 30.4 ms per 1.2 G rows instead of 26.1: measured, not used.
+#ifndef KGWAS_NARROW_DEPTH
+#define KGWAS_NARROW_DEPTH 1
+#endif
 __device__ __forceinline__ uint4 load_row_piece(const char* p) {
 #if KGWAS_NARROW_NT
     typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
@@ -330,29 +335,33 @@ __global__ void __launch_bounds__(256) narrow_staged_kernel(NarrowArgs a, uint32
     // loop-carried uint4 array in scratch memory)
     uint4 R0, R1, R2, R3, R4, R5, R6, R7, R8, R9, R10, R11;
 #define NARROW_EACH(X) X(0, R0) X(1, R1) X(2, R2) X(3, R3) X(4, R4) X(5, R5) X(6, R6) X(7, R7) X(8, R8) X(9, R9) X(10, R10) X(11, R11)
+#if KGWAS_NARROW_DEPTH == 2
+    // ... and a second set: the rows of the pass after the next (the bytes in flight are what sets the rate of a read
+    // stream whose latency under load is 4 us: 12 waves x 8.7 KB per CU keep 27 MB in flight on the chip, 6.2 TB/s)
+    uint4 S0, S1, S2, S3, S4, S5, S6, S7, S8, S9, S10, S11;
+#define NARROW_EACH2(X) X(0, S0) X(1, S1) X(2, S2) X(3, S3) X(4, S4) X(5, S5) X(6, S6) X(7, S7) X(8, S8) X(9, S9) X(10, S10) X(11, S11)
+#endif
 #define NARROW_LOAD(i, r) if (NP > i) r = (KGWAS_NARROW_ABLATE & 32) ? make_uint4(lane, i, (uint32_t)fb, 7u) : load_row_piece(fetch_ptr + 1024 * i);
 #define NARROW_PUT(i, r) if (NP > i) *reinterpret_cast<uint4*>(stage + 16u * (64u * i + lane)) = r;
-    {
-        const uint64_t fb = pass_row0(0u) * stride_b;
-        const char* fetch_ptr = rows_base + fb + 16u * lane;
-        if (fb < total_b) {
-            NARROW_EACH(NARROW_LOAD)
-        }
+#define NARROW_FETCH(EACH, q)                                                                     \
+    {                                                                                             \
+        const uint64_t fb = pass_row0(q) * stride_b;                                              \
+        const char* fetch_ptr = rows_base + fb + 16u * lane;                                      \
+        if (fb < total_b && ((q) * 4u + wave) * 64u < rows_per_block) { /* (scalar) */            \
+            EACH(NARROW_LOAD)                                                                     \
+        }                                                                                         \
     }
+    NARROW_FETCH(NARROW_EACH, 0u)
+#if KGWAS_NARROW_DEPTH == 2
+    NARROW_FETCH(NARROW_EACH2, 1u)
+#endif
     // where this lane's pieces of the four row tiles sit in the wave's stage
     uint32_t pofs[NRT];
 #pragma unroll
     for (int rt = 0; rt < NRT; rt++) pofs[rt] = (rt * 16u + m) * stride_b + off_b;
-    for (uint32_t ps = 0; pass_exists(ps); ps++) {
-        const uint64_t rbase = pass_row0(ps);
-        NARROW_EACH(NARROW_PUT)  // (the last piece may reach past the 64 rows: the stage area is sized in whole KB)
-        {
-            const uint64_t fb = pass_row0(ps + 1u) * stride_b;  // in flight while these 64 rows are processed
-            const char* fetch_ptr = rows_base + fb + 16u * lane;
-            if (fb < total_b && ((ps + 1u) * 4u + wave) * 64u < rows_per_block) {  // (scalar)
-                NARROW_EACH(NARROW_LOAD)
-            }
-        }
+    // One pass: the wave's 64 rows from the register set EACH into its stage, the set refilled with the rows of pass
+    // ps + KGWAS_NARROW_DEPTH (in flight while these rows are processed), MFMAs, test.
+    auto process = [&](uint64_t rbase) {
         __builtin_amdgcn_wave_barrier();
         nv4f acc[NRT];
 #pragma unroll
@@ -389,7 +398,26 @@ __global__ void __launch_bounds__(256) narrow_staged_kernel(NarrowArgs a, uint32
             narrow_test(a, lcols, L, acc, lane, rbase, mac_any, span, tested_local);
         }
         __builtin_amdgcn_wave_barrier();  // the pass's piece reads are done before the next pass's rows are stored
+    };
+#define NARROW_PASS(EACH, ps)                                                                                     \
+    {                                                                                                             \
+        EACH(NARROW_PUT) /* (the last piece may reach past the 64 rows: the stage area is sized in whole KB) */   \
+        NARROW_FETCH(EACH, (ps) + KGWAS_NARROW_DEPTH)                                                             \
+        process(pass_row0(ps));                                                                                   \
     }
+#if KGWAS_NARROW_DEPTH == 2
+    for (uint32_t ps = 0;; ps += 2u) {
+        if (!pass_exists(ps)) break;
+        NARROW_PASS(NARROW_EACH, ps)
+        if (!pass_exists(ps + 1u)) break;
+        NARROW_PASS(NARROW_EACH2, ps + 1u)
+    }
+#undef NARROW_EACH2
+#else
+    for (uint32_t ps = 0; pass_exists(ps); ps++) NARROW_PASS(NARROW_EACH, ps)
+#endif
+#undef NARROW_PASS
+#undef NARROW_FETCH
 #undef NARROW_EACH
 #undef NARROW_LOAD
 #undef NARROW_PUT
