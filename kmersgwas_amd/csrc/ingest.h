@@ -12,8 +12,6 @@
 // with most of them idle behind its last sub-piece). The consumer sees the rows in order, so results do not depend
 // on any of these sizes.
 #pragma once
-#include <pthread.h>
-#include <sched.h>
 #include <sys/mman.h>
 
 #include <chrono>
@@ -36,6 +34,13 @@ template <class T>
 struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) {
+        o.p = nullptr;
+        o.n = 0;
+    }
     void alloc(size_t count) {
         release();
         if (count) KGWAS_HIP(hipMalloc((void**)&p, count * sizeof(T)));
@@ -141,13 +146,7 @@ public:
     // the work on the piece complete (the device buffer is reused device_pieces_ pieces later).
     using Consume = std::function<void(const uint64_t*, uint64_t, uint64_t)>;
 
-    ~Ingest() {
-        for (auto& e : ev_)
-            if (e) (void)hipEventDestroy(e);
-        for (auto& e : ev_h_)
-            if (e) (void)hipEventDestroy(e);
-        if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
-    }
+    ~Ingest() { drop(); }
 
     // stride = 64-bit words per row; max_piece_rows bounds a piece (the consumer's own chunk limit).
     void run(uint64_t stride, uint64_t n_rows, uint64_t max_piece_rows, hipStream_t stream, const Fill& fill,
@@ -158,21 +157,26 @@ public:
             if (const char* e = getenv("KGWAS_INGEST_PIECE_ROWS"))
                 if (atoll(e) > 0) pr = (uint64_t)atoll(e);
             pr = std::max<uint64_t>(128, std::min<uint64_t>(pr, max_piece_rows) / 128 * 128);
-            piece_rows_ = pr;
             if (const char* e = getenv("KGWAS_INGEST_PINNED"))
                 if (atoi(e) >= 2 && atoi(e) <= 16) pinned_pieces_ = (unsigned)atoi(e);
-            h_.resize(pinned_pieces_);
-            ev_h_.assign(pinned_pieces_, nullptr);
-            for (auto& h : h_) h.alloc(pr * stride);
-            // (blocking: a producer that has to wait for a copy sleeps; the replay workers share its CPU)
-            for (auto& e : ev_h_) KGWAS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync));
             if (const char* e = getenv("KGWAS_INGEST_DEVICE"))
                 if (atoi(e) >= 2 && atoi(e) <= 64) device_pieces_ = (unsigned)atoi(e);
-            d_.resize(device_pieces_);
-            ev_.assign(device_pieces_, nullptr);
-            for (auto& d : d_) d.alloc(pr * stride);
-            KGWAS_HIP(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
-            for (auto& e : ev_) KGWAS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            try {
+                h_.resize(pinned_pieces_);
+                ev_h_.assign(pinned_pieces_, nullptr);
+                for (auto& h : h_) h.alloc(pr * stride);
+                // (blocking: a producer that has to wait for a copy sleeps; the replay workers share its CPU)
+                for (auto& e : ev_h_) KGWAS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync));
+                d_.resize(device_pieces_);
+                ev_.assign(device_pieces_, nullptr);
+                for (auto& d : d_) d.alloc(pr * stride);
+                KGWAS_HIP(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+                for (auto& e : ev_) KGWAS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            } catch (...) {
+                drop();  // (a later run starts over instead of finding half of the buffers)
+                throw;
+            }
+            piece_rows_ = pr;
         }
         const uint64_t piece = piece_rows_;
         const uint64_t n_pieces = (n_rows + piece - 1) / piece;
@@ -180,7 +184,7 @@ public:
 
         std::mutex mu;
         std::condition_variable cv;
-        // A piece is filled in SUB-PIECES of 16 MiB by several producer threads at once (a single thread tops out near
+        // A piece is filled in SUB-PIECES of 4 MiB by several producer threads at once (a single thread tops out near
         // 15 GB/s reading the page cache and 28 GB/s copying memory; one thread per 128 MiB piece, the first version, kept
         // at most three of them busy and delivered 27 / 42 GB/s). Items are handed out in order; a piece may be started
         // once the copy of the piece whose pinned buffer it takes has been queued (its producers then wait for that copy).
@@ -199,16 +203,6 @@ public:
         KGWAS_HIP(hipGetDevice(&dev));
         auto producer_main = [&] {
             (void)hipSetDevice(dev);
-            {
-                // The producers share their CPUs with the consumer's pinned replay workers, which wake up for a fraction of a
-                // millisecond per piece and must not wait out a copying thread's time slice: SCHED_IDLE gives way at once.
-                static const int pol = getenv("KGWAS_INGEST_SCHED") ? atoi(getenv("KGWAS_INGEST_SCHED")) : 1;  // experiments: 0 = leave as is
-                if (pol) {
-                    struct sched_param sp;
-                    sp.sched_priority = 0;
-                    (void)pthread_setschedparam(pthread_self(), SCHED_IDLE, &sp);
-                }
-            }
             try {
                 for (;;) {
                     uint64_t k, j;
@@ -338,6 +332,19 @@ public:
     }
 
 private:
+    void drop() {
+        for (auto& e : ev_)
+            if (e) (void)hipEventDestroy(e);
+        for (auto& e : ev_h_)
+            if (e) (void)hipEventDestroy(e);
+        ev_.clear();
+        ev_h_.clear();
+        if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
+        copy_stream_ = nullptr;
+        h_.clear();
+        d_.clear();
+        piece_rows_ = 0;
+    }
     std::vector<PinBuf<uint64_t>> h_;
     std::vector<hipEvent_t> ev_h_;  // per pinned piece: its copy to the device has completed
     std::vector<DevBuf<uint64_t>> d_;
