@@ -17,4 +17,3 @@ run KGWAS_INGEST_THREADS=12
 run KGWAS_INGEST_THREADS=16
 run KGWAS_INGEST_PIECE_ROWS=493440
 run KGWAS_INGEST_PIECE_ROWS=1973760
-run KGWAS_INGEST_SCHED=0
