@@ -283,6 +283,8 @@ __global__ void __launch_bounds__(256) narrow_kernel(NarrowArgs a, uint32_t rows
 // A row is read ONCE per scan: non-temporal loads (`global_load_dwordx4 ... nt`) keep the stream out of the L2's and the
 // MALL's retention policy, and the memory system then delivers 7.1 TB/s to a pure read kernel instead of 6.0-6.3
 // (tools/probe_hbm_read.hip: 8 KB per wave, lane-linear, as here). KGWAS_NARROW_NT=0 at compile time: plain loads.
+// (Four blocks per CU instead of three - one column's operand kept as its 4 distinct rows, 4 KB instead of 16, constants out
+// of LDS, 124 registers - measured SLOWER: 29.6 against 26.1-26.8 ms per 1.2 G rows. More waves are not what this kernel lacks.)
 // (Persistent blocks - a grid of what the chip holds, each block walking row blocks b, b + grid, ... so that the operands
 // are loaded once per block - measured SLOWER than one block per 1280 rows handed out by the hardware: 26.8-27.6 ms per
 // 1.2 G rows against 26.3 at every grid size from 512 to 4096.)
