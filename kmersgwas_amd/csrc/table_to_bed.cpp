@@ -17,16 +17,6 @@
 namespace kgwas {
 namespace {
 
-std::string bits_to_kmer_str(uint64_t w, size_t k) {  // bits2kmer31, src/kmer_general.cpp:77-87
-    static const char bp[4] = {'A', 'C', 'G', 'T'};
-    std::string s(k, 'X');
-    for (size_t i = 0; i < k; i++) {
-        s[k - 1 - i] = bp[w & 3u];
-        w >>= 2;
-    }
-    return s;
-}
-
 template <class T>
 struct Dev {
     T* p = nullptr;
@@ -121,6 +111,17 @@ extern "C" int kgwas_table_to_bed(kgwas_table* t, const uint64_t* col, uint64_t 
             KGWAS_HIP(hipMemcpyAsync(h_hash.p, d_hash.p, c * 8, hipMemcpyDeviceToHost, st));
             KGWAS_HIP(hipMemcpyAsync(h_bed.p, d_bed.p, c * bpr, hipMemcpyDeviceToHost, st));
             KGWAS_HIP(hipStreamSynchronize(st));
+            // The piece's kept rows go out in runs: consecutive rows' .bed bytes are adjacent in h_bed, their .bim lines are put
+            // together in one buffer (one ofstream call per row and field was most of the tool's time: 1.8 GB/s of files).
+            std::string bim_buf;
+            bim_buf.reserve((size_t)std::min<uint64_t>(c, 1u << 20) * (klen + 12));
+            uint64_t run0 = 0, run_n = 0;  // rows [run0, run0 + run_n) of the piece: kept and not yet written
+            auto flush_run = [&] {
+                if (run_n) bed.write(reinterpret_cast<const char*>(h_bed.p + run0 * bpr), (std::streamsize)(run_n * bpr));
+                run_n = 0;
+                if (!bim_buf.empty()) bim.write(bim_buf.data(), (std::streamsize)bim_buf.size());
+                bim_buf.clear();
+            };
             for (uint64_t r = 0; r < c; r++) {
                 if (!open) {  // a batch starts with the first row read in it
                     const std::string base = std::string(out_base) + "." + std::to_string(batch);
@@ -134,13 +135,27 @@ extern "C" int kgwas_table_to_bed(kgwas_table* t, const uint64_t* col, uint64_t 
                 if (S >= min_count && n1 >= min_count && n1 <= S - min_count) {
                     kept++;
                     if (!unique_patterns || seen.insert(h_hash.p[r]).second) {
-                        bim << "0\t" << bits_to_kmer_str(h_rows.p[r * stride], klen) << "\t0\t0\t0\t1\n";
-                        bed.write(reinterpret_cast<const char*>(h_bed.p + r * bpr), bpr);
+                        if (run_n && run0 + run_n != r) flush_run();
+                        if (!run_n) run0 = r;
+                        run_n++;
+                        bim_buf += "0\t";
+                        {
+                            const uint64_t w = h_rows.p[r * stride];
+                            char km[32];
+                            for (size_t i = 0; i < klen; i++) km[i] = "ACGT"[(w >> (2 * (klen - 1 - i))) & 3];  // bits2kmer31, src/kmer_general.cpp:77-87
+                            bim_buf.append(km, klen);
+                        }
+                        bim_buf += "\t0\t0\t0\t1\n";
                         written++;
+                        if (bim_buf.size() > (8u << 20)) flush_run();
                     }
-                    if (kept >= batch_size) close_batch();  // load_kmers stops reading once the batch is full
+                    if (kept >= batch_size) {  // load_kmers stops reading once the batch is full
+                        flush_run();
+                        close_batch();
+                    }
                 }
             }
+            if (open) flush_run();
         }
         if (open) close_batch();
         if (n_batches) *n_batches = batch;
