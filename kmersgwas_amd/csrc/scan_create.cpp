@@ -206,6 +206,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         KGWAS_HIP(hipEventCreate(&s->ev_d0));
         KGWAS_HIP(hipEventCreate(&s->ev_d1));
 
+        tcreate("events created");
         // ---- constant device data --------------------------------------------------------
         const uint64_t S = s->S, L = s->L, W_m = s->W_m, P = s->n_pheno;
         std::vector<uint32_t> dmask(2 * W_m, 0), colmap(L, 0xFFFFFFFFu);
@@ -253,6 +254,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                 nb++;
             s->nb_full = nb;
         }
+        tcreate("phenotype layouts built (host)");
         s->d_dmask.alloc(dmask.size());
         s->d_colmap.alloc(colmap.size());
         s->d_sums.alloc(P);
@@ -285,6 +287,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
             s->d_Yperm.alloc(Yperm.size());
             KGWAS_HIP(hipMemcpy(s->d_Yperm.p, Yperm.data(), Yperm.size() * 4, hipMemcpyHostToDevice));
         }
+        tcreate("small device buffers allocated and uploaded");
         if (s->coarse) {
             // int8 slices per column: y_i ~ c + u*(254*q0_i + q1_i) (two slices, ~15 bits) or c + u*q0_i (one),
             // centred at c = sum/N, sum being the reference's float32 sum of the column: then
