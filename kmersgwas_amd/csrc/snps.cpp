@@ -14,6 +14,7 @@
 #include <fstream>
 #include <iostream>
 #include <memory>
+#include <mutex>
 #include <sstream>
 #include <string>
 #include <system_error>
@@ -232,27 +233,82 @@ int kgwas_snps_write(kgwas_snps* s, uint64_t n_lists, const char* const* out_bas
                      const uint64_t* indices, uint64_t stride) {
     return guarded([&] {
         if (!s || (n_lists && (!out_bases || !counts || !indices))) throw Error(KGWAS_ERR_ARG, "kgwas_snps_write: null argument");
-        std::vector<std::ofstream> beds(n_lists), bims(n_lists);
-        for (uint64_t l = 0; l < n_lists; l++) {  // BedBimFilesHandle (src/kmer_general.h:133-147)
-            const std::string b(out_bases[l]);
-            beds[l].open(b + ".bed", std::ios::binary);
-            bims[l].open(b + ".bim");
-            if (!beds[l] || !bims[l]) throw Error(KGWAS_ERR_IO, "cannot create " + b + ".bed/.bim");
-            beds[l] << (char)0x6C << (char)0x1B << (char)0x01;
+        // The .bim is read once and its lines indexed; every list then writes its own two files - lines and genotype rows of its
+        // SNPs, in order - on one of a few threads. (One pass over the SNPs that asked every list about every SNP and
+        // flushed each line took 1.1 s for 101 lists of 10 001 among 2 M SNPs; the bytes are the same.)
+        std::string bim_text;
+        {
+            std::ifstream bim(s->base + ".bim", std::ios::binary | std::ios::ate);
+            if (bim) {
+                const std::streamsize sz = bim.tellg();
+                bim.seekg(0);
+                bim_text.resize((size_t)std::max<std::streamsize>(sz, 0));
+                bim.read(&bim_text[0], sz);
+                bim_text.resize((size_t)std::max<std::streamsize>(bim.gcount(), 0));
+            }
         }
-        std::ifstream bim(s->base + ".bim");
-        std::string line;
-        std::vector<uint64_t> last(n_lists, 0);
-        for (uint64_t i = 0; i < s->n_snps; i++) {
-            std::getline(bim, line);
-            for (uint64_t l = 0; l < n_lists; l++)
-                if (last[l] < counts[l] && indices[l * stride + last[l]] == i) {
-                    bims[l] << line << std::endl;
-                    beds[l].write(reinterpret_cast<const char*>(s->bed.data() + i * s->bytes_per_snp),
-                                  (std::streamsize)s->bytes_per_snp);
-                    last[l]++;
+        std::vector<size_t> line_at;  // start of line i; one more entry: the end of the text (a missing line reads as empty, as getline on a short file)
+        line_at.reserve(s->n_snps + 1);
+        for (size_t at = 0; line_at.size() < s->n_snps; ) {
+            line_at.push_back(std::min(at, bim_text.size()));
+            const size_t nl = at < bim_text.size() ? bim_text.find('\n', at) : std::string::npos;
+            at = nl == std::string::npos ? bim_text.size() + 1 : nl + 1;
+        }
+        auto line_of = [&](uint64_t i, const char*& p, size_t& n) {
+            const size_t a0 = line_at[i];
+            size_t e = a0 < bim_text.size() ? bim_text.find('\n', a0) : std::string::npos;
+            if (e == std::string::npos) e = bim_text.size();
+            p = bim_text.data() + std::min(a0, bim_text.size());
+            n = e > a0 ? e - a0 : 0;
+        };
+        std::atomic<uint64_t> next(0);
+        std::exception_ptr err;
+        std::mutex emu;
+        auto work = [&] {
+            try {
+                std::string out;
+                for (uint64_t l; (l = next.fetch_add(1, std::memory_order_relaxed)) < n_lists;) {
+                    const std::string b(out_bases[l]);  // BedBimFilesHandle (src/kmer_general.h:133-147)
+                    std::ofstream bed(b + ".bed", std::ios::binary), bimo(b + ".bim", std::ios::binary);
+                    if (!bed || !bimo) throw Error(KGWAS_ERR_IO, "cannot create " + b + ".bed/.bim");
+                    bed << (char)0x6C << (char)0x1B << (char)0x01;
+                    out.clear();
+                    uint64_t prev = 0;
+                    bool first = true;
+                    for (uint64_t q = 0; q < counts[l]; q++) {
+                        const uint64_t i = indices[l * stride + q];
+                        // (the one-pass form took a list's entries in ascending SNP order and stopped at the first one out of order
+                        // or past the end)
+                        if (i >= s->n_snps || (!first && i <= prev)) break;
+                        first = false;
+                        prev = i;
+                        const char* p;
+                        size_t n;
+                        line_of(i, p, n);
+                        out.append(p, n);
+                        out.push_back('\n');
+                        bed.write(reinterpret_cast<const char*>(s->bed.data() + i * s->bytes_per_snp), (std::streamsize)s->bytes_per_snp);
+                    }
+                    bimo.write(out.data(), (std::streamsize)out.size());
                 }
+            } catch (...) {
+                std::lock_guard<std::mutex> lk(emu);
+                if (!err) err = std::current_exception();
+                next.store(n_lists);
+            }
+        };
+        const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(usable_cpus(), 16), n_lists));
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; t++) {
+            try {
+                th.emplace_back(work);
+            } catch (const std::system_error&) {
+                break;
+            }
         }
+        work();
+        for (auto& t : th) t.join();
+        if (err) std::rethrow_exception(err);
     });
 }
 

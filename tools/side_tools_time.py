@@ -52,6 +52,12 @@ try:
         res = db.best(Y, 10001, 57.0)
         t3 = time.perf_counter()
         print("associate_snps: open %.3f s; best of %d SNPs x %d samples x %d columns %.3f s (%.2e SNP x phenotype / s)" % (t1 - t0, n_snps, S, Y.shape[0], t3 - t2, n_snps * Y.shape[0] / (t3 - t2)), flush=True)
+    out = os.path.join(d, "snp_out"); os.mkdir(out)
+    t0 = time.perf_counter()
+    db.write([os.path.join(out, "o.%d" % j) for j in range(Y.shape[0])], res)
+    dt = time.perf_counter() - t0
+    sz = sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out))
+    print("associate_snps: %d x %d winners written (%.0f MB) in %.3f s" % (Y.shape[0], 10001, sz / 1e6, dt), flush=True)
     db.close()
 finally:
     shutil.rmtree(d, ignore_errors=True)
