@@ -7,11 +7,17 @@
 // pattern hash, PLINK bytes); the host walks the rows in file order, applies the MAC filter and the hash set, and
 // writes. No CPU fallback: the per-row work needs the GPU.
 #include <fstream>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <exception>
+#include <future>
 #include <string>
 #include <unordered_set>
 #include <vector>
 
 #include "common.h"
+#include "ingest.h"
 #include "kernels.h"
 
 namespace kgwas {
@@ -25,15 +31,6 @@ struct Dev {
         if (p) (void)hipFree(p);
     }
 };
-template <class T>
-struct Pin {
-    T* p = nullptr;
-    void alloc(size_t n) { KGWAS_HIP(hipHostMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T), hipHostMallocDefault)); }
-    ~Pin() {
-        if (p) (void)hipHostFree(p);
-    }
-};
-
 }  // namespace
 }  // namespace kgwas
 
@@ -64,9 +61,13 @@ extern "C" int kgwas_table_to_bed(kgwas_table* t, const uint64_t* col, uint64_t 
         Dev<uint32_t> d_colmap, d_sq, d_n1;
         Dev<uint64_t> d_rows, d_hash;
         Dev<uint8_t> d_bed;
-        Pin<uint64_t> h_rows, h_hash;
-        Pin<uint32_t> h_n1;
-        Pin<uint8_t> h_bed;
+        // Two sets of host buffers: piece k + 1 is read, copied and processed on the GPU (this thread) while piece k's kept rows
+        // are written (the writer thread below: batches, the pattern set and the files are its alone, pieces in order).
+        struct HostSet {
+            PinBuf<uint64_t> rows, hash;
+            PinBuf<uint32_t> n1;
+            PinBuf<uint8_t> bed;
+        } hs[2];
         d_colmap.alloc(colmap.size());
         KGWAS_HIP(hipMemcpy(d_colmap.p, colmap.data(), colmap.size() * 4, hipMemcpyHostToDevice));
         d_rows.alloc(piece * stride);
@@ -74,10 +75,12 @@ extern "C" int kgwas_table_to_bed(kgwas_table* t, const uint64_t* col, uint64_t 
         d_n1.alloc(piece);
         d_hash.alloc(piece);
         d_bed.alloc(piece * bpr);
-        h_rows.alloc(piece * stride);
-        h_n1.alloc(piece);
-        h_hash.alloc(piece);
-        h_bed.alloc(piece * bpr);
+        for (HostSet& h : hs) {
+            h.rows.alloc(piece * stride);
+            h.n1.alloc(piece);
+            h.hash.alloc(piece);
+            h.bed.alloc(piece * bpr);
+        }
         hipStream_t st = nullptr;
         KGWAS_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         struct StreamGuard {
@@ -89,7 +92,12 @@ extern "C" int kgwas_table_to_bed(kgwas_table* t, const uint64_t* col, uint64_t 
         std::ofstream bed, bim;
         bool open = false;
         uint64_t batch = 0, kept = 0, written = 0;
+        std::future<void> bed_pending;  // the .bed bytes of the last run, written beside the formatting of the next run's .bim lines
+        auto bed_wait = [&] {
+            if (bed_pending.valid()) bed_pending.get();
+        };
         auto close_batch = [&] {
+            bed_wait();
             bed.close();
             bim.close();
             const std::string base = std::string(out_base) + "." + std::to_string(batch);
@@ -100,25 +108,27 @@ extern "C" int kgwas_table_to_bed(kgwas_table* t, const uint64_t* col, uint64_t 
             batch++;
             kept = 0;
         };
-        for (uint64_t pos = 0; pos < n_rows; pos += piece) {
-            const uint64_t c = std::min<uint64_t>(piece, n_rows - pos);
-            if (kgwas_table_read_rows(t, pos, c, h_rows.p) != KGWAS_OK) throw Error(KGWAS_ERR_IO, kgwas_last_error());
-            KGWAS_HIP(hipMemcpyAsync(d_rows.p, h_rows.p, c * stride * 8, hipMemcpyHostToDevice, st));
-            KGWAS_HIP(launch_squeeze(d_rows.p, stride, c, d_colmap.p, W_m, (uint32_t)W_f, d_sq.p, st));
-            KGWAS_HIP(launch_bed_rowinfo(d_sq.p, c, W_m, d_n1.p, d_hash.p, st));
-            KGWAS_HIP(launch_bed_bytes(d_sq.p, c, W_m, bpr, d_bed.p, st));
-            KGWAS_HIP(hipMemcpyAsync(h_n1.p, d_n1.p, c * 4, hipMemcpyDeviceToHost, st));
-            KGWAS_HIP(hipMemcpyAsync(h_hash.p, d_hash.p, c * 8, hipMemcpyDeviceToHost, st));
-            KGWAS_HIP(hipMemcpyAsync(h_bed.p, d_bed.p, c * bpr, hipMemcpyDeviceToHost, st));
-            KGWAS_HIP(hipStreamSynchronize(st));
-            // The piece's kept rows go out in runs: consecutive rows' .bed bytes are adjacent in h_bed, their .bim lines are put
-            // together in one buffer (one ofstream call per row and field was most of the tool's time: 1.8 GB/s of files).
+        // what the writer does with one piece: its kept rows go out in runs - consecutive rows' .bed bytes are adjacent, their
+        // .bim lines are put together in one buffer
+        auto write_piece = [&](const HostSet& h, uint64_t c) {
             std::string bim_buf;
             bim_buf.reserve((size_t)std::min<uint64_t>(c, 1u << 20) * (klen + 12));
-            uint64_t run0 = 0, run_n = 0;  // rows [run0, run0 + run_n) of the piece: kept and not yet written
-            auto flush_run = [&] {
-                if (run_n) bed.write(reinterpret_cast<const char*>(h_bed.p + run0 * bpr), (std::streamsize)(run_n * bpr));
+            uint64_t run0 = 0, run_n = 0;  // rows [run0, run0 + run_n) of the piece: kept, not yet in `runs`
+            std::vector<std::pair<const char*, std::streamsize>> runs;  // .bed bytes to write, in order
+            auto end_run = [&] {
+                if (run_n) runs.emplace_back(reinterpret_cast<const char*>(h.bed.p + run0 * bpr), (std::streamsize)(run_n * bpr));
                 run_n = 0;
+            };
+            auto flush_run = [&] {  // everything collected so far goes out: the .bed runs on a thread of their own, the .bim lines here
+                end_run();
+                if (!runs.empty()) {
+                    bed_wait();
+                    std::ofstream* bo = &bed;
+                    bed_pending = std::async(std::launch::async, [bo, rs = std::move(runs)] {
+                        for (const auto& pr : rs) bo->write(pr.first, pr.second);
+                    });
+                    runs.clear();
+                }
                 if (!bim_buf.empty()) bim.write(bim_buf.data(), (std::streamsize)bim_buf.size());
                 bim_buf.clear();
             };
@@ -131,16 +141,16 @@ extern "C" int kgwas_table_to_bed(kgwas_table* t, const uint64_t* col, uint64_t 
                     bed << (char)0x6C << (char)0x1B << (char)0x01;  // BedBimFilesHandle, src/kmer_general.h:138
                     open = true;
                 }
-                const uint64_t n1 = h_n1.p[r];
+                const uint64_t n1 = h.n1.p[r];
                 if (S >= min_count && n1 >= min_count && n1 <= S - min_count) {
                     kept++;
-                    if (!unique_patterns || seen.insert(h_hash.p[r]).second) {
-                        if (run_n && run0 + run_n != r) flush_run();
+                    if (!unique_patterns || seen.insert(h.hash.p[r]).second) {
+                        if (run_n && run0 + run_n != r) end_run();
                         if (!run_n) run0 = r;
                         run_n++;
                         bim_buf += "0\t";
                         {
-                            const uint64_t w = h_rows.p[r * stride];
+                            const uint64_t w = h.rows.p[r * stride];
                             char km[32];
                             for (size_t i = 0; i < klen; i++) km[i] = "ACGT"[(w >> (2 * (klen - 1 - i))) & 3];  // bits2kmer31, src/kmer_general.cpp:77-87
                             bim_buf.append(km, klen);
@@ -156,8 +166,85 @@ extern "C" int kgwas_table_to_bed(kgwas_table* t, const uint64_t* col, uint64_t 
                 }
             }
             if (open) flush_run();
+            bed_wait();  // (the piece's buffers go back to the reader)
+        };
+        const uint64_t n_pieces = (n_rows + piece - 1) / piece;
+        std::mutex mu;
+        std::condition_variable cv;
+        uint64_t ready = 0, done = 0;  // pieces handed to the writer / written
+        bool stop = false;
+        std::exception_ptr werr;
+        std::thread writer([&] {
+            try {
+                for (uint64_t k = 0; k < n_pieces; k++) {
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return stop || ready > k; });
+                        if (ready <= k) return;
+                    }
+                    write_piece(hs[k & 1], std::min<uint64_t>(piece, n_rows - k * piece));
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        done = k + 1;
+                    }
+                    cv.notify_all();
+                }
+                if (open) close_batch();
+            } catch (...) {
+                std::unique_lock<std::mutex> lk(mu);
+                werr = std::current_exception();
+                stop = true;
+                cv.notify_all();
+            }
+        });
+        struct WriterJoin {
+            std::thread& t;
+            std::mutex& mu;
+            std::condition_variable& cv;
+            bool& stop;
+            bool orderly = false;
+            ~WriterJoin() {
+                if (!orderly) {
+                    std::unique_lock<std::mutex> lk(mu);
+                    stop = true;
+                }
+                cv.notify_all();
+                if (t.joinable()) t.join();
+            }
+        } wj{writer, mu, cv, stop};
+        for (uint64_t k = 0; k < n_pieces; k++) {
+            const uint64_t pos = k * piece, c = std::min<uint64_t>(piece, n_rows - pos);
+            HostSet& h = hs[k & 1];
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || done + 2 > k; });  // the writer is through with piece k - 2 (this set)
+                if (stop) break;
+            }
+            if (kgwas_table_read_rows(t, pos, c, h.rows.p) != KGWAS_OK) throw Error(KGWAS_ERR_IO, kgwas_last_error());
+            KGWAS_HIP(hipMemcpyAsync(d_rows.p, h.rows.p, c * stride * 8, hipMemcpyHostToDevice, st));
+            KGWAS_HIP(launch_squeeze(d_rows.p, stride, c, d_colmap.p, W_m, (uint32_t)W_f, d_sq.p, st));
+            KGWAS_HIP(launch_bed_rowinfo(d_sq.p, c, W_m, d_n1.p, d_hash.p, st));
+            KGWAS_HIP(launch_bed_bytes(d_sq.p, c, W_m, bpr, d_bed.p, st));
+            KGWAS_HIP(hipMemcpyAsync(h.n1.p, d_n1.p, c * 4, hipMemcpyDeviceToHost, st));
+            KGWAS_HIP(hipMemcpyAsync(h.hash.p, d_hash.p, c * 8, hipMemcpyDeviceToHost, st));
+            KGWAS_HIP(hipMemcpyAsync(h.bed.p, d_bed.p, c * bpr, hipMemcpyDeviceToHost, st));
+            KGWAS_HIP(hipStreamSynchronize(st));
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                ready = k + 1;
+            }
+            cv.notify_all();
         }
-        if (open) close_batch();
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return stop || done >= n_pieces; });
+        }
+        wj.orderly = !stop;
+        if (writer.joinable()) {
+            if (stop) cv.notify_all();
+            writer.join();  // (closes the last batch)
+        }
+        if (werr) std::rethrow_exception(werr);
         if (n_batches) *n_batches = batch;
         if (n_written) *n_written = written;
     });
