@@ -252,11 +252,4 @@ hipError_t launch_copy_to_host(const void* src, void* dst_dev, size_t bytes, hip
     return hipGetLastError();
 }
 
-// Loads this file's code object (HIP does it at the first use of any of its kernels: tens of milliseconds for the whole
-// library in a fresh process - kgwas_scan_create does it on a thread of its own, beside the pinning of the record ring).
-hipError_t warm_aux_kernels() {
-    hipFuncAttributes at;
-    return hipFuncGetAttributes(&at, reinterpret_cast<const void*>(thr_update_kernel));
-}
-
 }  // namespace kgwas

@@ -43,3 +43,8 @@ int guarded(F&& body) {
 }
 
 }  // namespace kgwas
+
+// Names the calling thread (comm, <= 15 characters): a hang report (tools/fuzz_parity.py's watchdog reads /proc/self/task) or
+// a profiler then says WHICH of the library's helper threads it is looking at.
+#include <pthread.h>
+inline void kgwas_name_this_thread(const char* name) { (void)pthread_setname_np(pthread_self(), name); }

@@ -78,6 +78,7 @@ struct PinRegion {
                     std::vector<std::thread> th;
                     for (size_t i = 0; i < nt; i++)
                         th.emplace_back([=] {
+                            kgwas_name_this_thread("kgwas-touch");
                             const size_t a = len / nt / HUGE * HUGE * i, b = i + 1 == nt ? len : len / nt / HUGE * HUGE * (i + 1);
                             for (size_t o = a; o < b; o += 4096) al[o] = 0;
                         });
@@ -202,6 +203,7 @@ public:
         int dev = 0;
         KGWAS_HIP(hipGetDevice(&dev));
         auto producer_main = [&] {
+            kgwas_name_this_thread("kgwas-producer");
             (void)hipSetDevice(dev);
             try {
                 for (;;) {
@@ -272,6 +274,7 @@ public:
         // 40 M-row feed. Device pieces are cheap (128 MiB of 288 GB each), so there are enough of them to copy through it.
         const uint64_t ND = d_.size();
         auto copier_main = [&] {
+            kgwas_name_this_thread("kgwas-copier");
             try {
                 KGWAS_HIP(hipSetDevice(dev));
                 for (uint64_t k = 0; k < n_pieces; k++) {

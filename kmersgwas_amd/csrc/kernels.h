@@ -69,13 +69,6 @@ constexpr uint32_t HIST_BINS = 16384;   // 64 binades above the threshold at spa
 
 // thr[p] = max(thr[p], thr_host[p], largest bin boundary with >= topn[p] counted scores at or above it).
 hipError_t launch_copy_to_host(const void* src, void* dst_dev, size_t bytes, hipStream_t st);  // dst_dev: device address of mapped pinned memory
-// Each loads its file's code object (otherwise done by HIP at the first launch from that file).
-hipError_t warm_score_mfma();
-hipError_t warm_score_valu();
-hipError_t warm_score_coarse();
-hipError_t warm_score_mx();
-hipError_t warm_score_narrow();
-hipError_t warm_aux_kernels();
 // device pointers of the (mapped) pinned destination
 hipError_t launch_records_to_host(const double* sc, const uint64_t* km, const uint32_t* rw, uint32_t n, double* h_sc, uint64_t* h_km, uint32_t* h_rw,
                                   hipStream_t st);

@@ -136,71 +136,11 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         };
         KGWAS_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
         tcreate("stream created (HIP context up)");
-        // The library's code objects, loaded beside everything below (a fresh process spent 58 ms on them inside its first
-        // dense chunk). Errors are left to the launches that would have hit them.
-        const int warm_dev = s->device;
-        const hipStream_t warm_stream = s->stream;
-        std::thread warm([warm_dev, warm_stream, trace_create, tc0] {
-            if (getenv("KGWAS_NO_WARM")) return;  // experiments
-            (void)hipSetDevice(warm_dev);
-            (void)warm_aux_kernels();
-            {
-                // ... and the compute stream's first fill, launch and device-to-host copy (its hardware queue, the copy path)
-                void *d = nullptr, *h = nullptr;
-                hipEvent_t w0 = nullptr, w1 = nullptr;  // (timed events too: the dense chunk brackets its kernels with them)
-                (void)hipEventCreate(&w0);
-                (void)hipEventCreate(&w1);
-                if (hipMalloc(&d, 1 << 20) == hipSuccess && hipHostMalloc(&h, 1 << 20, hipHostMallocMapped) == hipSuccess) {
-                    (void)hipMemsetAsync(d, 0, 4096, warm_stream);
-                    if (w0) (void)hipEventRecord(w0, warm_stream);
-                    void* hd = nullptr;
-                    if (hipHostGetDevicePointer(&hd, h, 0) == hipSuccess)
-                        (void)launch_records_to_host((const double*)d, (const uint64_t*)d + 64, (const uint32_t*)d + 256, 8, (double*)hd, (uint64_t*)hd + 64,
-                                                     (uint32_t*)hd + 256, warm_stream);
-                    (void)launch_copy_to_host(d, hd ? hd : d, 2048, warm_stream);
-                    (void)hipMemcpyAsync(h, d, 2048, hipMemcpyDeviceToHost, warm_stream);
-                    // (a transfer large enough for the DMA engines: a fresh process's first one took ~20 ms host -> device - the
-                    // streamed feed's first piece - and 58 ms device -> host)
-                    (void)hipMemcpyAsync(h, d, 1 << 20, hipMemcpyDeviceToHost, warm_stream);
-                    // ... and the streamed feed's pattern: a transfer on ANOTHER stream, the compute stream's kernels behind its
-                    // event (the first piece's kernels started 18 ms after its copy had landed)
-                    hipStream_t s2 = nullptr;
-                    hipEvent_t w2 = nullptr;
-                    if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&w2, hipEventDisableTiming) == hipSuccess) {
-                        (void)hipMemcpyAsync(d, h, 1 << 20, hipMemcpyHostToDevice, s2);
-                        (void)hipEventRecord(w2, s2);
-                        (void)hipStreamWaitEvent(warm_stream, w2, 0);
-                        (void)launch_copy_to_host(d, hd ? hd : d, 2048, warm_stream);
-                        (void)hipStreamSynchronize(warm_stream);
-                    }
-                    if (w2) (void)hipEventDestroy(w2);
-                    if (s2) (void)hipStreamDestroy(s2);
-                    if (w1) (void)hipEventRecord(w1, warm_stream);
-                    (void)hipStreamSynchronize(warm_stream);
-                    float ms = 0;
-                    if (w0 && w1) (void)hipEventElapsedTime(&ms, w0, w1);
-                }
-                if (w0) (void)hipEventDestroy(w0);
-                if (w1) (void)hipEventDestroy(w1);
-                if (d) (void)hipFree(d);
-                if (h) (void)hipHostFree(h);
-                if (trace_create)
-                    fprintf(stderr, "[kgwas] scan_create +%.1f ms: compute stream warmed (side thread)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count());
-            }
-            (void)warm_score_mfma();
-            (void)warm_score_coarse();
-            (void)warm_score_mx();
-            (void)warm_score_narrow();
-            (void)warm_score_valu();
-            if (trace_create)
-                fprintf(stderr, "[kgwas] scan_create +%.1f ms: code objects loaded (side thread)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count());
-        });
-        struct WarmJoin {
-            std::thread& t;
-            ~WarmJoin() {
-                if (t.joinable()) t.join();
-            }
-        } warm_join{warm};
+        // (Round 4 tried a side thread here that loaded the library's code objects and exercised the stream's first launch, copy
+        // and cross-stream wait while this thread went on: ~20 ms of a fresh process. A fuzz run then hung INSIDE this function -
+        // one helper thread spinning, this thread blocked - about once per 3 500 s of randomised sessions, never before that
+        // thread existed: two threads driving the HIP runtime's allocation / registration / synchronisation paths at once is
+        // not worth 20 ms. The first uses are paid where they occur.)
         KGWAS_HIP(hipEventCreate(&s->ev_user));
         KGWAS_HIP(hipEventCreate(&s->ev_ds));
         KGWAS_HIP(hipEventCreate(&s->ev_d0));
@@ -823,7 +763,10 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                         std::vector<std::thread> th;
                         for (unsigned t = 1; t < nt; t++) {
                             try {
-                                th.emplace_back(work);
+                                th.emplace_back([&work] {
+                                    kgwas_name_this_thread("kgwas-quant");
+                                    work();
+                                });
                             } catch (const std::system_error&) {
                                 break;  // (no more threads to be had: the ones running share the columns)
                             }

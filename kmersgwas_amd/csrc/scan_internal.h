@@ -62,6 +62,7 @@ class Pool {
         for (unsigned i = 0; i < n; i++) {
             const std::vector<int> mine = i < cpus.size() ? cpus[i] : std::vector<int>();
             th_.emplace_back([this, i, mine] {
+                kgwas_name_this_thread("kgwas-replay");
                 if (!mine.empty()) {
                     cpu_set_t set;
                     CPU_ZERO(&set);

@@ -760,11 +760,4 @@ hipError_t launch_rescore_direct(const ScoreArgs& a, const uint32_t* keys, const
     return hipGetLastError();
 }
 
-// Loads this file's code object (HIP does it at the first use of any of its kernels: tens of milliseconds for the whole
-// library in a fresh process - kgwas_scan_create does it on a thread of its own, beside the pinning of the record ring).
-hipError_t warm_score_coarse() {
-    hipFuncAttributes at;
-    return hipFuncGetAttributes(&at, reinterpret_cast<const void*>(chunk_prep_kernel));
-}
-
 }  // namespace kgwas

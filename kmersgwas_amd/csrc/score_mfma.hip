@@ -345,11 +345,4 @@ hipError_t launch_score_mfma(const ScoreArgs& a, uint32_t rows_per_block, uint32
     return hipGetLastError();
 }
 
-// Loads this file's code object (HIP does it at the first use of any of its kernels: tens of milliseconds for the whole
-// library in a fresh process - kgwas_scan_create does it on a thread of its own, beside the pinning of the record ring).
-hipError_t warm_score_mfma() {
-    hipFuncAttributes at;
-    return hipFuncGetAttributes(&at, reinterpret_cast<const void*>(score_mfma_kernel<2>));
-}
-
 }  // namespace kgwas

@@ -542,10 +542,4 @@ hipError_t launch_mx(const MxArgs& a, uint32_t CT, uint32_t rows_per_block, hipS
 #endif
 }
 
-// Loads this file's code object (see warm_score_coarse).
-hipError_t warm_score_mx() {
-    hipFuncAttributes at;
-    return hipFuncGetAttributes(&at, reinterpret_cast<const void*>(mx_kernel<7, 4, 2, 4, 512>));
-}
-
 }  // namespace kgwas

@@ -790,11 +790,4 @@ hipError_t launch_narrow(const NarrowArgs& a, uint32_t rows_per_block, hipStream
     return hipGetLastError();
 }
 
-// Loads this file's code object (HIP does it at the first use of any of its kernels: tens of milliseconds for the whole
-// library in a fresh process - kgwas_scan_create does it on a thread of its own, beside the pinning of the record ring).
-hipError_t warm_score_narrow() {
-    hipFuncAttributes at;
-    return hipFuncGetAttributes(&at, reinterpret_cast<const void*>(narrow_keys_kernel));
-}
-
 }  // namespace kgwas

@@ -104,11 +104,4 @@ hipError_t launch_score_valu(const ScoreArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
-// Loads this file's code object (HIP does it at the first use of any of its kernels: tens of milliseconds for the whole
-// library in a fresh process - kgwas_scan_create does it on a thread of its own, beside the pinning of the record ring).
-hipError_t warm_score_valu() {
-    hipFuncAttributes at;
-    return hipFuncGetAttributes(&at, reinterpret_cast<const void*>(score_valu_kernel<1>));
-}
-
 }  // namespace kgwas

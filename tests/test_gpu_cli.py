@@ -67,11 +67,11 @@ def test_associate_kmers_ecoli_shaped_config(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{"KGWAS_PIN_PLAIN": "1", "KGWAS_CLI_FULL_TEARDOWN": "1"}, {"KGWAS_RECORD_COPY": "memcpy", "KGWAS_NO_WARM": "1"},
+@pytest.mark.parametrize("env", [{"KGWAS_PIN_PLAIN": "1", "KGWAS_CLI_FULL_TEARDOWN": "1"}, {"KGWAS_RECORD_COPY": "memcpy"},
                                  {"KGWAS_RECORD_COPY": "kernel", "KGWAS_INGEST_DEVICE": "2", "KGWAS_INGEST_PINNED": "2", "KGWAS_INGEST_PIECE_ROWS": "4096"}])
 def test_associate_kmers_process_switches_change_nothing(tmp_path, env):
     """The start-up / teardown / transfer switches of the tool (hipHostMalloc instead of registered huge-page mappings, an orderly
-    teardown instead of _exit, the records' two ways to the host, no warm-up thread, a minimal ingest ring with tiny pieces):
+    teardown instead of _exit, the records' two ways to the host, a minimal ingest ring with tiny pieces):
     the same files as the default run, byte for byte."""
     names, acc, Y = onp.load_phenotypes(os.path.join(GOLD, "resistence.pheno"))
     S_f = 241

@@ -10,6 +10,27 @@ import kmersgwas_amd as kg
 from oracle import binding as ob, oracle_np as onp
 from helpers import random_table, phenotypes
 
+import faulthandler, threading
+_progress = [time.time(), "start"]
+def _watchdog(limit=60.0):
+    # a scan that makes no progress for `limit` seconds: say where every thread is, then leave (a hang must not eat the call)
+    while True:
+        time.sleep(5.0)
+        if time.time() - _progress[0] > limit:
+            sys.stdout.write("HANG: no progress for %.0f s in: %s\n" % (time.time() - _progress[0], _progress[1])); sys.stdout.flush()
+            faulthandler.dump_traceback(file=sys.stdout, all_threads=True); sys.stdout.flush()
+            try:
+                for t in sorted(os.listdir("/proc/self/task"), key=int):
+                    def rd(f):
+                        try: return open("/proc/self/task/%s/%s" % (t, f)).read().strip()
+                        except Exception as e: return "?"
+                    st = rd("stat").split(") ")[-1].split()
+                    sys.stdout.write("tid %s comm %-16s state %s cpu_ticks %s+%s wchan %-28s syscall %s\n" % (t, rd("comm"), st[0], st[11] if len(st) > 12 else "?", st[12] if len(st) > 12 else "?", rd("wchan"), rd("syscall")[:40]))
+            except Exception as e:
+                sys.stdout.write("proc scan failed: %r\n" % (e,))
+            sys.stdout.flush()
+            os._exit(3)
+threading.Thread(target=_watchdog, daemon=True).start()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 BIG = len(sys.argv) > 3 and sys.argv[3] == "big"
@@ -55,14 +76,20 @@ while time.time() < t_end:
     Y = np.ascontiguousarray(Y, np.float32)
     mac = onp.min_count(S, 0.05, 5) if S >= 100 else 1
     desc = dict(S_f=S_f, S=S, P=P, n_rows=n_rows, topn=topn, chunk=chunk, dup=dup, kind=kind, kernel=kernel, env=env, reorder=bool(reorder))
+    if os.environ.get("KGWAS_FUZZ_VERBOSE"):  # name the scan BEFORE it runs: a hang then shows its configuration
+        print("scan %d:" % n_ok, desc, flush=True)
     try:
         if kernel == kg.KERNEL_MFMA and S > 2600: kernel = kg.KERNEL_AUTO
+        _progress[:] = [time.time(), "oracle %r" % (desc,)]
         exp = ob.associate(rows, S_f, col, Y, topn, mac, batch_size=int(rng.integers(100, 20000)), threads=16 if BIG else 4)
+        _progress[:] = [time.time(), "create %r" % (desc,)]
         scan = kg.AssociationScan(S_f, col, Y, topn, mac, kernel=kernel, chunk_rows=chunk, host_threads=int(rng.choice([0, 1, 3, 8])))
         cuts = sorted(set([0, n_rows] + [int(x) for x in rng.integers(0, n_rows + 1, size=int(rng.integers(0, 3)))]))
         for lo, hi in zip(cuts[:-1], cuts[1:]):
             if hi == n_rows and rng.random() < 0.5: scan.expect_finish()
+            _progress[:] = [time.time(), "feed_host [%d, %d) %r" % (lo, hi, desc)]
             scan.feed_host(rows[lo:hi], lo)
+        _progress[:] = [time.time(), "finish %r" % (desc,)]
         scan.finish()
         st = scan.stats()
         assert st["heap_pushes"] == exp["pushes"], ("pushes", st["heap_pushes"], exp["pushes"])
@@ -71,7 +98,9 @@ while time.time() < t_end:
             k, s, r = scan.result(j)
             o = exp["per_pheno"][j]
             assert len(k) == len(o["kmer"]) and (k == o["kmer"]).all() and (r == o["file_row"]).all() and s.tobytes() == o["score"].tobytes(), ("column", j)
+        _progress[:] = [time.time(), "close %r" % (desc,)]
         scan.close()
+        _progress[:] = [time.time(), "between scans"]
         n_ok += 1
     except kg.KgwasError as e:
         if "coarse filter" in str(e) or "MFMA scorer" in str(e):  # a forced kernel that does not apply to this shape
