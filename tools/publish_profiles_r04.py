@@ -1,7 +1,7 @@
 """Copy the rocprofv3 summaries tools/collect_profiles_r04.sh left under gpurun_out/prof_r04/ into profiles/ (the
 tracked, judged copies): kernel statistics of the bench workload, the one-column scan and the kinship accumulation, the
 PMC passes of the block-scaled filter's steady launches (HBM traffic, SQ counters, clock) and the bench lines.
-Usage: python tools/publish_profiles_r04.py"""
+Usage: python tools/publish_profiles_r04.py [traffic]   (traffic: only profiles/r04_mx_pmc_hbm_traffic.json)"""
 import collections, csv, glob, hashlib, json, os
 
 src = "gpurun_out/prof_r04"
@@ -23,14 +23,6 @@ def strip_stats(path, out, keep=25):
             if len(n) > 160:
                 n = n[:60] + " ... " + n[-60:]
             w.writerow([n, r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
-
-
-strip_stats(one("stats/*/*_kernel_stats.csv"), "profiles/r04_bench_kernel_stats.csv")
-strip_stats(one("p1_stats/*/*_kernel_stats.csv"), "profiles/r04_p1scan_kernel_stats.csv")
-strip_stats(one("kin_stats/*/*_kernel_stats.csv"), "profiles/r04_kinship_kernel_stats.csv")
-for name in ("bench_line", "config4_line", "shard250M_line"):
-    line = [l for l in open(os.path.join(src, name + ".json")) if l.startswith("{")][-1]
-    open("profiles/r04_%s.json" % name, "w").write(line)
 
 
 def counters(path, kname, grid):
@@ -68,6 +60,17 @@ j = {"kernel": KNAME, "kernel_source_sha16": sha,
              "profile was taken: bench.py does not use it for another version of the kernel."}
 json.dump(j, open("profiles/r04_mx_pmc_hbm_traffic.json", "w"), indent=1)
 print("traffic / algorithmic = %.3f" % j["traffic_over_algorithmic"])
+
+if "traffic" in sys.argv[1:]:  # (on the GPU box, between the PMC passes and the bench line: the line then quotes THIS profile)
+    sys.exit(0)
+
+strip_stats(one("stats/*/*_kernel_stats.csv"), "profiles/r04_bench_kernel_stats.csv")
+strip_stats(one("p1_stats/*/*_kernel_stats.csv"), "profiles/r04_p1scan_kernel_stats.csv")
+strip_stats(one("kin_stats/*/*_kernel_stats.csv"), "profiles/r04_kinship_kernel_stats.csv")
+for name in ("bench_line", "config4_line", "shard250M_line"):
+    line = [l for l in open(os.path.join(src, name + ".json")) if l.startswith("{")][-1]
+    open("profiles/r04_%s.json" % name, "w").write(line)
+
 
 # the same at 2048 samples x 201 columns (the per-GPU shape of BASELINE configs[3]): the largest launches of the pass
 def largest(path, counter):
