@@ -48,3 +48,36 @@ int guarded(F&& body) {
 // a profiler then says WHICH of the library's helper threads it is looking at.
 #include <pthread.h>
 inline void kgwas_name_this_thread(const char* name) { (void)pthread_setname_np(pthread_self(), name); }
+
+// Runs `work` on the calling thread and on up to n - 1 others (fewer if the system has no more threads to give), joins them all
+// whatever happens and rethrows the first exception any of them left: `work` takes its items from a shared counter.
+#include <exception>
+#include <mutex>
+#include <system_error>
+#include <thread>
+#include <vector>
+template <class F>
+void kgwas_run_on_threads(unsigned n, const char* name, F&& work) {
+    std::exception_ptr err;
+    std::mutex emu;
+    auto guarded_work = [&](bool named) {
+        try {
+            if (named) kgwas_name_this_thread(name);
+            work();
+        } catch (...) {
+            std::lock_guard<std::mutex> lk(emu);
+            if (!err) err = std::current_exception();
+        }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < n; t++) {
+        try {
+            th.emplace_back(guarded_work, true);
+        } catch (const std::system_error&) {
+            break;
+        }
+    }
+    guarded_work(false);
+    for (auto& t : th) t.join();
+    if (err) std::rethrow_exception(err);
+}

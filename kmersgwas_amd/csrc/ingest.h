@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <functional>
 #include <mutex>
@@ -73,16 +74,15 @@ struct PinRegion {
                 char* al = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(m) + HUGE - 1) & ~(uintptr_t)(HUGE - 1));
                 (void)madvise(al, len, MADV_HUGEPAGE);
                 {
+                    // touched in segments of 32 MiB by up to 8 threads (this one among them; fewer if no more are to be had)
                     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-                    const size_t nt = std::min<size_t>(std::min<size_t>(8, hw), std::max<size_t>(1, len / (32u << 20)));
-                    std::vector<std::thread> th;
-                    for (size_t i = 0; i < nt; i++)
-                        th.emplace_back([=] {
-                            kgwas_name_this_thread("kgwas-touch");
-                            const size_t a = len / nt / HUGE * HUGE * i, b = i + 1 == nt ? len : len / nt / HUGE * HUGE * (i + 1);
-                            for (size_t o = a; o < b; o += 4096) al[o] = 0;
-                        });
-                    for (auto& t : th) t.join();
+                    const size_t seg = 32u << 20, n_seg = (len + seg - 1) / seg;
+                    const unsigned nt = (unsigned)std::min<size_t>(std::min<size_t>(8, hw), n_seg);
+                    std::atomic<size_t> next(0);
+                    kgwas_run_on_threads(nt, "kgwas-touch", [&] {
+                        for (size_t i; (i = next.fetch_add(1, std::memory_order_relaxed)) < n_seg;)
+                            for (size_t o = i * seg, b = std::min(len, (i + 1) * seg); o < b; o += 4096) al[o] = 0;
+                    });
                 }
                 if (hipHostRegister(al, len, hipHostRegisterMapped) == hipSuccess) {
                     p = al;

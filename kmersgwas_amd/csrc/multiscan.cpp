@@ -72,9 +72,20 @@ template <class F>
 void for_each_shard(size_t G, F&& fn) {
     std::vector<int> rc(G, KGWAS_OK);
     std::vector<std::string> msg(G);
+    // (every shard needs a thread of its own - its session's calls block -: if the system has none to give, the threads that
+    // exist are joined and the call fails)
     std::vector<std::thread> th;
+    struct JoinAll {
+        std::vector<std::thread>& t;
+        ~JoinAll() {
+            for (auto& x : t)
+                if (x.joinable()) x.join();
+        }
+    } join_all{th};
+    th.reserve(G);
     for (size_t g = 0; g < G; g++)
         th.emplace_back([&, g] {
+            kgwas_name_this_thread("kgwas-shard");
             rc[g] = guarded([&] { fn(g); });
             if (rc[g] != KGWAS_OK) msg[g] = kgwas_last_error();
         });

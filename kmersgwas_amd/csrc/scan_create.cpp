@@ -742,11 +742,9 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                         std::vector<ErrBound> ebs(pl.n);
                         const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(usable_cpus(), 16), pl.n / 4));
                         std::atomic<uint64_t> next(0);
-                        std::exception_ptr err;
-                        std::mutex emu;
-                        auto work = [&] {
+                        kgwas_run_on_threads(nt, "kgwas-quant", [&] {
+                            std::vector<int> b0(S), b1(S);
                             try {
-                                std::vector<int> b0(S), b1(S);
                                 for (uint64_t i; (i = next.fetch_add(1, std::memory_order_relaxed)) < pl.n;) {
                                     const uint64_t j = pl.j0 + i, lg = i / pl.cper, slot = i % pl.cper;
                                     CoarseCol& cc = cols[lg * slots + slot];
@@ -755,25 +753,10 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                                     put(lg, slot, b0, b1);
                                 }
                             } catch (...) {
-                                std::lock_guard<std::mutex> lk(emu);
-                                if (!err) err = std::current_exception();
-                                next.store(pl.n);
+                                next.store(pl.n);  // (the other threads stop at their next column)
+                                throw;
                             }
-                        };
-                        std::vector<std::thread> th;
-                        for (unsigned t = 1; t < nt; t++) {
-                            try {
-                                th.emplace_back([&work] {
-                                    kgwas_name_this_thread("kgwas-quant");
-                                    work();
-                                });
-                            } catch (const std::system_error&) {
-                                break;  // (no more threads to be had: the ones running share the columns)
-                            }
-                        }
-                        work();
-                        for (auto& t : th) t.join();
-                        if (err) std::rethrow_exception(err);
+                        });
                         for (const ErrBound& eb : ebs) {
                             M.eg_max = std::max(M.eg_max, eb.egD);
                             M.rall_max = std::max(M.rall_max, eb.rallD);

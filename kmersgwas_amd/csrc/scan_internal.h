@@ -61,17 +61,24 @@ class Pool {
         if (n < 1) n = 1;
         for (unsigned i = 0; i < n; i++) {
             const std::vector<int> mine = i < cpus.size() ? cpus[i] : std::vector<int>();
-            th_.emplace_back([this, i, mine] {
-                kgwas_name_this_thread("kgwas-replay");
-                if (!mine.empty()) {
-                    cpu_set_t set;
-                    CPU_ZERO(&set);
-                    for (int c : mine)
-                        if (c >= 0 && c < CPU_SETSIZE) CPU_SET(c, &set);
-                    (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
-                }
-                loop(i);
-            });
+            try {
+                th_.emplace_back([this, i, mine] {
+                    kgwas_name_this_thread("kgwas-replay");
+                    if (!mine.empty()) {
+                        cpu_set_t set;
+                        CPU_ZERO(&set);
+                        for (int c : mine)
+                            if (c >= 0 && c < CPU_SETSIZE) CPU_SET(c, &set);
+                        (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+                    }
+                    loop(i);
+                });
+            } catch (const std::system_error&) {
+                // no more threads to be had: the pool is the workers that exist (items are claimed, not assigned, so any
+                // number of workers runs them all); with none at all the session cannot be built
+                if (th_.empty()) throw;
+                break;
+            }
         }
     }
     ~Pool() {

@@ -88,10 +88,10 @@ struct SnpScorer {
         d_planes.alloc(chunk * 3 * ndw);
         d_Y.alloc(P * L);
         d_scores.alloc(P * chunk);
-        KGWAS_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         KGWAS_HIP(hipMemcpy(d_bidx.p, s->byte_idx.data(), S * 4, hipMemcpyHostToDevice));
         KGWAS_HIP(hipMemcpy(d_shift.p, s->shift.data(), S * 4, hipMemcpyHostToDevice));
         KGWAS_HIP(hipMemcpy(d_Y.p, Yperm.data(), Yperm.size() * 4, hipMemcpyHostToDevice));
+        KGWAS_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));  // (last: a constructor that throws runs no destructor)
     }
     ~SnpScorer() {
         if (st) (void)hipStreamDestroy(st);
@@ -206,16 +206,7 @@ int kgwas_snps_best(kgwas_snps* s, const float* Y, uint64_t n_pheno, uint64_t to
                         for (uint64_t i = 0; i < c; i++) h.add(0, sc_j[i], (size_t)(pos + i));
                     }
                 };
-                std::vector<std::thread> th;
-                for (unsigned t = 1; t < nt; t++) {
-                    try {
-                        th.emplace_back(work);
-                    } catch (const std::system_error&) {
-                        break;
-                    }
-                }
-                work();
-                for (auto& t : th) t.join();
+                kgwas_run_on_threads(nt, "kgwas-snpheap", work);
             }
         }
         for (uint64_t j = 0; j < n_pheno; j++) {  // get_rows_sorted_indices
@@ -262,8 +253,6 @@ int kgwas_snps_write(kgwas_snps* s, uint64_t n_lists, const char* const* out_bas
             n = e > a0 ? e - a0 : 0;
         };
         std::atomic<uint64_t> next(0);
-        std::exception_ptr err;
-        std::mutex emu;
         auto work = [&] {
             try {
                 std::string out;
@@ -290,25 +279,17 @@ int kgwas_snps_write(kgwas_snps* s, uint64_t n_lists, const char* const* out_bas
                         bed.write(reinterpret_cast<const char*>(s->bed.data() + i * s->bytes_per_snp), (std::streamsize)s->bytes_per_snp);
                     }
                     bimo.write(out.data(), (std::streamsize)out.size());
+                    bed.flush();
+                    bimo.flush();
+                    if (!bed || !bimo) throw Error(KGWAS_ERR_IO, "error writing " + b + ".bed/.bim");
                 }
             } catch (...) {
-                std::lock_guard<std::mutex> lk(emu);
-                if (!err) err = std::current_exception();
-                next.store(n_lists);
+                next.store(n_lists);  // (the other threads stop at their next list)
+                throw;
             }
         };
         const unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(usable_cpus(), 16), n_lists));
-        std::vector<std::thread> th;
-        for (unsigned t = 1; t < nt; t++) {
-            try {
-                th.emplace_back(work);
-            } catch (const std::system_error&) {
-                break;
-            }
-        }
-        work();
-        for (auto& t : th) t.join();
-        if (err) std::rethrow_exception(err);
+        kgwas_run_on_threads(nt, "kgwas-snpwrite", work);
     });
 }
 

@@ -69,22 +69,14 @@ void parallel_items(unsigned threads, size_t n, const F& fn) {
         return;
     }
     std::atomic<size_t> next(0);
-    std::exception_ptr err;
-    std::mutex mu;
-    auto work = [&] {
+    kgwas_run_on_threads(threads, "kgwas-items", [&] {
         try {
             for (size_t i; (i = next.fetch_add(1, std::memory_order_relaxed)) < n;) fn(i);
         } catch (...) {
-            std::lock_guard<std::mutex> lk(mu);
-            if (!err) err = std::current_exception();
-            next.store(n);
+            next.store(n);  // (the other threads stop at their next item)
+            throw;
         }
-    };
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < threads; t++) th.emplace_back(work);
-    work();
-    for (auto& t : th) t.join();
-    if (err) std::rethrow_exception(err);
+    });
 }
 
 struct FdFile {  // output file written in large pieces; open only while a piece is written

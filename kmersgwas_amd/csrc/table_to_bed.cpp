@@ -101,6 +101,7 @@ extern "C" int kgwas_table_to_bed(kgwas_table* t, const uint64_t* col, uint64_t 
             bed.close();
             bim.close();
             const std::string base = std::string(out_base) + "." + std::to_string(batch);
+            if (!bed || !bim) throw Error(KGWAS_ERR_IO, "error writing " + base + ".bed/.bim");  // (a full disk shows here at the latest)
             std::ofstream fam(base + ".fam");  // src/kmers_table_to_bed.cpp:119-124
             if (!fam) throw Error(KGWAS_ERR_IO, "cannot create " + base + ".fam");
             for (uint64_t i = 0; i < S; i++) fam << acc_names[i] << " " << acc_names[i] << " 0 0 0 " << y[i] << std::endl;
@@ -238,10 +239,10 @@ extern "C" int kgwas_table_to_bed(kgwas_table* t, const uint64_t* col, uint64_t 
         {
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return stop || done >= n_pieces; });
+            wj.orderly = !stop;
         }
-        wj.orderly = !stop;
         if (writer.joinable()) {
-            if (stop) cv.notify_all();
+            cv.notify_all();
             writer.join();  // (closes the last batch)
         }
         if (werr) std::rethrow_exception(werr);
