@@ -231,6 +231,7 @@ void dense_fill(kgwas_scan* s, uint64_t n_rows, uint64_t first_row, std::chrono:
     }
     if (s->trace) fprintf(stderr, "[kgwas t=%.3f] dense fill: control thread done, fill %s\n", s->t_ms(), s->pool->finished() ? "done" : "running");
     s->pool->wait();
+    s->pool->rethrow();  // (a column whose push log could not grow)
     if (s->trace) fprintf(stderr, "[kgwas t=%.3f] dense fill done\n", s->t_ms());
     s->st.heap_pushes += pushes.load();
     s->st.replay_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -96,6 +96,18 @@ class Pool {
         if (n == 0) return;
         start(n, fn);
         wait();
+        rethrow();
+    }
+    // An item that throws (an allocation that fails) ends its worker's turn; the first such exception is kept until the next
+    // start() and rethrown here: by parallel_for itself, and by callers of start()/wait() once they are on their normal path.
+    void rethrow() {
+        std::exception_ptr e;
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            e = err_;
+            err_ = nullptr;
+        }
+        if (e) std::rethrow_exception(e);
     }
     // The two halves of parallel_for: start() hands the items out and returns, wait() blocks until every worker is
     // done. Between the two the workers run on their own (the streaming replay: items are worker loops that end when
@@ -107,6 +119,7 @@ class Pool {
         if (claimed_.size() < n) claimed_ = std::vector<std::atomic<uint8_t>>(n);
         for (size_t i = 0; i < n; i++) claimed_[i].store(0, std::memory_order_relaxed);
         pending_ = th_.size();
+        err_ = nullptr;
         done_.store(0, std::memory_order_relaxed);
         gen_.fetch_add(1, std::memory_order_release);
         lk.unlock();
@@ -154,9 +167,15 @@ class Pool {
                 seen = gen_.load(std::memory_order_acquire);
                 if (stop_) return;
             }
-            run(me);
+            std::exception_ptr err;
+            try {
+                run(me);
+            } catch (...) {
+                err = std::current_exception();
+            }
             {
                 std::unique_lock<std::mutex> lk(mu_);
+                if (err && !err_) err_ = err;
                 if (--pending_ == 0) {
                     done_.store(1, std::memory_order_release);
                     done_cv_.notify_all();
@@ -174,6 +193,7 @@ class Pool {
     size_t pending_;
     const std::function<void(size_t)>* fn_ = nullptr;
     size_t n_items_;
+    std::exception_ptr err_;  // the first exception an item of the current start() threw (guarded by mu_)
 };
 
 // scan_host.cpp: one CPU per replay worker near the GPU; the CPUs the process may really use (cgroup quota)
