@@ -253,6 +253,14 @@ def test_plink_writer_for_all_columns_matches_oracle_bytes(tmp_path, S_f, S, reo
             assert open(outs[j] + ext, "rb").read() == open(orc + ext, "rb").read(), (j, ext)
     with pytest.raises(kg.KgwasError):
         kg.write_plink_many(outs[:1], t, col, acc, Y[:1], [rows[:1, 0]], [np.asarray([n_rows], np.uint64)])  # row beyond the table
+    # a failure on the library's helper threads (files that cannot be created, several threads at work) comes back as the
+    # call's error - not as a terminated process - and the library goes on working
+    bad = [str(tmp_path / "no_such_dir" / ("x%d" % j)) for j in range(P)]
+    with pytest.raises(kg.KgwasError):
+        kg.write_plink_many(bad, t, col, acc, Y, [rows[p, 0] for p in picks], [p.astype(np.uint64) for p in picks], threads=4)
+    again = [str(tmp_path / ("again%d" % j)) for j in range(P)]
+    kg.write_plink_many(again, t, col, acc, Y, [rows[p, 0] for p in picks], [p.astype(np.uint64) for p in picks], threads=4)
+    assert open(again[3] + ".bed", "rb").read() == open(outs[3] + ".bed", "rb").read()
     t.close()
 
 
