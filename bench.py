@@ -11,6 +11,9 @@ in HBM when the timed region starts.
           table: the HBM-roofline configuration, BASELINE.md row 2'), "kinship" (configs[4] in shape: 8M rows x
           1135 samples through the kinship kernels, with the single-threaded CPU accumulation beside it),
           "parity_check" (the GPU's heaps over the CPU baseline's rows equal the oracle's) and "cpu_baseline".
+          "roofline.traffic" is measured in the run itself: at its end two short child runs of this script go through
+          rocprofv3's FETCH_SIZE / WRITE_SIZE passes (live_pmc_traffic; KGWAS_BENCH_LIVE_PMC=0 or any failure leaves the
+          quotation of the committed profile, gated by the kernel source's hash).
   N > 1 : BASELINE.json configs[3] per GPU: every rank scans its own shard of 2048 samples x 201 columns
           (2.5e8 rows = 66 GB per GPU unless --rows says otherwise; weak scaling, contiguous row shards) and the
           ranks' heap histories are merged over RCCL inside the timed region. "single_gpu_same_shard" is
@@ -434,6 +437,56 @@ def kernel_source_sha16(src_file):
     return h.hexdigest()[:16]
 
 
+def live_pmc_traffic(kname, grid, rows_per_launch, rows=40_000_000, timeout_s=90):
+    """HBM-side bytes per row of the filter's steady launches, measured NOW: two child runs of this script (short: `rows`
+    rows, one pass + one warm-up pass, no baseline, no sub-records) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and
+    `... WRITE_SIZE` (separate passes, nothing else traced: MI355X_MICROARCH.md, HBM section; counter values are KiB; on
+    gfx950 FETCH_SIZE tallies 128-byte read requests at 64, so read bytes = 2 x FETCH_SIZE x 1024). The launches of
+    `grid` threads (`rows_per_launch` rows each) are averaged. Returns a dict with "bytes_per_row" or with "error": the
+    caller then quotes the committed profile as before. A child that does not finish in `timeout_s` is killed with its
+    process group."""
+    import csv, glob, shutil, signal, subprocess, tempfile
+    if not shutil.which("rocprofv3"):
+        return {"error": "rocprofv3 not on PATH"}
+    env = dict(os.environ, TMPDIR="/tmp", KGWAS_BENCH_LIVE_PMC="0")
+    out = {"rows_of_the_child_runs": rows, "grid_threads_averaged": grid, "rows_per_launch": rows_per_launch}
+    t0 = time.perf_counter()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="kgwas_pmc_", dir="/tmp")
+        try:
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-f", "csv", "-d", d, "--", sys.executable, os.path.join(ROOT, "bench.py"),
+                   "--rows", str(rows), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-subrecords"]
+            p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = p.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                p.wait()
+                return {"error": "%s pass did not finish in %d s (killed)" % (counter, timeout_s)}
+            if rc != 0:
+                return {"error": "%s pass exited with %d" % (counter, rc)}
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if kname in r["Kernel_Name"] and r["Counter_Name"] == counter and int(r["Grid_Size"]) == grid:
+                        vals.append(float(r["Counter_Value"]))
+            if not vals:
+                return {"error": "%s pass: no %s launch of %d threads in the counter file" % (counter, kname, grid)}
+            out[counter + "_KiB_per_launch"] = sum(vals) / len(vals)
+            out[counter + "_launches_averaged"] = len(vals)
+        except Exception as e:  # (whatever the profiler did: the line falls back to the committed profile)
+            return {"error": "%s pass: %r" % (counter, e)}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    out["bytes_per_launch"] = 2.0 * out["FETCH_SIZE_KiB_per_launch"] * 1024.0 + out["WRITE_SIZE_KiB_per_launch"] * 1024.0
+    out["bytes_per_row"] = out["bytes_per_launch"] / rows_per_launch
+    out["seconds"] = time.perf_counter() - t0
+    return out
+
+
 def cgroup_throttle():
     """(nr_throttled, throttled_usec) of this container's CPU controller, (0, 0) if unreadable."""
     try:
@@ -845,6 +898,19 @@ def main():
                     out["ingest"] = ingest_record(kg, torch, stream, dev, host_threads, rows=args.ingest_rows)
                 except Exception as e:
                     out["ingest"] = {"error": repr(e)}
+            # `roofline.traffic` measured in THIS run (the GPU is free now: table and sessions are gone): PMC passes around two
+            # short child runs. KGWAS_BENCH_LIVE_PMC=0 (and every failure) leaves the quotation of the committed profile.
+            if kernel_name == "mx_kernel" and os.environ.get("KGWAS_BENCH_LIVE_PMC", "1") != "0":
+                torch.cuda.empty_cache()
+                live = live_pmc_traffic("mx_kernel", 2048 * 512, 8388608)
+                rl = out["roofline"]
+                rl["traffic_live_pmc"] = live
+                if "bytes_per_row" in live:
+                    rl["traffic_quoted_from_profile"] = rl["traffic"]
+                    rl["traffic"] = live["bytes_per_row"] * (rl["algorithmic_GB_per_launch"] * 1e9 / (8.0 * W)) / 1e9
+                    rl["traffic_from_profile"] = False
+                    rl["traffic_source"] = ("live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) around two child runs "
+                                            "of this script, bytes per row of the steady launches x rows per average launch of the timed steps")
         print(json.dumps(out))
     if last is not None:
         last.close()
