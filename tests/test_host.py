@@ -5,6 +5,7 @@ the synthetic-row generator's host twin, the CLIs' argument handling — each ag
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -354,3 +355,16 @@ def test_cli_fails_loudly_without_a_gpu(tmp_path, have_gpu):
               "--kmer_len", "31"])
     assert r.returncode == 3 and "no HIP device" in r.stderr
     assert "Effective minor allele count:\t5" in r.stderr
+
+
+def test_bench_live_traffic_measurement_falls_back_instead_of_failing(monkeypatch):
+    """bench.py measures roofline.traffic through rocprofv3 around child runs of itself; whatever goes wrong there - no
+    profiler, a child that hangs - must come back as an `error` entry (the line then quotes the committed profile), never as an
+    exception or a process left behind."""
+    sys.path.insert(0, ROOT)
+    import bench
+    r = bench.live_pmc_traffic("mx_kernel", 2048 * 512, 8388608, rows=1000, timeout_s=0.05)  # (killed with its process group)
+    assert set(r) == {"error"} and "killed" in r["error"]
+    monkeypatch.setenv("PATH", "/nonexistent")
+    r = bench.live_pmc_traffic("mx_kernel", 2048 * 512, 8388608, rows=1000, timeout_s=5)
+    assert set(r) == {"error"} and "rocprofv3" in r["error"]
