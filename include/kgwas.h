@@ -181,7 +181,12 @@ typedef struct kgwas_scan_stats {
     uint64_t columns_popped_ahead; /* columns whose result lists were made by idle replay workers at the end of the last feed
                                       (kgwas_scan_expect_finish) instead of by kgwas_scan_finish */
     uint32_t coarse_mx32;       /* block-scaled filter in its v_mfma_scale_f32_32x32x64_f8f6f4 form (score_mx32.hip) */
-    uint32_t reserved0;
+    uint32_t coarse_mx_stream;  /* block-scaled filter in its operand-streaming form (score_mxs.hip: all column tiles of an operand
+                                   group per wave, operands through an LDS ring; every row loaded and expanded once per group):
+                                   1 = the default shapes (one column group of up to 7 tiles, or two of them side by side in a
+                                   block), 2 / 3 = one column group of up to 13 tiles with eight waves of 32 rows / four waves of 64
+                                   (KGWAS_MXS_FORM=1 / 2). This field replaces the former `reserved0`: the struct's size and
+                                   layout are unchanged. */
 } kgwas_scan_stats;
 
 int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out);

@@ -78,7 +78,7 @@ class ScanStats(C.Structure):
         ("replay_min_ms", C.c_double), ("replay_wall_ms", C.c_double),
         ("replay_splits", C.c_uint64),
         ("columns_popped_ahead", C.c_uint64),
-        ("coarse_mx32", C.c_uint32), ("reserved0", C.c_uint32),
+        ("coarse_mx32", C.c_uint32), ("coarse_mx_stream", C.c_uint32),
     ]
 
     def as_dict(self):

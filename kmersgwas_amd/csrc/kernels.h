@@ -144,6 +144,14 @@ size_t mx_lds_bytes(uint32_t n_steps, uint32_t CT, uint32_t n_slices, uint32_t s
 uint32_t mx_step_bytes_rt(uint32_t n_slices, uint32_t s1_fp6);
 uint32_t mx_row_tiles(uint32_t CT);  // 16-row tiles per wave pass for this many column tiles
 hipError_t launch_mx(const MxArgs& a, uint32_t CT, uint32_t rows_per_block, hipStream_t st);
+// The same filter with its operands STREAMED through an LDS ring instead of resident (score_mxs.hip): the waves of a block keep
+// the accumulators of ALL column tiles of an operand group (NG column groups of CT tiles: up to 14 tiles, 222 columns), so a row
+// is loaded and expanded once per operand group however many samples there are. a.Bq: [n_lgroups][step][NG][CT][2560 B],
+// a.cols: [n_lgroups][NG][CT * 16] (each column group with its own ones column in its last slot); two slices, FP6 + FP4 only.
+// form (NG = 1, CT > 7 only): 1 = eight waves of 32 rows, 2 = four waves of 64 rows.
+bool mxs_supported(uint32_t CT, uint32_t NG, uint32_t n_slices, uint32_t s1_fp6);
+size_t mxs_lds_bytes(uint32_t CT, uint32_t NG);
+hipError_t launch_mxs(const MxArgs& a, uint32_t CT, uint32_t NG, uint32_t form, uint32_t rows_per_block, hipStream_t st);
 // The same filter on v_mfma_scale_f32_32x32x64_f8f6f4 (score_mx32.hip): ct32 column tiles of 32 (two slices each) + comb (0 / 1)
 // "combined" tile of up to 16 columns (both slices in one FP6 operand, per-lane block scales). a.n_full = whole 256-sample
 // groups (four K = 64 steps each), a.n_quarter <= 4 steps of 64 samples behind them; a.Bq / a.cols in that file's layout

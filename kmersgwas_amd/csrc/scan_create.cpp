@@ -73,13 +73,20 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                 coarse_T = T;
                 break;
             }
+        // The operand-streaming form of the block-scaled filter (score_mxs.hip) holds one step's operands in LDS, not a whole
+        // column tile's: no limit on the accessions. KGWAS_MXS: 0 never, 1 (default) wherever the resident form would need more
+        // than one LDS group, 2 wherever the form exists. The int8 filter (KGWAS_COARSE_MX=0) stops at 5120 accessions.
+        const int mxs_want = getenv("KGWAS_MXS") ? atoi(getenv("KGWAS_MXS")) : 1;
+        const bool mxs_can = mxs_want != 0 && !(getenv("KGWAS_COARSE_MX") && atoi(getenv("KGWAS_COARSE_MX")) == 0) && getenv("KGWAS_COARSE_SLICES") == nullptr &&
+                             !(getenv("KGWAS_MX_S1") && atoi(getenv("KGWAS_MX_S1")) == 6);
+        const bool filter_fits = coarse_T != 0 || mxs_can;
         bool want_coarse = false;
         if (kern == KGWAS_KERNEL_COARSE) {
-            if (!chain_safe || !coarse_T)
-                throw Error(KGWAS_ERR_ARG, "coarse filter needs finite phenotype values whose float32 sums cannot overflow (sum |y| < FLT_MAX per column) and <= 5120 accessions");
+            if (!chain_safe || !filter_fits)
+                throw Error(KGWAS_ERR_ARG, "coarse filter needs finite phenotype values whose float32 sums cannot overflow (sum |y| < FLT_MAX per column) and, for its int8 form, <= 5120 accessions");
             want_coarse = true;
             kern = KGWAS_KERNEL_AUTO;
-        } else if (kern == KGWAS_KERNEL_AUTO && chain_safe && coarse_T) {
+        } else if (kern == KGWAS_KERNEL_AUTO && chain_safe && filter_fits) {
             // any number of columns: even a single column (one mostly empty 16-column tile) runs twice as fast behind
             // the filter as through the exact VALU scorer (12.5 vs 27 ms per 100 M-row pass)
             want_coarse = true;
@@ -422,7 +429,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                 uint32_t ctm = 0;
                 for (uint32_t ct = 7; ct >= 1 && !ctm; ct--)
                     if (mx_lds_bytes(steps, ct, 2, 0) <= 160u * 1024u) ctm = ct;
-                use_mx = groups_for(ctm) <= groups_for(s->coarse_T) + 1;
+                use_mx = mxs_can || groups_for(ctm) <= groups_for(s->coarse_T) + 1;  // (streamed operands: one group whatever the shape)
             }
             // Where the int8 filter keeps the shape, its TWO-slice set (the ramp: the first chunks of a scan, many
             // candidates per row) is still the block-scaled one: at 2048 x 201 that is 13 column tiles x 2 slices x 16
@@ -483,7 +490,34 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                 uint32_t s1_fp6 = 0;
                 if (const char* e = getenv("KGWAS_MX_S1")) s1_fp6 = ns == 2 && atoi(e) == 6 && ct_max(1) ? 1u : 0u;
                 const uint32_t CTmax = ct_max(s1_fp6);
-                if (!CTmax) throw Error(KGWAS_ERR_ARG, "coarse filter: too many accessions for the LDS");
+                // Operand-streaming form (score_mxs.hip): every row is loaded and expanded ONCE per operand group of up to 14 column
+                // tiles, whatever the number of accessions; taken where the resident plan would pass every row through several LDS
+                // groups. Up to 7 tiles (111 columns + the ones column): one column group, eight waves of 64 rows each. Beyond: TWO
+                // column groups of up to 7 tiles per block (222 columns), the waves w and w + 4 working on the same 64 rows - each
+                // group with its own ones column - and as many such operand groups (grid blocks sharing rows) as the columns need.
+                // KGWAS_MXS_FORM=1 / 2: one column group of up to 13 tiles, eight waves of 32 rows / four waves of 64 rows.
+                uint64_t stream_groups = 0, stream_ct = 0, stream_ng = 1;
+                uint32_t stream_form = 0;
+                if (mxs_can && ns == 2 && !s1_fp6 && !s->narrow) {
+                    const int form_env = getenv("KGWAS_MXS_FORM") ? atoi(getenv("KGWAS_MXS_FORM")) : 0;
+                    uint64_t g = 1, ng = 1, ct = 0;
+                    if (P + 1 <= 7 * 16) {
+                        ct = std::max<uint64_t>(3, (P + 1 + 15) / 16);
+                    } else if (form_env == 1 || form_env == 2) {
+                        while (((P + g - 1) / g + 1 + 15) / 16 > 13) g++;
+                        ct = ((P + g - 1) / g + 1 + 15) / 16;
+                        if (ct > 7) stream_form = (uint32_t)form_env;
+                    } else {
+                        ng = 2;
+                        g = 2;
+                        while (((P + g - 1) / g + 1 + 15) / 16 > 7) g += 2;
+                        ct = std::max<uint64_t>(4, ((P + g - 1) / g + 1 + 15) / 16);
+                    }
+                    const bool resident_one = CTmax && groups_for(CTmax) == 1;
+                    if ((mxs_want >= 2 || !resident_one) && mxs_supported((uint32_t)ct, (uint32_t)ng, 2, 0) && mxs_lds_bytes((uint32_t)ct, (uint32_t)ng) <= 160u * 1024u)
+                        stream_groups = g, stream_ct = ct, stream_ng = ng;
+                }
+                if (!CTmax && !stream_groups) throw Error(KGWAS_ERR_ARG, "coarse filter: too many accessions for the LDS");
                 const int sh = ns == 1 ? 0 : (s1_fp6 ? 5 : 3);                 // t = 2^sh * a6 + a1
                 const double kappa = (ns == 2 && !s1_fp6) ? 0.25 : 0.0625;     // accumulator = kappa * sum g t
                 const int t_ones = (int)(1.0 / kappa);                         // in the LAST slice (a6 = 0 with two slices)
@@ -657,14 +691,14 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                 }
                 // LDS groups: as few as hold all columns (+ a ones column each); or groups filled to the last slot and one
                 // smaller launch for the rest when that multiplies fewer tiles
-                uint64_t n_lgroups = groups_for(CTmax);
+                uint64_t n_lgroups = stream_groups ? stream_groups : groups_for(CTmax);
                 uint64_t cper = (P + n_lgroups - 1) / n_lgroups;
                 struct Plan {
                     uint64_t j0, n, CT, groups, cper;
                 };
                 std::vector<Plan> plan;
-                plan.push_back(Plan{0, P, (cper + 1 + 15) / 16, n_lgroups, cper});
-                if (n_lgroups > 1) {
+                plan.push_back(Plan{0, P, stream_groups ? stream_ct : (cper + 1 + 15) / 16, n_lgroups, cper});
+                if (n_lgroups > 1 && !stream_groups) {
                     const uint64_t cpf = (uint64_t)CTmax * 16 - 1;
                     const uint64_t full = P / cpf, rem = P - full * cpf;
                     const uint64_t CTr = rem ? (rem + 1 + 15) / 16 : 0;
@@ -694,10 +728,17 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                     const uint32_t CT = (uint32_t)pl.CT, slots = CT * 16;
                     Pt.T = CT;
                     Pt.n_lgroups = (uint32_t)pl.groups;
+                    const uint64_t NGs = stream_groups ? stream_ng : 1;  // column groups per block (streaming form)
+                    if (stream_groups) {
+                        Pt.n_lgroups = (uint32_t)(pl.groups / NGs);  // operand groups = grid blocks per row block
+                        Pt.ng = (uint32_t)NGs;
+                        Pt.stream = 1u + stream_form;
+                        s->st.coarse_mx_stream = Pt.stream;
+                    }
                     M.tile_slices += CT * (uint32_t)ns * (uint32_t)pl.groups;
-                    groups_all += (uint32_t)pl.groups;
+                    groups_all += Pt.n_lgroups;
                     const size_t group_bytes = (size_t)n_steps * CT * SB;
-                    std::vector<uint8_t> Bq(pl.groups * group_bytes, 0);
+                    std::vector<uint8_t> Bq(pl.groups * group_bytes + 1024, 0);  // (the streaming form's last transfer of a slab reads up to 1 KB past it)
                     std::vector<CoarseCol> cols(pl.groups * slots);
                     for (auto& cc : cols) {
                         memset(&cc, 0, sizeof(cc));
@@ -707,7 +748,8 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                     auto put = [&](uint64_t lg, uint64_t slot, const std::vector<int>& v0, const std::vector<int>& v1) {
                         const uint64_t t = slot / 16, n = slot % 16;
                         for (uint64_t st = 0; st < n_steps; st++) {
-                            uint8_t* blk = &Bq[lg * group_bytes + (st * CT + t) * SB];
+                            // (streaming form: the NG column groups of a block lie side by side within a step's slab)
+                            uint8_t* blk = &Bq[(lg / NGs) * (NGs * group_bytes) + ((st * NGs + lg % NGs) * CT + t) * SB];
                             for (uint64_t kb = 0; kb < 4; kb++) {
                                 const uint64_t lane = kb * 16 + n;
                                 for (uint64_t e = 0; e < 32; e++) {
@@ -780,7 +822,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                 s->st.coarse_mx_steps = n_steps;
                 // the set's matrix work per row in int8 tile-slice equivalents (a K = 128 step is one of the 8 n_kgroups K = 64
                 // steps' worth of two; measured 30 % less efficient per MFMA with three column tiles per LDS group: 0.48 against 0.37 ms per M rows at 2048 x 201)
-                M.tile_slices_eq = (double)M.tile_slices * (double)n_steps / (8.0 * (double)n_kgroups) * (CTmax <= 3 ? 1.30 : 1.0);
+                M.tile_slices_eq = (double)M.tile_slices * (double)n_steps / (8.0 * (double)n_kgroups) * ((CTmax <= 3 && !stream_groups) ? 1.30 : 1.0);
                 M.ready = true;
             };
             for (int mi = 0; mi < 2; mi++) {

@@ -396,7 +396,9 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
                     x.eg_max = c.eg_max;
                     x.rall_max = c.rall_max;
                     x.rmax_max = c.rmax_max;
-                    if (M.mx32)
+                    if (Pt.stream)
+                        KGWAS_HIP(launch_mxs(x, Pt.T, Pt.ng, Pt.stream - 1u, rpb_env ? rpb_env : (n_rows >= (1u << 22) ? 4096u : n_rows >= (1u << 20) ? 2048u : 512u), s->stream));
+                    else if (M.mx32)
                         KGWAS_HIP(launch_mx32(x, Pt.ct32, Pt.comb, rpb_env ? rpb_env : (n_rows >= (1u << 22) ? 4096u : n_rows >= (1u << 20) ? 2048u : 512u), s->stream));
                     else
                     KGWAS_HIP(launch_mx(x, Pt.T, rpb_env ? rpb_env : (n_rows >= (1u << 22) ? 4096u : n_rows >= (1u << 20) ? 2048u : 512u), s->stream));

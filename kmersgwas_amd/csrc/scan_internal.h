@@ -327,6 +327,8 @@ struct kgwas_scan {
     struct CoarsePart {  // one launch of the filter: n_lgroups LDS groups of T operand tiles over a range of columns
         uint32_t T = 0, n_lgroups = 0;
         uint32_t ct32 = 0, comb = 0;  // 32 x 32 x 64 form of the block-scaled filter (score_mx32.hip): tiles of 32 columns + combined tile
+        uint32_t stream = 0;          // operand-streaming form (score_mxs.hip): 1 + launch_mxs's `form`; T = column tiles per column group
+        uint32_t ng = 1;              // ... column groups per block (n_lgroups then counts operand groups of ng column groups)
         DevBuf<int8_t> d_Bq;
         DevBuf<CoarseCol> d_cols;
     };

@@ -195,7 +195,8 @@ def test_finish_hint_with_a_small_last_chunk_and_idle_workers(monkeypatch):
 def test_coarse_filter_shapes(monkeypatch, mx, slices, S, P, shift):
     """The coarse filter - the block-scaled one (mx = 1, the default: FP4 table bits x FP6 (+ FP4 / FP6) slices, full and
     quarter sample groups, 1..7 column tiles per LDS group, 4 and 8 row tiles per wave) and the int8 one (mx = 0) - in every
-    operand-tile shape (one or more LDS groups, 1..6 512-sample groups), with one and with two slices per column, on
+    operand-tile shape (one or more LDS groups, 1..6 512-sample groups; a forced slice count keeps the RESIDENT form of the
+    block-scaled filter, test_block_scaled_filter_streaming_form covers the other), with one and with two slices per column, on
     shifted phenotypes (the quantisation is centred) and duplicated patterns: survivors, pop order, scores and push
     counts equal the oracle's."""
     monkeypatch.setenv("KGWAS_COARSE_MX", str(mx))
@@ -265,13 +266,85 @@ def test_block_scaled_filter_32x32x64_form(monkeypatch, S_f, S, P, kind, reorder
     scan.close()
 
 
-def test_mixed_filter_sets_int8_steady_state_block_scaled_ramp():
+@pytest.mark.parametrize("S_f,S,P,kind,reorder,mxs,form", [
+    (2048, 2048, 201, "normal", False, 1, 0),  # BASELINE configs[3] per GPU: ONE operand group, two column groups of 7 tiles side by side in a block
+    (2048, 2048, 201, "heavy", False, 1, 1),   # ... one column group of 13 tiles, eight waves of 32 rows
+    (2048, 2048, 201, "normal", False, 1, 2),  # ... four waves (one per SIMD, 512-register budget) of 64 rows
+    (1135, 1135, 101, "heavy", False, 1, 0),   # BASELINE configs[2]: 9 steps (2 groups + 1 quarter step) x 7 tiles instead of two LDS groups of 4
+    (1024, 1024, 101, "normal", False, 2, 0),  # BASELINE configs[1] forced onto the streaming form (the resident one takes it by default)
+    (241, 241, 40, "binary", False, 2, 0),     # quarter steps only, 3 tiles
+    (513, 513, 100, "normal", False, 2, 0),    # 1 group + 1 quarter step, 7 tiles
+    (2048, 2048, 230, "normal", False, 1, 0),  # more than 222 columns: two operand groups (grid blocks sharing rows) of 2 x 4 tiles
+    (2048, 2048, 230, "normal", False, 1, 1),  # ... of 8 tiles, eight waves of 32 rows
+    (700, 650, 130, "normal", True, 1, 0),     # squeezed rows (subset, shuffled); 2 x 5 tiles
+    (1500, 1500, 150, "constant", False, 1, 2),  # 10 tiles, 12 steps, one wave per SIMD
+    (6000, 6000, 30, "normal", False, 1, 0),   # beyond the int8 filter's 5120 accessions: 47 steps x 3 tiles
+    (5200, 5200, 120, "heavy", False, 1, 0),   # ... 2 x 4 tiles
+    (5200, 5200, 120, "heavy", False, 1, 2)])  # ... 8 tiles, one wave per SIMD
+def test_block_scaled_filter_streaming_form(monkeypatch, S_f, S, P, kind, reorder, mxs, form):
+    """score_mxs.hip: the block-scaled filter with its slice operands streamed through an LDS ring (one barrier per step of 128
+    samples, `global_load_lds_dwordx4` slabs and row pieces three steps ahead, counted `vmcnt` waits) and ALL column tiles of an
+    operand group accumulated by the waves of a block - taken wherever the resident form would pass a row through several LDS
+    groups (KGWAS_MXS=1, the default) or wherever it exists (=2). Every block shape (KGWAS_MXS_FORM), 3 to 14 column tiles, one
+    and two operand groups, whole 512-sample groups and quarter steps, direct and squeezed rows, chunks that end inside a wave's
+    rows, and shapes beyond the int8 filter's 5120 accessions: survivors, pop order, score bytes, push and tested counts equal
+    the oracle's."""
+    monkeypatch.setenv("KGWAS_COARSE_MX", "1")
+    monkeypatch.setenv("KGWAS_MXS", str(mxs))
+    monkeypatch.setenv("KGWAS_MXS_FORM", str(form))
+    n = 30_011 if S <= 2048 else 12_007
+    rows = random_table(n, S_f, seed=S_f * 13 + P, dup_frac=0.25)
+    rng = np.random.default_rng(S + P)
+    col = rng.permutation(S_f)[:S].astype(np.uint64) if reorder else np.arange(S, dtype=np.uint64)
+    Y = phenotypes(S, P - 1, seed=P + 17, binary=(kind == "binary"))
+    if kind == "heavy":
+        Y = Y.copy()
+        Y[:, 0] += np.float32(50.0)
+        Y[1] = (rng.standard_cauchy(S) * 3).astype(np.float32)
+    if kind == "constant":
+        Y = Y.copy()
+        Y[2] = np.float32(1.25)
+        Y[5] = np.float32(0.0)
+    mac = onp.min_count(S, 0.05, 5)
+    topn = 211
+    exp = ob.associate(rows, S_f, col, Y, topn, mac, batch_size=9000, threads=4)
+    scan = kg.AssociationScan(S_f, col, Y, topn, mac, kernel=kg.KERNEL_COARSE, chunk_rows=4096)
+    cut = n * 3 // 5 + 7
+    scan.feed_host(rows[:cut], 0)
+    scan.feed_host(rows[cut:], cut)
+    scan.finish()
+    st = scan.stats()
+    # the plan of scan_create.cpp: column groups of ct tiles, ng of them per block, `og` operand groups a row passes through
+    if P + 1 <= 112:
+        ng, g, ct, stream = 1, 1, max(3, (P + 1 + 15) // 16), 1
+    elif form in (1, 2):
+        ng, g = 1, 1
+        while ((P + g - 1) // g + 1 + 15) // 16 > 13:
+            g += 1
+        ct = ((P + g - 1) // g + 1 + 15) // 16
+        stream = 1 + form if ct > 7 else 1
+    else:
+        ng, g = 2, 2
+        while ((P + g - 1) // g + 1 + 15) // 16 > 7:
+            g += 2
+        ct, stream = max(4, ((P + g - 1) // g + 1 + 15) // 16), 1
+    assert st["kernel_used"] == kg.KERNEL_COARSE and st["coarse_mx"] == 1 and st["coarse_launches"] > 0
+    assert st["coarse_mx_stream"] == stream, st
+    assert st["coarse_mode_lgroups"][1] == g // ng and st["coarse_mode_tiles"][1] == ct and st["coarse_mode_tile_slices"][1] == 2 * ct * g, st
+    assert st["coarse_mx_steps"] == 4 * (S // 512) + (S % 512 + 127) // 128
+    _check_topn(scan, exp, P)
+    assert st["rows_tested"] == exp["tested"]
+    scan.close()
+
+
+def test_mixed_filter_sets_int8_steady_state_block_scaled_ramp(monkeypatch):
     """4096 samples x 100 columns with nothing forced: the block-scaled operands (one column tile per LDS group: seven groups)
     would make a row pass through more than one more LDS group than the int8 filter's single slice (four groups of two tiles),
     so the int8 one-slice set keeps the steady state - and the two-slice set of the scan's first chunks (many candidates per
     row) is the block-scaled one. Both sets run in one scan (a small top-N makes the session switch inside 50 k rows), chunk
     by chunk; heaps equal the oracle's."""
     S, P = 4096, 100
+    monkeypatch.setenv("KGWAS_MXS", "0")  # (with the streaming form available - the default - this shape is ONE operand group of 7 tiles)
     rows = random_table(50_000, S, seed=77, dup_frac=0.2)
     col = np.arange(S, dtype=np.uint64)
     Y = phenotypes(S, P - 1, seed=5)
@@ -1130,10 +1203,14 @@ def test_numeric_edges_of_the_phenotype_values(kernel, kind, S, P):
     scan.close()
 
 
+@pytest.mark.parametrize("mxs", [1, 0])
 @pytest.mark.parametrize("S,P", [(5121, 20), (5200, 3), (6000, 1)])
-def test_more_than_5120_samples_leave_the_filters(S, P):
-    """Beyond 5120 accessions the filters' operand sets are not built (scan_create.cpp): the session must say which scorer
-    runs instead, and the heaps still equal the oracle's."""
+def test_more_than_5120_samples(monkeypatch, S, P, mxs):
+    """Beyond 5120 accessions no filter keeps a whole column tile's operands in LDS. With the operand-streaming form of the
+    block-scaled filter (score_mxs.hip, the default) such sessions are filtered all the same - one operand group, at least three
+    column tiles, however few columns; without it (KGWAS_MXS=0) the operand sets are not built (scan_create.cpp) and the session
+    must say which exact scorer runs instead. The heaps equal the oracle's either way."""
+    monkeypatch.setenv("KGWAS_MXS", str(mxs))
     rows = random_table(6000, S, seed=S, dup_frac=0.2)
     col = np.arange(S, dtype=np.uint64)
     Y = phenotypes(S, P - 1, seed=P + 1)
@@ -1144,7 +1221,11 @@ def test_more_than_5120_samples_leave_the_filters(S, P):
     scan.feed_host(rows)
     scan.finish()
     st = scan.stats()
-    assert st["kernel_used"] in (kg.KERNEL_MFMA, kg.KERNEL_VALU) and st["coarse_launches"] == 0, st
+    if mxs:  # (a few columns fit the LDS as ONE resident column tile even at 6000 accessions; more stream)
+        assert st["kernel_used"] == kg.KERNEL_COARSE and st["coarse_launches"] > 0 and st["coarse_mx"] == 1, st
+        assert st["coarse_mode_lgroups"][1] == 1 and st["coarse_mx_stream"] == (1 if P > 15 else 0), st
+    else:
+        assert st["kernel_used"] in (kg.KERNEL_MFMA, kg.KERNEL_VALU) and st["coarse_launches"] == 0, st
     _check_topn(scan, exp, P)
     assert st["rows_tested"] == exp["tested"]
     scan.close()
