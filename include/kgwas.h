@@ -187,7 +187,19 @@ typedef struct kgwas_scan_stats {
                                    block), 2 / 3 = one column group of up to 13 tiles with eight waves of 32 rows / four waves of 64
                                    (KGWAS_MXS_FORM=1 / 2). This field replaces the former `reserved0`: the struct's size and
                                    layout are unchanged. */
+    /* -- added in ABI version 5 (kgwas_abi_version): the struct grew by 8 bytes -- */
+    uint32_t columns_selected;  /* columns whose result lists kgwas_scan_finish made by SELECTION: their N largest scores (and the
+                                   N + 1-th) were pairwise distinct, none NaN or negative, so the lists are the N largest in ascending
+                                   order whatever libstdc++'s heap layout; such columns' candidates were logged, not replayed, and
+                                   heap_pushes does not count them (KGWAS_FULL_REPLAY=1: every column is replayed, as before) */
+    uint32_t columns_replayed_at_finish; /* columns that were in select mode until finish and then needed the exact replay of their
+                                   log (a tie among their N + 1 largest scores that did not show in the first dense chunk) */
 } kgwas_scan_stats;
+
+/* Version of this header's struct layouts and entry points. A caller built against an older header must not pass its (smaller)
+ * kgwas_scan_stats to a newer library: compare KGWAS_ABI_VERSION with kgwas_abi_version() at start-up. */
+#define KGWAS_ABI_VERSION 5
+uint32_t kgwas_abi_version(void);
 
 int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out);
 /* A hint, never needed for correctness: the NEXT feed is the last one before kgwas_scan_finish (the tools know it: they

@@ -22,7 +22,7 @@ KERNEL_AUTO, KERNEL_VALU, KERNEL_MFMA, KERNEL_COARSE, KERNEL_NARROW = 0, 1, 2, 3
 
 # Every symbol include/kgwas.h declares (tests check the library exports each one).
 SYMBOLS = [
-    "kgwas_last_error", "kgwas_version", "kgwas_device_count", "kgwas_host_cpu_quota",
+    "kgwas_last_error", "kgwas_version", "kgwas_abi_version", "kgwas_device_count", "kgwas_host_cpu_quota",
     "kgwas_table_open", "kgwas_table_info", "kgwas_table_name", "kgwas_table_column_map", "kgwas_table_read_rows",
     "kgwas_table_close",
     "kgwas_pheno_load", "kgwas_pheno_info", "kgwas_pheno_name", "kgwas_pheno_accession", "kgwas_pheno_values",
@@ -79,6 +79,7 @@ class ScanStats(C.Structure):
         ("replay_splits", C.c_uint64),
         ("columns_popped_ahead", C.c_uint64),
         ("coarse_mx32", C.c_uint32), ("coarse_mx_stream", C.c_uint32),
+        ("columns_selected", C.c_uint32), ("columns_replayed_at_finish", C.c_uint32),
     ]
 
     def as_dict(self):
@@ -135,6 +136,11 @@ _pstr = C.POINTER(C.c_char_p)
 lib.kgwas_last_error.restype = C.c_char_p
 lib.kgwas_version.restype = C.c_int
 lib.kgwas_device_count.argtypes = [C.POINTER(C.c_int)]
+lib.kgwas_abi_version.argtypes = []
+lib.kgwas_abi_version.restype = C.c_uint32
+ABI_VERSION = 5  # KGWAS_ABI_VERSION of include/kgwas.h this mirror was written against
+if lib.kgwas_abi_version() != ABI_VERSION:
+    raise ImportError("libkgwas.so speaks ABI version %d, kmersgwas_amd/capi.py %d: rebuild (make -C kmersgwas_amd/csrc)" % (lib.kgwas_abi_version(), ABI_VERSION))
 lib.kgwas_host_cpu_quota.argtypes = []
 lib.kgwas_host_cpu_quota.restype = C.c_uint32
 lib.kgwas_table_open.argtypes = [C.c_char_p, _u32, _pp]

@@ -41,6 +41,7 @@ MsgPlan plan_msgs(const kgwas_scan* s, uint64_t n_msgs, const uint64_t* col0, co
 extern "C" {
 
 uint32_t kgwas_host_cpu_quota(void) { return usable_cpus(); }
+uint32_t kgwas_abi_version(void) { return KGWAS_ABI_VERSION; }
 
 int kgwas_device_count(int* n_devices) {
     return guarded([&] {
@@ -143,6 +144,20 @@ int kgwas_scan_finish(kgwas_scan* s) {
         // on 16 workers - finish took 3-5 ms instead of 1.8 on boxes with busy neighbours).
         // (Batches are made of the columns w, w + T, ... whose heaps worker w replayed last and are laid out so that the
         // pool hands worker w its own ones first: item r * T + w is worker w's r-th batch.)
+        // columns in select mode first (scan_lazy.cpp): a selection each - or, where the scores do not decide the result, the
+        // replay of the column's log through its heap and its pops
+        if (s->lazy_any.load(std::memory_order_relaxed)) {
+            std::vector<size_t> lz;
+            for (size_t j = 0; j < s->n_pheno; j++)
+                if (s->lazy[j].on && s->col_popped[j].load(std::memory_order_acquire) != 2) lz.push_back(j);
+            s->pool->parallel_for(lz.size(), [&](size_t i) {
+                lazy_finish_column(s, lz[i]);
+                s->col_popped[lz[i]].store(2, std::memory_order_release);
+            });
+        }
+        s->st.heap_pushes += s->lazy_pushes.exchange(0);
+        s->st.columns_selected = (uint32_t)s->n_selected.exchange(0);  // (as of this finish)
+        s->st.columns_replayed_at_finish = (uint32_t)s->n_unselected.exchange(0);
         const size_t Tw = s->pool->size();
         const size_t per = std::min<size_t>(8, std::max<size_t>(1, (s->n_pheno + 2 * Tw - 1) / (2 * Tw)));
         std::vector<std::vector<std::vector<size_t>>> of_worker(Tw);  // [worker][batch][column]
@@ -228,6 +243,60 @@ int kgwas_scan_history_above(kgwas_scan* s, const double* thr, uint64_t* counts,
         if (!s || !thr || !counts) throw Error(KGWAS_ERR_ARG, "kgwas_scan_history_above: null argument");
         if (!s->record_history && !s->history_ring) throw Error(KGWAS_ERR_STATE, "scan was created without record_history");
         const uint64_t P = s->n_pheno;
+        if (s->lazy_log_mode && s->lazy_any.load(std::memory_order_relaxed)) {
+            // Columns in select mode (scan_lazy.cpp): every record the column was shipped above thr, in row order - a superset of
+            // its effective pushes above thr, and the same thing to the heap they are merged into: a record this shard's heap
+            // rejected (score <= its minimum at that row) is rejected there too, where the minimum is at least as high. A column
+            // that has been given its heap meanwhile (kgwas_scan_finish on a column with ties) answers from the heap's ring.
+            const double ninf = -std::numeric_limits<double>::infinity();
+            auto keepl = [&](uint64_t j, double sc) { return sc != ninf && (thr[j] == ninf || sc > thr[j]); };  // (-inf: a narrow chunk's placeholder)
+            _mm_sfence();
+            std::vector<std::vector<BestHeap::Rec>> recs(P);
+            std::vector<char> ok(P, 1);
+            s->pool->parallel_for(P, [&](size_t j) {
+                if (!s->lazy[j].on) {
+                    ok[j] = s->heaps[j].pushes_above(thr[j], recs[j]) ? 1 : 0;
+                    counts[j] = recs[j].size();
+                    return;
+                }
+                const LazyCol& h = s->lazy[j];
+                uint64_t c = 0;
+                for (size_t i = 0; i < h.l_n; i++) c += keepl(j, h.l_sc[i]) ? 1 : 0;
+                counts[j] = c;
+            });
+            for (uint64_t j = 0; j < P; j++)
+                if (!ok[j]) throw Error(KGWAS_ERR_STATE, "record_history = 2: column " + std::to_string(j) + " needs evictions that left its ring (raise KGWAS_HISTORY_RING, or use record_history = 1)");
+            std::vector<uint64_t> off(P + 1, 0);
+            for (uint64_t j = 0; j < P; j++) off[j + 1] = off[j] + counts[j];
+            s->exp_kmer.resize(off[P]);
+            s->exp_score.resize(off[P]);
+            s->exp_row.resize(off[P]);
+            s->pool->parallel_for(P, [&](size_t j) {
+                uint64_t o = off[j];
+                if (!s->lazy[j].on) {
+                    for (const BestHeap::Rec& r : recs[j]) {
+                        s->exp_kmer[o] = r.kmer;
+                        s->exp_score[o] = r.score;
+                        s->exp_row[o] = r.row;
+                        o++;
+                    }
+                    return;
+                }
+                const LazyCol& h = s->lazy[j];
+                for (size_t i = 0; i < h.l_n; i++)
+                    if (keepl(j, h.l_sc[i])) {
+                        s->exp_kmer[o] = h.l_km[i];
+                        s->exp_score[o] = h.l_sc[i];
+                        s->exp_row[o] = h.l_rw[i];
+                        o++;
+                    }
+            });
+            if (kmer) *kmer = s->exp_kmer.data();
+            if (score) *score = s->exp_score.data();
+            if (row) *row = s->exp_row.data();
+            return;
+        }
+        lazy_materialize_all(s);
         if (s->history_ring) {  // mode 2: the heap's entries and its last evictions above thr, put in row order
             std::vector<std::vector<BestHeap::Rec>> recs(P);
             std::vector<char> ok(P, 1);
@@ -294,6 +363,7 @@ int kgwas_scan_heaps_export(kgwas_scan* s, uint64_t n_cols, const uint64_t* cols
                             const double** score, const uint64_t** row) {
     return guarded([&] {
         if (!s || (n_cols && (!cols || !sizes))) throw Error(KGWAS_ERR_ARG, "kgwas_scan_heaps_export: null argument");
+        lazy_materialize_all(s);  // (columns in select mode get their heaps first: scan_lazy.cpp)
         std::vector<uint64_t> off(n_cols + 1, 0);
         for (uint64_t c = 0; c < n_cols; c++) {
             if (cols[c] >= s->n_pheno) throw Error(KGWAS_ERR_ARG, "kgwas_scan_heaps_export: column out of range");
@@ -316,6 +386,7 @@ int kgwas_scan_heaps_import(kgwas_scan* s, uint64_t n_cols, const uint64_t* cols
                             const double* score, const uint64_t* row) {
     return guarded([&] {
         if (!s || (n_cols && (!cols || !sizes))) throw Error(KGWAS_ERR_ARG, "kgwas_scan_heaps_import: null argument");
+        lazy_materialize_all(s);  // (columns in select mode get their heaps first: scan_lazy.cpp)
         for (uint64_t c = 0; c < n_cols; c++) {
             if (cols[c] >= s->n_pheno) throw Error(KGWAS_ERR_ARG, "kgwas_scan_heaps_import: column out of range");
             if (sizes[c] && (!kmer || !score || !row)) throw Error(KGWAS_ERR_ARG, "kgwas_scan_heaps_import: null data");
@@ -343,6 +414,8 @@ int kgwas_scan_history_above_msgs(kgwas_scan* s, const double* thr, uint64_t n_m
     return guarded([&] {
         if (!s || !thr || (n_msgs && (!msg_col0 || !msg_ncols || !msg_words))) throw Error(KGWAS_ERR_ARG, "kgwas_scan_history_above_msgs: null argument");
         if (!s->record_history && !s->history_ring) throw Error(KGWAS_ERR_STATE, "scan was created without record_history");
+        const bool from_logs = s->lazy_log_mode && s->lazy_any.load(std::memory_order_relaxed);  // (see kgwas_scan_history_above)
+        if (!from_logs) lazy_materialize_all(s);
         const uint64_t P = s->n_pheno;
         std::vector<char> wanted(P, 0);
         for (uint64_t m = 0; m < n_msgs; m++) {  // (ranges first: nothing below loops over an unchecked count)
@@ -354,10 +427,15 @@ int kgwas_scan_history_above_msgs(kgwas_scan* s, const double* thr, uint64_t n_m
         std::vector<std::vector<BestHeap::Rec>> recs(s->history_ring ? P : 0);
         std::vector<uint64_t> counts(P, 0);
         std::vector<char> ok(P, 1);
-        if (!s->history_ring) _mm_sfence();
+        if (!s->history_ring || from_logs) _mm_sfence();
         s->pool->parallel_for(P, [&](size_t j) {
             if (!wanted[j]) return;
-            if (s->history_ring) {  // mode 2: the heap's entries and its last evictions above thr, put in row order
+            if (from_logs && s->lazy[j].on) {
+                const LazyCol& h = s->lazy[j];
+                uint64_t c = 0;
+                for (size_t i = 0; i < h.l_n; i++) c += (h.l_sc[i] != ninf && keep(j, h.l_sc[i])) ? 1 : 0;
+                counts[j] = c;
+            } else if (s->history_ring) {  // mode 2: the heap's entries and its last evictions above thr, put in row order
                 ok[j] = s->heaps[j].pushes_above(thr[j], recs[j]) ? 1 : 0;
                 counts[j] = recs[j].size();
             } else {
@@ -401,7 +479,11 @@ int kgwas_scan_history_above_msgs(kgwas_scan* s, const double* thr, uint64_t n_m
                 rw[o] = row;
                 o++;
             };
-            if (s->history_ring) {
+            if (from_logs && s->lazy[b.j].on) {
+                const LazyCol& h = s->lazy[b.j];
+                for (size_t e = 0; e < h.l_n; e++)
+                    if (h.l_sc[e] != ninf && keep(b.j, h.l_sc[e])) put(h.l_km[e], h.l_sc[e], h.l_rw[e]);
+            } else if (s->history_ring) {
                 for (const BestHeap::Rec& r : recs[b.j]) put(r.kmer, r.score, r.row);
             } else {
                 const History& h = s->hist[b.j];
@@ -416,6 +498,7 @@ int kgwas_scan_heaps_export_msgs(kgwas_scan* s, uint64_t n_msgs, const uint64_t*
                                  uint64_t* out, uint64_t cap_words, uint64_t* msg_words) {
     return guarded([&] {
         if (!s || (n_msgs && (!msg_col0 || !msg_ncols || !msg_words))) throw Error(KGWAS_ERR_ARG, "kgwas_scan_heaps_export_msgs: null argument");
+        lazy_materialize_all(s);
         const MsgPlan plan = plan_msgs(s, n_msgs, msg_col0, msg_ncols, msg_words, [&](uint64_t j) { return (uint64_t)s->heaps[j].size(); }, "kgwas_scan_heaps_export_msgs");
         if (!out || cap_words < plan.total()) return;
         struct Job {
@@ -442,10 +525,19 @@ int kgwas_scan_heaps_export_msgs(kgwas_scan* s, uint64_t n_msgs, const uint64_t*
     });
 }
 
-int kgwas_scan_lowest(const kgwas_scan* s, double* lowest, uint8_t* full) {
+int kgwas_scan_lowest(const kgwas_scan* cs, double* lowest, uint8_t* full) {
     return guarded([&] {
-        if (!s || !lowest || !full) throw Error(KGWAS_ERR_ARG, "kgwas_scan_lowest: null argument");
+        if (!cs || !lowest || !full) throw Error(KGWAS_ERR_ARG, "kgwas_scan_lowest: null argument");
+        kgwas_scan* s = const_cast<kgwas_scan*>(cs);
         for (uint64_t j = 0; j < s->n_pheno; j++) {
+            if (s->lazy[j].on) {  // select mode: the N-th largest score logged IS the heap's minimum (scan_lazy.cpp)
+                bool f = false;
+                if (lazy_lowest(s, j, &lowest[j], &f)) {
+                    full[j] = f ? 1 : 0;
+                    continue;
+                }
+                s->st.heap_pushes += lazy_materialize(s, j);
+            }
             lowest[j] = s->heaps[j].lowest();
             full[j] = s->heaps[j].full() ? 1 : 0;
         }
@@ -464,6 +556,13 @@ int kgwas_scan_absorb(kgwas_scan* s, uint64_t n_shards, const uint64_t* counts, 
         s->pool->parallel_for(P, [&](size_t j) {
             BestHeap& h = s->heaps[j];
             uint64_t local = 0;
+            if (s->lazy[j].on) {  // select mode: the later shards' records join the column's log (rows behind everything it holds)
+                for (uint64_t g = 0; g < n_shards; g++) {
+                    const uint64_t o = off[g][j], n = counts[g * P + j];
+                    for (uint64_t i = 0; i < n; i++) s->lazy[j].add(kmer[g][o + i], score[g][o + i], row[g][o + i]);
+                }
+                return;
+            }
             for (uint64_t g = 0; g < n_shards; g++) {  // shards in row order
                 const uint64_t o = off[g][j], n = counts[g * P + j];
                 for (uint64_t i = 0; i < n; i++)
@@ -492,6 +591,7 @@ int kgwas_scan_reset(kgwas_scan* s) {
         KGWAS_HIP(hipSetDevice(s->device));
         KGWAS_HIP(hipStreamSynchronize(s->stream));
         make_heaps(s);
+        lazy_reset(s);
         for (uint64_t j = 0; j < s->n_pheno; j++) s->col_popped[j].store(0);
         s->final_feed_next = false;
         for (auto& h : s->hist) h.clear();

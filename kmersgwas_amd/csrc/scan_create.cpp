@@ -989,6 +989,8 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                 sl.d_so_row.alloc(s->key_slots);
                 sl.d_meta.alloc(2 * P + 4);
                 sl.h_meta.alloc(2 * P + 4);
+                sl.h_thr.alloc(P);
+                memset(sl.h_thr.p, 0, P * sizeof(double));
                 memset(sl.h_meta.p, 0, (2 * P + 4) * sizeof(uint32_t));
                 KGWAS_HIP(hipEventCreateWithFlags(&sl.ev_counts, hipEventBlockingSync));
             } else {
@@ -1018,6 +1020,12 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         s->d_tested_dense.alloc(TESTED_SHARDS);
 
         make_heaps(s.get());
+        {
+            const char* fr = getenv("KGWAS_FULL_REPLAY");
+            s->lazy_enabled = s->coarse && !s->record_history && !(fr && atoi(fr) != 0);
+            s->lazy_log_mode = s->lazy_enabled && s->history_ring != 0;
+            lazy_reset(s.get());
+        }
         s->hist.resize(P);
         s->keys.resize(P);
         s->col_ms.assign(P, 0.0);

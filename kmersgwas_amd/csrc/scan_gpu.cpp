@@ -96,7 +96,8 @@ void upload_thresholds(kgwas_scan* s) {
     double* h = s->h_thr.p + (s->thr_flip % 8u) * s->n_pheno;  // ring: uploads may queue behind long kernels
     s->thr_flip++;
     // (a heap that is still filling has no bound to offer: its smallest entry so far may well exceed its final minimum)
-    for (uint64_t j = 0; j < s->n_pheno; j++) h[j] = s->heaps[j].full() ? s->heaps[j].lowest() : 0.0;
+    // (a column in select mode offers its pool's bound: racy reads of monotone values, as the heaps' minima are)
+    for (uint64_t j = 0; j < s->n_pheno; j++) h[j] = s->lazy[j].on ? s->lazy[j].bound() : (s->heaps[j].full() ? s->heaps[j].lowest() : 0.0);
     KGWAS_HIP(hipMemcpyAsync(s->d_thr_host.p, h, s->n_pheno * sizeof(double), hipMemcpyHostToDevice, s->stream));
     if (!s->hist_ready)
         KGWAS_HIP(hipMemcpyAsync(s->d_thr.p, h, s->n_pheno * sizeof(double), hipMemcpyHostToDevice, s->stream));
@@ -105,7 +106,7 @@ void upload_thresholds(kgwas_scan* s) {
 // First sparse chunk: histogram bin 0 of every column starts at its current exact minimum.
 void start_histograms(kgwas_scan* s) {
     for (uint64_t j = 0; j < s->n_pheno; j++) {
-        const double low = s->sel_valid ? s->h_sel.p[j] : s->heaps[j].lowest();
+        const double low = s->sel_valid ? s->h_sel.p[j] : (s->lazy[j].on ? s->lazy[j].bound() : s->heaps[j].lowest());
         uint64_t bits = 0;
         if (low == low && low > 0) memcpy(&bits, &low, 8);
         s->h_hist_base.p[j] = (uint32_t)(bits >> HIST_SHIFT);
@@ -118,7 +119,7 @@ void start_histograms(kgwas_scan* s) {
 
 void refresh_full(kgwas_scan* s) {
     bool all = true;
-    for (auto& h : s->heaps) all = all && h.full();
+    for (uint64_t j = 0; j < s->n_pheno; j++) all = all && (s->lazy[j].on ? s->lazy[j].full() : s->heaps[j].full());
     s->all_full = all;
 }
 
@@ -207,6 +208,20 @@ void dense_fill(kgwas_scan* s, uint64_t n_rows, uint64_t first_row, std::chrono:
         BestHeap& h = s->heaps[j];
         const double* sc = s->h_dense.p + j * n_rows;
         uint64_t local = 0;
+        if (s->lazy[j].on) {
+            // select mode (scan_lazy.cpp): the rows go to the column's log and pool. A tie among the column's N largest so far
+            // (a table whose rows repeat presence/absence patterns shows them at once) means its result will depend on the
+            // heap's layout: the column is replayed from here on, beginning with what it has logged.
+            LazyCol& L = s->lazy[j];
+            for (uint64_t r = 0; r < n_rows; r++) {
+                const uint64_t n1 = s->h_n1.p[r];
+                if (!(S >= mc && n1 >= mc && n1 <= S - mc)) continue;
+                L.add(s->h_kmer.p[r], sc[r], first_row + r);
+            }
+            if (!s->lazy_log_mode && L.ties_now()) local = lazy_materialize(s, j);
+            pushes += local;
+            return;
+        }
         for (uint64_t r = 0; r < n_rows; r++) {
             const uint64_t n1 = s->h_n1.p[r];
             if (!(S >= mc && n1 >= mc && n1 <= S - mc)) continue;
@@ -282,7 +297,7 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
         // reflect these very rows (or later ones), which is only valid for rows after them. The re-run is
         // synchronous and in order, so the host heaps hold exactly the rows before this range: use their
         // minima, nothing newer.
-        for (uint64_t j = 0; j < s->n_pheno; j++) s->h_thr_redo.p[j] = s->heaps[j].lowest();
+        for (uint64_t j = 0; j < s->n_pheno; j++) s->h_thr_redo.p[j] = s->lazy[j].on ? s->lazy[j].bound() : s->heaps[j].lowest();
         KGWAS_HIP(hipMemcpyAsync(s->d_thr_redo.p, s->h_thr_redo.p, s->n_pheno * sizeof(double), hipMemcpyHostToDevice,
                                  s->stream));
         a.thr = s->d_thr_redo.p;
@@ -442,6 +457,9 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
     if (use_coarse) {
         // the record copies follow on the copy stream once the control thread has read the counts (fetch_records)
         KGWAS_HIP(hipMemcpyAsync(sl.h_meta.p, sl.d_meta.p, (2 * s->n_pheno + 4) * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+        // (columns in select mode prune their pools with the device's thresholds as they stand behind this chunk)
+        if (s->lazy_any.load(std::memory_order_relaxed))
+            KGWAS_HIP(hipMemcpyAsync(sl.h_thr.p, s->d_thr.p, s->n_pheno * sizeof(double), hipMemcpyDeviceToHost, s->stream));
         KGWAS_HIP(hipEventRecord(sl.ev_counts, s->stream));
     } else {
         KGWAS_HIP(hipMemcpyAsync(sl.h_cnt.p, sl.d_cnt.p, s->n_pheno * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));

@@ -236,6 +236,89 @@ struct History {
         cap = nc;
     }
     void clear() { n = 0; }
+    void release() {
+        free(p);
+        p = nullptr;
+        n = cap = 0;
+    }
+};
+
+// A column whose top-N is selected instead of replayed (scan_lazy.cpp).
+struct LazyCol {
+    struct Ent {
+        uint64_t bits;  // the score's bit pattern (+0 .. +inf: ordered like the scores)
+        uint64_t kmer, row;
+    };
+    static constexpr uint64_t NEG_INF = 0xFFF0000000000000ull;  // "a survivor that is no candidate" in a narrow chunk's records
+    bool on = false;   // the column is in select mode (its BestHeap is empty)
+    bool bad = false;  // a NaN or negative score came by: the heap's order is not the scores' order - materialise at finish
+    uint64_t topn = 0;
+    uint64_t n_logged = 0;  // records logged (dense chunks: every MAC-passing row - "is the heap full")
+    uint64_t bound_bits = 0;
+    bool have_bound = false;
+    uint32_t n_prunes = 0;
+    // the LOG, three arrays (a chunk's records arrive as three arrays and are copied as such: 2 ns per record)
+    double* l_sc = nullptr;
+    uint64_t* l_km = nullptr;
+    uint64_t* l_rw = nullptr;
+    size_t l_n = 0, l_cap = 0;
+    std::vector<Ent> pool;
+    LazyCol() = default;
+    LazyCol(const LazyCol&) = delete;
+    LazyCol& operator=(const LazyCol&) = delete;
+    LazyCol(LazyCol&& o) noexcept { *this = std::move(o); }
+    LazyCol& operator=(LazyCol&& o) noexcept {
+        if (this != &o) {
+            release_log();
+            on = o.on, bad = o.bad, topn = o.topn, n_logged = o.n_logged, bound_bits = o.bound_bits, have_bound = o.have_bound, n_prunes = o.n_prunes;
+            l_sc = o.l_sc, l_km = o.l_km, l_rw = o.l_rw, l_n = o.l_n, l_cap = o.l_cap;
+            o.l_sc = nullptr, o.l_km = nullptr, o.l_rw = nullptr, o.l_n = o.l_cap = 0;
+            pool = std::move(o.pool);
+        }
+        return *this;
+    }
+    ~LazyCol() { release_log(); }
+    void release_log() {
+        free(l_sc);
+        free(l_km);
+        free(l_rw);
+        l_sc = nullptr, l_km = nullptr, l_rw = nullptr;
+        l_n = l_cap = 0;
+    }
+    void reserve_log(size_t need);
+    void reset(bool enable, uint64_t topn_);
+    void compact();
+    void prune(uint64_t thr_bits);
+    bool select(std::vector<uint64_t>& kmer, std::vector<double>& score, std::vector<uint64_t>& row);
+    bool ties_now();
+    // a sparse chunk's records of this column (row order; rw: rows within the chunk), the device's threshold behind the chunk
+    void take_chunk(const double* sc, const uint64_t* km, const uint32_t* rw, uint32_t n, uint64_t row0, uint64_t thr_bits);
+    inline bool full() const { return n_logged >= topn; }
+    // a valid lower bound of what the reference heap's minimum is by now (0: none yet)
+    inline double bound() const {
+        double v = 0.0;
+        if (have_bound) memcpy(&v, &bound_bits, 8);
+        return v;
+    }
+    // one record (dense chunks' rows, records absorbed from other shards, exact-scorer candidates)
+    inline void add(uint64_t kmer, double score, uint64_t row) {
+        uint64_t b;
+        memcpy(&b, &score, 8);
+        if (b == NEG_INF) return;  // never an add_association call
+        if (l_n == l_cap) reserve_log(l_n + 1);
+        l_sc[l_n] = score;
+        l_km[l_n] = kmer;
+        l_rw[l_n] = row;
+        l_n++;
+        n_logged++;
+        if (b > 0x7FF0000000000000ull) {  // NaN, or the sign bit set
+            bad = true;
+            return;
+        }
+        if (have_bound && b < bound_bits) return;
+        pool.push_back(Ent{b, kmer, row});
+        if (pool.size() >= 8 * (size_t)topn + 64) compact();  // (the chunks' device thresholds normally prune it long before)
+    }
 };
 
 // Evictions a heap of N entries keeps for the cross-shard merge (record_history = 2): the entries of a shard above
@@ -273,6 +356,8 @@ struct Slot {
     DevBuf<uint32_t> d_so_row;
     DevBuf<uint32_t> d_meta;
     PinBuf<uint32_t> h_meta;
+    PinBuf<double> h_thr;  // the device's thresholds behind this chunk (columns in select mode prune their pools with them, scan_lazy.cpp)
+    bool tie_check = false;          // columns in select mode look at their pools for ties after this chunk (scan_lazy.cpp)
     bool tested_in_meta = false;     // the chunk's MAC-passing rows came in h_meta (narrow scans), not in h_tested
     hipEvent_t ev_counts = nullptr;  // compute stream: compaction done, h_meta copied
     DevBuf<unsigned long long> d_tested;
@@ -414,6 +499,16 @@ struct kgwas_scan {
     } heap_arena;
     std::unique_ptr<std::pmr::monotonic_buffer_resource> heap_mr;
     std::vector<BestHeap> heaps;
+    // columns whose top-N is selected, not replayed (scan_lazy.cpp): lazy[j].on; lazy_any: some column may be
+    bool lazy_enabled = false;
+    // record_history = 2 sessions (the later shards of a cross-shard merge): their columns stay in select mode whatever their
+    // ties - such a session is asked for its final minima and for its records above a threshold (kgwas_scan_lowest,
+    // kgwas_scan_history_above: both served from the logs), not for result lists
+    bool lazy_log_mode = false;
+    std::vector<LazyCol> lazy;
+    std::atomic<bool> lazy_any{false};
+    std::atomic<uint64_t> n_selected{0}, n_unselected{0}, lazy_pushes{0};
+    uint64_t tie_check_rows = 0;  // rows_submitted at which the next chunk is flagged for a tie check (geometric: x 1.25)
     std::vector<History> hist;
     std::vector<uint64_t> exp_kmer, exp_row;  // scratch of kgwas_scan_history_above / kgwas_scan_heaps_export
     std::vector<double> exp_score;
@@ -507,6 +602,12 @@ bool chunk_complete(kgwas_scan* s, Slot& sl);
 uint64_t next_sparse_chunk(const kgwas_scan* s);
 void wait_event(kgwas_scan* s, hipEvent_t ev);
 bool fetch_records(kgwas_scan* s, Slot& sl, uint64_t seq);
+// ---- scan_lazy.cpp: selection instead of replay
+uint64_t lazy_materialize(kgwas_scan* s, size_t j);
+void lazy_materialize_all(kgwas_scan* s);
+void lazy_finish_column(kgwas_scan* s, size_t j);
+void lazy_reset(kgwas_scan* s);
+bool lazy_lowest(kgwas_scan* s, size_t j, double* lowest, bool* full);
 // ---- scan_replay.cpp: the host side
 void replay_group(kgwas_scan* s, Slot& sl, size_t g, ReplayAcc& acc);
 void add_replay_stats(kgwas_scan* s, const ReplayAcc& a);

@@ -1,0 +1,287 @@
+// scan_lazy.cpp — columns whose top-N is SELECTED instead of replayed.
+//
+// add_association (src/best_associations_heap.cpp:43-59) keeps the N largest scores; WHICH of several equal scores stay, and
+// the order equal scores pop in (output_to_file_with_scores, :82-92), depend on libstdc++'s heap layout, i.e. on the whole
+// history of effective pushes - that is why scan_replay.cpp replays every one of them (27 ns each, 10 M per 100 M-row pass
+// at 101 columns: the scan's critical path on 16 CPUs). But where a column's N largest scores - and the (N + 1)-th - are
+// pairwise DISTINCT, none of them NaN or negative, the result does not depend on the layout at all: the heap ends up
+// holding exactly the N largest, and N pops from ANY valid heap of distinct keys yield them in ascending order. Such a
+// column needs a selection, not a replay.
+//
+// A lazy column keeps
+//   * its LOG: every record the column was shipped (the dense chunks' MAC-passing rows, then the sparse chunks' candidates)
+//     in row order - 24 B each, ~1.4 N (1 + ln(rows / N)) records; what an exact replay would need, should it come to that;
+//   * its POOL: (score bits, k-mer, row) of the records that can still be among the N largest: a record enters if its score is
+//     >= the pool's bound. When the pool holds 2 N entries it is PRUNED with the device's own threshold behind the chunk at
+//     hand (a valid lower bound of the reference heap's minimum, within 0.4 % of the N-th largest score: one linear pass);
+//     should that leave more than 2 N, nth_element finds the N-th largest score v, everything below v goes, entries EQUAL to v
+//     stay (a tie at the boundary must remain visible), and v becomes the bound.
+// At finish the pool is cut to its N largest and sorted; if more than N entries are >= the N-th score (boundary tie), two
+// neighbours are equal (tie inside), or the column ever saw a NaN / negative score, the column is MATERIALISED instead: its log
+// is replayed through its BestHeap, exactly as the streaming replay would have done, and popped. Tables whose rows repeat
+// presence/absence patterns (real k-mer tables: the rule) tie all over the place - a column whose first dense chunk shows a
+// tie among its top N is materialised on the spot and replayed from then on, as every column was before round 5; the pools
+// are looked at again for ties every fourth pruning (a radix sort of ~N keys), so that a column that will need the replay
+// gets it beside the GPU's work and not at finish.
+// KGWAS_FULL_REPLAY=1: no column is ever lazy (the effective-push count, which the tests use as a tripwire, exists for
+// replayed columns only).
+#include "scan_internal.h"
+
+namespace kgwas {
+
+void LazyCol::reset(bool enable, uint64_t topn_) {
+    on = enable;
+    bad = false;
+    topn = topn_;
+    n_logged = 0;
+    bound_bits = 0;
+    have_bound = false;
+    n_prunes = 0;
+    l_n = 0;
+    pool.clear();
+    if (enable && pool.capacity() < 3 * (size_t)std::min<uint64_t>(topn_, 1u << 22) + 64) pool.reserve(3 * (size_t)std::min<uint64_t>(topn_, 1u << 22) + 64);
+}
+
+void LazyCol::reserve_log(size_t need) {
+    if (need <= l_cap) return;
+    size_t nc = l_cap ? l_cap + l_cap / 2 : (size_t)1 << 14;
+    if (nc < need) nc = need;
+    void* a = realloc(l_sc, nc * sizeof(double));
+    if (!a) throw std::bad_alloc();
+    l_sc = static_cast<double*>(a);
+    void* b = realloc(l_km, nc * sizeof(uint64_t));
+    if (!b) throw std::bad_alloc();
+    l_km = static_cast<uint64_t*>(b);
+    void* c = realloc(l_rw, nc * sizeof(uint64_t));
+    if (!c) throw std::bad_alloc();
+    l_rw = static_cast<uint64_t*>(c);
+    l_cap = nc;
+}
+
+// A sparse chunk's records of this column: into the log as they are (three copies; a narrow chunk's placeholders - survivors
+// that are no candidates, score -inf - travel along and are skipped by every reader), and those that can still be among the N
+// largest - score >= the device's threshold behind this very chunk - into the pool.
+void LazyCol::take_chunk(const double* sc, const uint64_t* km, const uint32_t* rw, uint32_t n, uint64_t row0, uint64_t thr_bits) {
+    if (thr_bits <= 0x7FF0000000000000ull && (!have_bound || thr_bits > bound_bits)) {
+        bound_bits = thr_bits;
+        have_bound = true;
+    }
+    reserve_log(l_n + n);
+    memcpy(l_sc + l_n, sc, (size_t)n * sizeof(double));
+    memcpy(l_km + l_n, km, (size_t)n * sizeof(uint64_t));
+    uint64_t* dr = l_rw + l_n;
+    for (uint32_t i = 0; i < n; i++) dr[i] = row0 + rw[i];
+    l_n += n;
+    n_logged += n;
+    const uint64_t lim = have_bound ? bound_bits : 0;
+    for (uint32_t i = 0; i < n; i++) {
+        uint64_t b;
+        memcpy(&b, &sc[i], 8);
+        if (b < lim) continue;
+        if (b > 0x7FF0000000000000ull) {
+            if (b != NEG_INF) bad = true;
+            continue;
+        }
+        pool.push_back(Ent{b, km[i], row0 + rw[i]});
+    }
+    if (pool.size() >= 2 * (size_t)topn + 64) prune(bound_bits);
+}
+
+// thr: a valid lower bound of the reference heap's minimum (the device's threshold behind some chunk: the highest boundary of
+// its score histogram with at least N counted scores at or above it, within 0.4 % of the N-th largest). Everything below it
+// goes - one linear pass instead of a selection; entries EQUAL to it stay (it may be the N-th largest itself).
+void LazyCol::prune(uint64_t thr_bits) {
+    n_prunes++;
+    if (thr_bits <= 0x7FF0000000000000ull && (!have_bound || thr_bits > bound_bits)) {  // (NaN: a frozen column)
+        bound_bits = thr_bits;
+        have_bound = true;
+    }
+    if (have_bound) {  // (entries that came in under an earlier, lower bound)
+        size_t keep = 0;
+        for (size_t i = 0; i < pool.size(); i++)
+            if (pool[i].bits >= bound_bits) pool[keep++] = pool[i];
+        pool.resize(keep);
+    }
+    if (pool.size() >= 2 * (size_t)topn + 64) compact();  // (a threshold that lags far behind: select after all)
+}
+
+// the pool's N largest stay (with everything equal to the N-th); the N-th becomes the bound
+void LazyCol::compact() {
+    const size_t N = (size_t)topn;
+    if (pool.size() <= N) return;
+    std::nth_element(pool.begin(), pool.begin() + (N - 1), pool.end(), [](const Ent& a, const Ent& b) { return a.bits > b.bits; });
+    const uint64_t v = pool[N - 1].bits;
+    size_t keep = N;
+    for (size_t i = N; i < pool.size(); i++)
+        if (pool[i].bits == v) pool[keep++] = pool[i];
+    pool.resize(keep);
+    bound_bits = v;
+    have_bound = true;
+}
+
+// Result lists by selection (any number of entries: a heap that never filled holds them all). false: the scores alone do not
+// decide the result - the caller materialises the column.
+bool LazyCol::select(std::vector<uint64_t>& kmer, std::vector<double>& score, std::vector<uint64_t>& row) {
+    if (bad) return false;
+    compact();
+    const size_t N = (size_t)topn;
+    if (pool.size() > N) return false;  // entries equal to the N-th largest beyond the N: which of them stay is the layout's business
+    const size_t n = pool.size();
+    // ascending by bits: LSD radix over the digits in which the keys differ (as BestHeap::pop_all_sorted)
+    static thread_local std::vector<Ent> a, b;
+    if (a.size() < n) a.resize(n), b.resize(n);
+    uint64_t all_or = 0, all_and = ~0ull;
+    for (size_t i = 0; i < n; i++) {
+        a[i] = pool[i];
+        all_or |= pool[i].bits;
+        all_and &= pool[i].bits;
+    }
+    const uint64_t varying = all_or ^ all_and;
+    Ent* src = a.data();
+    Ent* dst = b.data();
+    for (int shift = 0; shift < 64; shift += 11) {
+        if (((varying >> shift) & 0x7FFull) == 0) continue;
+        uint32_t cnt[2048] = {0};
+        for (size_t i = 0; i < n; i++) cnt[(src[i].bits >> shift) & 0x7FFu]++;
+        uint32_t run = 0;
+        for (int d = 0; d < 2048; d++) {
+            const uint32_t c = cnt[d];
+            cnt[d] = run;
+            run += c;
+        }
+        for (size_t i = 0; i < n; i++) dst[cnt[(src[i].bits >> shift) & 0x7FFu]++] = src[i];
+        std::swap(src, dst);
+    }
+    for (size_t i = 1; i < n; i++)
+        if (src[i].bits == src[i - 1].bits) return false;  // a tie inside the N largest: its pop order is the layout's business
+    kmer.resize(n);
+    score.resize(n);
+    row.resize(n);
+    for (size_t i = 0; i < n; i++) {
+        kmer[i] = src[i].kmer;
+        memcpy(&score[i], &src[i].bits, 8);
+        row[i] = src[i].row;
+    }
+    return true;
+}
+
+// Are two of the pool's N largest scores equal, or does the (N + 1)-th equal the N-th, right now? The pool is pruned with its
+// bound (~1.04 N entries stay), its keys are radix-sorted (LSD over the digits in which they differ: the N largest scores of a
+// column share sign, exponent and often the leading mantissa bits) and the top N + 1 compared with their neighbours: ~80 us
+// at N = 10 001.
+bool LazyCol::ties_now() {
+    if (bad) return true;
+    const size_t N = (size_t)topn;
+    prune(bound_bits);
+    if (pool.size() > N + N / 2) compact();
+    const size_t n = pool.size();
+    static thread_local std::vector<uint64_t> k, k2;
+    if (k.size() < n) k.resize(n), k2.resize(n);
+    uint64_t all_or = 0, all_and = ~0ull;
+    for (size_t i = 0; i < n; i++) {
+        k[i] = pool[i].bits;
+        all_or |= k[i];
+        all_and &= k[i];
+    }
+    const uint64_t varying = all_or ^ all_and;
+    uint64_t* src = k.data();
+    uint64_t* dst = k2.data();
+    for (int shift = 0; shift < 64; shift += 11) {
+        if (((varying >> shift) & 0x7FFull) == 0) continue;
+        uint32_t cnt[2048] = {0};
+        for (size_t i = 0; i < n; i++) cnt[(src[i] >> shift) & 0x7FFu]++;
+        uint32_t run = 0;
+        for (int d = 0; d < 2048; d++) {
+            const uint32_t c = cnt[d];
+            cnt[d] = run;
+            run += c;
+        }
+        for (size_t i = 0; i < n; i++) dst[cnt[(src[i] >> shift) & 0x7FFu]++] = src[i];
+        std::swap(src, dst);
+    }
+    // ascending: the N largest are src[n - N .. n), the (N + 1)-th is src[n - N - 1]
+    const size_t lo = n > N ? n - N - 1 : 0;
+    for (size_t i = lo + 1; i < n; i++)
+        if (src[i] == src[i - 1]) return true;
+    return false;
+}
+
+// The column leaves select mode: its log goes through its (empty) heap, in row order, as the streaming replay would have
+// sent it; returns the effective pushes.
+uint64_t lazy_materialize(kgwas_scan* s, size_t j) {
+    LazyCol& L = s->lazy[j];
+    if (!L.on) return 0;
+    BestHeap& h = s->heaps[j];
+    uint64_t pushes = 0;
+    const double none = -std::numeric_limits<double>::infinity();
+    for (size_t i = 0; i < L.l_n; i++) {
+        if (L.l_sc[i] == none) continue;  // (a narrow chunk's survivor that was no candidate)
+        if (h.add(L.l_km[i], L.l_sc[i], (size_t)L.l_rw[i])) pushes++;
+    }
+    L.on = false;
+    L.release_log();
+    std::vector<LazyCol::Ent>().swap(L.pool);
+    return pushes;
+}
+
+// Every column starts a scan in select mode (or none does: KGWAS_FULL_REPLAY=1, sessions that record push histories for a
+// cross-shard merge, exact-scorer sessions).
+void lazy_reset(kgwas_scan* s) {
+    s->lazy.resize(s->n_pheno);
+    for (uint64_t j = 0; j < s->n_pheno; j++) s->lazy[j].reset(s->lazy_enabled, s->topn[j]);
+    s->lazy_any.store(s->lazy_enabled, std::memory_order_relaxed);
+    s->n_selected.store(0);
+    s->n_unselected.store(0);
+    s->lazy_pushes.store(0);
+    s->tie_check_rows = 4ull << 20;
+}
+
+// BestHeap::lowest() / full() of a column in select mode without giving it a heap: a full heap's minimum is the N-th largest
+// score it was offered (whatever the ties), one that is still filling reports the smallest. false: the column saw a NaN or
+// negative score - only its heap knows (the caller materialises it).
+bool lazy_lowest(kgwas_scan* s, size_t j, double* lowest, bool* full) {
+    LazyCol& L = s->lazy[j];
+    if (L.bad) return false;
+    *full = L.full();
+    if (L.full()) {
+        L.compact();
+        uint64_t v = L.bound_bits;
+        if (!L.have_bound) {  // exactly N entries so far: the smallest of them
+            v = ~0ull;
+            for (const LazyCol::Ent& e : L.pool) v = std::min(v, e.bits);
+        }
+        memcpy(lowest, &v, 8);
+    } else {
+        uint64_t v = ~0ull;
+        for (const LazyCol::Ent& e : L.pool) v = std::min(v, e.bits);
+        if (L.pool.empty()) v = 0;  // (BestHeap: lowest_ = 0 until something is pushed)
+        memcpy(lowest, &v, 8);
+    }
+    return true;
+}
+
+void lazy_materialize_all(kgwas_scan* s) {
+    if (!s->lazy_any.load(std::memory_order_relaxed)) return;
+    std::atomic<uint64_t> pushes(0);
+    s->pool->parallel_for(s->n_pheno, [&](size_t j) { pushes += lazy_materialize(s, j); });
+    s->st.heap_pushes += pushes.load();
+    s->lazy_any.store(false, std::memory_order_relaxed);
+    refresh_full(s);
+}
+
+// Result lists of column j (finish, or an idle worker at the tail of the last feed): by selection where the scores decide,
+// else through the heap.
+void lazy_finish_column(kgwas_scan* s, size_t j) {
+    LazyCol& L = s->lazy[j];
+    if (L.on) {
+        if (L.select(s->res_kmer[j], s->res_score[j], s->res_row[j])) {
+            s->n_selected.fetch_add(1, std::memory_order_relaxed);
+            return;
+        }
+        s->lazy_pushes.fetch_add(lazy_materialize(s, j), std::memory_order_relaxed);
+        s->n_unselected.fetch_add(1, std::memory_order_relaxed);
+    }
+    s->heaps[j].pop_all(s->res_kmer[j], s->res_score[j], s->res_row[j]);
+}
+
+}  // namespace kgwas

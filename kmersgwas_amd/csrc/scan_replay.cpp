@@ -38,6 +38,20 @@ void replay_group(kgwas_scan* s, Slot& sl, size_t g, ReplayAcc& acc) {
             const uint32_t n = sl.h_meta.p[j];
             if (!n) continue;
             const uint64_t o = sl.h_meta.p[s->n_pheno + j];
+            if (s->lazy[j].on) {
+                // a column in select mode (scan_lazy.cpp): its records go to its log and, where they can still be among the
+                // N largest, to its pool - no heap is touched
+                LazyCol& L = s->lazy[j];
+                uint64_t tb;
+                memcpy(&tb, &sl.h_thr.p[j], 8);
+                L.take_chunk(sl.so_score + o, sl.so_kmer + o, sl.so_row + o, n, row0, tb);
+                nc += n;
+                // behind chunks the control thread picked (flag_tie_check) the pool is looked at for a tie: a column whose N
+                // largest scores are not distinct will need the exact replay, and that costs less now, beside the GPU, than at
+                // finish
+                if (sl.tie_check && !s->lazy_log_mode && L.full() && L.ties_now()) local += lazy_materialize(s, j);
+                continue;
+            }
             cols[n_cols++] = Cur{sl.so_score + o, sl.so_kmer + o, sl.so_row + o, 0, n, &s->heaps[j], j};
         }
         // The records were just written by the GPU (no CPU cache holds them) and the replay walks several short
@@ -153,11 +167,20 @@ void replay_group(kgwas_scan* s, Slot& sl, size_t g, ReplayAcc& acc) {
             // compact (row-in-chunk, index) keys.
             std::vector<uint64_t>& keys = s->keys[j];
             keys.clear();
-            const bool full = h.full();
+            LazyCol& L = s->lazy[j];
+            const bool full = L.on ? false : h.full();
             const double low = h.lowest();
             for (uint32_t i = 0; i < n; i++)
                 if (!full || c[i].score > low) keys.push_back(((c[i].row - row0) << 32) | i);
             std::sort(keys.begin(), keys.end());
+            if (L.on) {  // select mode: everything that came, in row order, into the column's log
+                for (uint64_t key : keys) {
+                    const Cand& e = c[(uint32_t)key];
+                    L.add(e.kmer, e.score, e.row);
+                }
+                nc += n;
+                continue;
+            }
             for (uint64_t key : keys) {
                 const Cand& e = c[(uint32_t)key];
                 if (h.add(e.kmer, e.score, (size_t)e.row)) {
@@ -259,7 +282,7 @@ static bool pop_ahead(kgwas_scan* s, size_t NG, uint64_t pub) {
             if (s->col_popped[j].load(std::memory_order_relaxed) != 0 ||
                 !s->col_popped[j].compare_exchange_strong(expect, 1, std::memory_order_acq_rel))
                 continue;
-            s->heaps[j].pop_all(s->res_kmer[j], s->res_score[j], s->res_row[j]);
+            lazy_finish_column(s, j);
             s->col_popped[j].store(2, std::memory_order_release);
             s->n_popped_ahead.fetch_add(1, std::memory_order_relaxed);
             return true;
@@ -404,6 +427,26 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
     if (s->count_patterns) hash_patterns(s, d_rows, n_rows);
     const uint64_t depth = s->direct ? (uint64_t)s->n_slots : 1;  // squeezed mode has a single squeeze buffer
     uint64_t sub = 0, cpy = 0, pub = 0;  // chunks submitted / record copies ordered / published in this feed
+    // Chunks behind which the columns in select mode look at their pools for ties (~80 us per column): those that cross 40 and
+    // 65 % of a large feed - a column that will need the exact replay (~5 ms for 10^5 pushes) gets it while its worker still has
+    // slack beside the GPU; a tie found later than that would only move those 5 ms from kgwas_scan_finish, where the columns
+    // with ties are replayed side by side, to the end of the feed (measured: checks at 87 / 94 / 97 % left the step where it
+    // was and cost 40 ms of CPU) - and, for tables that arrive in many small feeds, those that take the session's row count
+    // past the next power of 1.25.
+    auto flag_tie_check = [&](Slot& sl, uint64_t pos_before, uint64_t c) {
+        sl.tie_check = false;
+        if (!s->lazy_any.load(std::memory_order_relaxed) || s->lazy_log_mode) return;
+        if (n_rows >= (16ull << 20)) {
+            for (const double f : {0.4, 0.65}) {
+                const uint64_t at = (uint64_t)(f * (double)n_rows);
+                if (pos_before < at && pos_before + c >= at) sl.tie_check = true;
+            }
+        }
+        if (s->rows_submitted + c >= s->tie_check_rows) {
+            if (n_rows < (16ull << 20)) sl.tie_check = true;
+            s->tie_check_rows = std::max<uint64_t>(4ull << 20, (uint64_t)(1.25 * (double)(s->rows_submitted + c)));
+        }
+    };
     bool running = false;
     std::chrono::steady_clock::time_point t_start;
     auto replayed = [&]() { return s->seq_replayed.load(std::memory_order_acquire); };
@@ -486,7 +529,7 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
                 // a 28 ms step at 101 columns, 8 of 126 at 250 M rows x 201).
                 static const bool no_overlap = getenv("KGWAS_NO_DENSE_OVERLAP") != nullptr;  // experiments
                 bool empty = s->coarse && !no_overlap && n_rows - pos > c && sub == 0;
-                for (uint64_t j = 0; j < s->n_pheno && empty; j++) empty = s->heaps[j].size() == 0;
+                for (uint64_t j = 0; j < s->n_pheno && empty; j++) empty = s->heaps[j].size() == 0 && s->lazy[j].n_logged == 0;
                 if (empty) {
                     const auto td0 = std::chrono::steady_clock::now();
                     run_dense(s, d_rows + pos * stride, c, first_row + pos, nullptr, nullptr, true, /*select=*/true);
@@ -505,6 +548,7 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
                             const size_t si = (size_t)(sub % (uint64_t)s->n_slots);
                             s->slot_left[si].store((uint32_t)s->n_pheno, std::memory_order_release);  // (columns: groups may be split)
                             s->slack_rows = n_rows - pos - cs;
+                            flag_tie_check(s->slot[si], pos, cs);
                             submit_sparse(s, s->slot[si], d_rows + pos * stride, cs, first_row + pos, /*count_hist=*/true);
                             s->slack_rows = 0;
                             s->rows_submitted += cs;
@@ -552,6 +596,7 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
                 const size_t si = (size_t)(sub % (uint64_t)s->n_slots);  // its previous chunk was replayed n_slots chunks ago
                 s->slot_left[si].store((uint32_t)s->n_pheno, std::memory_order_release);  // (columns: groups may be split)
                 s->slack_rows = n_rows - pos - c;
+                flag_tie_check(s->slot[si], pos, c);
                 submit_sparse(s, s->slot[si], d_rows + pos * stride, c, first_row + pos, /*count_hist=*/true);
                 s->slack_rows = 0;
                 if (s->trace) fprintf(stderr, "[kgwas t=%.3f] submit chunk %llu (%llu rows)\n", s->t_ms(), (unsigned long long)sub, (unsigned long long)c);

@@ -224,7 +224,8 @@ def test_bench_ranks_merge_over_torch_distributed(ranks, merge):
     # every rank's own record: which rank, and which side of it (GPU kernels, host replay, merge), set the pace
     assert [x["rank"] for x in j["ranks"]] == list(range(ranks))
     for x in j["ranks"]:
-        assert x["step_ms"] > 0 and x["kernels_ms"] > 0 and x["replay_threads"] >= 1 and x["heap_pushes"] > 0
+        # (a rank's columns are replayed - pushes - or kept in select mode and never touch a heap, scan_lazy.cpp)
+        assert x["step_ms"] > 0 and x["kernels_ms"] > 0 and x["replay_threads"] >= 1 and x["candidates"] > 0
     if ranks == 2:
         assert j["parity_check"] is True
 

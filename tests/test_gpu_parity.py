@@ -18,7 +18,10 @@ KERNELS = [kg.KERNEL_VALU, kg.KERNEL_MFMA, kg.KERNEL_COARSE]
 
 
 def _check_topn(scan, oracle_res, n_pheno, check_pushes=True):
-    if check_pushes:  # no effective add_association lost or invented on the way (ties make this visible)
+    # no effective add_association lost or invented on the way (ties make this visible). Columns whose lists were made by
+    # selection (no tie among their N + 1 largest scores: kmersgwas_amd/csrc/scan_lazy.cpp) were never replayed and have no push
+    # count; KGWAS_FULL_REPLAY=1 replays every column.
+    if check_pushes and scan.stats()["columns_selected"] == 0:
         assert scan.stats()["heap_pushes"] == oracle_res["pushes"], (scan.stats()["heap_pushes"], oracle_res["pushes"])
     for j in range(n_pheno):
         k, s, r = scan.result(j)
@@ -264,6 +267,93 @@ def test_block_scaled_filter_32x32x64_form(monkeypatch, S_f, S, P, kind, reorder
     _check_topn(scan, exp, P)
     assert st["rows_tested"] == exp["tested"]
     scan.close()
+
+
+def _late_dup_table(n, S, seed, first_dup_row, dup_frac):
+    """A table whose rows repeat earlier rows' presence/absence patterns (tied scores) only from `first_dup_row` on."""
+    rows = random_table(n, S, seed=seed, dup_frac=0.0)
+    rng = np.random.default_rng(seed + 1)
+    n_dup = int((n - first_dup_row) * dup_frac)
+    dst = rng.choice(np.arange(first_dup_row + 1, n), size=n_dup, replace=False)
+    src = first_dup_row + (rng.random(n_dup) * (dst - first_dup_row)).astype(np.int64)
+    rows[dst, 1:] = rows[src, 1:]
+    return rows
+
+
+@pytest.mark.parametrize("full_replay", [0, 1])
+@pytest.mark.parametrize("S,P,topn,n,kind", [
+    (1024, 40, 2001, 120_000, "clean"),    # no two rows share a pattern: every column is finished by selection
+    (1024, 40, 2001, 120_000, "late"),     # ties only among rows far behind the dense start: columns stay in select mode and are replayed at finish
+    (1024, 40, 2001, 120_000, "binary"),   # a 0/1 trait: few distinct scores, ties at once - every column is replayed from the start
+    (241, 3, 301, 90_000, "clean"),        # the narrow filter's records (survivors that are no candidates travel as -inf)
+    (241, 1, 301, 90_000, "late"),
+    (2048, 201, 257, 40_000, "clean"),     # the streaming filter's shape
+    (300, 20, 50_000, 30_000, "clean")])   # heaps larger than the table: they never fill, every MAC-passing row stays
+def test_tie_free_columns_are_selected_not_replayed(monkeypatch, S, P, topn, n, kind, full_replay):
+    """scan_lazy.cpp: a column whose N + 1 largest scores are pairwise distinct (none NaN or negative) is finished by SELECTION -
+    its candidates are logged and pooled, no heap is touched, the lists are the N largest in ascending order - and only columns
+    that fail that test go through the exact replay: at once if the first dense chunk shows a tie, at finish (from the log) if
+    a tie turns up later. Lists equal the oracle's (a literal std::priority_queue) in all cases, with KGWAS_FULL_REPLAY=1 (every
+    column replayed, push counts equal) and without; three feeds with the finish hint, then a reset and one feed."""
+    monkeypatch.setenv("KGWAS_FULL_REPLAY", str(full_replay))
+    if kind == "late":
+        rows = _late_dup_table(n, S, seed=S + P, first_dup_row=30_000, dup_frac=0.5)
+    else:
+        rows = random_table(n, S, seed=S + P, dup_frac=0.0)
+    col = np.arange(S, dtype=np.uint64)
+    Y = phenotypes(S, P - 1, seed=P + 5, binary=(kind == "binary"))
+    mac = onp.min_count(S, 0.05, 5)
+    exp = ob.associate(rows, S, col, Y, topn, mac, batch_size=20_000, threads=4)
+    scan = kg.AssociationScan(S, col, Y, topn, mac, chunk_rows=8192)
+    for rep in range(2):
+        if rep == 0:
+            a, b = n // 3, 2 * n // 3 + 11
+            scan.feed_host(rows[:a], 0)
+            scan.feed_host(rows[a:b], a)
+            scan.expect_finish()
+            scan.feed_host(rows[b:], b)
+        else:
+            scan.feed_host(rows)
+        scan.finish()
+        st = scan.stats()
+        assert st["kernel_used"] in (kg.KERNEL_COARSE, kg.KERNEL_NARROW)
+        if full_replay:
+            assert st["columns_selected"] == 0 and st["columns_replayed_at_finish"] == 0 and st["heap_pushes"] == exp["pushes"]
+        elif kind == "clean":  # (two different rows can still score the same: a column or two may need the replay after all)
+            assert st["columns_selected"] >= P - 2, st
+        elif kind == "late":  # (found at one of the periodic looks at the pools, or at finish)
+            assert st["columns_selected"] < P and st["heap_pushes"] > 0, st
+        else:
+            assert st["columns_selected"] == 0 and st["columns_replayed_at_finish"] == 0 and st["heap_pushes"] == exp["pushes"], st
+        _check_topn(scan, exp, P)
+        assert st["rows_tested"] == exp["tested"]
+        scan.reset()
+    scan.close()
+
+
+def test_select_mode_columns_get_their_heaps_when_the_merge_api_asks(monkeypatch):
+    """The heap-level entry points (kgwas_scan_lowest, kgwas_scan_heaps_export / _import, kgwas_scan_absorb) need real heaps:
+    columns in select mode replay their logs first. Two half-table scans without push histories, the second one's heaps
+    exported and imported into a third session, a further feed on top: equal to one scan of everything."""
+    monkeypatch.delenv("KGWAS_FULL_REPLAY", raising=False)
+    S, P, topn, n = 512, 24, 700, 80_000
+    rows = random_table(n, S, seed=99, dup_frac=0.0)
+    col = np.arange(S, dtype=np.uint64)
+    Y = phenotypes(S, P - 1, seed=3)
+    mac = onp.min_count(S, 0.05, 5)
+    exp = ob.associate(rows, S, col, Y, topn, mac, batch_size=20_000, threads=4)
+    a = kg.AssociationScan(S, col, Y, topn, mac, chunk_rows=8192)
+    a.feed_host(rows[: n // 2], 0)
+    low, full = a.lowest()
+    assert full.all() and (low > 0).all()
+    state = a.heaps_export(np.arange(P, dtype=np.uint64))
+    b = kg.AssociationScan(S, col, Y, topn, mac, chunk_rows=8192)
+    b.heaps_import(np.arange(P, dtype=np.uint64), *state)
+    b.feed_host(rows[n // 2:], n // 2)
+    b.finish()
+    _check_topn(b, exp, P, check_pushes=False)
+    a.close()
+    b.close()
 
 
 @pytest.mark.parametrize("S_f,S,P,kind,reorder,mxs,form", [
@@ -538,6 +628,8 @@ def test_eviction_ring_history_equals_full_log(monkeypatch):
     """record_history = 2 (each heap keeps only its last evictions) must hand kgwas_scan_history_above exactly what the
     full log (record_history = 1) hands out, for thresholds around the heaps' own final minima (what another shard of
     the same size produces), with heavy ties; and must fail loudly when the ring is too short for the threshold."""
+    monkeypatch.setenv("KGWAS_FULL_REPLAY", "1")  # (without it such a session keeps its columns in select mode and answers from their logs:
+    # a superset of the effective pushes that merges to the same heaps - test_column_distributed_merge_protocol, test_merge_messages_*)
     S_f, S, P, topn = 130, 130, 6, 400
     rows = random_table(40_000, S_f, seed=3, dup_frac=0.5)
     col = np.arange(S, dtype=np.uint64)
@@ -602,8 +694,10 @@ def test_merge_messages_equal_flat_exports():
         sc = kg.AssociationScan(S_f, col, Y, topn, mac, chunk_rows=4096, record_history=mode)
         sc.feed_host(rows, 0)
         thr = sc.lowest()[0] * 0.99
-        flat = [np.array(x) for x in sc.history_above(thr)]
+        # (the heap export first: it gives columns that were in select mode their heaps, and the history of such a session is
+        # answered from the heaps' rings from then on - before, from the columns' logs: a superset with the same merge result)
         heaps = [np.array(x) for x in sc.heaps_export(np.arange(P, dtype=np.uint64))]
+        flat = [np.array(x) for x in sc.history_above(thr)]
         for col0, ncols in (([0, 2, 2, 5], [2, 0, 3, 2]), ([0], [P]), ([3, 0], [4, 3]), ([6, 0, 0], [1, 0, 0])):
             for ref, writer in ((flat, lambda o: sc.history_above_msgs(thr, col0, ncols, o)), (heaps, lambda o: sc.heaps_export_msgs(col0, ncols, o))):
                 words = writer(None)
@@ -776,7 +870,8 @@ def test_adversarial_order_overflows_candidate_lists(kernel):
     _check_topn(scan, exp, 4)
     st = scan.stats()
     assert st["rows_tested"] == exp["tested"]
-    assert st["heap_pushes"] >= int(0.9 * kept.sum())  # column 0 pushes on (almost) every kept row
+    if st["columns_selected"] == 0:
+        assert st["heap_pushes"] >= int(0.9 * kept.sum())  # column 0 pushes on (almost) every kept row
     scan.close()
 
 
@@ -1054,6 +1149,9 @@ def test_exact_rational_topn_through_the_production_kernels(monkeypatch, name, m
         monkeypatch.setenv("KGWAS_MX_S1", "6")
     if mode == "int8":
         monkeypatch.setenv("KGWAS_COARSE_MX", "0")
+    # (the case that carries the simulated push count replays every column; in the others the columns whose N + 1 largest
+    # scores are distinct - integer phenotypes leave many that are not - are finished by selection, scan_lazy.cpp)
+    monkeypatch.setenv("KGWAS_FULL_REPLAY", "1" if "effective_pushes" in fx else "0")
     scan = kg.AssociationScan(S, np.arange(S, dtype=np.uint64), Y, topn, mac, kernel=kernel)
     cut = 120_000
     scan.feed_host(rows[:cut], 0)
@@ -1075,7 +1173,7 @@ def test_exact_rational_topn_through_the_production_kernels(monkeypatch, name, m
         k, s, r = scan.result(j)
         ex.compare((r, k, s), exp[j])
     if "effective_pushes" in fx:  # (a function of the score multiset alone: simulated with heapq for the smallest case)
-        assert st["heap_pushes"] == fx["effective_pushes"]
+        assert st["columns_selected"] == 0 and st["heap_pushes"] == fx["effective_pushes"]
     scan.close()
 
 

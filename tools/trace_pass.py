@@ -16,5 +16,11 @@ scan = kg.AssociationScan(S, np.arange(S, dtype=np.uint64), Y, 10001, mac, devic
 scan.feed_device(table.data_ptr(), M, 0, stream)
 scan.reset()
 sys.stderr.write("==== second pass\n")
+import time
+scan.expect_finish()
+t0 = time.perf_counter()
 scan.feed_device(table.data_ptr(), M, 0, stream)
+t1 = time.perf_counter()
 scan.finish()
+t2 = time.perf_counter()
+sys.stderr.write("==== feed %.2f ms, finish %.2f ms; columns selected %d, replayed at finish %d\n" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, scan.stats()["columns_selected"], scan.stats()["columns_replayed_at_finish"]))
