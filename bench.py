@@ -204,6 +204,217 @@ def p1_scan_large_record(kg, torch, stream, S, Y, topn, mac, dev, host_threads, 
         torch.cuda.empty_cache()
 
 
+def _timed_steps(torch, scan, table_ptr, rows, stream, steps):
+    """`steps` passes of reset / feed_device / finish over a resident table after one warm-up pass: mean ms, the sessions' stats."""
+    def one():
+        scan.reset()
+        scan.feed_device(table_ptr, rows, 0, stream)
+        scan.finish()
+        return scan.stats()
+    one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sts = [one() for _ in range(steps)]
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3, sts
+
+
+def _step_fields(ms, sts, rows, P):
+    n = len(sts)
+    return {"ms_per_step": ms, "value": rows * P / (ms * 1e-3), "unit": "k-mer x phenotype pairs / s",
+            "all_scoring_kernels_ms_per_step": sum(s["score_kernel_ms"] for s in sts) / n,
+            "filter_kernel_ms_per_step": sum(s["coarse_kernel_ms"] for s in sts) / n,
+            "replay_busiest_worker_ms": sum(s["replay_ms"] for s in sts) / n, "replay_cpu_ms_per_step": sum(s["replay_cpu_ms"] for s in sts) / n,
+            "replay_tail_after_gpu_ms": sum(s["replay_tail_ms"] for s in sts) / n, "replay_threads": int(sts[-1]["replay_threads"]),
+            "heap_pushes_per_step": sum(s["heap_pushes"] for s in sts) // n, "records_per_step": sum(s["candidates"] for s in sts) // n,
+            "columns_selected": int(sts[-1]["columns_selected"]), "columns_replayed_at_finish": int(sts[-1]["columns_replayed_at_finish"])}
+
+
+def starved_host_record(kg, torch, table, stream, M, S, Y, topn, mac, dev, threads=2, steps=5):
+    """The headline workload with `threads` replay threads - what each rank of an 8-rank run gets under a 16-CPU quota. Columns in
+    select mode cost the host a copy and a compare per record instead of a heap update per effective push (scan_lazy.cpp)."""
+    scan = kg.AssociationScan(S, np.arange(S, dtype=np.uint64), Y, topn, mac, device=dev, host_threads=threads)
+    try:
+        ms, sts = _timed_steps(torch, scan, table.data_ptr(), M, stream, steps)
+        rec = {"workload": "the headline table and columns, host_threads = %d" % threads}
+        rec.update(_step_fields(ms, sts, M, Y.shape[0]))
+        return rec
+    finally:
+        scan.close()
+
+
+def tie_heavy_record(kg, torch, table, stream, M, S, Y, topn, mac, dev, host_threads, dup_frac=0.3, steps=5, check_rows=2_000_000):
+    """The headline shape on a table in which `dup_frac` of the rows repeat an earlier row's presence/absence pattern - what real
+    k-mer tables look like (k-mers of one variant share their pattern), and the case in which the scores of a column's top N
+    tie: every column shows that in its first dense chunk, leaves select mode and is replayed exactly, push by push, as before
+    round 5. The table is the headline's, modified in place (it is not needed afterwards); the heaps over its first `check_rows`
+    rows are compared with the oracle's (identities, score bytes, push and tested counts)."""
+    from oracle import binding as ob
+    W = 1 + (S + 63) // 64
+    P = Y.shape[0]
+    v = table.view(M, W)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(20240602)
+    n_dup = int(M * dup_frac)
+    piece = 10_000_000
+    for lo in range(0, n_dup, piece):  # (in pieces: the gather's temporaries stay small)
+        n = min(piece, n_dup - lo)
+        dst = torch.randint(1, M, (n,), device="cuda", generator=g)
+        src = (torch.rand(n, device="cuda", generator=g, dtype=torch.float64) * dst.to(torch.float64)).to(torch.int64)
+        v[dst, 1:] = v[src, 1:]
+    torch.cuda.synchronize()
+    col = np.arange(S, dtype=np.uint64)
+    scan = kg.AssociationScan(S, col, Y, topn, mac, device=dev, host_threads=host_threads)
+    try:
+        ms, sts = _timed_steps(torch, scan, table.data_ptr(), M, stream, steps)
+    finally:
+        scan.close()
+    host = table[: check_rows * W].cpu().numpy().view(np.uint64).reshape(check_rows, W)
+    t0 = time.perf_counter()
+    exp = ob.associate(host, S, col, Y, topn, mac, batch_size=10_000_000, threads=min(usable_cpus(), P))
+    cpu_dt = time.perf_counter() - t0
+    ok = parity_check(kg, table.data_ptr(), stream, S, col, Y, topn, mac, check_rows, exp, dev, host_threads)
+    rec = {"workload": "%dM k-mers x %d samples x %d columns, %.0f %% of the rows repeat an earlier row's pattern" % (M // 1_000_000, S, P, 100 * dup_frac)}
+    rec.update(_step_fields(ms, sts, M, P))
+    rec["parity_check"] = bool(ok)
+    rec["parity_check_scope"] = "the GPU's heaps over the first %d rows of this table against the oracle's (%.1f s on %d threads)" % (check_rows, cpu_dt, min(usable_cpus(), P))
+    return rec
+
+
+def config3_at_scale_record(kg, torch, stream, dev, host_threads, S=1135, n_perm=100, topn=10001, seed=20240601, check_rows=2_000_000,
+                            kin_passes=2, steps=2, want_rows=1_600_000_000):
+    """BASELINE.json configs[2] and configs[4] at the size SURVEY.md 8(d) names: synthetic S = 1135, as many rows as fit the HBM
+    (~1.6 G rows = 243 GB of the 288), column 0 = the reference's FT10 example phenotype, 100 permutations; the association scan
+    over the resident table, emma_kinship_kmers' accumulation over the same rows, and - host memory permitting - the same table
+    streamed from host memory through the ingest pipeline."""
+    from oracle import binding as ob
+    from oracle import oracle_np as onp
+    W = 1 + (S + 63) // 64
+    P = n_perm + 1
+    free_b, total_b = torch.cuda.mem_get_info()
+    rows = int(min(want_rows, (free_b - (14 << 30)) // (8 * W)))
+    if rows < 200_000_000:
+        return {"skipped": "only %.0f GB of HBM free" % (free_b / 1e9)}
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "FT10.pheno")
+    y0 = onp.load_phenotypes(gold)[2][0, :S].astype(np.float32)
+    rng = np.random.default_rng(10)
+    Y = np.ascontiguousarray(np.stack([y0] + [rng.permutation(y0) for _ in range(n_perm)]).astype(np.float32))
+    mac = kg.min_count(S, 0.05, 5)
+    col = np.arange(S, dtype=np.uint64)
+    table = torch.empty(rows * W, dtype=torch.int64, device="cuda")
+    kg.synth_rows_device(table.data_ptr(), 0, rows, S, seed, stream)
+    torch.cuda.synchronize()
+    gb = rows * 8.0 * W / 1e9
+    out = {"workload": "%.2fG k-mers x %d samples (%.0f GB resident in HBM), FT10 example phenotype + %d permutations, top-%d" % (rows / 1e9, S, gb, n_perm, topn),
+           "rows": rows, "table_GB": gb}
+    try:
+        scan = kg.AssociationScan(S, col, Y, topn, mac, device=dev, host_threads=host_threads)
+        try:
+            ms, sts = _timed_steps(torch, scan, table.data_ptr(), rows, stream, steps)
+            res0 = [scan.result(j) for j in (0, P - 1)]
+            tested = sts[-1]["rows_tested"]
+        finally:
+            scan.close()
+        a = _step_fields(ms, sts, rows, P)
+        nst = 4 * (S // 512) + (S % 512 + 127) // 128
+        a["filter"] = {"kernel": "mxs_kernel" if sts[-1]["coarse_mx_stream"] else "mx_kernel", "column_tiles": int(sts[-1]["coarse_mode_tiles"][1]),
+                       "operand_groups": int(sts[-1]["coarse_mode_lgroups"][1]), "steps_of_128_samples": nst}
+        k_ms = a["filter_kernel_ms_per_step"]
+        a["filter_frac_of_fp4_fp6_peak"] = 2.0 * S * (P + 1) * rows / (k_ms * 1e-3) / 1e12 / MX_MFMA_PEAK_TOPS if k_ms > 0 else None
+        a["chunks_per_step"] = sum(s_["chunks"] for s_ in sts) // len(sts)
+        a["replay_share_of_step"] = a["replay_busiest_worker_ms"] / ms
+        host = kg.synth_rows_host(0, check_rows, S, seed)
+        t0 = time.perf_counter()
+        exp = ob.associate(host, S, col, Y, topn, mac, batch_size=10_000_000, threads=min(usable_cpus(), P))
+        a["parity_check"] = bool(parity_check(kg, table.data_ptr(), stream, S, col, Y, topn, mac, check_rows, exp, dev, host_threads))
+        a["parity_check_scope"] = "the GPU's heaps over the first %d rows against the oracle's (%.1f s)" % (check_rows, time.perf_counter() - t0)
+        out["association_scan"] = a
+        # ---- configs[4]: kinship over the same resident rows
+        mc = int(np.ceil(S * 0.05))
+        kern, wall = [], []
+        for i in range(kin_passes + 1):
+            kin = kg.Kinship(S, mc, device=dev)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            kin.feed_device(table.data_ptr(), rows, stream)
+            torch.cuda.synchronize()
+            if i:
+                wall.append((time.perf_counter() - t0) * 1e3)
+                kern.append(kin.stats()["kernel_ms"])
+            if i == kin_passes:
+                Hk, n_used = kin.partials()
+            kin.close()
+        kk = float(np.mean(kern))
+        # size-independent checks (no CPU can accumulate 1.6 G rows x 1135^2): the Gram partials are symmetric, and they are
+        # additive over row ranges - rows [0, 4 M) + rows [4 M, 8 M) = rows [0, 8 M) - as partials of chunks, shards and GPUs must be
+        def part(lo, n):
+            kin = kg.Kinship(S, mc, device=dev)
+            kin.feed_device(table.data_ptr() + lo * W * 8, n, stream)
+            H, nu = kin.partials()
+            kin.close()
+            return np.asarray(H), nu
+        Ha, na = part(0, 4_000_000)
+        Hb, nb = part(4_000_000, 4_000_000)
+        Hc, nc_ = part(0, 8_000_000)
+        Hk = np.asarray(Hk)
+        out["kinship"] = {"kernels_ms": kk, "wall_ms": float(np.mean(wall)), "rows_per_s": rows / (kk * 1e-3), "rows_used": int(n_used),
+                          "frac_of_fp4_peak": 2.0 * (0.5 * float(S) * S * rows) / (kk * 1e-3) / 1e12 / MX_MFMA_PEAK_TOPS,
+                          "partials_symmetric": bool((Hk == Hk.T).all()),
+                          "partials_additive_over_row_ranges": bool((Ha + Hb == Hc).all() and na + nb == nc_)}
+        # ---- the same table streamed from host memory
+        avail = 0
+        try:
+            for line in open("/proc/meminfo"):
+                if line.startswith("MemAvailable:"):
+                    avail = int(line.split()[1]) * 1024
+            cg = "/sys/fs/cgroup/memory.max"
+            if os.path.exists(cg):
+                v = open(cg).read().strip()
+                if v != "max":
+                    avail = min(avail, int(v) - 8 * (1 << 30))
+        except Exception:
+            pass
+        need = rows * 8 * W
+        if avail < need + (24 << 30):
+            srows = int(max(0, (avail - (24 << 30)) // (8 * W)))
+            srows = min(srows, rows)
+        else:
+            srows = rows
+        if srows < 50_000_000:
+            out["streamed_from_host"] = {"skipped": "host memory: %.0f GB available for a %.0f GB table" % (avail / 1e9, need / 1e9)}
+        else:
+            hostbuf = np.empty(srows * W, dtype=np.int64)
+            step_r = 100_000_000
+            for lo in range(0, srows, step_r):  # device -> host in pieces (the table is synthetic: this is how the host copy is made)
+                n = min(step_r, srows - lo)
+                hostbuf[lo * W:(lo + n) * W] = table[lo * W:(lo + n) * W].cpu().numpy()
+            hview = hostbuf.view(np.uint64).reshape(srows, W)
+            del table
+            table = None
+            torch.cuda.empty_cache()
+            scan = kg.AssociationScan(S, col, Y, topn, mac, device=dev, host_threads=host_threads)
+            try:
+                scan.expect_finish()
+                t0 = time.perf_counter()
+                scan.feed_host(hview, 0)
+                scan.finish()
+                dt = time.perf_counter() - t0
+                st = scan.stats()
+                same = srows == rows and st["rows_tested"] == tested and all(
+                    all(x.tobytes() == y.tobytes() for x, y in zip(scan.result(j), r)) for j, r in zip((0, P - 1), res0))
+            finally:
+                scan.close()
+            out["streamed_from_host"] = {"rows": srows, "GB": srows * 8.0 * W / 1e9, "seconds": dt, "GBps": srows * 8.0 * W / 1e9 / dt,
+                                         "frac_of_pcie_gen5_x16": srows * 8.0 * W / 1e9 / dt / 63.0,
+                                         "identical_to_the_resident_scan": bool(same) if srows == rows else None,
+                                         "whole_table": srows == rows}
+        return out
+    finally:
+        if table is not None:
+            del table
+        torch.cuda.empty_cache()
+
+
 def kinship_record(kg, torch, stream, dev, rows=8_000_000, S_f=1135, seed=20240601, cpu_rows=20_000, passes=3):
     """BASELINE.json configs[4] in shape: emma_kinship_kmers' accumulation over `rows` rows x 1135 accessions
     resident in HBM, and the reference's single-threaded loop (oracle) on a slice of the same rows."""
@@ -512,6 +723,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-subrecords", action="store_true", help="skip p1_scan / kinship / ingest")
     ap.add_argument("--no-ingest", action="store_true", help="skip the streamed-path sub-record")
+    ap.add_argument("--no-scale-records", action="store_true", help="skip configs[2] / [4] at HBM-filling size (243 GB table)")
     ap.add_argument("--ingest-rows", type=int, default=40_000_000)
     ap.add_argument("--check-merge", action="store_true",
                     help="N > 1: rank 0 also scans all shards' rows in one session and compares the merged heaps with it (small runs)")
@@ -879,9 +1091,17 @@ def main():
                 out["p1_scan"] = p1_scan_record(kg, torch, table, stream, M, S, Y, args.topn, mac, dev, host_threads)
             except Exception as e:
                 out["p1_scan"] = {"error": repr(e)}
+            try:
+                out["starved_host"] = starved_host_record(kg, torch, table, stream, M, S, Y, args.topn, mac, dev)
+            except Exception as e:
+                out["starved_host"] = {"error": repr(e)}
             last.close()
             last = None
             session.close()
+            try:  # (modifies the table in place: last of its users)
+                out["tie_heavy"] = tie_heavy_record(kg, torch, table, stream, M, S, Y, args.topn, mac, dev, host_threads)
+            except Exception as e:
+                out["tie_heavy"] = {"error": repr(e)}
             del table
             torch.cuda.empty_cache()
             try:
@@ -894,6 +1114,12 @@ def main():
             except Exception as e:
                 out["kinship"] = {"error": repr(e)}
             torch.cuda.empty_cache()
+            if not args.no_scale_records:
+                try:
+                    out["configs_2_and_4_at_scale"] = config3_at_scale_record(kg, torch, stream, dev, host_threads)
+                except Exception as e:
+                    out["configs_2_and_4_at_scale"] = {"error": repr(e)}
+                torch.cuda.empty_cache()
             if not args.no_ingest:
                 try:
                     out["ingest"] = ingest_record(kg, torch, stream, dev, host_threads, rows=args.ingest_rows)

@@ -203,8 +203,8 @@ def test_associate_kmers_parallel_1_is_raised_to_the_cpu_quota(tmp_path):
     _compare_dirs(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("ranks,merge", [(2, "root"), (3, "column")])
-def test_bench_ranks_merge_over_torch_distributed(ranks, merge):
+@pytest.mark.parametrize("ranks,merge,shape", [(2, "root", "small"), (3, "column", "small"), (2, "root", "north_star"), (2, "column", "north_star")])
+def test_bench_ranks_merge_over_torch_distributed(ranks, merge, shape):
     """bench.py's N > 1 path with real scan sessions: `ranks` processes (torch.distributed over gloo, all on the one GPU of
     the test box), each scanning its own row shard, merged with kmersgwas_amd.dist (to the root / by column); rank 0 then
     scans all the rows in one session and compares every column's heap bytes (--check-merge)."""
@@ -213,9 +213,12 @@ def test_bench_ranks_merge_over_torch_distributed(ranks, merge):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
            "--master-port", str(29500 + ranks), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "1", "--warmup", "1",
            "--rows", "600000", "--samples", "241", "--perms", "12", "--topn", "2001", "--check-merge"]
-    if ranks != 2:
+    if shape == "north_star":  # BASELINE configs[3]'s columns and heap size: 2048 samples x 201 columns, top-10001, 2 M rows per rank
+        cmd[cmd.index("--rows") + 1:cmd.index("--check-merge")] = ["2000000", "--samples", "2048", "--perms", "200", "--topn", "10001"]
+        cmd[cmd.index("--master-port") + 1] = str(29520 + ranks + (1 if merge == "column" else 0))
+    if ranks != 2 or shape == "north_star":
         cmd.append("--no-cpu-baseline")  # (with two ranks the line also carries rank 0's shard-parity check against the oracle)
-    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     j = json.loads(line)
@@ -226,7 +229,7 @@ def test_bench_ranks_merge_over_torch_distributed(ranks, merge):
     for x in j["ranks"]:
         # (a rank's columns are replayed - pushes - or kept in select mode and never touch a heap, scan_lazy.cpp)
         assert x["step_ms"] > 0 and x["kernels_ms"] > 0 and x["replay_threads"] >= 1 and x["candidates"] > 0
-    if ranks == 2:
+    if ranks == 2 and shape == "small":
         assert j["parity_check"] is True
 
 

@@ -817,6 +817,39 @@ def test_multi_device_scan_equals_single_scan(tmp_path, shards):
     tbl.close()
 
 
+@pytest.mark.parametrize("full_replay,ring", [(0, 0), (1, 0), (1, 64)])
+def test_north_star_shape_through_the_multi_shard_merge(monkeypatch, tmp_path, full_replay, ring):
+    """BASELINE configs[3]'s shape - 2048 samples x 201 columns, top-10001 - through kgwas_multiscan (three contiguous row
+    shards on device 0, merged in C++ as `associate_kmers --gpus 3` does): (a) the later shards in select mode, answering the
+    merge from their logs; (b) every column replayed, the later shards' histories from the heaps' eviction rings; (c) as (b)
+    with a ring of 64 evictions - far too short for 10 001-entry heaps, so the shards ARE scanned again with the full push log
+    (`rescans`). A 201-column heap set (2 x 10^6 entries) against the oracle's, every time."""
+    monkeypatch.setenv("KGWAS_FULL_REPLAY", str(full_replay))
+    if ring:
+        monkeypatch.setenv("KGWAS_HISTORY_RING", str(ring))
+    S, P, topn, n, shards = 2048, 201, 10_001, 90_000, 3
+    rows = random_table(n, S, seed=2048201, dup_frac=0.1)
+    col = np.arange(S, dtype=np.uint64)
+    Y = phenotypes(S, P - 1, seed=200)
+    mac = onp.min_count(S, 0.05, 5)
+    exp = ob.associate(rows, S, col, Y, topn, mac, batch_size=30_000, threads=8)
+    base = str(tmp_path / "t")
+    onp.write_table(base, ["a%d" % i for i in range(S)], 31, rows[:, 0], rows[:, 1:])
+    tbl = kg.KmersTable(base, 31)
+    ms = kg.MultiDeviceScan(S, col, Y, topn, mac, devices=[0] * shards, host_threads=6)
+    ms.run_table(tbl, 0, n)
+    ms.finish()
+    for j in range(P):
+        kk, ss, rr = ms.result(j)
+        o = exp["per_pheno"][j]
+        assert (kk == o["kmer"]).all() and (rr == o["file_row"]).all() and ss.tobytes() == o["score"].tobytes(), j
+    st = ms.stats()
+    assert st["rows_tested"] == exp["tested"] and len(st["per_shard"]) == shards
+    assert (st["rescans"] > 0) == bool(ring), st["rescans"]
+    ms.close()
+    tbl.close()
+
+
 @pytest.mark.parametrize("fresh", [True, False])
 def test_heaps_import_then_feed(fresh):
     """kgwas_scan_heaps_import promises that an imported heap goes on exactly as it would have in the exporting

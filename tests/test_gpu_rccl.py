@@ -113,13 +113,16 @@ def test_dist_merges_and_exchanges_over_rccl_on_one_rank(tmp_path):
     assert "rccl-ok" in r.stdout
 
 
-@pytest.mark.parametrize("merge", ["root", "column"])
-def test_bench_n_gt_1_path_over_rccl_on_one_rank(merge):
+@pytest.mark.parametrize("merge,shape", [("root", "small"), ("column", "small"), ("column", "north_star")])
+def test_bench_n_gt_1_path_over_rccl_on_one_rank(merge, shape):
     """bench.py's N > 1 path (init_process_group("nccl", device_id=...), merge inside the timed region, max over ranks,
     per-rank records gathered on device tensors, shard parity check, --check-merge) with one rank on RCCL."""
     env = dict(_env(), KGWAS_BENCH_FORCE_DIST="1", KGWAS_BENCH_MERGE=merge)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--rows", "600000",
            "--samples", "241", "--perms", "12", "--topn", "2001", "--check-merge", "--cpu-sample-rows", "300000"]
+    if shape == "north_star":  # BASELINE configs[3]'s columns and heap size over RCCL
+        cmd[cmd.index("--rows") + 1:cmd.index("--check-merge")] = ["2000000", "--samples", "2048", "--perms", "200", "--topn", "10001"]
+        cmd[cmd.index("--cpu-sample-rows") + 1] = "200000"
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-4000:]
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
