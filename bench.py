@@ -972,7 +972,7 @@ def main():
         # The profile names the kernel and carries the hash of the kernel source it was taken of: a profile of another
         # kernel, or of an older version of this one, is not used (traffic: null, traffic_stale_profile: true).
         traffic, traffic_src, traffic_stale = None, None, False
-        cands = (["r04_mx_pmc_hbm_traffic.json", "r03_mx_pmc_hbm_traffic.json"] if mx else ["r02_coarse_pmc_hbm_traffic.json", "r01b_coarse_pmc_hbm_traffic.json"]) \
+        cands = (["r05_mx_pmc_hbm_traffic.json", "r04_mx_pmc_hbm_traffic.json", "r03_mx_pmc_hbm_traffic.json"] if mx else ["r02_coarse_pmc_hbm_traffic.json", "r01b_coarse_pmc_hbm_traffic.json"]) \
             if ku == 3 else ["r01a_exactmfma_pmc_hbm_traffic.json"]
         src_file = {"mx_kernel": "score_mx.hip", "coarse_kernel": "score_coarse.hip", "score_mfma_kernel": "score_mfma.hip"}.get(kernel_name)
         for cand in cands:

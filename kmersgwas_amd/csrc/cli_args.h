@@ -114,9 +114,14 @@ class CliArgs {
 // buffers and tearing the HIP runtime down one object at a time - the kernel reclaims all of it at process exit, and
 // for `associate_kmers` on a 40 M-row table the orderly way was 0.35 s of a 0.88 s run (0.19 s in the session's
 // destructors, the rest in the runtime's exit handlers). KGWAS_CLI_FULL_TEARDOWN=1 returns instead (leak checkers).
+// A result that could not be written (a full disk, a closed pipe behind `emma_kinship_kmers`' matrix) is an error, not exit 0.
 inline void cli_finish() {
     std::cout.flush();
     std::cerr.flush();
-    fflush(nullptr);
+    const bool ok = std::cout.good() && fflush(nullptr) == 0;
+    if (!ok) {
+        fputs("error: writing the output failed\n", stderr);
+        _exit(1);
+    }
     if (!getenv("KGWAS_CLI_FULL_TEARDOWN")) _exit(0);
 }

@@ -168,9 +168,10 @@ public:
                 for (auto& h : h_) h.alloc(pr * stride);
                 // (blocking: a producer that has to wait for a copy sleeps; the replay workers share its CPU)
                 for (auto& e : ev_h_) KGWAS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync));
+                // (the device pieces themselves are allocated below, as many as the feed at hand has pieces: a session that is
+                // fed a few small host buffers and then device-resident tables does not hold ten 128 MiB pieces of HBM)
                 d_.resize(device_pieces_);
                 ev_.assign(device_pieces_, nullptr);
-                for (auto& d : d_) d.alloc(pr * stride);
                 KGWAS_HIP(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
                 for (auto& e : ev_) KGWAS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             } catch (...) {
@@ -181,6 +182,12 @@ public:
         }
         const uint64_t piece = piece_rows_;
         const uint64_t n_pieces = (n_rows + piece - 1) / piece;
+        // device pieces for this feed: min(device_pieces_, its pieces), never fewer than an earlier feed had (nothing is in
+        // flight between feeds, so the ring may grow here)
+        while (device_ready_ < std::min<uint64_t>(device_pieces_, n_pieces)) {
+            d_[device_ready_].alloc(piece * stride);
+            device_ready_++;
+        }
         auto count_of = [&](uint64_t k) { return std::min<uint64_t>(piece, n_rows - k * piece); };
 
         std::mutex mu;
@@ -272,7 +279,7 @@ public:
         // FIRST piece's takes 15 ms at 101 columns (the heaps fill, and most of a scan's pushes belong to its first rows):
         // with the copies queued between the consumer's calls, the link stood still for 14 of those 15 ms - an eighth of a
         // 40 M-row feed. Device pieces are cheap (128 MiB of 288 GB each), so there are enough of them to copy through it.
-        const uint64_t ND = d_.size();
+        const uint64_t ND = device_ready_;  // (>= min(device_pieces_, n_pieces): a feed with fewer pieces than the ring uses each buffer once)
         auto copier_main = [&] {
             kgwas_name_this_thread("kgwas-copier");
             try {
@@ -346,6 +353,7 @@ private:
         copy_stream_ = nullptr;
         h_.clear();
         d_.clear();
+        device_ready_ = 0;
         piece_rows_ = 0;
     }
     std::vector<PinBuf<uint64_t>> h_;
@@ -359,7 +367,8 @@ public:
     unsigned producer_cpus_ = 16;  // CPUs the process may use (the owner sets it: cgroup quota / GPUs sharing the host)
     bool file_feed_ = false;       // the next run's fill reads a file (set by the owner before run())
     unsigned pinned_pieces_ = 3;   // pinned pieces the producers fill ahead of the copies
-    unsigned device_pieces_ = 10;  // device pieces: copies queued ahead of the consumer
+    unsigned device_pieces_ = 10;  // device pieces: copies queued ahead of the consumer (at most; allocated as feeds need them)
+    uint64_t device_ready_ = 0;    // device pieces allocated so far
 };
 
 }  // namespace kgwas

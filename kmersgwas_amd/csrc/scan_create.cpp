@@ -74,8 +74,12 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                 break;
             }
         // The operand-streaming form of the block-scaled filter (score_mxs.hip) holds one step's operands in LDS, not a whole
-        // column tile's: no limit on the accessions. KGWAS_MXS: 0 never, 1 (default) wherever the resident form would need more
-        // than one LDS group, 2 wherever the form exists. The int8 filter (KGWAS_COARSE_MX=0) stops at 5120 accessions.
+        // column tile's: no limit on the accessions. KGWAS_MXS: 0 never; 1 (default) where the resident form does not exist
+        // (no column tile's operands fit the LDS) or would pass every row through several LDS groups of ONE or TWO column
+        // tiles (its matrix instructions run at a fraction of a full group's efficiency there); 2 wherever the resident form
+        // needs more than one LDS group - measured level with it, not ahead: 2048 x 201 40.4-41.0 against 39.2-40.3 ms per
+        // 100 M rows, 1135 x 101 13.3 against 13.4 -; 3 wherever the form exists. The int8 filter
+        // (KGWAS_COARSE_MX=0) stops at 5120 accessions.
         const int mxs_want = getenv("KGWAS_MXS") ? atoi(getenv("KGWAS_MXS")) : 1;
         const bool mxs_can = mxs_want != 0 && !(getenv("KGWAS_COARSE_MX") && atoi(getenv("KGWAS_COARSE_MX")) == 0) && getenv("KGWAS_COARSE_SLICES") == nullptr &&
                              !(getenv("KGWAS_MX_S1") && atoi(getenv("KGWAS_MX_S1")) == 6);
@@ -429,7 +433,10 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                 uint32_t ctm = 0;
                 for (uint32_t ct = 7; ct >= 1 && !ctm; ct--)
                     if (mx_lds_bytes(steps, ct, 2, 0) <= 160u * 1024u) ctm = ct;
-                use_mx = mxs_can || groups_for(ctm) <= groups_for(s->coarse_T) + 1;  // (streamed operands: one group whatever the shape)
+                // (streamed operands - where that form is taken, see mxs_want above - are one group whatever the shape)
+                const bool will_stream = mxs_can && (mxs_want >= 3 || !ctm || (groups_for(ctm) >= 2 && (mxs_want >= 2 || ctm <= 2)));
+                // (beyond 5120 accessions there is no int8 plan to compare with: coarse_T = 0)
+                use_mx = will_stream || !s->coarse_T || groups_for(ctm) <= groups_for(s->coarse_T) + 1;
             }
             // Where the int8 filter keeps the shape, its TWO-slice set (the ramp: the first chunks of a scan, many
             // candidates per row) is still the block-scaled one: at 2048 x 201 that is 13 column tiles x 2 slices x 16
@@ -513,8 +520,8 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                         while (((P + g - 1) / g + 1 + 15) / 16 > 7) g += 2;
                         ct = std::max<uint64_t>(4, ((P + g - 1) / g + 1 + 15) / 16);
                     }
-                    const bool resident_one = CTmax && groups_for(CTmax) == 1;
-                    if ((mxs_want >= 2 || !resident_one) && mxs_supported((uint32_t)ct, (uint32_t)ng, 2, 0) && mxs_lds_bytes((uint32_t)ct, (uint32_t)ng) <= 160u * 1024u)
+                    const bool take = mxs_want >= 3 || !CTmax || (groups_for(CTmax) >= 2 && (mxs_want >= 2 || CTmax <= 2));
+                    if (take && mxs_supported((uint32_t)ct, (uint32_t)ng, 2, 0) && mxs_lds_bytes((uint32_t)ct, (uint32_t)ng) <= 160u * 1024u)
                         stream_groups = g, stream_ct = ct, stream_ng = ng;
                 }
                 if (!CTmax && !stream_groups) throw Error(KGWAS_ERR_ARG, "coarse filter: too many accessions for the LDS");
@@ -573,7 +580,8 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                 };
                 // ---- the 32 x 32 x 64 form (score_mx32.hip): tiles of 32 columns + one combined tile for a remainder of up to 16.
                 // Taken when it multiplies no more 16-column tile equivalents, in no more LDS groups, than the 16 x 16 x 128
-                // plan below would (KGWAS_MX32=0: never; =1: whenever its operands fit).
+                // plan below would (KGWAS_MX32 unset or 0: never - the form is opt-in, it measured slower; =1: where it
+                // multiplies no more tile equivalents in no more LDS groups than the 16 x 16 x 128 plan; =2: wherever its operands fit).
                 {
                     const char* e32 = getenv("KGWAS_MX32");
                     const int want32 = e32 ? atoi(e32) : 0;

@@ -89,11 +89,13 @@ void replay_group(kgwas_scan* s, Slot& sl, size_t g, ReplayAcc& acc) {
                 uint64_t rejected = 0;
                 while (cu.i < cu.n) {
                     const double v = cu.sc[cu.i];
-                    if (open || v > low) {  // (-inf, "not a candidate", never gets here: the device ships candidates only)
-                        ready = v != none;
-                        if (ready) break;
+                    if (v == none) {  // a narrow chunk's survivor that is no candidate (launch_rescore_direct): never an add_association call
                         advance(cu);
                         continue;
+                    }
+                    if (open || v > low) {
+                        ready = true;
+                        break;
                     }
                     rejected++;
                     advance(cu);

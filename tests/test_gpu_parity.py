@@ -357,25 +357,27 @@ def test_select_mode_columns_get_their_heaps_when_the_merge_api_asks(monkeypatch
 
 
 @pytest.mark.parametrize("S_f,S,P,kind,reorder,mxs,form", [
-    (2048, 2048, 201, "normal", False, 1, 0),  # BASELINE configs[3] per GPU: ONE operand group, two column groups of 7 tiles side by side in a block
-    (2048, 2048, 201, "heavy", False, 1, 1),   # ... one column group of 13 tiles, eight waves of 32 rows
-    (2048, 2048, 201, "normal", False, 1, 2),  # ... four waves (one per SIMD, 512-register budget) of 64 rows
-    (1135, 1135, 101, "heavy", False, 1, 0),   # BASELINE configs[2]: 9 steps (2 groups + 1 quarter step) x 7 tiles instead of two LDS groups of 4
-    (1024, 1024, 101, "normal", False, 2, 0),  # BASELINE configs[1] forced onto the streaming form (the resident one takes it by default)
-    (241, 241, 40, "binary", False, 2, 0),     # quarter steps only, 3 tiles
-    (513, 513, 100, "normal", False, 2, 0),    # 1 group + 1 quarter step, 7 tiles
-    (2048, 2048, 230, "normal", False, 1, 0),  # more than 222 columns: two operand groups (grid blocks sharing rows) of 2 x 4 tiles
-    (2048, 2048, 230, "normal", False, 1, 1),  # ... of 8 tiles, eight waves of 32 rows
-    (700, 650, 130, "normal", True, 1, 0),     # squeezed rows (subset, shuffled); 2 x 5 tiles
-    (1500, 1500, 150, "constant", False, 1, 2),  # 10 tiles, 12 steps, one wave per SIMD
-    (6000, 6000, 30, "normal", False, 1, 0),   # beyond the int8 filter's 5120 accessions: 47 steps x 3 tiles
-    (5200, 5200, 120, "heavy", False, 1, 0),   # ... 2 x 4 tiles
-    (5200, 5200, 120, "heavy", False, 1, 2)])  # ... 8 tiles, one wave per SIMD
+    (2048, 2048, 201, "normal", False, 2, 0),  # BASELINE configs[3] per GPU: ONE operand group, two column groups of 7 tiles side by side in a block
+    (2048, 2048, 201, "heavy", False, 2, 1),   # ... one column group of 13 tiles, eight waves of 32 rows
+    (2048, 2048, 201, "normal", False, 2, 2),  # ... four waves (one per SIMD, 512-register budget) of 64 rows
+    (1135, 1135, 101, "heavy", False, 2, 0),   # BASELINE configs[2]: 9 steps (2 groups + 1 quarter step) x 7 tiles instead of two LDS groups of 4
+    (1024, 1024, 101, "normal", False, 3, 0),  # BASELINE configs[1] forced onto the streaming form (the resident one takes it by default)
+    (241, 241, 40, "binary", False, 3, 0),     # quarter steps only, 3 tiles
+    (513, 513, 100, "normal", False, 3, 0),    # 1 group + 1 quarter step, 7 tiles
+    (2048, 2048, 230, "normal", False, 2, 0),  # more than 222 columns: two operand groups (grid blocks sharing rows) of 2 x 4 tiles
+    (2048, 2048, 230, "normal", False, 2, 1),  # ... of 8 tiles, eight waves of 32 rows
+    (700, 650, 130, "normal", True, 2, 0),     # squeezed rows (subset, shuffled); 2 x 5 tiles
+    (1500, 1500, 150, "constant", False, 2, 2),  # 10 tiles, 12 steps, one wave per SIMD
+    (6000, 6000, 30, "normal", False, 2, 0),   # beyond the int8 filter's 5120 accessions: 47 steps x 3 tiles
+    (5200, 5200, 120, "heavy", False, 2, 0),   # ... 2 x 4 tiles
+    (5200, 5200, 120, "heavy", False, 2, 2),   # ... 8 tiles, one wave per SIMD
+    (4096, 4096, 100, "normal", False, 1, 0)])  # the DEFAULT policy: the resident form would be seven LDS groups of one tile - streamed, 32 steps x 7 tiles
 def test_block_scaled_filter_streaming_form(monkeypatch, S_f, S, P, kind, reorder, mxs, form):
     """score_mxs.hip: the block-scaled filter with its slice operands streamed through an LDS ring (one barrier per step of 128
     samples, `global_load_lds_dwordx4` slabs and row pieces three steps ahead, counted `vmcnt` waits) and ALL column tiles of an
-    operand group accumulated by the waves of a block - taken wherever the resident form would pass a row through several LDS
-    groups (KGWAS_MXS=1, the default) or wherever it exists (=2). Every block shape (KGWAS_MXS_FORM), 3 to 14 column tiles, one
+    operand group accumulated by the waves of a block - forced here wherever the resident form would pass a row through several
+    LDS groups (KGWAS_MXS=2) or wherever it exists (=3); by default it is taken where the resident form does not exist or has one
+    or two column tiles per group (the 6000- and 5200-accession cases, test_more_than_5120_samples). Every block shape (KGWAS_MXS_FORM), 3 to 14 column tiles, one
     and two operand groups, whole 512-sample groups and quarter steps, direct and squeezed rows, chunks that end inside a wave's
     rows, and shapes beyond the int8 filter's 5120 accessions: survivors, pop order, score bytes, push and tested counts equal
     the oracle's."""

@@ -4,7 +4,7 @@
 cd "$GRAFT_REPO_ROOT"; O=gpurun_out/ab_mxs; mkdir -p $O
 S=${1:-2048}; P=${2:-200}; R=${3:-100000000}
 for rep in 1 2; do
-for v in "0 0" "1 0" "1 1" "1 2"; do
+for v in "0 0" "2 0" "2 1" "2 2"; do
   set -- $v
   KGWAS_MXS=$1 KGWAS_MXS_FORM=$2 python bench.py --samples $S --perms $P --rows $R --steps 3 --warmup 1 --no-cpu-baseline --no-subrecords > $O/line_${S}_$1_$2_$rep.json 2> $O/err_${S}_$1_$2_$rep.txt
   python - <<PY

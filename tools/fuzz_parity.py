@@ -56,7 +56,7 @@ while time.time() < t_end:
     kernel = int(rng.choice([kg.KERNEL_AUTO, kg.KERNEL_AUTO, kg.KERNEL_COARSE, kg.KERNEL_MFMA, kg.KERNEL_VALU]))
     env = {"KGWAS_COARSE_MX": str(rng.choice(["", "0", "1"])), "KGWAS_MX32": str(rng.choice(["0", "0", "2"])),
            "KGWAS_COARSE_SLICES": str(rng.choice(["", "", "1", "2"])),
-           "KGWAS_MXS": str(rng.choice(["", "", "0", "2", "2"])), "KGWAS_MXS_FORM": str(rng.choice(["", "", "1", "2"])),
+           "KGWAS_MXS": str(rng.choice(["", "", "0", "2", "3", "3"])), "KGWAS_MXS_FORM": str(rng.choice(["", "", "1", "2"])),
            "KGWAS_FULL_REPLAY": str(rng.choice(["", "", "1"]))}
     for k, v in env.items():
         if v: os.environ[k] = v
