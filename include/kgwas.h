@@ -101,6 +101,11 @@ int kgwas_heap_size(const kgwas_heap* h, uint64_t* size, uint64_t* insertions, d
 int kgwas_heap_pop_all(const kgwas_heap* h, uint64_t* kmer, double* score, uint64_t* row);
 /* get_kmers_for_output: (kmer, rank, row) sorted by row; rank = queue size at pop (best = 1). */
 int kgwas_heap_output_list(const kgwas_heap* h, uint64_t* kmer, uint64_t* rank, uint64_t* row);
+/* get_rows_sorted_indices (src/best_associations_heap.cpp:135-147): the entries' row indices, ascending; `size` entries. */
+int kgwas_heap_rows_sorted(const kgwas_heap* h, uint64_t* row);
+/* output_to_file (:65-74, with_scores = 0: the k-mers as 8 bytes each) / output_to_file_with_scores (:80-90, with_scores = 1:
+ * k-mer + score, 16 bytes each), in ascending pop order; the file is created or truncated. */
+int kgwas_heap_output_to_file(const kgwas_heap* h, const char* path, int with_scores);
 void kgwas_heap_free(kgwas_heap* h);
 
 /* ------------------------------------------------------------------------------------

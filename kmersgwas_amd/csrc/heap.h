@@ -418,6 +418,13 @@ class alignas(128) BestHeap {
         if (pop_all_sorted(kmer, score, row)) return;
         pop_all_classic(kmer, score, row);
     }
+    // get_rows_sorted_indices (src/best_associations_heap.cpp:135-147): the entries' rows, ascending
+    std::vector<uint64_t> rows_sorted() const {
+        std::vector<uint64_t> r(pay_.size());
+        for (size_t i = 0; i < pay_.size(); i++) r[i] = pay_[i].row;
+        std::sort(r.begin(), r.end());
+        return r;
+    }
     // N pops on a copy of the array, with std::pop_heap's moves
     void pop_all_classic(std::vector<uint64_t>& kmer, std::vector<double>& score, std::vector<uint64_t>& row) const {
         std::vector<Ent> tmp(v_.begin(), v_.end());

@@ -709,6 +709,30 @@ int kgwas_heap_output_list(const kgwas_heap* h, uint64_t* kmer, uint64_t* rank, 
         }
     });
 }
+int kgwas_heap_rows_sorted(const kgwas_heap* h, uint64_t* row) {
+    return guarded([&] {
+        if (!h || !row) throw Error(KGWAS_ERR_ARG, "kgwas_heap_rows_sorted: null");
+        const std::vector<uint64_t> r = h->h.rows_sorted();
+        std::copy(r.begin(), r.end(), row);
+    });
+}
+int kgwas_heap_output_to_file(const kgwas_heap* h, const char* path, int with_scores) {
+    return guarded([&] {
+        if (!h || !path) throw Error(KGWAS_ERR_ARG, "kgwas_heap_output_to_file: null");
+        std::vector<uint64_t> k, r;
+        std::vector<double> sc;
+        h->h.pop_all(k, sc, r);
+        FILE* f = fopen(path, "wb");
+        if (!f) throw Error(KGWAS_ERR_IO, std::string("cannot open ") + path);
+        bool ok = true;
+        for (size_t i = 0; i < k.size() && ok; i++) {
+            ok = fwrite(&k[i], 8, 1, f) == 1;
+            if (ok && with_scores) ok = fwrite(&sc[i], 8, 1, f) == 1;
+        }
+        ok = (fclose(f) == 0) && ok;
+        if (!ok) throw Error(KGWAS_ERR_IO, std::string("cannot write ") + path);
+    });
+}
 void kgwas_heap_free(kgwas_heap* h) { delete h; }
 
 int kgwas_merge_shards(uint64_t n_pheno, const uint64_t* topn, uint64_t n_shards, const uint64_t* counts,

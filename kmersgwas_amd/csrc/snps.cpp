@@ -210,10 +210,7 @@ int kgwas_snps_best(kgwas_snps* s, const float* Y, uint64_t n_pheno, uint64_t to
             }
         }
         for (uint64_t j = 0; j < n_pheno; j++) {  // get_rows_sorted_indices
-            std::vector<uint64_t> k, r;
-            std::vector<double> sc;
-            heaps[j].pop_all(k, sc, r);
-            std::sort(r.begin(), r.end());
+            const std::vector<uint64_t> r = heaps[j].rows_sorted();
             counts[j] = r.size();
             std::copy(r.begin(), r.end(), indices + j * topn);
         }

@@ -123,6 +123,16 @@ class BestAssociationsHeap:
         check(lib.kgwas_heap_output_list(self._h, ptr(k), ptr(rk), ptr(r)))
         return k, rk, r
 
+    def get_rows_sorted_indices(self):
+        """src/best_associations_heap.cpp:135-147."""
+        r = np.zeros(len(self), np.uint64)
+        check(lib.kgwas_heap_rows_sorted(self._h, ptr(r)))
+        return r
+
+    def output_to_file(self, path: str, with_scores: bool = False):
+        """output_to_file / output_to_file_with_scores (src/best_associations_heap.cpp:65-90)."""
+        check(lib.kgwas_heap_output_to_file(self._h, path.encode(), 1 if with_scores else 0))
+
     def __del__(self):
         if getattr(self, "_h", None):
             lib.kgwas_heap_free(self._h)

@@ -162,6 +162,18 @@ def test_heap_mirror_equals_oracle_heap_under_ties(N, n, levels, flavour):
     for a, b in zip(h.get_kmers_for_output(), o.output_list()):
         assert (a == b).all()
     assert len(h) == min(N, n)
+    # get_rows_sorted_indices (:135-147), output_to_file / _with_scores (:65-90): the rows ascending; the pops as raw bytes
+    ok, os_, orow = o.pop_all()
+    assert (h.get_rows_sorted_indices() == np.sort(orow)).all()
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        h.output_to_file(os.path.join(d, "k"))
+        h.output_to_file(os.path.join(d, "ks"), with_scores=True)
+        assert open(os.path.join(d, "k"), "rb").read() == ok.tobytes()
+        both = np.empty((len(ok), 2), np.uint64)
+        both[:, 0] = ok
+        both[:, 1] = os_.view(np.uint64)
+        assert open(os.path.join(d, "ks"), "rb").read() == both.tobytes()
 
 
 def _python_history(kmer, score, row, N):
