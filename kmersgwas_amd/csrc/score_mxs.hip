@@ -45,7 +45,7 @@
 
 #include "score_common.h"
 
-#ifndef KGWAS_MXS_DEPHASE  // 1: the upper half of a block's waves issue their vector-memory operations in the middle of the step (measured +-0: off)
+#ifndef KGWAS_MXS_DEPHASE  // 1: the upper half of a block's waves runs its passes half a pass behind the lower half (see `dephase`): measured SLOWER, off
 #define KGWAS_MXS_DEPHASE 0
 #endif
 #ifndef KGWAS_MXS_ABLATE  // timing experiments only (wrong results): 1 no tests, 8 no row loads, 16 no operand DMA, 64 no barriers
@@ -160,9 +160,9 @@ __global__ void __launch_bounds__(TH) mxs_kernel(MxArgs a, uint32_t rows_per_blo
     constexpr uint32_t WAIT_N = RT + (MXS_AHEAD - 2u) * (ROUNDS + RT);
     static_assert(MXS_AHEAD >= 2u && WAIT_N < 64u, "vmcnt is a 6-bit immediate");
     const uint32_t lds_fill = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds + MXS_RING * SLOT + 3u * SLOTS_ALL * 4u + (TH / 64u) * (RT * 48u * 4u) + wave * 256u;
-    // this wave's row staging area: RT x (64 lanes x 16 B), behind the fillers' scratch (waves of different column groups that
-    // work on the same rows request the same bytes into the same area: identical writes)
-    const uint32_t stage_off = MXS_RING * SLOT + 3u * SLOTS_ALL * 4u + (TH / 64u) * (RT * 48u * 4u) + (TH / 64u) * 256u + wig * (RT * 1024u);
+    // this wave's row staging area: RT x (64 lanes x 16 B), behind the fillers' scratch (one per wave: waves of different column
+    // groups work on the same rows, but - KGWAS_MXS_DEPHASE - half a pass apart)
+    const uint32_t stage_off = MXS_RING * SLOT + 3u * SLOTS_ALL * 4u + (TH / 64u) * (RT * 48u * 4u) + (TH / 64u) * 256u + (KGWAS_MXS_DEPHASE ? wave : wig) * (RT * 1024u);
     const uint32_t lds_stage = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds + stage_off;
     const uint32_t voff4 = lane * 4u;
     auto filler_ops = [&]() {
@@ -284,27 +284,48 @@ __global__ void __launch_bounds__(TH) mxs_kernel(MxArgs a, uint32_t rows_per_blo
     // next group of the pass or group 0 of the wave's next rows) is requested in step 1 of the current group and picked up at
     // the top of its own step 0, behind that step's wait.
     uint32_t piece[RT][4];
-    uint32_t pf_ps = 0, pf_g = 0;  // the group the next request fetches
+    // The waves w and w + 4 of a block share a SIMD and meet at every step's barrier. Had both the same pass boundaries, both
+    // would run their epilogues - 4000 cycles of vector work per 43 000-cycle pass - at the same time, with nobody feeding the
+    // matrix pipe (in the free-running resident kernel the two waves' epilogues hide behind each other's MFMAs). The slab stream
+    // is cyclic and the accumulation order is free, so the upper half of the block's waves (LATE) takes its passes HALF A PASS
+    // behind: a late wave's pass is the groups off .. n_full - 1, the quarter steps, then the groups 0 .. off - 1 of the next
+    // cycle of the stream (off = n_full / 2 whole groups) - the same slabs at the same barriers, its epilogue in the middle of
+    // the early waves' main loop and vice versa. The late waves idle through the block's first 4 off steps (barrier and
+    // transfers only), the early ones through the 4 off steps behind their last pass.
+    // MEASURED (round 5, alternating builds on one box, ms of filter per 100 M rows): 2048 x 201 45.7-46.3 with the offset
+    // against 42.3 without, 1135 x 101 14.3-14.4 against 13.0 - slower by 8-10 %, although the results are identical and the
+    // epilogues provably no longer coincide: partner waves then fetch their rows at different times (the second fetch no
+    // longer hits what the first brought in) and every block runs 4 off steps more. Compiled out (KGWAS_MXS_DEPHASE=0).
+    const bool dephase = KGWAS_MXS_DEPHASE && TH >= 512 && a.n_full >= 2u;
+    const bool late = dephase && wave >= TH / 128;
+    const uint32_t off = late ? a.n_full / 2u : 0u;
+    const uint32_t n_dummy = dephase ? 4u * (a.n_full / 2u) : 0u;
+    uint32_t pf_ps = 0, pf_g = off;  // the group the next request fetches (in the wave's own order: off, off + 1, ..., off - 1)
     auto prefetch = [&]() {
         uint32_t o[RT];
         set_rows(o, wave_row0 + (uint64_t)pf_ps * rows_per_pass);
         request_group(o, pf_g);
-        const bool wrap = pf_g + 1u == a.n_full;
-        pf_g = wrap ? 0u : pf_g + 1u;
-        pf_ps = wrap ? pf_ps + 1u : pf_ps;
+        pf_g = pf_g + 1u == a.n_full ? 0u : pf_g + 1u;
+        pf_ps = pf_g == off ? pf_ps + 1u : pf_ps;
     };
     set_rows(ro, wave_row0);
     if (a.n_full) prefetch();  // (the first group: picked up at the top of the first step, as every group's pieces are)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the steps' waits count from an empty queue)
     StepAddr sadr = step_addr(0);
     read_unit(0, sadr);  // step 0 of the first pass; every step's last unit fetches the next step's first
-    // The waves w and w + 4 of a block share a SIMD and meet at every step's barrier. Had both the same order of work, both
-    // would spend the first few hundred cycles of every step on its vector-memory operations (the slab's transfers, the row
-    // requests or fillers: ~40 cycles of issue each) with nobody feeding the matrix pipe. LATE waves - the upper half of the
-    // block - issue theirs in the middle of the step, between two units of their MFMAs, while the early wave of their SIMD is
-    // multiplying; the order of a wave's vector-memory operations, and so the counted waits, are the same in both roles.
-    auto run_passes = [&](auto role_tag) {
-    constexpr bool LATE = decltype(role_tag)::value;
+    // a step without work for this wave: the barrier and the wave's share of the transfers (the sequence of vector-memory
+    // operations stays uniform), and the next step's first operands
+    auto dummy_step = [&]() __attribute__((always_inline)) {
+        step_sync();
+        issue_slab();
+        filler_ops();
+        const uint32_t slot_next = slot_cur + 1u == MXS_RING ? 0u : slot_cur + 1u;
+        sadr = step_addr(slot_next);
+        read_unit(0, sadr);
+        slot_cur = slot_next;
+    };
+    if (late)
+        for (uint32_t i = 0; i < n_dummy; i++) dummy_step();
     for (uint32_t ps = 0; ps < n_passes; ps++) {
         const uint64_t rbase = wave_row0 + (uint64_t)ps * rows_per_pass;
         uint32_t ro_next[RT];
@@ -331,7 +352,7 @@ __global__ void __launch_bounds__(TH) mxs_kernel(MxArgs a, uint32_t rows_per_blo
         // step = [B_s, slab s + AHEAD, row operations | operands A | reads of unit 1 | MFMAs of unit 0 | reads of unit 2 | MFMAs of unit 1
         //         | ... | reads of the next step's unit 0 | MFMAs of the last unit]
         // kind: 0..3 = step j of a 512-sample group (table bits from `piece`), 4 = a quarter step (operands handed in)
-        auto run_step = [&](auto kind, mxsv8i (&A)[RT], int sa) {
+        auto run_step = [&](auto kind, mxsv8i (&A)[RT], int sa) __attribute__((always_inline)) {
             constexpr int J = decltype(kind)::value;
             __builtin_amdgcn_sched_barrier(0);
 #if KGWAS_MXS_PROF
@@ -351,7 +372,7 @@ __global__ void __launch_bounds__(TH) mxs_kernel(MxArgs a, uint32_t rows_per_blo
                 pf_issue += __builtin_readcyclecounter() - t2;
 #endif
             };
-            if (!LATE) vmem_ops();
+            vmem_ops();
             __builtin_amdgcn_sched_barrier(0);
             if (J == 0) pickup_group(piece);
             if (J < 4) {
@@ -375,10 +396,6 @@ __global__ void __launch_bounds__(TH) mxs_kernel(MxArgs a, uint32_t rows_per_blo
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_unit(u, A, sa);
                 __builtin_amdgcn_sched_barrier(0);
-                if (LATE && u == (NU - 1) / 2) {
-                    vmem_ops();
-                    __builtin_amdgcn_sched_barrier(0);
-                }
             }
             sadr = nadr;
             slot_cur = slot_next;
@@ -389,14 +406,15 @@ __global__ void __launch_bounds__(TH) mxs_kernel(MxArgs a, uint32_t rows_per_blo
         };
 
         __builtin_amdgcn_s_setprio(0);
-        for (uint32_t g = 0; g < a.n_full; g++) {
+        auto group_steps = [&]() __attribute__((always_inline)) {
             mxsv8i A[RT];
             // nibble bit 0 / 1 / 2 / 2 (bit 3 shifted down): 0.5 / 1.0 / 2.0 / 2.0 x 2^0 / 2^-1 / 2^-2 / 2^-2 = 0.5
             run_step(std::integral_constant<int, 0>(), A, 0x7F7F7F7F);
             run_step(std::integral_constant<int, 1>(), A, 0x7E7E7E7E);
             run_step(std::integral_constant<int, 2>(), A, 0x7D7D7D7D);
             run_step(std::integral_constant<int, 3>(), A, 0x7D7D7D7D);
-        }
+        };
+        for (uint32_t g = off; g < a.n_full; g++) group_steps();
         // quarter groups: 128 samples per step, the lane's own dword shifted by 0..3
         for (uint32_t x = 0; x < a.n_quarter; x++) {
             uint32_t b0 = 64u * a.n_full + 16u * x + 4u * kb;
@@ -410,6 +428,7 @@ __global__ void __launch_bounds__(TH) mxs_kernel(MxArgs a, uint32_t rows_per_blo
             }
             run_step(std::integral_constant<int, 4>(), A, 0x7F7F7F7F);
         }
+        for (uint32_t g = 0; g < off; g++) group_steps();  // (late waves: the first groups, from the stream's next cycle)
 
 #if KGWAS_MXS_PROF
         const unsigned long long te0 = __builtin_readcyclecounter();
@@ -532,11 +551,8 @@ __global__ void __launch_bounds__(TH) mxs_kernel(MxArgs a, uint32_t rows_per_blo
         pf_epi += __builtin_readcyclecounter() - te0;
 #endif
     }
-    };
-    if (TH >= 512 && KGWAS_MXS_DEPHASE && wave >= TH / 128)
-        run_passes(std::true_type());
-    else
-        run_passes(std::false_type());
+    if (!late)
+        for (uint32_t i = 0; i < n_dummy; i++) dummy_step();
 #if KGWAS_MXS_PROF
     if (threadIdx.x == 0) {
         atomicAdd(&mxs_prof[0], pf_sync);
@@ -562,7 +578,7 @@ __global__ void __launch_bounds__(TH) mxs_kernel(MxArgs a, uint32_t rows_per_blo
 // ring + per-column constants + the waves' row-term exchange areas + the fillers' scratch + the row staging areas
 static size_t mxs_lds_bytes_t(uint32_t cta, uint32_t rt, uint32_t ng, uint32_t th, uint32_t ring) {
     const uint32_t waves = th / 64u;
-    return (size_t)ring * ((cta * MXS_SB + 1023u) / 1024u * 1024u) + 3u * cta * 16u * 4u + waves * (rt * 192u) + waves * 256u + (waves / ng) * (rt * 1024u);
+    return (size_t)ring * ((cta * MXS_SB + 1023u) / 1024u * 1024u) + 3u * cta * 16u * 4u + waves * (rt * 192u) + waves * 256u + (KGWAS_MXS_DEPHASE ? waves : waves / ng) * (rt * 1024u);
 }
 
 template <int CT, int RT, int NG, int TH>
