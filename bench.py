@@ -789,7 +789,7 @@ def main():
     # (the by-column merge - more than four ranks - starts from rank 0's heaps in heap-array order: columns that sat in select
     # mode would have to replay their logs first, all at once and at merge time, so rank 0 replays as it scans there; the later
     # ranks answer the merge from their logs either way, and the merge to the root works on logs and pools throughout)
-    by_column = world > 4 if os.environ.get("KGWAS_BENCH_MERGE", "") == "" else os.environ.get("KGWAS_BENCH_MERGE") == "column"
+    by_column = os.environ.get("KGWAS_BENCH_MERGE", "") == "column"  # (else kdist.merge_shards: to the root while the sessions are in select mode)
     if world > 1 and rank == 0 and by_column and "KGWAS_FULL_REPLAY" not in os.environ:
         os.environ["KGWAS_FULL_REPLAY"] = "1"
     session = kg.AssociationScan(S, col, Y, args.topn, mac, device=dev, kernel=args.kernel,

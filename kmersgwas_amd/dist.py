@@ -340,8 +340,13 @@ def merge_shards(scan, dst: int = 0):
     """merge_to_root for up to four ranks, merge_by_column beyond (see there). Sessions that keep their columns in select mode
     (kmersgwas_amd/csrc/scan_lazy.cpp: the default without push histories, and every record_history = 2 session) merge to the
     root on logs and pools alone; the by-column merge exports rank 0's heaps in heap-array order, which makes rank 0 replay
-    its logs first - create rank 0's session under KGWAS_FULL_REPLAY=1 there (bench.py does), so that it replays as it scans."""
-    return merge_to_root(scan, dst) if dist.get_world_size() <= 4 else merge_by_column(scan, dst)
+    its logs first - so sessions in select mode (`scan.select_mode`, the same on every rank) merge to the root whatever the number
+    of ranks: rank 0 then APPENDS the later shards' records to its columns' logs (no heap work; ~7 N records per column at eight
+    ranks) and finishes by selection. Who forces merge_by_column creates rank 0's session under KGWAS_FULL_REPLAY=1 (bench.py
+    does), so that it replays as it scans."""
+    if dist.get_world_size() <= 4 or getattr(scan, "select_mode", False):
+        return merge_to_root(scan, dst)
+    return merge_by_column(scan, dst)
 
 
 def merge_on_root(scan: "engine.AssociationScan", dst: int = 0):

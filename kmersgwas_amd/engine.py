@@ -14,6 +14,7 @@ replay); this module only moves buffers.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Sequence
 
 import numpy as np
@@ -169,6 +170,9 @@ class AssociationScan:
         p.chunk_rows = chunk_rows
         p.host_threads = host_threads
         p.kernel = kernel
+        # columns may be finished by selection instead of the push-by-push replay (kmersgwas_amd/csrc/scan_lazy.cpp): what
+        # kmersgwas_amd.dist.merge_shards looks at (it must come out the same on every rank of a merge)
+        self.select_mode = int(record_history) != 1 and os.environ.get("KGWAS_FULL_REPLAY", "0") in ("", "0")
         p.record_history = int(record_history)  # False/0 off, True/1 full log, 2 eviction ring
         p.count_patterns = 1 if count_patterns else 0
         self._h = C.c_void_p()
