@@ -48,6 +48,9 @@
 #ifndef KGWAS_MXS_DEPHASE  // 1: the upper half of a block's waves runs its passes half a pass behind the lower half (see `dephase`): measured SLOWER, off
 #define KGWAS_MXS_DEPHASE 0
 #endif
+#ifndef KGWAS_MXS_ROWS_NT
+#define KGWAS_MXS_ROWS_NT 0  // (measured: 3.7 x the algorithmic HBM bytes - the second column group's request of a row then always misses - and + 10 % time)
+#endif
 #ifndef KGWAS_MXS_ABLATE  // timing experiments only (wrong results): 1 no tests, 8 no row loads, 16 no operand DMA, 64 no barriers
 #define KGWAS_MXS_ABLATE 0
 #endif
@@ -209,7 +212,7 @@ __global__ void __launch_bounds__(TH) mxs_kernel(MxArgs a, uint32_t rows_per_blo
     __syncthreads();  // (colc; the compiler's own barrier with its waits)
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // the first slabs are in the ring
 
-    uint32_t ro[RT];  // 32-bit byte offsets of this lane's rows (launch_mxs guarantees the chunk spans < 4 GiB)
+    // (32-bit byte offsets of a lane's rows: launch_mxs guarantees the chunk spans < 4 GiB)
     const uint64_t wave_row0 = blk_row0 + wig * (RT * 16u);
     auto set_rows = [&](uint32_t (&o)[RT], uint64_t rb0) {
 #pragma unroll
@@ -233,7 +236,13 @@ __global__ void __launch_bounds__(TH) mxs_kernel(MxArgs a, uint32_t rows_per_blo
             uint32_t off = o[rt] + b0;
             if (KGWAS_MXS_ABLATE & 8) off = lane * 16u;
             const uint32_t m0v = lds_stage + rt * 1024u;
+            // (non-temporal: a row is read once - by both column groups' waves at nearly the same time -, and must not push the
+            // operand slabs, which every block re-reads once per pass, out of the L2)
+#if KGWAS_MXS_ROWS_NT
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt" ::"s"(m0v), "v"(off), "s"(rows_base) : "memory");
+#else
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(off), "s"(rows_base) : "memory");
+#endif
         }
     };
     auto pickup_group = [&](uint32_t (&pc)[RT][4]) {
@@ -308,7 +317,6 @@ __global__ void __launch_bounds__(TH) mxs_kernel(MxArgs a, uint32_t rows_per_blo
         pf_g = pf_g + 1u == a.n_full ? 0u : pf_g + 1u;
         pf_ps = pf_g == off ? pf_ps + 1u : pf_ps;
     };
-    set_rows(ro, wave_row0);
     if (a.n_full) prefetch();  // (the first group: picked up at the top of the first step, as every group's pieces are)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the steps' waits count from an empty queue)
     StepAddr sadr = step_addr(0);
@@ -328,8 +336,6 @@ __global__ void __launch_bounds__(TH) mxs_kernel(MxArgs a, uint32_t rows_per_blo
         for (uint32_t i = 0; i < n_dummy; i++) dummy_step();
     for (uint32_t ps = 0; ps < n_passes; ps++) {
         const uint64_t rbase = wave_row0 + (uint64_t)ps * rows_per_pass;
-        uint32_t ro_next[RT];
-        set_rows(ro_next, rbase + rows_per_pass);
         mxsv4f acc[RT][CT];
 #pragma unroll
         for (int rt = 0; rt < RT; rt++)
@@ -364,6 +370,9 @@ __global__ void __launch_bounds__(TH) mxs_kernel(MxArgs a, uint32_t rows_per_blo
                 const unsigned long long t2 = __builtin_readcyclecounter();
 #endif
                 issue_slab();
+                // (two column groups share rows and staging areas and BOTH request them - identical transfers, the second one an L2
+                // hit. Letting only the lower group request - the upper one finds the rows behind the barrier - measured 4 % slower
+                // with the same HBM-side traffic; non-temporal requests 10 % slower with 3.7 x the algorithmic traffic.)
                 if (J == 1)
                     prefetch();
                 else
@@ -416,6 +425,8 @@ __global__ void __launch_bounds__(TH) mxs_kernel(MxArgs a, uint32_t rows_per_blo
         };
         for (uint32_t g = off; g < a.n_full; g++) group_steps();
         // quarter groups: 128 samples per step, the lane's own dword shifted by 0..3
+        uint32_t ro[RT];  // (made here, not kept across the groups' steps: eight registers the main loop has no room for)
+        if (a.n_quarter) set_rows(ro, rbase);
         for (uint32_t x = 0; x < a.n_quarter; x++) {
             uint32_t b0 = 64u * a.n_full + 16u * x + 4u * kb;
             b0 = b0 + 4u <= avail_b ? b0 : avail_b - 4u;
@@ -545,8 +556,6 @@ __global__ void __launch_bounds__(TH) mxs_kernel(MxArgs a, uint32_t rows_per_blo
             }
         }
         __builtin_amdgcn_wave_barrier();  // the exchange area is rewritten by the next pass
-#pragma unroll
-        for (int rt = 0; rt < RT; rt++) ro[rt] = ro_next[rt];
 #if KGWAS_MXS_PROF
         pf_epi += __builtin_readcyclecounter() - te0;
 #endif

@@ -77,11 +77,19 @@ strip_stats(one("p1_stats/*/*_kernel_stats.csv"), "profiles/r05_p1scan_kernel_st
 strip_stats(one("p1l_stats/*/*_kernel_stats.csv"), "profiles/r05_p1scan_large_kernel_stats.csv")
 strip_stats(one("kin_stats/*/*_kernel_stats.csv"), "profiles/r05_kinship_kernel_stats.csv")
 strip_stats(one("c3_stats/*/*_kernel_stats.csv"), "profiles/r05_config4_kernel_stats.csv")
-for name in ("bench_line", "config4_line", "config4_resident_line", "shard250M_line"):
+for name in ("bench_line", "config4_line", "config4_streaming_line", "shard250M_line", "shard250M_2threads_line"):
     line = [l for l in open(os.path.join(src, name + ".json")) if l.startswith("{")][-1]
     open("profiles/r05_%s.json" % name, "w").write(line)
 
-# ---- the streaming filter at 2048 x 201: the largest launches of the pass (row blocks of 4096 rows x 512 threads, one operand group)
+# ---- the resident plan at 2048 x 201 (the default there): five LDS groups x 768 threads per row block of 4096 rows
+fr = steady(one("pmc_c3r_fetch/*/*_counter_collection.csv"), "mx_kernel", "FETCH_SIZE")
+wr = steady(one("pmc_c3r_write/*/*_counter_collection.csv"), "mx_kernel", "WRITE_SIZE", fr[2])
+rowsr = fr[2] // 768 // 5 * 4096
+tr = 2.0 * fr[0] * 1024.0 + wr[0] * 1024.0
+RES = {"kernel": "mx_kernel", "grid_threads": fr[2], "rows_per_launch_upper_bound": rowsr, "traffic_bytes_per_launch": tr,
+       "traffic_over_algorithmic_lower_bound": tr / (rowsr * 264)}
+print("mx_kernel (resident, 5 LDS groups) 2048 x 201: traffic / algorithmic >= %.3f" % (tr / (rowsr * 264)))
+# ---- the streaming filter at 2048 x 201 (KGWAS_MXS=2): the largest launches of the pass (row blocks of 4096 rows x 512 threads, one operand group)
 KS = "mxs_kernel"
 f3 = steady(one("pmc_c3_fetch/*/*_counter_collection.csv"), KS, "FETCH_SIZE")
 w3 = steady(one("pmc_c3_write/*/*_counter_collection.csv"), KS, "WRITE_SIZE", f3[2])
@@ -93,7 +101,7 @@ json.dump({"kernel": KS, "kernel_source_sha16": kernel_source_sha16("score_mxs.h
            "write": {"counter": "WRITE_SIZE", "launches_averaged": w3[1], "value_KiB_per_launch": w3[0]},
            "grid_threads": f3[2], "rows_per_launch_upper_bound": rows3, "algorithmic_bytes_per_launch_upper_bound": rows3 * 264,
            "traffic_bytes_per_launch": t3, "traffic_over_algorithmic_lower_bound": t3 / (rows3 * 264),
-           "round_4_resident_plan": "profiles/r04_mx_pmc_hbm_traffic_2048x201.json: >= 1.86 (five LDS groups of a row block share rows through one XCD's L2)",
+           "resident_plan_same_run": RES,
            "note": NOTE + " Rows per launch from the grid (the last row block of a chunk may be short: an upper bound, the ratio a lower bound by less than 0.5 %)."},
           open("profiles/r05_mx_pmc_hbm_traffic_2048x201.json", "w"), indent=1)
 print("mxs_kernel 2048 x 201: traffic / algorithmic >= %.3f" % (t3 / (rows3 * 264)))
