@@ -550,6 +550,7 @@ struct kgwas_scan {
     std::atomic<uint64_t> n_splits{0};
     std::atomic<uint64_t> seq_submitted{0}, seq_published{0}, seq_replayed{0};
     std::atomic<bool> rp_quit{false}, rp_failed{false};
+    std::atomic<bool> rp_drain{false};  // with rp_quit: make the result lists of the columns that have none yet, then leave (scan_replay.cpp)
     std::atomic<int> rp_idle{0};
     std::mutex rp_mu;
     std::condition_variable rp_cv_work, rp_cv_done;
@@ -605,7 +606,7 @@ bool fetch_records(kgwas_scan* s, Slot& sl, uint64_t seq);
 // ---- scan_lazy.cpp: selection instead of replay
 uint64_t lazy_materialize(kgwas_scan* s, size_t j);
 void lazy_materialize_all(kgwas_scan* s);
-void lazy_finish_column(kgwas_scan* s, size_t j);
+void lazy_finish_column(kgwas_scan* s, size_t j, bool known_tie = false);
 void lazy_reset(kgwas_scan* s);
 bool lazy_lowest(kgwas_scan* s, size_t j, double* lowest, bool* full);
 // ---- scan_replay.cpp: the host side

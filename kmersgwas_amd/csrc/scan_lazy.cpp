@@ -271,15 +271,25 @@ void lazy_materialize_all(kgwas_scan* s) {
 
 // Result lists of column j (finish, or an idle worker at the tail of the last feed): by selection where the scores decide,
 // else through the heap.
-void lazy_finish_column(kgwas_scan* s, size_t j) {
+void lazy_finish_column(kgwas_scan* s, size_t j, bool known_tie) {
     LazyCol& L = s->lazy[j];
     if (L.on) {
-        if (L.select(s->res_kmer[j], s->res_score[j], s->res_row[j])) {
+        static const bool trace = getenv("KGWAS_FINISH_TRACE") != nullptr;
+        const double t0 = trace ? s->t_ms() : 0;
+        if (!known_tie && L.select(s->res_kmer[j], s->res_score[j], s->res_row[j])) {
             s->n_selected.fetch_add(1, std::memory_order_relaxed);
+            if (trace) fprintf(stderr, "finish col %zu: select %.3f ms\n", j, s->t_ms() - t0);
             return;
         }
-        s->lazy_pushes.fetch_add(lazy_materialize(s, j), std::memory_order_relaxed);
+        const double t1 = trace ? s->t_ms() : 0;
+        const size_t ln = L.l_n;
+        const uint64_t pu = lazy_materialize(s, j);
+        s->lazy_pushes.fetch_add(pu, std::memory_order_relaxed);
         s->n_unselected.fetch_add(1, std::memory_order_relaxed);
+        const double t2 = trace ? s->t_ms() : 0;
+        s->heaps[j].pop_all(s->res_kmer[j], s->res_score[j], s->res_row[j]);
+        if (trace) fprintf(stderr, "finish col %zu: failed select %.3f, materialize %.3f (%zu records, %llu pushes), pops %.3f ms\n", j, t1 - t0, t2 - t1, ln, (unsigned long long)pu, s->t_ms() - t2);
+        return;
     }
     s->heaps[j].pop_all(s->res_kmer[j], s->res_score[j], s->res_row[j]);
 }

@@ -14,12 +14,14 @@ stream = torch.cuda.current_stream().cuda_stream
 kg.synth_rows_device(table.data_ptr(), 0, M, S, 20240601, stream)
 torch.cuda.synchronize()
 scan = kg.AssociationScan(S, np.arange(S, dtype=np.uint64), Y, 10001, mac, device=0)
-for it in range(6):
+for it in range(int(os.environ.get("STEPS", "6"))):
     t = [time.perf_counter()]
     scan.reset(); t.append(time.perf_counter())
+    if os.environ.get("EXPECT"): scan.expect_finish()
     scan.feed_device(table.data_ptr(), M, 0, stream); t.append(time.perf_counter())
     scan.finish(); t.append(time.perf_counter())
     st = scan.stats(); t.append(time.perf_counter())
     d = [(b - a) * 1e3 for a, b in zip(t, t[1:])]
-    print("step %d: reset %.2f feed %.2f finish %.2f stats %.2f | replay %.1f dense %.1f gpu_wait %.2f kernels %.1f" %
-          (it, d[0], d[1], d[2], d[3], st["replay_ms"], st["dense_ms"], st["gpu_wait_ms"], st["score_kernel_ms"]))
+    print("step %d: reset %.2f feed %.2f finish %.2f stats %.2f | replay %.1f dense %.1f gpu_wait %.2f kernels %.1f tail %.2f | selected %d replayed_at_finish %d popped_ahead %d pushes %d chunks %d" %
+          (it, d[0], d[1], d[2], d[3], st["replay_ms"], st["dense_ms"], st["gpu_wait_ms"], st["score_kernel_ms"], st["replay_tail_ms"],
+           st["columns_selected"], st["columns_replayed_at_finish"], st["columns_popped_ahead"], st["heap_pushes"], st["chunks"]))
