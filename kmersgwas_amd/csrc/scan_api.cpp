@@ -265,7 +265,7 @@ int kgwas_scan_history_above(kgwas_scan* s, const double* thr, uint64_t* counts,
                 }
                 const LazyCol& h = s->lazy[j];
                 uint64_t c = 0;
-                for (size_t i = 0; i < h.l_n; i++) c += keepl(j, h.l_sc[i]) ? 1 : 0;
+                h.for_each([&](double sc, uint64_t, uint64_t) { c += keepl(j, sc) ? 1 : 0; });
                 counts[j] = c;
             });
             for (uint64_t j = 0; j < P; j++)
@@ -287,13 +287,13 @@ int kgwas_scan_history_above(kgwas_scan* s, const double* thr, uint64_t* counts,
                     return;
                 }
                 const LazyCol& h = s->lazy[j];
-                for (size_t i = 0; i < h.l_n; i++)
-                    if (keepl(j, h.l_sc[i])) {
-                        s->exp_kmer[o] = h.l_km[i];
-                        s->exp_score[o] = h.l_sc[i];
-                        s->exp_row[o] = h.l_rw[i];
-                        o++;
-                    }
+                h.for_each([&](double sc, uint64_t km, uint64_t rw) {
+                    if (!keepl(j, sc)) return;
+                    s->exp_kmer[o] = km;
+                    s->exp_score[o] = sc;
+                    s->exp_row[o] = rw;
+                    o++;
+                });
             });
             if (kmer) *kmer = s->exp_kmer.data();
             if (score) *score = s->exp_score.data();
@@ -437,7 +437,7 @@ int kgwas_scan_history_above_msgs(kgwas_scan* s, const double* thr, uint64_t n_m
             if (from_logs && s->lazy[j].on) {
                 const LazyCol& h = s->lazy[j];
                 uint64_t c = 0;
-                for (size_t i = 0; i < h.l_n; i++) c += (h.l_sc[i] != ninf && keep(j, h.l_sc[i])) ? 1 : 0;
+                h.for_each([&](double sc, uint64_t, uint64_t) { c += (sc != ninf && keep(j, sc)) ? 1 : 0; });
                 counts[j] = c;
             } else if (s->history_ring) {  // mode 2: the heap's entries and its last evictions above thr, put in row order
                 ok[j] = s->heaps[j].pushes_above(thr[j], recs[j]) ? 1 : 0;
@@ -485,8 +485,9 @@ int kgwas_scan_history_above_msgs(kgwas_scan* s, const double* thr, uint64_t n_m
             };
             if (from_logs && s->lazy[b.j].on) {
                 const LazyCol& h = s->lazy[b.j];
-                for (size_t e = 0; e < h.l_n; e++)
-                    if (h.l_sc[e] != ninf && keep(b.j, h.l_sc[e])) put(h.l_km[e], h.l_sc[e], h.l_rw[e]);
+                h.for_each([&](double sc, uint64_t km, uint64_t rw) {
+                    if (sc != ninf && keep(b.j, sc)) put(km, sc, rw);
+                });
             } else if (s->history_ring) {
                 for (const BestHeap::Rec& r : recs[b.j]) put(r.kmer, r.score, r.row);
             } else {

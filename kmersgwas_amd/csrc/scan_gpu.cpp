@@ -565,6 +565,19 @@ void wait_event(kgwas_scan* s, hipEvent_t ev) {
     s->st.gpu_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
 }
 
+// The ring has run full while the columns' logs refer to its records (ring_keep). Called by the control thread when every
+// published chunk is replayed (no worker is inside a column): the logs take copies, and the ring is recycled from here on -
+// free up to the end of the last replayed chunk; chunks that are fetched but not yet published keep their records where
+// they are and are copied into the logs when their turn comes.
+void ring_to_recycling(kgwas_scan* s, uint64_t replayed) {
+    for (uint64_t j = 0; j < s->n_pheno; j++)
+        if (s->lazy[j].on) s->lazy[j].detach();
+    s->ring_keep.store(false, std::memory_order_release);
+    s->ring_tail = replayed ? s->slot[(size_t)((replayed - 1) % (uint64_t)s->n_slots)].ring_end : s->ring_feed_start;
+    s->ring_freed = replayed;
+    if (s->trace) fprintf(stderr, "[kgwas t=%.3f] record ring full: logs detached, ring recycles from %zu (head %zu of %zu)\n", s->t_ms(), s->ring_tail, s->ring_head, s->ring_size);
+}
+
 // Coarse chunk: wait for its counts, then order the copy of exactly that many candidate records (three arrays) from
 // HBM on the copy stream; ev_done follows the copies. Other chunks recorded ev_done at submission.
 // Returns false if the record ring has no room yet (nothing was ordered: retry after more chunks are replayed).
@@ -578,6 +591,7 @@ bool fetch_records(kgwas_scan* s, Slot& sl, uint64_t seq) {
         // give back what the replay has finished with (chunks are replayed, hence freed, in order); before this slot's
         // ring_end is overwritten below: its previous chunk is among them
         const uint64_t rep = s->seq_replayed.load(std::memory_order_acquire);
+        if (s->ring_keep.load(std::memory_order_relaxed)) s->ring_freed = rep;  // (the logs refer to the records: nothing is given back)
         while (s->ring_freed < rep) {
             s->ring_tail = s->slot[(size_t)(s->ring_freed % (uint64_t)s->n_slots)].ring_end;
             s->ring_freed++;
@@ -585,12 +599,15 @@ bool fetch_records(kgwas_scan* s, Slot& sl, uint64_t seq) {
         // empty: start over at the bottom - but only when every chunk fetched before this one has been freed: a fetched,
         // not yet replayed chunk without records (or one that overflowed) carries a ring_end taken from the old head,
         // and freeing it later would move the tail back over records placed at the bottom in the meantime
-        if (s->ring_tail == s->ring_head && s->ring_freed == seq) s->ring_head = s->ring_tail = 0;
+        if (!s->ring_keep.load(std::memory_order_relaxed) && s->ring_tail == s->ring_head && s->ring_freed == seq) s->ring_head = s->ring_tail = 0;
     }
     if (copy) {
         const size_t need = ((size_t)n * 20 + 63) / 64 * 64;
         size_t at;
-        if (s->ring_head >= s->ring_tail) {  // used part does not wrap (or the ring is empty)
+        if (s->ring_keep.load(std::memory_order_relaxed)) {  // linear: [0, head) is referred to by the columns' logs
+            if (s->ring_size - s->ring_head < need) return false;  // (the caller lets the replay catch up, then ring_to_recycling)
+            at = s->ring_head;
+        } else if (s->ring_head >= s->ring_tail) {  // used part does not wrap (or the ring is empty)
             if (s->ring_size - s->ring_head >= need)
                 at = s->ring_head;
             else if (s->ring_tail > need)  // wrap: the bytes up to the end stay unused until this chunk is freed

@@ -257,12 +257,42 @@ struct LazyCol {
     uint64_t bound_bits = 0;
     bool have_bound = false;
     uint32_t n_prunes = 0;
-    // the LOG, three arrays (a chunk's records arrive as three arrays and are copied as such: 2 ns per record)
+    // the LOG: segments in row order. A sparse chunk's records stay where the GPU put them - in the session's pinned record
+    // ring, which is not recycled while columns refer to it (fetch_records) - and the log holds a reference (sc != null);
+    // single records (dense chunks' rows, absorbed shards, exact-scorer candidates) and, once the ring has run full and gone
+    // back to recycling, the chunks' records as well are copied into the three owned arrays (sc == null: [off, off + n) there).
+    struct Seg {
+        const double* sc;
+        const uint64_t* km;
+        const uint32_t* rw;  // rows within the chunk
+        uint64_t row0;
+        size_t off;
+        uint32_t n;
+    };
+    std::vector<Seg> segs;
     double* l_sc = nullptr;
     uint64_t* l_km = nullptr;
     uint64_t* l_rw = nullptr;
-    size_t l_n = 0, l_cap = 0;
+    size_t l_n = 0, l_cap = 0;  // owned records
     std::vector<Ent> pool;
+    // every logged record, in row order: f(score, kmer, row)
+    template <class F>
+    inline void for_each(F&& f) const {
+        for (const Seg& g : segs) {
+            if (g.sc) {
+                for (uint32_t i = 0; i < g.n; i++) f(g.sc[i], g.km[i], g.row0 + g.rw[i]);
+            } else {
+                for (size_t i = g.off; i < g.off + g.n; i++) f(l_sc[i], l_km[i], l_rw[i]);
+            }
+        }
+    }
+    inline void owned_appended(size_t n) {  // n records were appended to the owned arrays at l_n - n
+        if (!segs.empty() && !segs.back().sc && segs.back().off + segs.back().n == l_n - n && (uint64_t)segs.back().n + n < (1ull << 32))
+            segs.back().n += (uint32_t)n;
+        else
+            segs.push_back(Seg{nullptr, nullptr, nullptr, 0, l_n - n, (uint32_t)n});
+    }
+    void detach();  // referenced records -> owned copies (the ring is about to be recycled)
     LazyCol() = default;
     LazyCol(const LazyCol&) = delete;
     LazyCol& operator=(const LazyCol&) = delete;
@@ -273,6 +303,9 @@ struct LazyCol {
             on = o.on, bad = o.bad, topn = o.topn, n_logged = o.n_logged, bound_bits = o.bound_bits, have_bound = o.have_bound, n_prunes = o.n_prunes;
             l_sc = o.l_sc, l_km = o.l_km, l_rw = o.l_rw, l_n = o.l_n, l_cap = o.l_cap;
             o.l_sc = nullptr, o.l_km = nullptr, o.l_rw = nullptr, o.l_n = o.l_cap = 0;
+            segs = std::move(o.segs);
+            o.segs.clear();
+            scan_seg = o.scan_seg, scan_off = o.scan_off, unscanned = o.unscanned;
             pool = std::move(o.pool);
         }
         return *this;
@@ -284,6 +317,8 @@ struct LazyCol {
         free(l_rw);
         l_sc = nullptr, l_km = nullptr, l_rw = nullptr;
         l_n = l_cap = 0;
+        segs.clear();
+        scan_seg = 0, scan_off = 0, unscanned = 0;
     }
     void reserve_log(size_t need);
     void reset(bool enable, uint64_t topn_);
@@ -292,7 +327,8 @@ struct LazyCol {
     bool select(std::vector<uint64_t>& kmer, std::vector<double>& score, std::vector<uint64_t>& row);
     bool ties_now();
     // a sparse chunk's records of this column (row order; rw: rows within the chunk), the device's threshold behind the chunk
-    void take_chunk(const double* sc, const uint64_t* km, const uint32_t* rw, uint32_t n, uint64_t row0, uint64_t thr_bits);
+    // by_ref: the records stay where they are (see Seg)
+    void take_chunk(const double* sc, const uint64_t* km, const uint32_t* rw, uint32_t n, uint64_t row0, uint64_t thr_bits, bool by_ref);
     inline bool full() const { return n_logged >= topn; }
     // a valid lower bound of what the reference heap's minimum is by now (0: none yet)
     inline double bound() const {
@@ -310,15 +346,18 @@ struct LazyCol {
         l_km[l_n] = kmer;
         l_rw[l_n] = row;
         l_n++;
+        owned_appended(1);
         n_logged++;
-        if (b > 0x7FF0000000000000ull) {  // NaN, or the sign bit set
-            bad = true;
-            return;
-        }
-        if (have_bound && b < bound_bits) return;
-        pool.push_back(Ent{b, kmer, row});
-        if (pool.size() >= 8 * (size_t)topn + 64) compact();  // (the chunks' device thresholds normally prune it long before)
+        if (++unscanned >= 4 * topn + 1024) scan_pending();
     }
+    // The POOL is derived from the log: the records that are not in it yet are looked at - one pass over their scores - and
+    // those at or above the bound AS IT STANDS NOW join it (a record that would have passed when it arrived and does not pass
+    // now is never touched again: looking late is looking at less). Called every ~4 N logged records and by everything that
+    // reads the pool, `bad` or the N-th largest score.
+    void scan_pending();
+    size_t scan_seg = 0;   // segs[scan_seg] from record scan_off on, and every later segment, are not in the pool yet
+    uint32_t scan_off = 0;
+    uint64_t unscanned = 0;
 };
 
 // Evictions a heap of N entries keeps for the cross-shard merge (record_history = 2): the entries of a shard above
@@ -475,6 +514,12 @@ struct kgwas_scan {
     uint32_t* h_n1_dev = nullptr;
     uint64_t* h_kmer_dev = nullptr;
     size_t ring_size = 0, ring_head = 0, ring_tail = 0;  // used: [tail, head) circularly; head == tail: empty
+    // Columns in select mode keep their sparse chunks' records where the GPU wrote them (LazyCol::Seg): while this is set the
+    // ring is filled linearly and nothing is given back - from one kgwas_scan_reset to the next, across feeds. Should it run full
+    // (ring_to_recycling, scan_gpu.cpp), the logs take copies of what they refer to and the ring recycles as it does for
+    // sessions that replay every column; from then on the workers copy each chunk's records into the logs.
+    std::atomic<bool> ring_keep{false};
+    size_t ring_feed_start = 0;  // ring_head when the current feed began
     uint64_t ring_freed = 0;                              // chunks (of this feed) whose records have been given back
     Slot redo;  // coarse mode: the only slot with exact-scorer candidate records (synchronous overflow re-runs)
     int n_slots = MAX_SLOTS;  // as many as fit 1 GiB of mapped pinned candidate memory (at least 4)
@@ -603,6 +648,7 @@ bool chunk_complete(kgwas_scan* s, Slot& sl);
 uint64_t next_sparse_chunk(const kgwas_scan* s);
 void wait_event(kgwas_scan* s, hipEvent_t ev);
 bool fetch_records(kgwas_scan* s, Slot& sl, uint64_t seq);
+void ring_to_recycling(kgwas_scan* s, uint64_t replayed);
 // ---- scan_lazy.cpp: selection instead of replay
 uint64_t lazy_materialize(kgwas_scan* s, size_t j);
 void lazy_materialize_all(kgwas_scan* s);

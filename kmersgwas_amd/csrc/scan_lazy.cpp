@@ -38,6 +38,8 @@ void LazyCol::reset(bool enable, uint64_t topn_) {
     have_bound = false;
     n_prunes = 0;
     l_n = 0;
+    segs.clear();
+    scan_seg = 0, scan_off = 0, unscanned = 0;
     pool.clear();
     if (enable && pool.capacity() < 3 * (size_t)std::min<uint64_t>(topn_, 1u << 22) + 64) pool.reserve(3 * (size_t)std::min<uint64_t>(topn_, 1u << 22) + 64);
 }
@@ -61,30 +63,98 @@ void LazyCol::reserve_log(size_t need) {
 // A sparse chunk's records of this column: into the log as they are (three copies; a narrow chunk's placeholders - survivors
 // that are no candidates, score -inf - travel along and are skipped by every reader), and those that can still be among the N
 // largest - score >= the device's threshold behind this very chunk - into the pool.
-void LazyCol::take_chunk(const double* sc, const uint64_t* km, const uint32_t* rw, uint32_t n, uint64_t row0, uint64_t thr_bits) {
+void LazyCol::take_chunk(const double* sc, const uint64_t* km, const uint32_t* rw, uint32_t n, uint64_t row0, uint64_t thr_bits, bool by_ref) {
     if (thr_bits <= 0x7FF0000000000000ull && (!have_bound || thr_bits > bound_bits)) {
         bound_bits = thr_bits;
         have_bound = true;
     }
-    reserve_log(l_n + n);
-    memcpy(l_sc + l_n, sc, (size_t)n * sizeof(double));
-    memcpy(l_km + l_n, km, (size_t)n * sizeof(uint64_t));
-    uint64_t* dr = l_rw + l_n;
-    for (uint32_t i = 0; i < n; i++) dr[i] = row0 + rw[i];
-    l_n += n;
-    n_logged += n;
-    const uint64_t lim = have_bound ? bound_bits : 0;
-    for (uint32_t i = 0; i < n; i++) {
-        uint64_t b;
-        memcpy(&b, &sc[i], 8);
-        if (b < lim) continue;
-        if (b > 0x7FF0000000000000ull) {
-            if (b != NEG_INF) bad = true;
-            continue;
-        }
-        pool.push_back(Ent{b, km[i], row0 + rw[i]});
+    if (by_ref) {
+        segs.push_back(Seg{sc, km, rw, row0, 0, n});
+    } else {
+        reserve_log(l_n + n);
+        memcpy(l_sc + l_n, sc, (size_t)n * sizeof(double));
+        memcpy(l_km + l_n, km, (size_t)n * sizeof(uint64_t));
+        uint64_t* dr = l_rw + l_n;
+        for (uint32_t i = 0; i < n; i++) dr[i] = row0 + rw[i];
+        l_n += n;
+        owned_appended(n);
     }
-    if (pool.size() >= 2 * (size_t)topn + 64) prune(bound_bits);
+    n_logged += n;
+    unscanned += n;
+    if (unscanned >= 4 * topn + 1024) scan_pending();
+}
+
+void LazyCol::scan_pending() {
+    if (!unscanned) return;
+    uint64_t lim = have_bound ? bound_bits : 0;
+    auto look = [&](uint64_t b, uint64_t km, uint64_t rw) {
+        if (b > 0x7FF0000000000000ull) {  // NaN, or the sign bit set
+            if (b != NEG_INF) bad = true;  // (-inf: a narrow chunk's survivor that was no candidate)
+            return;
+        }
+        pool.push_back(Ent{b, km, rw});
+        if (pool.size() >= 2 * (size_t)topn + 64) {
+            prune(bound_bits);
+            lim = have_bound ? bound_bits : 0;  // (a selection may have raised it)
+        }
+    };
+    for (; scan_seg < segs.size(); scan_seg++, scan_off = 0) {
+        const Seg& g = segs[scan_seg];
+        if (g.sc) {
+            const uint64_t* sb = reinterpret_cast<const uint64_t*>(g.sc);
+            for (uint32_t i = scan_off; i < g.n; i++)
+                if (sb[i] >= lim) look(sb[i], g.km[i], g.row0 + g.rw[i]);
+        } else {
+            const uint64_t* sb = reinterpret_cast<const uint64_t*>(l_sc);
+            for (size_t i = g.off + scan_off; i < g.off + g.n; i++)
+                if (sb[i] >= lim) look(sb[i], l_km[i], l_rw[i]);
+        }
+    }
+    // (the last segment may still grow - single records are appended to an owned one: it is looked at again from where this
+    // pass ended)
+    if (!segs.empty()) {
+        scan_seg = segs.size() - 1;
+        scan_off = segs.back().n;
+    }
+    unscanned = 0;
+}
+
+// Every referenced segment becomes an owned copy (the order of the log is kept): one pass, new arrays.
+void LazyCol::detach() {
+    scan_pending();
+    bool any = false;
+    size_t total = 0;
+    for (const Seg& g : segs) {
+        any |= g.sc != nullptr;
+        total += g.n;
+    }
+    if (!any) return;
+    double* nsc = static_cast<double*>(malloc(std::max<size_t>(total, 1) * sizeof(double)));
+    uint64_t* nkm = static_cast<uint64_t*>(malloc(std::max<size_t>(total, 1) * sizeof(uint64_t)));
+    uint64_t* nrw = static_cast<uint64_t*>(malloc(std::max<size_t>(total, 1) * sizeof(uint64_t)));
+    if (!nsc || !nkm || !nrw) {
+        free(nsc), free(nkm), free(nrw);
+        throw std::bad_alloc();
+    }
+    size_t o = 0;
+    for_each([&](double sc, uint64_t km, uint64_t rw) {
+        nsc[o] = sc;
+        nkm[o] = km;
+        nrw[o] = rw;
+        o++;
+    });
+    free(l_sc), free(l_km), free(l_rw);
+    l_sc = nsc, l_km = nkm, l_rw = nrw;
+    l_n = l_cap = total;
+    segs.clear();
+    size_t at = 0;
+    while (at < total) {  // (a segment counts its records in 32 bits)
+        const size_t c = std::min<size_t>(total - at, 0xFFFFFFFFull);
+        segs.push_back(Seg{nullptr, nullptr, nullptr, 0, at, (uint32_t)c});
+        at += c;
+    }
+    scan_seg = segs.size() - 1;
+    scan_off = segs.back().n;
 }
 
 // thr: a valid lower bound of the reference heap's minimum (the device's threshold behind some chunk: the highest boundary of
@@ -122,6 +192,7 @@ void LazyCol::compact() {
 // Result lists by selection (any number of entries: a heap that never filled holds them all). false: the scores alone do not
 // decide the result - the caller materialises the column.
 bool LazyCol::select(std::vector<uint64_t>& kmer, std::vector<double>& score, std::vector<uint64_t>& row) {
+    scan_pending();
     if (bad) return false;
     compact();
     const size_t N = (size_t)topn;
@@ -170,6 +241,7 @@ bool LazyCol::select(std::vector<uint64_t>& kmer, std::vector<double>& score, st
 // column share sign, exponent and often the leading mantissa bits) and the top N + 1 compared with their neighbours: ~80 us
 // at N = 10 001.
 bool LazyCol::ties_now() {
+    scan_pending();
     if (bad) return true;
     const size_t N = (size_t)topn;
     prune(bound_bits);
@@ -214,10 +286,10 @@ uint64_t lazy_materialize(kgwas_scan* s, size_t j) {
     BestHeap& h = s->heaps[j];
     uint64_t pushes = 0;
     const double none = -std::numeric_limits<double>::infinity();
-    for (size_t i = 0; i < L.l_n; i++) {
-        if (L.l_sc[i] == none) continue;  // (a narrow chunk's survivor that was no candidate)
-        if (h.add(L.l_km[i], L.l_sc[i], (size_t)L.l_rw[i])) pushes++;
-    }
+    L.for_each([&](double sc, uint64_t km, uint64_t rw) {
+        if (sc == none) return;  // (a narrow chunk's survivor that was no candidate)
+        if (h.add(km, sc, (size_t)rw)) pushes++;
+    });
     L.on = false;
     L.release_log();
     std::vector<LazyCol::Ent>().swap(L.pool);
@@ -234,6 +306,9 @@ void lazy_reset(kgwas_scan* s) {
     s->n_unselected.store(0);
     s->lazy_pushes.store(0);
     s->tie_check_rows = 4ull << 20;
+    // nothing refers to the record ring any more; a session in select mode fills it linearly (scan_internal.h, ring_keep)
+    s->ring_head = s->ring_tail = 0;
+    s->ring_keep.store(s->lazy_enabled && s->coarse && !(getenv("KGWAS_LOG_BY_REF") && atoi(getenv("KGWAS_LOG_BY_REF")) == 0), std::memory_order_release);
 }
 
 // BestHeap::lowest() / full() of a column in select mode without giving it a heap: a full heap's minimum is the N-th largest
@@ -241,6 +316,7 @@ void lazy_reset(kgwas_scan* s) {
 // negative score - only its heap knows (the caller materialises it).
 bool lazy_lowest(kgwas_scan* s, size_t j, double* lowest, bool* full) {
     LazyCol& L = s->lazy[j];
+    L.scan_pending();
     if (L.bad) return false;
     *full = L.full();
     if (L.full()) {
@@ -266,6 +342,7 @@ void lazy_materialize_all(kgwas_scan* s) {
     s->pool->parallel_for(s->n_pheno, [&](size_t j) { pushes += lazy_materialize(s, j); });
     s->st.heap_pushes += pushes.load();
     s->lazy_any.store(false, std::memory_order_relaxed);
+    s->ring_keep.store(false, std::memory_order_release);  // (no log is left: the next feed recycles the ring)
     refresh_full(s);
 }
 
@@ -282,7 +359,7 @@ void lazy_finish_column(kgwas_scan* s, size_t j, bool known_tie) {
             return;
         }
         const double t1 = trace ? s->t_ms() : 0;
-        const size_t ln = L.l_n;
+        const size_t ln = (size_t)L.n_logged;
         const uint64_t pu = lazy_materialize(s, j);
         s->lazy_pushes.fetch_add(pu, std::memory_order_relaxed);
         s->n_unselected.fetch_add(1, std::memory_order_relaxed);

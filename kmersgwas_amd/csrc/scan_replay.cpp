@@ -34,6 +34,7 @@ void replay_group(kgwas_scan* s, Slot& sl, size_t g, ReplayAcc& acc) {
         constexpr int MK = BestHeap::MAX_LOCKSTEP;
         Cur cols[MK];
         size_t n_cols = 0;
+        const bool by_ref = s->ring_keep.load(std::memory_order_acquire);  // (constant while chunks are being replayed)
         for (const uint32_t j : members) {
             const uint32_t n = sl.h_meta.p[j];
             if (!n) continue;
@@ -44,7 +45,7 @@ void replay_group(kgwas_scan* s, Slot& sl, size_t g, ReplayAcc& acc) {
                 LazyCol& L = s->lazy[j];
                 uint64_t tb;
                 memcpy(&tb, &sl.h_thr.p[j], 8);
-                L.take_chunk(sl.so_score + o, sl.so_kmer + o, sl.so_row + o, n, row0, tb);
+                L.take_chunk(sl.so_score + o, sl.so_kmer + o, sl.so_row + o, n, row0, tb, by_ref);
                 nc += n;
                 // behind chunks the control thread picked (flag_tie_check) the pool is looked at for a tie: a column whose N
                 // largest scores are not distinct will need the exact replay, and that costs less now, beside the GPU, than at
@@ -455,7 +456,9 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
     auto flag_tie_check = [&](Slot& sl, uint64_t pos_before, uint64_t c) {
         sl.tie_check = false;
         if (!s->lazy_any.load(std::memory_order_relaxed) || s->lazy_log_mode) return;
-        if (n_rows >= (16ull << 20)) {
+        // (a host with few threads for many columns is the scan's bottleneck whenever its replays happen: looking early buys
+        // nothing there and costs ~0.1 ms per column and look)
+        if (n_rows >= (16ull << 20) && s->n_pheno <= 8 * (uint64_t)s->pool->size()) {
             for (const double f : {0.4, 0.65}) {
                 const uint64_t at = (uint64_t)(f * (double)n_rows);
                 if (pos_before < at && pos_before + c >= at) sl.tie_check = true;
@@ -521,7 +524,11 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
     s->seq_submitted.store(0);
     s->seq_published.store(0);
     s->seq_replayed.store(0);
-    s->ring_head = s->ring_tail = 0;
+    if (s->ring_keep.load(std::memory_order_relaxed))
+        s->ring_tail = 0;  // (the records of earlier feeds stay: the columns' logs refer to them)
+    else
+        s->ring_head = s->ring_tail = 0;
+    s->ring_feed_start = s->ring_head;
     s->ring_freed = 0;
     // the session's own column groups (a feed may have split some, split_group)
     for (size_t g = 0; g < s->n_groups0 + (size_t)s->n_pheno; g++) {
@@ -643,6 +650,12 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
                     continue;
                 }
                 // the record ring is full: publish what is fetched; if all of that is published, wait for the replay
+                if (pub == cpy && s->ring_keep.load(std::memory_order_relaxed)) {
+                    wait_replayed(pub);
+                    if (s->rp_failed.load(std::memory_order_acquire)) break;
+                    ring_to_recycling(s, pub);
+                    continue;
+                }
                 if (pub == cpy) {
                     wait_replayed(rep_now + 1);
                     if (s->rp_failed.load(std::memory_order_acquire)) break;

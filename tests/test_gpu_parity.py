@@ -910,10 +910,14 @@ def test_adversarial_order_overflows_candidate_lists(kernel):
     scan.close()
 
 
-def test_record_ring_wraps_and_fills(monkeypatch):
+@pytest.mark.parametrize("by_ref", ["1", "0"])
+def test_record_ring_wraps_and_fills(monkeypatch, by_ref):
     """The host copies of the candidate records live in one pinned ring (FIFO, exact sizes). With a ring barely larger
     than one chunk's worst case the allocations wrap around and the control thread has to wait for the replay to give
-    memory back - results must not change."""
+    memory back - results must not change. Columns in select mode refer to their records IN the ring (by_ref, the default),
+    which is then not recycled: when it runs full - here at once, and with a second feed behind it - their logs take copies
+    and the ring goes back to recycling (ring_to_recycling); KGWAS_LOG_BY_REF=0: the logs copy from the start."""
+    monkeypatch.setenv("KGWAS_LOG_BY_REF", by_ref)
     S = 128
     rows = random_table(600_000, S, seed=77)
     col = np.arange(S, dtype=np.uint64)

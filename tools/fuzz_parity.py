@@ -57,7 +57,8 @@ while time.time() < t_end:
     env = {"KGWAS_COARSE_MX": str(rng.choice(["", "0", "1"])), "KGWAS_MX32": str(rng.choice(["0", "0", "2"])),
            "KGWAS_COARSE_SLICES": str(rng.choice(["", "", "1", "2"])),
            "KGWAS_MXS": str(rng.choice(["", "", "0", "2", "3", "3"])), "KGWAS_MXS_FORM": str(rng.choice(["", "", "1", "2"])),
-           "KGWAS_FULL_REPLAY": str(rng.choice(["", "", "1"]))}
+           "KGWAS_FULL_REPLAY": str(rng.choice(["", "", "", "1"])), "KGWAS_LOG_BY_REF": str(rng.choice(["", "", "0"])),
+           "KGWAS_RING_BYTES": str(rng.choice(["", "", "1", "3000000"]))}
     for k, v in env.items():
         if v: os.environ[k] = v
         else: os.environ.pop(k, None)
