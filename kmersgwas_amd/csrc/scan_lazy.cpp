@@ -10,10 +10,17 @@
 //
 // A lazy column keeps
 //   * its LOG: every record the column was shipped (the dense chunks' MAC-passing rows, then the sparse chunks' candidates)
-//     in row order - 24 B each, ~1.4 N (1 + ln(rows / N)) records; what an exact replay would need, should it come to that;
-//   * its POOL: (score bits, k-mer, row) of the records that can still be among the N largest: a record enters if its score is
-//     >= the pool's bound. When the pool holds 2 N entries it is PRUNED with the device's own threshold behind the chunk at
-//     hand (a valid lower bound of the reference heap's minimum, within 0.4 % of the N-th largest score: one linear pass);
+//     in row order; what an exact replay would need, should it come to that. A sparse chunk's records are not copied: they
+//     stay where the GPU wrote them, in the session's pinned record ring, and the log holds a reference (LazyCol::Seg) - the
+//     ring is filled linearly and not recycled while logs refer to it (scan_internal.h, ring_keep; sized for a pass's records:
+//     390 MB at 101 columns, 775 MB at 201). If it runs full after all, the logs take copies (detach) and the ring recycles;
+//     from then on every chunk's records are copied into the logs (three memcpys), as all of them were before.
+//   * its POOL: (score bits, k-mer, row) of the records that can still be among the N largest. It is DERIVED from the log:
+//     every ~4 N logged records - and whenever somebody needs the pool - the records not looked at yet are scanned, scores
+//     only, and those at or above the column's bound as it stands THEN join the pool (a record that would have passed when
+//     it arrived and no longer does is never touched: 1 ns per record instead of the 7.5 ns of copy + compare + insert). The
+//     bound is the device's own threshold behind the latest chunk (a valid lower bound of the reference heap's minimum, within
+//     0.4 % of the N-th largest score). When the pool holds 2 N entries it is PRUNED with the bound (one linear pass);
 //     should that leave more than 2 N, nth_element finds the N-th largest score v, everything below v goes, entries EQUAL to v
 //     stay (a tie at the boundary must remain visible), and v becomes the bound.
 // At finish the pool is cut to its N largest and sorted; if more than N entries are >= the N-th score (boundary tie), two
@@ -21,8 +28,10 @@
 // is replayed through its BestHeap, exactly as the streaming replay would have done, and popped. Tables whose rows repeat
 // presence/absence patterns (real k-mer tables: the rule) tie all over the place - a column whose first dense chunk shows a
 // tie among its top N is materialised on the spot and replayed from then on, as every column was before round 5; the pools
-// are looked at again for ties every fourth pruning (a radix sort of ~N keys), so that a column that will need the replay
-// gets it beside the GPU's work and not at finish.
+// are looked at again for ties behind the chunks that cross 40 and 65 % of a large feed (a radix sort of ~N keys), so that a
+// column that will need the replay gets it beside the GPU's work; a tie that turns up later still is replayed - ~4 ms at
+// N = 10 001 and 10^8 rows, all such columns side by side - by the replay workers before they leave the last feed
+// (scan_replay.cpp, drain) or, without kgwas_scan_expect_finish, by kgwas_scan_finish.
 // KGWAS_FULL_REPLAY=1: no column is ever lazy (the effective-push count, which the tests use as a tripwire, exists for
 // replayed columns only).
 #include "scan_internal.h"
@@ -60,9 +69,9 @@ void LazyCol::reserve_log(size_t need) {
     l_cap = nc;
 }
 
-// A sparse chunk's records of this column: into the log as they are (three copies; a narrow chunk's placeholders - survivors
-// that are no candidates, score -inf - travel along and are skipped by every reader), and those that can still be among the N
-// largest - score >= the device's threshold behind this very chunk - into the pool.
+// A sparse chunk's records of this column: into the log as they are - by reference, or three copies (a narrow chunk's
+// placeholders - survivors that are no candidates, score -inf - travel along and are skipped by every reader); the device's
+// threshold behind this very chunk raises the bound. The pool sees them at the next scan_pending.
 void LazyCol::take_chunk(const double* sc, const uint64_t* km, const uint32_t* rw, uint32_t n, uint64_t row0, uint64_t thr_bits, bool by_ref) {
     if (thr_bits <= 0x7FF0000000000000ull && (!have_bound || thr_bits > bound_bits)) {
         bound_bits = thr_bits;

@@ -12,6 +12,13 @@ void process_range_sync(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_
 // chunk's records of those columns in row order. A group's chunks must be replayed in submission order; different
 // groups are independent (columns never interact). Two drivers use it: the streaming replay below (workers pick
 // (chunk, group) units as the GPU completes chunks, no barrier between chunks) and the synchronous overflow path.
+// KGWAS_TIE_CHECKS (experiments): 0 = the pools are never looked at for ties during a large feed, 1 = behind every flagged
+// chunk; default: where the host keeps up with the GPU.
+static int tie_checks_mode() {
+    static const int m = getenv("KGWAS_TIE_CHECKS") ? atoi(getenv("KGWAS_TIE_CHECKS")) : -1;
+    return m;
+}
+
 void replay_group(kgwas_scan* s, Slot& sl, size_t g, ReplayAcc& acc) {
     const auto tb0 = std::chrono::steady_clock::now();
     const uint64_t row0 = sl.first_row;
@@ -35,6 +42,12 @@ void replay_group(kgwas_scan* s, Slot& sl, size_t g, ReplayAcc& acc) {
         Cur cols[MK];
         size_t n_cols = 0;
         const bool by_ref = s->ring_keep.load(std::memory_order_acquire);  // (constant while chunks are being replayed)
+        // A look at a column's pool costs ~0.1 ms, and the replay it may set off ~4 ms x the share of the feed that is over. A
+        // worker with nothing else waiting has that time beside the GPU; one that has fallen behind - few threads for many
+        // columns: the host is the scan's bottleneck whenever its replays happen - would only add the looks to its backlog
+        // (two threads under the headline: 47 ms per step without looks, 59 with).
+        const bool look = sl.tie_check && !s->lazy_log_mode &&
+                          (tie_checks_mode() == 1 || s->seq_published.load(std::memory_order_relaxed) <= s->gstate[g].done.load(std::memory_order_relaxed) + 2);
         for (const uint32_t j : members) {
             const uint32_t n = sl.h_meta.p[j];
             if (!n) continue;
@@ -50,7 +63,7 @@ void replay_group(kgwas_scan* s, Slot& sl, size_t g, ReplayAcc& acc) {
                 // behind chunks the control thread picked (flag_tie_check) the pool is looked at for a tie: a column whose N
                 // largest scores are not distinct will need the exact replay, and that costs less now, beside the GPU, than at
                 // finish
-                if (sl.tie_check && !s->lazy_log_mode && L.full() && L.ties_now()) local += lazy_materialize(s, j);
+                if (look && L.full() && L.ties_now()) local += lazy_materialize(s, j);
                 continue;
             }
             cols[n_cols++] = Cur{sl.so_score + o, sl.so_kmer + o, sl.so_row + o, 0, n, &s->heaps[j], j};
@@ -456,9 +469,8 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
     auto flag_tie_check = [&](Slot& sl, uint64_t pos_before, uint64_t c) {
         sl.tie_check = false;
         if (!s->lazy_any.load(std::memory_order_relaxed) || s->lazy_log_mode) return;
-        // (a host with few threads for many columns is the scan's bottleneck whenever its replays happen: looking early buys
-        // nothing there and costs ~0.1 ms per column and look)
-        if (n_rows >= (16ull << 20) && s->n_pheno <= 8 * (uint64_t)s->pool->size()) {
+        // (whether a flagged chunk's columns ARE looked at is the worker's decision when it gets there: replay_group)
+        if (n_rows >= (16ull << 20) && tie_checks_mode() != 0) {
             for (const double f : {0.4, 0.65}) {
                 const uint64_t at = (uint64_t)(f * (double)n_rows);
                 if (pos_before < at && pos_before + c >= at) sl.tie_check = true;

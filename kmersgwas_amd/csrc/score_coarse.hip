@@ -401,8 +401,8 @@ typedef __attribute__((address_space(4))) const float* kconst_f32p;
 // kernels 4.06 -> 3.75 ms per 100 M rows at 1024 x 101, all kernels 49.9 -> 49.1 at 2048 x 201. (Also tried on top: the fma's
 // 0.0f / 1.0f factors from a bank-conflict-free table in LDS instead of byte expansion + v_cvt_f32_ubyteK - a third of the
 // vector instructions - measured +-0: twice the LDS reads then saturate the LDS pipe)
-template <bool YLDS>
-__device__ __forceinline__ void rescore_block(const uint32_t (&w)[4], const float* yb, float (&acc)[4]) {
+template <bool YLDS, int NS = 1>
+__device__ __forceinline__ void rescore_block(const uint32_t (&w)[NS][4], const float* yb, float (&acc)[NS][4]) {
     kconst_f32p yc = (kconst_f32p)yb;
     const float4* yl = reinterpret_cast<const float4*>(yb);
     (void)yc;
@@ -411,13 +411,23 @@ __device__ __forceinline__ void rescore_block(const uint32_t (&w)[4], const floa
     // acc + (bit ? y : +0) == fma((float)bit, y, acc) for finite y (the filters only run on finite phenotypes): the bits of a
     // dword become bytes 0 / 1 eight at a time ((w >> j) & 0x01010101: two lane-ops per four bits), v_cvt_f32_ubyteK makes
     // 0.0f / 1.0f of one, and v_pk_fma_f32 advances two chains: 2.0 lane-ops per sample instead of 2.5.
+    // NS = 2 (experiments, launch_rescore): the lane carries two survivors of the column; the sample's four values are read once
+    // for both (one broadcast ds_read_b128 per sample and survivor is 32 KB per wave and 128-sample block through a 128 B/clk
+    // LDS pipe, against 896 issue cycles of lane-ops per SIMD) - measured slower, see launch_rescore.
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    uint32_t e[4][8];
+    uint32_t e[NS][4][8];
 #pragma unroll
-    for (int l = 0; l < 4; l++)
+    for (int v = 0; v < NS; v++)
 #pragma unroll
-        for (int j = 0; j < 8; j++) e[l][j] = (w[l] >> j) & 0x01010101u;
-    f32x2 a01 = {acc[0], acc[1]}, a23 = {acc[2], acc[3]};
+        for (int l = 0; l < 4; l++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) e[v][l][j] = (w[v][l] >> j) & 0x01010101u;
+    f32x2 a01[NS], a23[NS];
+#pragma unroll
+    for (int v = 0; v < NS; v++) {
+        a01[v] = (f32x2){acc[v][0], acc[v][1]};
+        a23[v] = (f32x2){acc[v][2], acc[v][3]};
+    }
 #pragma unroll
     for (int s = 0; s < 32; s++) {
         const int b = 31 - s, j = b & 7, k = b >> 3;
@@ -438,15 +448,21 @@ __device__ __forceinline__ void rescore_block(const uint32_t (&w)[4], const floa
             if (k == 3) asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(f) : "v"(x));
             return f;
         };
-        const f32x2 g01 = {byte_f32(e[0][j]), byte_f32(e[1][j])};
-        const f32x2 g23 = {byte_f32(e[2][j]), byte_f32(e[3][j])};
-        a01 = __builtin_elementwise_fma(g01, y01, a01);
-        a23 = __builtin_elementwise_fma(g23, y23, a23);
+#pragma unroll
+        for (int v = 0; v < NS; v++) {
+            const f32x2 g01 = {byte_f32(e[v][0][j]), byte_f32(e[v][1][j])};
+            const f32x2 g23 = {byte_f32(e[v][2][j]), byte_f32(e[v][3][j])};
+            a01[v] = __builtin_elementwise_fma(g01, y01, a01[v]);
+            a23[v] = __builtin_elementwise_fma(g23, y23, a23[v]);
+        }
     }
-    acc[0] = a01.x;
-    acc[1] = a01.y;
-    acc[2] = a23.x;
-    acc[3] = a23.y;
+#pragma unroll
+    for (int v = 0; v < NS; v++) {
+        acc[v][0] = a01[v].x;
+        acc[v][1] = a01[v].y;
+        acc[v][2] = a23[v].x;
+        acc[v][3] = a23[v].y;
+    }
     return;
 #endif
 #pragma unroll
@@ -454,13 +470,15 @@ __device__ __forceinline__ void rescore_block(const uint32_t (&w)[4], const floa
         const float yv[4] = {YLDS ? yb[4 * s] : yc[4 * s], YLDS ? yb[4 * s + 1] : yc[4 * s + 1], YLDS ? yb[4 * s + 2] : yc[4 * s + 2],
                              YLDS ? yb[4 * s + 3] : yc[4 * s + 3]};
 #pragma unroll
-        for (int l = 0; l < 4; l++) {
-            // bit 31 - s as 0 / -1 in one v_bfe_i32, kept from the optimiser, which turns bfe & y (like a shift pair)
-            // into and + compare + select: 3.5 lane-ops per sample, 2.5 this way with the packed add
-            int mk = __builtin_amdgcn_sbfe((int)w[l], 31 - s, 1);
-            asm volatile("" : "+v"(mk));
-            acc[l] = acc[l] + __int_as_float(mk & __float_as_int(yv[l]));
-        }
+        for (int v = 0; v < NS; v++)
+#pragma unroll
+            for (int l = 0; l < 4; l++) {
+                // bit 31 - s as 0 / -1 in one v_bfe_i32, kept from the optimiser, which turns bfe & y (like a shift pair)
+                // into and + compare + select: 3.5 lane-ops per sample, 2.5 this way with the packed add
+                int mk = __builtin_amdgcn_sbfe((int)w[v][l], 31 - s, 1);
+                asm volatile("" : "+v"(mk));
+                acc[v][l] = acc[v][l] + __int_as_float(mk & __float_as_int(yv[l]));
+            }
     }
 }
 
@@ -483,7 +501,9 @@ __device__ __forceinline__ void rescore_finish(const ScoreArgs& a, uint32_t p, b
 // coalesced copies - every line fetched once - measured 30-50 % SLOWER: the gathers are not what this kernel waits for.)
 // DIRECT (scans of a few columns, launch_rescore_direct): the survivor's record is written at its place in the key order -
 // score or -inf, k-mer, row - and nothing is counted or compacted afterwards.
-template <bool YLDS, bool DIRECT = false>
+// NS = 2 (experiments): a block takes two consecutive tiles at a time and, where both belong to the same column - all but
+// one pair per column -, every lane carries one survivor of each: the column's values are read from LDS once for both.
+template <bool YLDS, bool DIRECT = false, int NS = 1>
 __global__ void __launch_bounds__(256) rescore_kernel(ScoreArgs a, const uint32_t* keys, const uint32_t* surv_off,
                                                       const uint32_t* surv_cnt, const uint32_t* tile_pref, uint32_t row_mask,
                                                       double* tmp_score, uint32_t* tile_cnt) {
@@ -493,57 +513,90 @@ __global__ void __launch_bounds__(256) rescore_kernel(ScoreArgs a, const uint32_
     const uint32_t n_tiles = tile_pref[a.n_pheno];
     const uint32_t L = 64u * a.W_m;
     const uint32_t nblk = a.W_m / 2u;
-    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        const uint32_t p = __builtin_amdgcn_readfirstlane(tile_column(tile_pref, a.n_pheno, t));
-        const uint32_t i = (t - tile_pref[p]) * 256u + threadIdx.x;
-        const bool valid = i < surv_cnt[p];
-        const uint32_t gi = surv_off[p] + (valid ? i : 0u);
-        const uint64_t r = keys[gi] & row_mask;
-        const uint32_t* rp = a.src.base + r * a.src.stride_dw + a.src.off_dw;
-        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        uint32_t n1 = 0;
+    // tiles t0 .. t0 + nv - 1 of column p (nv <= NS)
+    auto run = [&](uint32_t t0, uint32_t p, uint32_t nv) {
+        bool valid[NS];
+        uint32_t gi[NS];
+        uint64_t r[NS];
+        const uint32_t* rp[NS];
+#pragma unroll
+        for (int v = 0; v < NS; v++) {
+            const uint32_t i = (t0 + (uint32_t)v - tile_pref[p]) * 256u + threadIdx.x;
+            valid[v] = (uint32_t)v < nv && i < surv_cnt[p];
+            gi[v] = surv_off[p] + (valid[v] ? i : 0u);
+            r[v] = keys[gi[v]] & row_mask;
+            rp[v] = a.src.base + r[v] * a.src.stride_dw + a.src.off_dw;
+        }
+        float acc[NS][4];
+        uint32_t n1[NS];
+#pragma unroll
+        for (int v = 0; v < NS; v++) {
+            n1[v] = 0;
+#pragma unroll
+            for (int l = 0; l < 4; l++) acc[v][l] = 0.0f;
+        }
         if (YLDS) {  // (the previous tile's readers are past rescore_finish's barriers)
             const float4* ysrc = reinterpret_cast<const float4*>(a.Yperm + (size_t)p * L);
             for (uint32_t k = threadIdx.x; k < L / 4u; k += 256u) ytile[k] = ysrc[k];
             __syncthreads();
         }
-        // the row's words for block b + 1 are asked for before block b's 320 lane-ops start
-        uint2 nx[2];
+        // the rows' words for block b + 1 are asked for before block b's lane-ops start
+        uint2 nx[NS][2];
         auto fetch = [&](uint32_t b) {
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                nx[h] = make_uint2(0u, 0u);
-                if (4u * b + 2u * h + 1u < a.src.avail_dw) nx[h] = *reinterpret_cast<const uint2*>(rp + 4u * b + 2u * h);
-            }
+            for (int v = 0; v < NS; v++)
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    nx[v][h] = make_uint2(0u, 0u);
+                    if (4u * b + 2u * h + 1u < a.src.avail_dw) nx[v][h] = *reinterpret_cast<const uint2*>(rp[v] + 4u * b + 2u * h);
+                }
         };
         if (nblk) fetch(0);
         for (uint32_t b = 0; b < nblk; b++) {
-            uint32_t w[4];
+            uint32_t w[NS][4];
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                w[2 * h] = nx[h].x & a.dmask[4 * b + 2 * h];
-                w[2 * h + 1] = nx[h].y & a.dmask[4 * b + 2 * h + 1];
+            for (int v = 0; v < NS; v++) {
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    w[v][2 * h] = nx[v][h].x & a.dmask[4 * b + 2 * h];
+                    w[v][2 * h + 1] = nx[v][h].y & a.dmask[4 * b + 2 * h + 1];
+                }
+                n1[v] += __popc(w[v][0]) + __popc(w[v][1]) + __popc(w[v][2]) + __popc(w[v][3]);
             }
             if (b + 1u < nblk) fetch(b + 1u);
-            n1 += __popc(w[0]) + __popc(w[1]) + __popc(w[2]) + __popc(w[3]);
             if (YLDS)
-                rescore_block<true>(w, reinterpret_cast<const float*>(ytile) + 128u * b, acc);
+                rescore_block<true, NS>(w, reinterpret_cast<const float*>(ytile) + 128u * b, acc);
             else
-                rescore_block<false>(w, a.Yperm + (size_t)p * L + 128u * b, acc);
+                rescore_block<false, NS>(w, a.Yperm + (size_t)p * L + 128u * b, acc);
         }
         if (DIRECT) {
-            const float yf = ((acc[0] + acc[1]) + acc[2]) + acc[3];
-            double q, d, sc, out = -__builtin_huge_val();
-            score_terms(a, yf, n1, a.sums[p], q, d);
-            if (valid && mac_pass(a, n1) && candidate_score(a, p, q, d, a.thr[p], sc)) out = sc;
-            if (valid) {
-                a.so_score[gi] = out;
-                a.so_kmer[gi] = a.file_rows[r * a.file_stride_w];
-                a.so_row[gi] = (uint32_t)r;
+#pragma unroll
+            for (int v = 0; v < NS; v++) {
+                const float yf = ((acc[v][0] + acc[v][1]) + acc[v][2]) + acc[v][3];
+                double q, d, sc, out = -__builtin_huge_val();
+                score_terms(a, yf, n1[v], a.sums[p], q, d);
+                if (valid[v] && mac_pass(a, n1[v]) && candidate_score(a, p, q, d, a.thr[p], sc)) out = sc;
+                if (valid[v]) {
+                    a.so_score[gi[v]] = out;
+                    a.so_kmer[gi[v]] = a.file_rows[r[v] * a.file_stride_w];
+                    a.so_row[gi[v]] = (uint32_t)r[v];
+                }
             }
             if (YLDS) __syncthreads();  // the next tile's column overwrites ytile
         } else {
-            rescore_finish(a, p, valid, gi, acc, n1, tmp_score, tile_cnt, t, wcnt);
+#pragma unroll
+            for (int v = 0; v < NS; v++)
+                if ((uint32_t)v < nv) rescore_finish(a, p, valid[v], gi[v], acc[v], n1[v], tmp_score, tile_cnt, t0 + (uint32_t)v, wcnt);  // (nv is block-uniform)
+        }
+    };
+    for (uint32_t t = (uint32_t)NS * blockIdx.x; t < n_tiles; t += (uint32_t)NS * gridDim.x) {
+        const uint32_t p = __builtin_amdgcn_readfirstlane(tile_column(tile_pref, a.n_pheno, t));
+        if (NS == 1) {
+            run(t, p, 1u);
+        } else {
+            const bool two = t + 1u < n_tiles && t + 1u < tile_pref[p + 1u];  // the next tile is the same column's
+            run(t, p, two ? 2u : 1u);
+            if (!two && t + 1u < n_tiles) run(t + 1u, __builtin_amdgcn_readfirstlane(tile_column(tile_pref, a.n_pheno, t + 1u)), 1u);
         }
     }
 }
@@ -732,7 +785,14 @@ hipError_t launch_rescore(const ScoreArgs& a, const uint32_t* keys, const uint32
     // the tile's column goes through LDS while it fits beside eight blocks per CU (16 KB: 4096 samples); beyond, scalar loads
     const size_t ybytes = 64u * (size_t)a.W_m * sizeof(float);
     static const bool ylds_ok = getenv("KGWAS_RESCORE_YLDS") ? atoi(getenv("KGWAS_RESCORE_YLDS")) != 0 : true;  // experiments
-    if (ylds_ok && ybytes <= 16384u)
+    // (KGWAS_RESCORE_NS=2, experiments: two survivors per lane, the column's values read from LDS once for both - half the LDS
+    // reads, but 146 registers instead of 84, three waves per SIMD instead of five: all scoring kernels 14.0 ms per 100 M rows x
+    // 1024 x 101 against 13.5; what this kernel waits for is its row gathers, and fewer waves hide them worse)
+    static const int ns_env = getenv("KGWAS_RESCORE_NS") ? atoi(getenv("KGWAS_RESCORE_NS")) : 1;
+    if (ylds_ok && ybytes <= 16384u && ns_env == 2)
+        hipLaunchKernelGGL((rescore_kernel<true, false, 2>), dim3(2048), dim3(256), ybytes, st, a, keys, surv_off, surv_cnt, tile_pref, row_mask,
+                           tmp_score, tile_cnt);
+    else if (ylds_ok && ybytes <= 16384u)
         hipLaunchKernelGGL(rescore_kernel<true>, dim3(2048), dim3(256), ybytes, st, a, keys, surv_off, surv_cnt, tile_pref, row_mask,
                            tmp_score, tile_cnt);
     else
