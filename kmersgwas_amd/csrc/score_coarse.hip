@@ -43,6 +43,9 @@
 #ifndef KGWAS_COARSE_ABLATE
 #define KGWAS_COARSE_ABLATE 0
 #endif
+#ifndef KGWAS_RESCORE_HALVES
+#define KGWAS_RESCORE_HALVES 0  // experiments (rescore_block): with KGWAS_RESCORE_WAVES, tools/rescore_variants.sh - none ahead, see there
+#endif
 #ifndef KGWAS_RESCORE_FMA
 #define KGWAS_RESCORE_FMA 1  // 0: the select-and-add form of rounds 1-2 (2.5 lane-ops per sample)
 #endif
@@ -415,6 +418,40 @@ __device__ __forceinline__ void rescore_block(const uint32_t (&w)[NS][4], const 
     // for both (one broadcast ds_read_b128 per sample and survivor is 32 KB per wave and 128-sample block through a 128 B/clk
     // LDS pipe, against 896 issue cycles of lane-ops per SIMD) - measured slower, see launch_rescore.
     typedef float f32x2 __attribute__((ext_vector_type(2)));
+#if KGWAS_RESCORE_HALVES
+    // chains 0, 1 over the block's 32 steps, then chains 2, 3: sixteen expanded dwords live instead of thirty-two
+    if (NS == 1 && YLDS) {
+        const float2* yh = reinterpret_cast<const float2*>(yb);
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            uint32_t eh[2][8];
+#pragma unroll
+            for (int l = 0; l < 2; l++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) eh[l][j] = (w[0][2 * half + l] >> j) & 0x01010101u;
+            f32x2 ah = {acc[0][2 * half], acc[0][2 * half + 1]};
+#pragma unroll
+            for (int s = 0; s < 32; s++) {
+                const int b = 31 - s, j = b & 7, k = b >> 3;
+                const float2 yv = yh[2 * s + half];
+                const f32x2 yy = {yv.x, yv.y};
+                auto byte_f32 = [&](uint32_t x) {
+                    float f;
+                    if (k == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(f) : "v"(x));
+                    if (k == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(f) : "v"(x));
+                    if (k == 2) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(f) : "v"(x));
+                    if (k == 3) asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(f) : "v"(x));
+                    return f;
+                };
+                const f32x2 g = {byte_f32(eh[0][j]), byte_f32(eh[1][j])};
+                ah = __builtin_elementwise_fma(g, yy, ah);
+            }
+            acc[0][2 * half] = ah.x;
+            acc[0][2 * half + 1] = ah.y;
+        }
+        return;
+    }
+#endif
     uint32_t e[NS][4][8];
 #pragma unroll
     for (int v = 0; v < NS; v++)
@@ -503,8 +540,20 @@ __device__ __forceinline__ void rescore_finish(const ScoreArgs& a, uint32_t p, b
 // score or -inf, k-mer, row - and nothing is counted or compacted afterwards.
 // NS = 2 (experiments): a block takes two consecutive tiles at a time and, where both belong to the same column - all but
 // one pair per column -, every lane carries one survivor of each: the column's values are read from LDS once for both.
+#ifndef KGWAS_RESCORE_WAVES
+// experiments: waves per SIMD the register allocation is held to (0: the compiler's choice, 84 registers = 5 waves). Re-score +
+// small kernels per 100 M rows x 1024 x 101: 3.66-3.70 ms as is; 6 waves + KGWAS_RESCORE_HALVES 3.80, 7 waves 3.76, 7 + halves
+// 3.81-3.85, 8 + halves 4.13 (a few spills each), halves alone 3.89: neither more waves nor fewer LDS reads (KGWAS_RESCORE_NS=2)
+// is what this kernel lacks.
+#define KGWAS_RESCORE_WAVES 0
+#endif
+#if KGWAS_RESCORE_WAVES
+#define KGWAS_RESCORE_OCC __attribute__((amdgpu_waves_per_eu(KGWAS_RESCORE_WAVES, KGWAS_RESCORE_WAVES)))
+#else
+#define KGWAS_RESCORE_OCC
+#endif
 template <bool YLDS, bool DIRECT = false, int NS = 1>
-__global__ void __launch_bounds__(256) rescore_kernel(ScoreArgs a, const uint32_t* keys, const uint32_t* surv_off,
+__global__ void __launch_bounds__(256) KGWAS_RESCORE_OCC rescore_kernel(ScoreArgs a, const uint32_t* keys, const uint32_t* surv_off,
                                                       const uint32_t* surv_cnt, const uint32_t* tile_pref, uint32_t row_mask,
                                                       double* tmp_score, uint32_t* tile_cnt) {
     __shared__ uint32_t wcnt[4];
