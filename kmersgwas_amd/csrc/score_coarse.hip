@@ -555,8 +555,9 @@ __device__ __forceinline__ void rescore_finish(const ScoreArgs& a, uint32_t p, b
 template <bool YLDS, bool DIRECT = false, int NS = 1>
 __global__ void __launch_bounds__(256) KGWAS_RESCORE_OCC rescore_kernel(ScoreArgs a, const uint32_t* keys, const uint32_t* surv_off,
                                                       const uint32_t* surv_cnt, const uint32_t* tile_pref, uint32_t row_mask,
-                                                      double* tmp_score, uint32_t* tile_cnt) {
+                                                      double* tmp_score, uint32_t* tile_cnt, uint32_t* ticket) {
     __shared__ uint32_t wcnt[4];
+    __shared__ uint32_t next_tile;
     extern __shared__ float4 ytile[];  // YLDS: the tile's column, 64 * W_m floats
 
     const uint32_t n_tiles = tile_pref[a.n_pheno];
@@ -638,7 +639,15 @@ __global__ void __launch_bounds__(256) KGWAS_RESCORE_OCC rescore_kernel(ScoreArg
                 if ((uint32_t)v < nv) rescore_finish(a, p, valid[v], gi[v], acc[v], n1[v], tmp_score, tile_cnt, t0 + (uint32_t)v, wcnt);  // (nv is block-uniform)
         }
     };
-    for (uint32_t t = (uint32_t)NS * blockIdx.x; t < n_tiles; t += (uint32_t)NS * gridDim.x) {
+    // (tiles by ticket where the caller passes one - the counter is zeroed by the chunk's prep launch -: experiments, launch_rescore)
+    for (uint32_t t = (uint32_t)NS * blockIdx.x;; t += (uint32_t)NS * gridDim.x) {
+        if (ticket) {
+            if (threadIdx.x == 0) next_tile = atomicAdd(ticket, (uint32_t)NS);
+            __syncthreads();
+            t = next_tile;
+            __syncthreads();
+        }
+        if (t >= n_tiles) break;
         const uint32_t p = __builtin_amdgcn_readfirstlane(tile_column(tile_pref, a.n_pheno, t));
         if (NS == 1) {
             run(t, p, 1u);
@@ -724,7 +733,7 @@ __global__ void __launch_bounds__(256) chunk_prep_kernel(uint32_t* cand_cnt, uin
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_pheno) cand_cnt[i] = 0u;
     if (i < TESTED_SHARDS) tested[i] = 0ull;
-    if (i == 0 && key_count) *key_count = 0u;
+    if (i == 0 && key_count) key_count[0] = 0u, key_count[1] = 0u;  // ([1]: rescore_kernel's tile ticket)
     if (i < n_seg_words) seg_cnt[i] = 0u;
     // the bitmap, two words (16 bytes) per thread and turn
     ulonglong2* b2 = reinterpret_cast<ulonglong2*>(bitmap);
@@ -838,15 +847,20 @@ hipError_t launch_rescore(const ScoreArgs& a, const uint32_t* keys, const uint32
     // reads, but 146 registers instead of 84, three waves per SIMD instead of five: all scoring kernels 14.0 ms per 100 M rows x
     // 1024 x 101 against 13.5; what this kernel waits for is its row gathers, and fewer waves hide them worse)
     static const int ns_env = getenv("KGWAS_RESCORE_NS") ? atoi(getenv("KGWAS_RESCORE_NS")) : 1;
+    // (KGWAS_RESCORE_DYN=1, experiments: tiles handed out by an atomic ticket instead of round-robin - a launch is 800-3700 tiles on
+    // 1280 block slots - measured slower: re-score + small kernels 4.10-4.12 ms per 100 M rows x 1024 x 101 against 3.65-3.71)
+    static const bool dyn = getenv("KGWAS_RESCORE_DYN") && atoi(getenv("KGWAS_RESCORE_DYN")) != 0;
+    static const uint32_t grid = getenv("KGWAS_RESCORE_GRID") ? (uint32_t)atoi(getenv("KGWAS_RESCORE_GRID")) : 2048u;
+    uint32_t* ticket = dyn ? const_cast<uint32_t*>(key_count) + 1 : nullptr;  // (d_key_count has two words; chunk_prep_kernel zeroes both)
     if (ylds_ok && ybytes <= 16384u && ns_env == 2)
-        hipLaunchKernelGGL((rescore_kernel<true, false, 2>), dim3(2048), dim3(256), ybytes, st, a, keys, surv_off, surv_cnt, tile_pref, row_mask,
-                           tmp_score, tile_cnt);
+        hipLaunchKernelGGL((rescore_kernel<true, false, 2>), dim3(grid), dim3(256), ybytes, st, a, keys, surv_off, surv_cnt, tile_pref, row_mask,
+                           tmp_score, tile_cnt, ticket);
     else if (ylds_ok && ybytes <= 16384u)
-        hipLaunchKernelGGL(rescore_kernel<true>, dim3(2048), dim3(256), ybytes, st, a, keys, surv_off, surv_cnt, tile_pref, row_mask,
-                           tmp_score, tile_cnt);
+        hipLaunchKernelGGL(rescore_kernel<true>, dim3(grid), dim3(256), ybytes, st, a, keys, surv_off, surv_cnt, tile_pref, row_mask,
+                           tmp_score, tile_cnt, ticket);
     else
-        hipLaunchKernelGGL(rescore_kernel<false>, dim3(2048), dim3(256), 0, st, a, keys, surv_off, surv_cnt, tile_pref, row_mask,
-                           tmp_score, tile_cnt);
+        hipLaunchKernelGGL(rescore_kernel<false>, dim3(grid), dim3(256), 0, st, a, keys, surv_off, surv_cnt, tile_pref, row_mask,
+                           tmp_score, tile_cnt, ticket);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, tile_cnt, tile_pref, a.n_pheno, key_count, tile_off, meta);
     hipLaunchKernelGGL(compact_kernel, dim3(2048), dim3(256), 0, st, a, keys, surv_off, surv_cnt, tile_pref, row_mask, tmp_score,
                        tile_off);
@@ -862,10 +876,10 @@ hipError_t launch_rescore_direct(const ScoreArgs& a, const uint32_t* keys, const
     // these launches)
     if (ybytes <= 16384u)
         hipLaunchKernelGGL((rescore_kernel<true, true>), dim3(512), dim3(256), ybytes, st, a, keys, surv_off, surv_cnt, tile_pref, row_mask,
-                           (double*)nullptr, (uint32_t*)nullptr);
+                           (double*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
     else
         hipLaunchKernelGGL((rescore_kernel<false, true>), dim3(512), dim3(256), 0, st, a, keys, surv_off, surv_cnt, tile_pref, row_mask,
-                           (double*)nullptr, (uint32_t*)nullptr);
+                           (double*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
     return hipGetLastError();
 }
 
