@@ -128,6 +128,12 @@ __device__ __forceinline__ uint32_t transpose32(uint32_t x, uint32_t lane) {
 // Two threads per row (blockDim.x = 2 x rows per block): thread (row, half h) counts and transposes half of the row's
 // dwords, so a block's phases - copy in, count, transpose, copy out - run on twice the waves for the same LDS footprint
 // (the footprint, not the registers, is what limits a CU to two of these blocks).
+// DIRECT_IN (experiments, launch_kin_transpose: measured slower): no verbatim copy of the rows in LDS - every thread loads its
+// own part of its row (at most KIN_DIRECT_DW dwords) from global memory into registers, once, for the count and for the
+// transposes: the block's LDS is the planes alone (37 KB instead of 76 at 1135 samples), one barrier and two passes over LDS
+// fewer; but a wave's loads touch 64 rows x 36 bytes at a 152-byte stride - 64 addresses per instruction.
+constexpr uint32_t KIN_DIRECT_DW = 12u;
+template <bool DIRECT_IN>
 __global__ void __launch_bounds__(1024) kin_transpose_kernel(const uint64_t* file_rows, uint64_t file_stride_w, uint64_t n_rows,
                                                             uint32_t S_f, uint32_t S_pad, uint32_t min_count, uint32_t* T,
                                                             uint64_t n_rw, unsigned long long* n_used, uint32_t rpb) {
@@ -135,36 +141,49 @@ __global__ void __launch_bounds__(1024) kin_transpose_kernel(const uint64_t* fil
     const uint32_t tpr = blockDim.x / rpb;  // threads per row (rows per block: 256, 128 or 64)
     const uint32_t wpb = rpb / 32u;        // plane words per block and sample
     const uint32_t stride_dw = (uint32_t)(2u * file_stride_w);
-    uint32_t* lin = kin_lds;                        // [rpb][stride_dw] verbatim rows (k-mer word included)
-    uint32_t* lout = kin_lds + rpb * stride_dw;     // [S_pad][wpb]
-    uint32_t* pn = lout + S_pad * wpb;              // [tpr][rpb] partial popcounts of the parts of a row
+    uint32_t* lin = kin_lds;                                            // [rpb][stride_dw] verbatim rows (k-mer word included)
+    uint32_t* lout = kin_lds + (DIRECT_IN ? 0u : rpb * stride_dw);     // [S_pad][wpb]
+    uint32_t* pn = lout + S_pad * wpb;                                  // [tpr][rpb] partial popcounts of the parts of a row
     const uint32_t in_dw = 2u * ((S_f + 63u) / 64u);
     const uint64_t row0 = (uint64_t)blockIdx.x * rpb;
     const uint32_t rr = threadIdx.x % rpb, half = threadIdx.x / rpb;
     const uint32_t lane = threadIdx.x & 63u, wave = rr >> 6;  // wave: of the row set
-    if (row0 < n_rows) {  // coalesced verbatim copy of up to rpb contiguous rows
+    const uint64_t r = row0 + rr;
+    const uint32_t n_d = S_pad / 32u, d_half = (n_d + tpr - 1u) / tpr;
+    const uint32_t d0 = half * d_half < n_d ? half * d_half : n_d, d1 = (d0 + d_half < n_d) ? d0 + d_half : n_d;
+    uint32_t own[KIN_DIRECT_DW];
+    if (DIRECT_IN) {
+        const uint32_t* g = reinterpret_cast<const uint32_t*>(file_rows + (r < n_rows ? r : 0) * file_stride_w) + 2u;
+#pragma unroll
+        for (uint32_t i = 0; i < KIN_DIRECT_DW; i++) own[i] = (r < n_rows && d0 + i < d1 && d0 + i < in_dw) ? g[d0 + i] : 0u;
+    } else if (row0 < n_rows) {  // coalesced verbatim copy of up to rpb contiguous rows
         const uint64_t left = n_rows - row0;
         const uint32_t n2 = (uint32_t)((left < rpb ? left : rpb) * file_stride_w);
         const uint2* src = reinterpret_cast<const uint2*>(file_rows + row0 * file_stride_w);
         uint2* dst = reinterpret_cast<uint2*>(lin);
         for (uint32_t i = threadIdx.x; i < n2; i += blockDim.x) dst[i] = src[i];
     }
-    __syncthreads();
-    const uint64_t r = row0 + rr;
+    if (!DIRECT_IN) __syncthreads();
     const uint32_t* my = lin + (size_t)rr * stride_dw + 2u;
     // file padding bits (>= S_f) count neither in the predicate nor in the planes: calculate_unsqueezed_popcnt masks
     // with m_map_mask (src/kmers_multiple_databases.cpp:149-154)
-    auto masked = [&](uint32_t d) {
-        uint32_t x = my[d];
+    auto mask_of = [&](uint32_t d, uint32_t x) {
         if (32u * d + 32u > S_f) x &= (32u * d < S_f) ? ((1u << (S_f - 32u * d)) - 1u) : 0u;
         return x;
     };
-    const uint32_t n_d = S_pad / 32u, d_half = (n_d + tpr - 1u) / tpr;
-    const uint32_t d0 = half * d_half < n_d ? half * d_half : n_d, d1 = (d0 + d_half < n_d) ? d0 + d_half : n_d;
+    auto masked = [&](uint32_t d) { return mask_of(d, my[d]); };
+    if (DIRECT_IN) {
+#pragma unroll
+        for (uint32_t i = 0; i < KIN_DIRECT_DW; i++) own[i] = mask_of(d0 + i, own[i]);
+    }
     {
         uint32_t c = 0;
-        if (r < n_rows)
+        if (DIRECT_IN) {
+#pragma unroll
+            for (uint32_t i = 0; i < KIN_DIRECT_DW; i++) c += __popc(own[i]);  // (zero beyond the thread's part and beyond the rows)
+        } else if (r < n_rows) {
             for (uint32_t d = d0; d < d1 && d < in_dw; d++) c += __popc(masked(d));
+        }
         pn[half * rpb + rr] = c;
     }
     __syncthreads();
@@ -173,13 +192,19 @@ __global__ void __launch_bounds__(1024) kin_transpose_kernel(const uint64_t* fil
     // src/emma_kinship_kmers.cpp:83,89 -> load_kmers' predicate with all S_f columns
     const bool pass = (r < n_rows) && (S_f >= min_count) && (n1 >= min_count) && (n1 <= S_f - min_count);
     const unsigned long long kept = half == 0u ? __popcll(__ballot(pass)) : 0ull;  // (half is wave-uniform: rpb >= 64)
-    for (uint32_t d = d0; d < d1; d++) {
-        uint32_t x = (pass && d < in_dw) ? masked(d) : 0u;
+    auto plane_store = [&](uint32_t d, uint32_t x) {
         x = transpose32(x, lane);
         // lane s of 32-lane group g now holds sample 32d + s over the group's 32 rows
         // (the word index is XORed with bits 3..5 of the sample where a sample has 8 plane words: 64 lanes, 64 banks)
         const uint32_t smp = 32u * d + (lane & 31u), wd = wave * 2u + (lane >> 5);
         lout[smp * wpb + (wpb == 8u ? (wd ^ ((smp >> 3) & 7u)) : wd)] = x;
+    };
+    if (DIRECT_IN) {
+#pragma unroll
+        for (uint32_t i = 0; i < KIN_DIRECT_DW; i++)
+            if (d0 + i < d1) plane_store(d0 + i, pass ? own[i] : 0u);  // (d0, d1 are wave-uniform: transpose32 runs with all lanes)
+    } else {
+        for (uint32_t d = d0; d < d1; d++) plane_store(d, (pass && d < in_dw) ? masked(d) : 0u);
     }
     if (lane == 0 && kept) atomicAdd(&n_used[blockIdx.x % TESTED_SHARDS], kept);  // each wave adds the rows it counted
     __syncthreads();
@@ -353,6 +378,7 @@ __global__ void __launch_bounds__(256) kin_reduce_kernel(const kin_f32x4* part, 
 size_t kin_transpose_lds_bytes(uint64_t file_stride_w, uint32_t S_pad, uint32_t rpb) {
     return ((size_t)rpb * 2u * file_stride_w + (size_t)S_pad * (rpb / 32u) + 4u * rpb) * 4u;
 }
+static size_t kin_transpose_lds_bytes_direct(uint32_t S_pad, uint32_t rpb) { return ((size_t)S_pad * (rpb / 32u) + 4u * rpb) * 4u; }
 
 // Rows per transpose block: the most (256, 128, 64) whose verbatim rows + planes fit the 160 KB of LDS; 0 = none does.
 uint32_t kin_transpose_rows_per_block(uint64_t file_stride_w, uint32_t S_pad) {
@@ -369,16 +395,26 @@ hipError_t launch_kin_transpose(const uint64_t* file_rows, uint64_t file_stride_
     if (n_rows == 0) return hipSuccess;
     const uint32_t rpb = kin_transpose_rows_per_block(file_stride_w, S_pad);
     if (!rpb) return hipErrorInvalidValue;  // kgwas_kinship_create rejects such sessions with a message
-    const size_t lds = kin_transpose_lds_bytes(file_stride_w, S_pad, rpb);
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)kin_transpose_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
     static const uint32_t tpr_env = getenv("KGWAS_KIN_TPR") ? (uint32_t)atoi(getenv("KGWAS_KIN_TPR")) : 0u;  // experiments
     const uint32_t tpr = tpr_env ? tpr_env : 4u;  // threads per row (1: 3.55 ms per 8 M rows x 1135, 2: 3.16, 4: 3.11)
+    // KGWAS_KIN_DIRECT=1 (experiments): rows straight into registers where a thread's part of a row is at most KIN_DIRECT_DW
+    // dwords (up to 1536 accessions at four threads per row) instead of through the verbatim copy in LDS - four blocks per CU
+    // instead of two, one barrier fewer: measured SLOWER, 3.30 against 3.13 ms per 8 M rows x 1135 (both kernels; the strided
+    // row loads cost more than the LDS passes they replace)
+    static const bool direct_ok = getenv("KGWAS_KIN_DIRECT") && atoi(getenv("KGWAS_KIN_DIRECT")) != 0;
+    const bool direct = direct_ok && (S_pad / 32u + tpr - 1u) / tpr <= KIN_DIRECT_DW;
+    const size_t lds = direct ? kin_transpose_lds_bytes_direct(S_pad, rpb) : kin_transpose_lds_bytes(file_stride_w, S_pad, rpb);
+    const void* fn = direct ? (const void*)kin_transpose_kernel<true> : (const void*)kin_transpose_kernel<false>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
     // every word of T up to n_rw is written (blocks beyond the rows write zeros): n_rw / 8 tiles x 256 / rpb blocks
-    hipLaunchKernelGGL(kin_transpose_kernel, dim3((uint32_t)(n_rw / 8u * (256u / rpb))), dim3(tpr * rpb), lds, st, file_rows,
-                       file_stride_w, n_rows, S_f, S_pad, min_count, T, n_rw, n_used, rpb);
+    const dim3 grid((uint32_t)(n_rw / 8u * (256u / rpb))), block(tpr * rpb);
+    if (direct)
+        hipLaunchKernelGGL(kin_transpose_kernel<true>, grid, block, lds, st, file_rows, file_stride_w, n_rows, S_f, S_pad, min_count, T, n_rw, n_used, rpb);
+    else
+        hipLaunchKernelGGL(kin_transpose_kernel<false>, grid, block, lds, st, file_rows, file_stride_w, n_rows, S_f, S_pad, min_count, T, n_rw, n_used, rpb);
     return hipGetLastError();
 }
 
