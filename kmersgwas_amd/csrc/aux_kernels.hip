@@ -169,12 +169,108 @@ __global__ void __launch_bounds__(256) dense_select_kernel(const double* dense, 
     }
 }
 
+// The same selection for chunks of up to 16 x 1024 rows (the first dense chunk is 11 776 at N = 10 001), which is every scan's
+// first 0.2 ms with the kernel above - nine passes over the column in L2, and the scores of a column share their sign, exponent
+// and leading mantissa bits, so in the first passes all 256 threads' atomics land in one or two bins: a block of 1024 threads
+// keeps the keys in registers (read once), and a wave whose active lanes all fall into one bin adds their count with one
+// atomic: the dense start of a one-column scan 0.49-0.51 -> 0.33-0.41 ms (KGWAS_DSEL_REG=0: the kernel above).
+constexpr int DSEL_KPT = 16;
+__global__ void __launch_bounds__(1024) dense_select_reg_kernel(const double* dense, const uint32_t* n1, uint32_t n_rows, uint32_t S,
+                                                                uint32_t min_count, const uint64_t* topn, double* thr_a, double* thr_b,
+                                                                double* thr_host_copy, uint32_t* info) {
+    __shared__ uint32_t hist[256];
+    __shared__ unsigned long long prefix_s, need_s;
+    __shared__ uint32_t kept_s, nan_s;
+    const uint32_t p = blockIdx.x, t = threadIdx.x, lane = t & 63u;
+    const double* sc = dense + (size_t)p * n_rows;
+    if (t == 0) {
+        kept_s = 0;
+        nan_s = 0;
+    }
+    __syncthreads();
+    unsigned long long key[DSEL_KPT];
+    uint32_t valid = 0, kcnt = 0, bad = 0;
+#pragma unroll
+    for (int i = 0; i < DSEL_KPT; i++) {
+        const uint32_t r = t + (uint32_t)i * 1024u;
+        key[i] = 0;
+        if (r < n_rows) {
+            const uint32_t c = n1[r];
+            if (S >= min_count && c >= min_count && c <= S - min_count) {
+                const double v = sc[r];
+                bad |= (v != v) ? 1u : 0u;
+                const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+                key[i] = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+                valid |= 1u << i;
+                kcnt++;
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) kcnt += __shfl_xor(kcnt, o);
+    if (lane == 0 && kcnt) atomicAdd(&kept_s, kcnt);
+    if (__ballot(bad != 0u) && lane == 0) atomicOr(&nan_s, 1u);
+    __syncthreads();
+    const uint32_t kept = kept_s;
+    if (p == 0 && t == 0) info[0] = kept;
+    if (t == 0 && nan_s) atomicOr(&info[1], 1u);
+    const unsigned long long N = topn[p];
+    if (kept < N || nan_s) return;  // (block-uniform) not enough rows to fill this heap: the caller falls back
+    if (t == 0) {
+        prefix_s = 0;
+        need_s = N;
+    }
+    for (int byte = 7; byte >= 0; byte--) {
+        if (t < 256u) hist[t] = 0;
+        __syncthreads();
+        const unsigned long long prefix = prefix_s;
+#pragma unroll
+        for (int i = 0; i < DSEL_KPT; i++) {
+            const bool act = ((valid >> i) & 1u) && (byte == 7 || (key[i] >> (8 * (byte + 1))) == prefix);
+            const unsigned long long m = __ballot(act);
+            if (!m) continue;  // (wave-uniform)
+            const uint32_t bin = (uint32_t)(key[i] >> (8 * byte)) & 255u;
+            const int first = __ffsll((long long)m) - 1;
+            const uint32_t b0 = (uint32_t)__shfl((int)bin, first);
+            if (__ballot(act && bin == b0) == m) {
+                if ((int)lane == first) atomicAdd(&hist[b0], (uint32_t)__popcll(m));
+            } else if (act) {
+                atomicAdd(&hist[bin], 1u);
+            }
+        }
+        __syncthreads();
+        if (t == 0) {
+            unsigned long long need = need_s;
+            int b = 255;
+            for (; b > 0; b--) {
+                if (hist[b] >= need) break;
+                need -= hist[b];
+            }
+            need_s = need;
+            prefix_s = (prefix << 8) | (unsigned long long)b;
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        const unsigned long long k = prefix_s;
+        const unsigned long long b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+        const double v = __longlong_as_double((long long)b);
+        thr_a[p] = v;
+        thr_b[p] = v;
+        thr_host_copy[p] = v;
+    }
+}
+
 hipError_t launch_dense_select(const double* dense, const uint32_t* n1, uint32_t n_rows, uint32_t n_pheno, uint32_t S, uint32_t min_count,
                                const uint64_t* topn, double* thr_a, double* thr_b, double* thr_host_copy, uint32_t* info, hipStream_t st) {
     hipError_t e = hipMemsetAsync(info, 0, 2 * sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(dense_select_kernel, dim3(n_pheno), dim3(256), 0, st, dense, n1, n_rows, S, min_count, topn, thr_a, thr_b,
-                       thr_host_copy, info);
+    static const bool reg_ok = !(getenv("KGWAS_DSEL_REG") && atoi(getenv("KGWAS_DSEL_REG")) == 0);  // experiments: 0 = the first version
+    if (reg_ok && n_rows <= (uint32_t)DSEL_KPT * 1024u)
+        hipLaunchKernelGGL(dense_select_reg_kernel, dim3(n_pheno), dim3(1024), 0, st, dense, n1, n_rows, S, min_count, topn, thr_a, thr_b,
+                           thr_host_copy, info);
+    else
+        hipLaunchKernelGGL(dense_select_kernel, dim3(n_pheno), dim3(256), 0, st, dense, n1, n_rows, S, min_count, topn, thr_a, thr_b,
+                           thr_host_copy, info);
     return hipGetLastError();
 }
 
