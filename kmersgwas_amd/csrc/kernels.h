@@ -70,6 +70,9 @@ constexpr uint32_t HIST_BINS = 16384;   // 64 binades above the threshold at spa
 // thr[p] = max(thr[p], thr_host[p], largest bin boundary with >= topn[p] counted scores at or above it).
 hipError_t launch_copy_to_host(const void* src, void* dst_dev, size_t bytes, hipStream_t st);  // dst_dev: device address of mapped pinned memory
 // device pointers of the (mapped) pinned destination
+// a chunk's counts, tested-row shards and current thresholds into mapped host buffers, one launch (n_* = 0: skip that part)
+hipError_t launch_chunk_tail(const uint32_t* meta, uint32_t n_meta, uint32_t* h_meta, const unsigned long long* tested, uint32_t n_tested,
+                             unsigned long long* h_tested, const double* thr, uint32_t n_thr, double* h_thr, hipStream_t st);
 hipError_t launch_records_to_host(const double* sc, const uint64_t* km, const uint32_t* rw, uint32_t n, double* h_sc, uint64_t* h_km, uint32_t* h_rw,
                                   hipStream_t st);
 hipError_t launch_thr_update(const uint32_t* hist, const uint32_t* hist_base, uint32_t bins, const uint64_t* topn,

@@ -1000,6 +1000,8 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                 sl.h_thr.alloc(P);
                 memset(sl.h_thr.p, 0, P * sizeof(double));
                 memset(sl.h_meta.p, 0, (2 * P + 4) * sizeof(uint32_t));
+                sl.h_meta_dev = sl.h_meta.dev();
+                sl.h_thr_dev = sl.h_thr.dev();
                 KGWAS_HIP(hipEventCreateWithFlags(&sl.ev_counts, hipEventBlockingSync));
             } else {
                 sl.cand.alloc((uint64_t)s->cap * P);
@@ -1009,6 +1011,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
             sl.h_cnt.alloc(P);
             sl.d_tested.alloc(TESTED_SHARDS);
             sl.h_tested.alloc(TESTED_SHARDS);
+            sl.h_tested_dev = sl.h_tested.dev();
             KGWAS_HIP(hipEventCreate(&sl.ev_sq0));
             KGWAS_HIP(hipEventCreate(&sl.ev_k0));
             KGWAS_HIP(hipEventCreate(&sl.ev_k1));

@@ -450,11 +450,21 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
     if (s->hist_ready && !fused_tail)  // raise the thresholds for whatever is queued next; no host round trip
         KGWAS_HIP(launch_thr_update(s->d_hist.p, s->d_hist_base.p, HIST_BINS, s->d_topn.p, s->d_thr_host.p, s->d_thr.p,
                                     (uint32_t)s->n_pheno, s->stream));
-    if (!fused_tail)
+    static const bool tail_kernel = !(getenv("KGWAS_TAIL_KERNEL") && atoi(getenv("KGWAS_TAIL_KERNEL")) == 0);  // experiments: 0 = hipMemcpyAsync calls
+    const bool one_launch = use_coarse && tail_kernel && sl.h_meta_dev;
+    if (!fused_tail && !one_launch)
         KGWAS_HIP(hipMemcpyAsync(sl.h_tested.p, sl.d_tested.p, TESTED_SHARDS * sizeof(unsigned long long), hipMemcpyDeviceToHost,
                                  s->stream));
     sl.tested_in_meta = fused_tail;
-    if (use_coarse) {
+    if (one_launch) {
+        // counts, tested-row shards and - for the columns in select mode, which bound their pools with them - the device's
+        // thresholds as they stand behind this chunk: one launch into the mapped buffers; the record copies follow on the copy
+        // stream once the control thread has read the counts (fetch_records)
+        const bool thr_too = s->lazy_any.load(std::memory_order_relaxed);
+        KGWAS_HIP(launch_chunk_tail(sl.d_meta.p, (uint32_t)(2 * s->n_pheno + 4), sl.h_meta_dev, sl.d_tested.p, fused_tail ? 0u : (uint32_t)TESTED_SHARDS,
+                                    sl.h_tested_dev, s->d_thr.p, thr_too ? (uint32_t)s->n_pheno : 0u, sl.h_thr_dev, s->stream));
+        KGWAS_HIP(hipEventRecord(sl.ev_counts, s->stream));
+    } else if (use_coarse) {
         // the record copies follow on the copy stream once the control thread has read the counts (fetch_records)
         KGWAS_HIP(hipMemcpyAsync(sl.h_meta.p, sl.d_meta.p, (2 * s->n_pheno + 4) * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
         // (columns in select mode prune their pools with the device's thresholds as they stand behind this chunk)

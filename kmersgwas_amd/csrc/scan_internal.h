@@ -395,6 +395,9 @@ struct Slot {
     DevBuf<uint32_t> d_so_row;
     DevBuf<uint32_t> d_meta;
     PinBuf<uint32_t> h_meta;
+    uint32_t* h_meta_dev = nullptr;  // the mapped buffers' device addresses (launch_chunk_tail)
+    double* h_thr_dev = nullptr;
+    unsigned long long* h_tested_dev = nullptr;
     PinBuf<double> h_thr;  // the device's thresholds behind this chunk (columns in select mode prune their pools with them, scan_lazy.cpp)
     bool tie_check = false;          // columns in select mode look at their pools for ties after this chunk (scan_lazy.cpp)
     bool tested_in_meta = false;     // the chunk's MAC-passing rows came in h_meta (narrow scans), not in h_tested
