@@ -108,6 +108,17 @@ int kgwas_heap_rows_sorted(const kgwas_heap* h, uint64_t* row);
 int kgwas_heap_output_to_file(const kgwas_heap* h, const char* path, int with_scores);
 void kgwas_heap_free(kgwas_heap* h);
 
+/* Test hook: one phenotype column's select-or-replay decision on the host alone (scan_lazy.cpp). The records
+ * of n_chunks chunks (chunk c: chunk_n[c] records, rows chunk_row0[c] + row_in_chunk[i], ascending; a score of -inf is a
+ * placeholder and no record) are logged - by reference into the caller's arrays (by_ref != 0) or by copy, the logs detached from
+ * the caller's arrays behind chunk `detach_after_chunk` (< 0: never) - with chunk_thr[c] as the device's threshold behind chunk c
+ * (any lower bound of the N-th largest score up to there; 0: none). Then the column is finished: *selected = 1 if its N + 1
+ * largest scores were pairwise distinct, none NaN or negative, and the lists were made by selection; 0 if its log was replayed
+ * through the heap mirror. out_*: the result lists in ascending pop order (room for topn entries), *out_n their length. */
+int kgwas_select_check(uint64_t topn, uint64_t n_chunks, const uint64_t* chunk_n, const uint64_t* chunk_row0, const double* chunk_thr,
+                       const double* score, const uint64_t* kmer, const uint32_t* row_in_chunk, int by_ref, int64_t detach_after_chunk,
+                       int* selected, uint64_t* out_kmer, double* out_score, uint64_t* out_row, uint64_t* out_n);
+
 /* ------------------------------------------------------------------------------------
  * Association scan session = pass 1 of associate_kmers (src/associate_kmers.cpp:99-148):
  * MultipleKmersDataBases::load_kmers (MAC filter + squeeze, :103-146),

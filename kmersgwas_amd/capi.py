@@ -27,7 +27,7 @@ SYMBOLS = [
     "kgwas_table_close",
     "kgwas_pheno_load", "kgwas_pheno_info", "kgwas_pheno_name", "kgwas_pheno_accession", "kgwas_pheno_values",
     "kgwas_pheno_free", "kgwas_min_count",
-    "kgwas_heap_new", "kgwas_heap_add_many", "kgwas_heap_size", "kgwas_heap_pop_all", "kgwas_heap_output_list", "kgwas_heap_rows_sorted", "kgwas_heap_output_to_file",
+    "kgwas_heap_new", "kgwas_heap_add_many", "kgwas_heap_size", "kgwas_heap_pop_all", "kgwas_heap_output_list", "kgwas_heap_rows_sorted", "kgwas_heap_output_to_file", "kgwas_select_check",
     "kgwas_heap_free",
     "kgwas_scan_create", "kgwas_scan_feed_device", "kgwas_scan_feed_host", "kgwas_scan_feed_table", "kgwas_scan_finish", "kgwas_scan_result",
     "kgwas_scan_history", "kgwas_scan_get_stats", "kgwas_scan_reset", "kgwas_scan_lowest", "kgwas_scan_absorb", "kgwas_scan_history_above", "kgwas_scan_heaps_export", "kgwas_scan_heaps_import", "kgwas_scan_expect_finish", "kgwas_scan_history_above_msgs", "kgwas_scan_heaps_export_msgs", "kgwas_scan_destroy", "kgwas_scan_scores_dense",
@@ -166,6 +166,7 @@ lib.kgwas_heap_pop_all.argtypes = [_vp, _vp, _vp, _vp]
 lib.kgwas_heap_output_list.argtypes = [_vp, _vp, _vp, _vp]
 lib.kgwas_heap_rows_sorted.argtypes = [_vp, _vp]
 lib.kgwas_heap_output_to_file.argtypes = [_vp, C.c_char_p, C.c_int]
+lib.kgwas_select_check.argtypes = [C.c_uint64, C.c_uint64, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int64, C.POINTER(C.c_int), _vp, _vp, _vp, C.POINTER(C.c_uint64)]
 lib.kgwas_heap_free.argtypes = [_vp]
 lib.kgwas_heap_free.restype = None
 lib.kgwas_scan_create.argtypes = [C.POINTER(ScanParams), _pp]

@@ -392,3 +392,45 @@ void lazy_finish_column(kgwas_scan* s, size_t j, bool known_tie) {
 }
 
 }  // namespace kgwas
+
+// The select-or-replay decision of one column on the host alone (include/kgwas.h, kgwas_select_check): the CPU suite feeds it
+// record streams with and without ties and holds the lists against the heap mirror's.
+extern "C" int kgwas_select_check(uint64_t topn, uint64_t n_chunks, const uint64_t* chunk_n, const uint64_t* chunk_row0, const double* chunk_thr,
+                                  const double* score, const uint64_t* kmer, const uint32_t* row_in_chunk, int by_ref,
+                                  int64_t detach_after_chunk, int* selected, uint64_t* out_kmer, double* out_score, uint64_t* out_row,
+                                  uint64_t* out_n) {
+    using namespace kgwas;
+    return guarded([&] {
+        if (!topn || !chunk_n || !selected || !out_n) throw Error(KGWAS_ERR_ARG, "kgwas_select_check: bad argument");
+        LazyCol L;
+        L.reset(true, topn);
+        size_t at = 0;
+        for (uint64_t c = 0; c < n_chunks; c++) {
+            const uint32_t n = (uint32_t)chunk_n[c];
+            uint64_t tb;
+            memcpy(&tb, &chunk_thr[c], 8);
+            L.take_chunk(score + at, kmer + at, row_in_chunk + at, n, chunk_row0[c], tb, by_ref != 0);
+            at += n;
+            if ((int64_t)c == detach_after_chunk) L.detach();
+        }
+        std::vector<uint64_t> km, rw;
+        std::vector<double> sc;
+        if (L.select(km, sc, rw)) {
+            *selected = 1;
+        } else {
+            *selected = 0;
+            BestHeap h((size_t)topn);
+            const double none = -std::numeric_limits<double>::infinity();
+            L.for_each([&](double s_, uint64_t k_, uint64_t r_) {
+                if (s_ != none) h.add(k_, s_, (size_t)r_);
+            });
+            h.pop_all(km, sc, rw);
+        }
+        *out_n = km.size();
+        for (size_t i = 0; i < km.size(); i++) {
+            if (out_kmer) out_kmer[i] = km[i];
+            if (out_score) out_score[i] = sc[i];
+            if (out_row) out_row[i] = rw[i];
+        }
+    });
+}

@@ -7,6 +7,7 @@ import re
 import subprocess
 import sys
 
+import ctypes as C
 import numpy as np
 import pytest
 
@@ -174,6 +175,76 @@ def test_heap_mirror_equals_oracle_heap_under_ties(N, n, levels, flavour):
         both[:, 0] = ok
         both[:, 1] = os_.view(np.uint64)
         assert open(os.path.join(d, "ks"), "rb").read() == both.tobytes()
+
+
+@pytest.mark.parametrize("by_ref,detach", [(1, -1), (0, -1), (1, 2), (1, 0)])
+@pytest.mark.parametrize("N,n_chunks,per,flavour", [
+    (500, 12, 900, "distinct"), (500, 12, 900, "tie_inside"), (500, 12, 900, "tie_at_boundary"), (500, 12, 900, "tie_below"),
+    (500, 12, 900, "nan"), (500, 12, 900, "negative"), (500, 12, 900, "placeholders"), (500, 12, 900, "levels"),
+    (5000, 3, 700, "distinct"), (1, 5, 50, "distinct"), (64, 40, 300, "late_tie")])
+def test_select_mode_decision_equals_the_oracle_heap(N, n_chunks, per, flavour, by_ref, detach):
+    """scan_lazy.cpp on the host alone (kgwas_select_check): a column's records arrive in chunks, each with a threshold that is
+    some lower bound of the N-th largest score so far; the column is finished by SELECTION iff its N + 1 largest scores are
+    pairwise distinct and no score is NaN or negative, by a replay of its log otherwise - and its lists equal the oracle's
+    std::priority_queue either way. Logs by reference and by copy, detached from the caller's arrays mid-stream, pools pruned
+    with the thresholds, -inf placeholders (the narrow filter's survivors that are no candidates), heaps that never fill."""
+    rng = np.random.default_rng(N * 7 + n_chunks * 13 + per + len(flavour))
+    n = n_chunks * per
+    score = rng.permutation(n).astype(np.float64) * 0.37 + rng.random(n) * 0.1  # all different, all positive
+    order = np.argsort(score)
+    top = order[-min(N, n):]  # ascending: top[0] is the N-th largest
+    expect_selected = 1
+    if flavour == "tie_inside":
+        score[top[len(top) // 2]] = score[top[-1]]
+        expect_selected = 0
+    elif flavour == "tie_at_boundary" and n > N:
+        score[order[-N - 1]] = score[top[0]]  # the (N + 1)-th largest equals the N-th
+        expect_selected = 0
+    elif flavour == "tie_below" and n > N + 3:
+        score[order[-N - 3]] = score[order[-N - 2]]  # two equal scores that are not among the N + 1 largest: no matter
+    elif flavour == "late_tie":
+        last = np.arange(n - per, n)
+        a = last[np.argmax(score[last])]
+        score[a] = score[top[-1]] if top[-1] != a else score[top[-2]]  # a row of the LAST chunk repeats one of the best scores
+        expect_selected = 0
+    elif flavour == "nan":
+        score[rng.integers(0, n)] = np.nan
+        expect_selected = 0
+    elif flavour == "negative":
+        score[rng.integers(0, n)] = -0.0
+        expect_selected = 0
+    elif flavour == "levels":
+        score = rng.integers(0, 40, size=n).astype(np.float64) / 8.0
+        expect_selected = 0
+    if flavour == "placeholders":
+        score[rng.random(n) < 0.2] = -np.inf
+    kmer = (np.arange(n, dtype=np.uint64) * 5 + 11)
+    row_in_chunk = np.tile(np.arange(per, dtype=np.uint32) * 2, n_chunks)
+    chunk_row0 = (np.arange(n_chunks, dtype=np.uint64) * (2 * per + 3))
+    chunk_n = np.full(n_chunks, per, np.uint64)
+    # thresholds: the N-th largest real score up to the end of each chunk, lowered by a random bit (0 while there are fewer than N)
+    thr = np.zeros(n_chunks)
+    for c in range(n_chunks):
+        seen = score[: (c + 1) * per]
+        seen = seen[np.isfinite(seen) & (seen >= 0)]
+        if len(seen) >= N and flavour not in ("nan", "negative"):
+            thr[c] = np.partition(seen, len(seen) - N)[len(seen) - N] * (1.0 - 0.004 * rng.random())
+    real = score != -np.inf
+    rows = (np.repeat(chunk_row0, per) + row_in_chunk)
+    o = ob.Heap(N)
+    o.add_many(kmer[real], score[real], rows[real])
+    ek, es, er = o.pop_all()
+    sel = C.c_int(-1)
+    out_n = C.c_uint64(0)
+    ok_ = np.zeros(N, np.uint64); os_ = np.zeros(N, np.float64); or_ = np.zeros(N, np.uint64)
+    from kmersgwas_amd import capi
+    rc = capi.lib.kgwas_select_check(N, n_chunks, chunk_n.ctypes.data, chunk_row0.ctypes.data, thr.ctypes.data, score.ctypes.data, kmer.ctypes.data,
+                                     row_in_chunk.ctypes.data, by_ref, detach, C.byref(sel), ok_.ctypes.data, os_.ctypes.data, or_.ctypes.data, C.byref(out_n))
+    assert rc == 0, capi.last_error() if hasattr(capi, "last_error") else rc
+    m = out_n.value
+    assert m == len(ek)
+    assert ok_[:m].tobytes() == ek.tobytes() and os_[:m].tobytes() == es.tobytes() and or_[:m].tobytes() == er.tobytes()
+    assert sel.value == expect_selected, (flavour, sel.value)
 
 
 def _python_history(kmer, score, row, N):
