@@ -280,7 +280,7 @@ def _late_dup_table(n, S, seed, first_dup_row, dup_frac):
     return rows
 
 
-@pytest.mark.parametrize("full_replay", [0, 1])
+@pytest.mark.parametrize("full_replay", [0, 1, 2])  # (2: select mode on two host threads - more columns to replay at the feed's tail than workers)
 @pytest.mark.parametrize("S,P,topn,n,kind", [
     (1024, 40, 2001, 120_000, "clean"),    # no two rows share a pattern: every column is finished by selection
     (1024, 40, 2001, 120_000, "late"),     # ties only among rows far behind the dense start: columns stay in select mode and are replayed at finish
@@ -295,6 +295,8 @@ def test_tie_free_columns_are_selected_not_replayed(monkeypatch, S, P, topn, n, 
     that fail that test go through the exact replay: at once if the first dense chunk shows a tie, at finish (from the log) if
     a tie turns up later. Lists equal the oracle's (a literal std::priority_queue) in all cases, with KGWAS_FULL_REPLAY=1 (every
     column replayed, push counts equal) and without; three feeds with the finish hint, then a reset and one feed."""
+    few_threads = full_replay == 2
+    full_replay = 1 if full_replay == 1 else 0
     monkeypatch.setenv("KGWAS_FULL_REPLAY", str(full_replay))
     if kind == "late":
         rows = _late_dup_table(n, S, seed=S + P, first_dup_row=30_000, dup_frac=0.5)
@@ -304,7 +306,7 @@ def test_tie_free_columns_are_selected_not_replayed(monkeypatch, S, P, topn, n, 
     Y = phenotypes(S, P - 1, seed=P + 5, binary=(kind == "binary"))
     mac = onp.min_count(S, 0.05, 5)
     exp = ob.associate(rows, S, col, Y, topn, mac, batch_size=20_000, threads=4)
-    scan = kg.AssociationScan(S, col, Y, topn, mac, chunk_rows=8192)
+    scan = kg.AssociationScan(S, col, Y, topn, mac, chunk_rows=8192, **({"host_threads": 2} if few_threads else {}))
     for rep in range(2):
         if rep == 0:
             a, b = n // 3, 2 * n // 3 + 11
