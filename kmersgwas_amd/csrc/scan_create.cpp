@@ -1091,10 +1091,11 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
             if (const char* e = getenv("KGWAS_SPLIT_LAGGING")) s->split_lagging = atoi(e) != 0;
             if (const char* e = getenv("KGWAS_FLOAT_LEAD")) s->float_lead = (uint64_t)std::max(0, atoi(e));
             if (const char* e = getenv("KGWAS_DEBUG_SLOW_WORKER")) {
-                int w = -1, pct = 100;
-                if (sscanf(e, "%d:%d", &w, &pct) >= 1) {
+                int w = -1, pct = 100, min_us = 0;
+                if (sscanf(e, "%d:%d:%d", &w, &pct, &min_us) >= 1) {
                     s->dbg_slow_worker = w;
                     s->dbg_slow_pct = pct;
+                    s->dbg_slow_min_us = min_us;
                 }
             }
             s->slot_left.reset(new std::atomic<uint32_t>[MAX_SLOTS]);

@@ -594,7 +594,7 @@ struct kgwas_scan {
     bool split_lagging = true;                     // KGWAS_SPLIT_LAGGING=0: groups stay whole
     uint64_t float_lead = 2;                       // KGWAS_FLOAT_LEAD=n: a home group n chunks behind the foremost one floats (0: never)
     std::atomic<uint64_t> n_floated{0};
-    int dbg_slow_worker = -1, dbg_slow_pct = 0;    // KGWAS_DEBUG_SLOW_WORKER=w:pct - worker w idles pct % of every unit's time on top (a busy co-tenant on its CPU)
+    int dbg_slow_worker = -1, dbg_slow_pct = 0, dbg_slow_min_us = 0;  // KGWAS_DEBUG_SLOW_WORKER=w:pct[:min_us] - worker w idles pct % of every unit's time on top (a busy co-tenant on its CPU), at least min_us microseconds (tests: a lag that does not depend on how long a unit takes)
     std::atomic<uint64_t> n_splits{0};
     std::atomic<uint64_t> seq_submitted{0}, seq_published{0}, seq_replayed{0};
     std::atomic<bool> rp_quit{false}, rp_failed{false};

@@ -368,7 +368,7 @@ void replay_worker(kgwas_scan* s, size_t w) {
                 replay_group(s, s->slot[si], best, acc);
                 if ((int)w == s->dbg_slow_worker) {  // experiments: this worker's CPU is shared with somebody else
                     const auto dur = std::chrono::steady_clock::now() - tu0;
-                    const auto until = std::chrono::steady_clock::now() + dur * s->dbg_slow_pct / 100;
+                    const auto until = std::chrono::steady_clock::now() + std::max<std::chrono::steady_clock::duration>(dur * s->dbg_slow_pct / 100, std::chrono::microseconds(s->dbg_slow_min_us));
                     while (std::chrono::steady_clock::now() < until) __builtin_ia32_pause();
                 }
                 if (s->trace && (NG <= 4 || best == 0))

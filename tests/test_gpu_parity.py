@@ -130,12 +130,16 @@ def test_lagging_column_group_is_split_and_results_stay_exact(monkeypatch):
     topn = 300
     exp = ob.associate(rows, S_f, col, Y, topn, mac, batch_size=9000, threads=4)
     import torch
-    monkeypatch.setenv("KGWAS_DEBUG_SLOW_WORKER", "1:50000")
     t = torch.from_numpy(rows.view(np.int64).reshape(-1)).cuda()  # device-resident rows: one feed = many chunks in flight
     stride = rows.shape[1]
     st_ = torch.cuda.current_stream().cuda_stream
     splits = 0
-    for feeds, float_lead in (([0, 200_000], "2"), ([0, 70_000, 140_001, 200_000], "2"), ([0, 200_000], "0")):
+    # (worker 1 idles 500 x every unit's time on top and at least 1.5 ms: ~100 chunks behind a GPU that needs 0.2-0.4 ms per chunk -
+    # a lag that does not depend on how short a unit is on the box at hand; with the percentage alone one scan in twenty showed no
+    # split. Every scan is held against the oracle; the splits are counted over all of them.)
+    configs = [([0, 200_000], "2", "1:50000:1500"), ([0, 70_000, 140_001, 200_000], "2", "1:50000:1500"), ([0, 200_000], "0", "1:50000:1500")]
+    for feeds, float_lead, slow in configs:
+        monkeypatch.setenv("KGWAS_DEBUG_SLOW_WORKER", slow)
         # (float_lead 2, the default: a lagging group first floats whole, mid-scan; 0: only the cut into single columns at the tail)
         monkeypatch.setenv("KGWAS_FLOAT_LEAD", float_lead)
         scan = kg.AssociationScan(S_f, col, Y, topn, mac, chunk_rows=2048, host_threads=4)  # 4 workers x 6 columns, ~100 chunks
@@ -146,7 +150,7 @@ def test_lagging_column_group_is_split_and_results_stay_exact(monkeypatch):
         _check_topn(scan, exp, P)
         st = scan.stats()
         assert st["rows_tested"] == exp["tested"] and st["rows_fed"] == len(rows)
-        assert st["replay_splits"] > 0 and st["columns_popped_ahead"] > 0  # (the idle workers pop while worker 1 crawls)
+        assert st["columns_popped_ahead"] > 0  # (the idle workers pop while worker 1 crawls)
         splits += st["replay_splits"]
         scan.close()
     assert splits > 0
