@@ -181,7 +181,8 @@ def test_heap_mirror_equals_oracle_heap_under_ties(N, n, levels, flavour):
 @pytest.mark.parametrize("N,n_chunks,per,flavour", [
     (500, 12, 900, "distinct"), (500, 12, 900, "tie_inside"), (500, 12, 900, "tie_at_boundary"), (500, 12, 900, "tie_below"),
     (500, 12, 900, "nan"), (500, 12, 900, "negative"), (500, 12, 900, "placeholders"), (500, 12, 900, "levels"),
-    (5000, 3, 700, "distinct"), (1, 5, 50, "distinct"), (64, 40, 300, "late_tie")])
+    (5000, 3, 700, "distinct"), (1, 5, 50, "distinct"), (64, 40, 300, "late_tie"),
+    (300, 30, 800, "no_thresholds"), (300, 30, 800, "no_thresholds_tie")])
 def test_select_mode_decision_equals_the_oracle_heap(N, n_chunks, per, flavour, by_ref, detach):
     """scan_lazy.cpp on the host alone (kgwas_select_check): a column's records arrive in chunks, each with a threshold that is
     some lower bound of the N-th largest score so far; the column is finished by SELECTION iff its N + 1 largest scores are
@@ -216,6 +217,9 @@ def test_select_mode_decision_equals_the_oracle_heap(N, n_chunks, per, flavour, 
     elif flavour == "levels":
         score = rng.integers(0, 40, size=n).astype(np.float64) / 8.0
         expect_selected = 0
+    elif flavour == "no_thresholds_tie":
+        score[top[3]] = score[top[7]]
+        expect_selected = 0
     if flavour == "placeholders":
         score[rng.random(n) < 0.2] = -np.inf
     kmer = (np.arange(n, dtype=np.uint64) * 5 + 11)
@@ -227,7 +231,8 @@ def test_select_mode_decision_equals_the_oracle_heap(N, n_chunks, per, flavour, 
     for c in range(n_chunks):
         seen = score[: (c + 1) * per]
         seen = seen[np.isfinite(seen) & (seen >= 0)]
-        if len(seen) >= N and flavour not in ("nan", "negative"):
+        # (no_thresholds: the device never raised a bound - the pool is cut by selection alone, LazyCol::compact)
+        if len(seen) >= N and flavour not in ("nan", "negative", "no_thresholds", "no_thresholds_tie"):
             thr[c] = np.partition(seen, len(seen) - N)[len(seen) - N] * (1.0 - 0.004 * rng.random())
     real = score != -np.inf
     rows = (np.repeat(chunk_row0, per) + row_in_chunk)
