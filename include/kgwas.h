@@ -91,7 +91,14 @@ uint64_t kgwas_min_count(uint64_t n_acc, double maf, uint64_t mac);
  * test boxes. A libstdc++ whose heap algorithms move elements differently would fail those tests;
  * the reference itself would then produce different tie orders with it.
  * Used by the scan for its host-side replay and exposed for cross-shard merges.
+ * RUN-TIME GUARD (csrc/heap_guard.cpp): once per process, before the first heap or session exists, a fixed stream of ties, NaNs,
+ * negative and infinite scores goes through the emulation (single pushes and the lockstep form) and through a literal
+ * std::priority_queue over the reference's tuple / comparator of THE LIBSTDC++ THIS PROCESS RUNS WITH; on any difference
+ * kgwas_heap_new, kgwas_scan_create, kgwas_multiscan_create and kgwas_snps_* return KGWAS_ERR_STATE. kgwas_heap_selfcheck(0) runs
+ * (or re-reports) that check; kgwas_heap_selfcheck(1) is a test hook that holds the emulation against a reference with a
+ * DIFFERENT tie rule and must therefore fail.
  * ---------------------------------------------------------------------------------- */
+int kgwas_heap_selfcheck(uint32_t flags);
 typedef struct kgwas_heap kgwas_heap;
 int kgwas_heap_new(uint64_t max_results, kgwas_heap** out);
 /* add_association for n entries in the given order. */
@@ -253,8 +260,15 @@ void kgwas_scan_destroy(kgwas_scan* s);
  * Exactness: the heap of shard 0 is what a single scan holds after those rows; an entry of shard g >= 1
  * whose score is not above max(final minima of the full heaps of shards < g) is rejected by
  * add_association whenever it arrives, so the sender may drop it. counts/kmer/score/row as in
- * kgwas_merge_shards (shards in row order, all after this scan's rows). Call kgwas_scan_finish again. */
-int kgwas_scan_lowest(const kgwas_scan* s, double* lowest, uint8_t* full);
+ * kgwas_merge_shards (shards in row order, all after this scan's rows). Call kgwas_scan_finish again.
+ * kgwas_scan_lowest MUTATES the session (it is not a read-only query): for columns in select mode it brings their pools up to
+ * date and may run a selection, and a column that saw a NaN or negative score is given its heap (its log replayed, heap_pushes
+ * grows). It must not overlap a feed or another call on the same session.
+ * kgwas_scan_select_mode: *on = 1 if the session keeps its columns in select mode (logs + pools, result lists by selection where
+ * the scores decide) - i.e. a filter session without a full push log and without KGWAS_FULL_REPLAY=1 -, 0 if
+ * every column is replayed as it streams (exact-scorer sessions among them). Merge layers use it to pick their route. */
+int kgwas_scan_lowest(kgwas_scan* s, double* lowest, uint8_t* full);
+int kgwas_scan_select_mode(const kgwas_scan* s, int* on);
 int kgwas_scan_absorb(kgwas_scan* s, uint64_t n_shards, const uint64_t* counts, const uint64_t* const* kmer,
                       const double* const* score, const uint64_t* const* row);
 /* The part of the recorded history that can still matter after heaps whose minima are thr[j]: entries with

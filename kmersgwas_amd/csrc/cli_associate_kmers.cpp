@@ -127,22 +127,27 @@ int main(int argc, char* argv[]) {
         sp.topn = topn.data();
         sp.min_count = min_count;
         sp.chunk_rows = 0;
-        // --parallel: the reference's pool of scoring tasks (src/associate_kmers.cpp:104-148), 4 by default and 1 from the
-        // pipeline (src/py/pipeline_parser.py:31). Here the host threads replay heap pushes beside the GPU(s), and fewer
-        // than the CPUs this process may use only makes the scan host-bound: when the option is absent or is the
-        // pipeline's 1 the pool takes the CPUs the process may use (cgroup quota, affinity mask); an explicit N > 1 is the
-        // user's cap, as in the reference, and is kept (KGWAS_STRICT_PARALLEL=1 keeps a 1 too).
-        uint64_t replay_threads = threads ? threads : 1;
+        // --parallel: the reference's pool of scoring tasks (src/associate_kmers.cpp:66, 104-148), 4 by default and 1 from the
+        // pipeline (src/py/pipeline_parser.py:31). Here the host threads replay heap pushes beside the GPU(s). The argument is
+        // HONOURED as the reference honours it - on a shared node the user's cap is the user's cap -; a value below the CPUs
+        // this process may use only earns a hint on stderr, because the scan may then be host-bound. Opt-in: `--parallel 0`
+        // (the reference has no use for 0) or KGWAS_AUTO_PARALLEL=1 take every CPU the process may use (cgroup quota,
+        // affinity mask). Results never depend on it.
+        uint64_t replay_threads = threads;
         {
             const uint64_t quota = kgwas_host_cpu_quota();
-            const char* strict = getenv("KGWAS_STRICT_PARALLEL");
-            const bool is_default = !vm.count("parallel") || threads <= 1;
-            if (!(strict && atoi(strict) != 0) && is_default && replay_threads < quota) {
+            const char* autop = getenv("KGWAS_AUTO_PARALLEL");
+            if (threads == 0 || (autop && atoi(autop) != 0)) {
+                replay_threads = std::max<uint64_t>(quota, 1);
+                cerr << "[kgwas] --parallel " << (threads ? "overridden by KGWAS_AUTO_PARALLEL" : "0") << ": " << replay_threads
+                     << " replay threads (the CPUs this process may use)" << endl;
+            } else if (replay_threads < quota) {
                 cerr << "[kgwas] --parallel " << threads << (vm.count("parallel") ? "" : " (default)") << " is below the " << quota
-                     << " CPUs this process may use: " << quota << " replay threads (KGWAS_STRICT_PARALLEL=1 keeps --parallel)" << endl;
-                replay_threads = quota;
+                     << " CPUs this process may use: the replay keeps to " << threads
+                     << " thread(s) and may bound the scan (--parallel 0 or KGWAS_AUTO_PARALLEL=1: all of them)" << endl;
             }
         }
+        cerr << "[kgwas] replay threads requested: " << replay_threads << endl;
         sp.host_threads = (uint32_t)replay_threads;
         sp.kernel = (uint32_t)vm.u64("kernel", 0);
         sp.record_history = 0;

@@ -24,6 +24,9 @@ struct Error : std::runtime_error {
             throw ::kgwas::Error(KGWAS_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));      \
     } while (0)
 
+// heap_guard.cpp: throws KGWAS_ERR_STATE unless csrc/heap.h reproduces this process's std::priority_queue (checked once).
+void require_heap_emulation();
+
 // Run body, translate exceptions into a status code + message. No exception crosses the C ABI.
 template <class F>
 int guarded(F&& body) {

@@ -530,10 +530,16 @@ int kgwas_scan_heaps_export_msgs(kgwas_scan* s, uint64_t n_msgs, const uint64_t*
     });
 }
 
-int kgwas_scan_lowest(const kgwas_scan* cs, double* lowest, uint8_t* full) {
+int kgwas_scan_select_mode(const kgwas_scan* s, int* on) {
     return guarded([&] {
-        if (!cs || !lowest || !full) throw Error(KGWAS_ERR_ARG, "kgwas_scan_lowest: null argument");
-        kgwas_scan* s = const_cast<kgwas_scan*>(cs);
+        if (!s || !on) throw Error(KGWAS_ERR_ARG, "kgwas_scan_select_mode: null argument");
+        *on = s->lazy_enabled ? 1 : 0;
+    });
+}
+
+int kgwas_scan_lowest(kgwas_scan* s, double* lowest, uint8_t* full) {
+    return guarded([&] {
+        if (!s || !lowest || !full) throw Error(KGWAS_ERR_ARG, "kgwas_scan_lowest: null argument");
         for (uint64_t j = 0; j < s->n_pheno; j++) {
             if (s->lazy[j].on) {  // select mode: the N-th largest score logged IS the heap's minimum (scan_lazy.cpp)
                 bool f = false;
@@ -669,6 +675,7 @@ struct kgwas_heap {
 int kgwas_heap_new(uint64_t max_results, kgwas_heap** out) {
     return guarded([&] {
         if (!out || max_results == 0) throw Error(KGWAS_ERR_ARG, "kgwas_heap_new: bad argument");
+        require_heap_emulation();
         *out = new kgwas_heap((size_t)max_results);
     });
 }

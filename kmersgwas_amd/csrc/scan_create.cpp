@@ -13,6 +13,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
             throw Error(KGWAS_ERR_ARG, "kgwas_scan_create: empty problem");
         if (p->n_acc > p->n_acc_file) throw Error(KGWAS_ERR_ARG, "more phenotyped accessions than table columns");
         if (p->n_acc_file >= (1ull << 31)) throw Error(KGWAS_ERR_ARG, "too many accessions");
+        require_heap_emulation();  // tie order = libstdc++'s heap moves (src/kmer_general.h:113-128): verified against THIS process's library
         check_device(p->device);
         KGWAS_HIP(hipSetDevice(p->device));
         std::unique_ptr<kgwas_scan> s(new kgwas_scan);

@@ -73,10 +73,12 @@ void LazyCol::reserve_log(size_t need) {
 // placeholders - survivors that are no candidates, score -inf - travel along and are skipped by every reader); the device's
 // threshold behind this very chunk raises the bound. The pool sees them at the next scan_pending.
 void LazyCol::take_chunk(const double* sc, const uint64_t* km, const uint32_t* rw, uint32_t n, uint64_t row0, uint64_t thr_bits, bool by_ref) {
-    if (thr_bits <= 0x7FF0000000000000ull && (!have_bound || thr_bits > bound_bits)) {
+    // (a threshold of 0 is "none yet": it must not pass for a bound that a selection has established - lazy_lowest)
+    if (thr_bits != 0 && thr_bits <= 0x7FF0000000000000ull && (!have_bound || thr_bits > bound_bits)) {
         bound_bits = thr_bits;
         have_bound = true;
     }
+    if (n == 0) return;
     if (by_ref) {
         segs.push_back(Seg{sc, km, rw, row0, 0, n});
     } else {
@@ -98,7 +100,10 @@ void LazyCol::scan_pending() {
     uint64_t lim = have_bound ? bound_bits : 0;
     auto look = [&](uint64_t b, uint64_t km, uint64_t rw) {
         if (b > 0x7FF0000000000000ull) {  // NaN, or the sign bit set
-            if (b != NEG_INF) bad = true;  // (-inf: a narrow chunk's survivor that was no candidate)
+            if (b != NEG_INF)
+                bad = true;
+            else
+                n_logged--;  // -inf: a narrow chunk's survivor that was no candidate - no add_association call, no record (full())
             return;
         }
         pool.push_back(Ent{b, km, rw});
@@ -138,6 +143,11 @@ void LazyCol::detach() {
         total += g.n;
     }
     if (!any) return;
+    if (!total) {  // only empty references: nothing to copy, nothing left to refer to
+        segs.clear();
+        scan_seg = 0, scan_off = 0;
+        return;
+    }
     double* nsc = static_cast<double*>(malloc(std::max<size_t>(total, 1) * sizeof(double)));
     uint64_t* nkm = static_cast<uint64_t*>(malloc(std::max<size_t>(total, 1) * sizeof(uint64_t)));
     uint64_t* nrw = static_cast<uint64_t*>(malloc(std::max<size_t>(total, 1) * sizeof(uint64_t)));
@@ -340,11 +350,17 @@ bool lazy_lowest(kgwas_scan* s, size_t j, double* lowest, bool* full) {
     if (L.bad) return false;
     *full = L.full();
     if (L.full()) {
-        L.compact();
-        uint64_t v = L.bound_bits;
-        if (!L.have_bound) {  // exactly N entries so far: the smallest of them
-            v = ~0ull;
+        // The heap's minimum is the N-th largest score logged. More than N entries in the pool: the selection finds it (and
+        // makes it the bound). N or fewer: the pool holds exactly the records at or above the bound, and since N records were
+        // logged and at most N passed, the N-th largest is the pool's smallest entry - NOT the bound, which is a device
+        // threshold and only a lower bound of it (up to 0.4 % low).
+        uint64_t v = ~0ull;
+        if (L.pool.size() > (size_t)L.topn) {
+            L.compact();
+            v = L.bound_bits;
+        } else {
             for (const LazyCol::Ent& e : L.pool) v = std::min(v, e.bits);
+            if (L.pool.empty()) v = L.have_bound ? L.bound_bits : 0;  // (unreachable while the bound is a lower bound; kept total)
         }
         memcpy(lowest, &v, 8);
     } else {

@@ -54,6 +54,13 @@
 #define KGWAS_MX_NT 0
 #endif
 
+// KGWAS_MX_WARM=1: every wave asks for the cache lines of its NEXT pass's rows at the top of a pass - one
+// `global_load_lds_dword` per 8 KB, a lane per 128-byte line, landing in a junk LDS word - so that the pass's real row loads
+// (one step ahead of their use: all the registers allow) find the rows in the L2 instead of waiting out HBM's latency.
+#ifndef KGWAS_MX_WARM
+#define KGWAS_MX_WARM 0
+#endif
+
 namespace kgwas {
 
 typedef int mxv8i __attribute__((ext_vector_type(8)));
@@ -220,6 +227,24 @@ __global__ void __launch_bounds__(TH) mx_kernel(MxArgs a, uint32_t rows_per_bloc
             if (rbase >= a.n_rows) break;  // wave-uniform
             uint32_t ro_next[RT];
             set_rows(ro_next, rbase + rows_per_pass);
+#if KGWAS_MX_WARM
+            {
+                // rows [rbase + rows_per_pass, + RT*16) of this wave: a contiguous span of the table (whatever the stride)
+                const uint64_t r0 = rbase + rows_per_pass;
+                if (r0 < a.n_rows) {  // wave-uniform
+                    const uint64_t r1 = r0 + RT * 16u < a.n_rows ? r0 + RT * 16u : a.n_rows;
+                    const uint32_t b0 = ((uint32_t)r0 * (uint32_t)a.src.stride_dw + a.src.off_dw) * 4u & ~127u;
+                    const uint32_t b1 = ((uint32_t)(r1 - 1u) * (uint32_t)a.src.stride_dw + a.src.off_dw) * 4u + avail_b - 4u;
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (this pass's first pieces: requested before the last epilogue)
+                    const uint32_t junk = (uint32_t)(reinterpret_cast<char*>(colc + 3 * SLOTS + (TH / 64) * (RT * 48u)) - lds);
+                    const uint32_t n_warm = (b1 - b0) / 8192u + 1u;
+                    for (uint32_t k = 0; k < n_warm; k++) {
+                        uint32_t off = (b1 - b0) - k * 8192u >= lane * 128u ? b0 + k * 8192u + lane * 128u : b1;
+                        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(junk), "v"(off), "s"(rows_base) : "memory");
+                    }
+                }
+            }
+#endif
             mxv4f acc[RT][CT];
 #pragma unroll
             for (int rt = 0; rt < RT; rt++)
@@ -479,6 +504,9 @@ __global__ void __launch_bounds__(TH) mx_kernel(MxArgs a, uint32_t rows_per_bloc
             for (int rt = 0; rt < RT; rt++) ro[rt] = ro_next[rt];
         }
     }
+#if KGWAS_MX_WARM
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no transfer may outlive the block's LDS
+#endif
     if (a.tested) {
         uint32_t v = tested_local;
 #pragma unroll
@@ -491,7 +519,7 @@ __global__ void __launch_bounds__(TH) mx_kernel(MxArgs a, uint32_t rows_per_bloc
 // exchange areas (RT*48 words each: 1536 B per wave at RT = 8)
 size_t mx_lds_bytes(uint32_t n_steps, uint32_t CT, uint32_t n_slices, uint32_t s1_fp6) {
     const uint32_t sb = n_slices == 1 ? MX_PART0 : (s1_fp6 ? 2u * MX_PART0 : MX_PART0 + 1024u);
-    return (size_t)n_steps * CT * sb + 3u * 112u * 4u + 12u * 768u;  // (twelve waves where CT <= 3)
+    return (size_t)n_steps * CT * sb + 3u * 112u * 4u + 12u * 768u + 256u;  // (twelve waves where CT <= 3; 256: junk words of KGWAS_MX_WARM)
 }
 uint32_t mx_step_bytes_rt(uint32_t n_slices, uint32_t s1_fp6) { return n_slices == 1 ? MX_PART0 : (s1_fp6 ? 2u * MX_PART0 : MX_PART0 + 1024u); }
 uint32_t mx_row_tiles(uint32_t CT) { return 4u; }

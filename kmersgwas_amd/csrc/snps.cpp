@@ -186,6 +186,7 @@ int kgwas_snps_best(kgwas_snps* s, const float* Y, uint64_t n_pheno, uint64_t to
     return guarded([&] {
         if (!s || (n_pheno && (!Y || !counts || !indices))) throw Error(KGWAS_ERR_ARG, "kgwas_snps_best: null argument");
         need_device(device);
+        require_heap_emulation();
         std::vector<BestHeap> heaps;
         for (uint64_t j = 0; j < n_pheno; j++) heaps.emplace_back((size_t)topn);
         if (n_pheno && s->n_snps) {

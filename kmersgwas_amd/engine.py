@@ -170,13 +170,16 @@ class AssociationScan:
         p.chunk_rows = chunk_rows
         p.host_threads = host_threads
         p.kernel = kernel
-        # columns may be finished by selection instead of the push-by-push replay (kmersgwas_amd/csrc/scan_lazy.cpp): what
-        # kmersgwas_amd.dist.merge_shards looks at (it must come out the same on every rank of a merge)
-        self.select_mode = int(record_history) != 1 and os.environ.get("KGWAS_FULL_REPLAY", "0") in ("", "0")
         p.record_history = int(record_history)  # False/0 off, True/1 full log, 2 eviction ring
         p.count_patterns = 1 if count_patterns else 0
         self._h = C.c_void_p()
         check(lib.kgwas_scan_create(C.byref(p), C.byref(self._h)))
+        # columns may be finished by selection instead of the push-by-push replay (kmersgwas_amd/csrc/scan_lazy.cpp): what
+        # kmersgwas_amd.dist.merge_shards looks at (it must come out the same on every rank of a merge). Asked of the library:
+        # sessions that fell back to the exact scorers (non-finite phenotypes, an explicit kernel) are NOT in select mode.
+        on = C.c_int(0)
+        check(lib.kgwas_scan_select_mode(self._h, C.byref(on)))
+        self.select_mode = bool(on.value)
 
     # rows: uint64 array (n_rows, 1 + W_f) in host memory
     def feed_host(self, rows: np.ndarray, first_row: int = 0):

@@ -169,10 +169,11 @@ def _quota():
     return n
 
 
-def test_associate_kmers_parallel_1_is_raised_to_the_cpu_quota(tmp_path):
-    """kmers_gwas.py passes --parallel 1 by default (src/py/pipeline_parser.py:31); here that would be ONE replay thread per
-    GPU, ~20x slower than the GPU it serves. The tool raises a --parallel below the CPU quota to the quota (divided among
-    the GPUs), says so on stderr, and KGWAS_STRICT_PARALLEL=1 keeps the literal value. Results do not depend on it."""
+def test_associate_kmers_parallel_is_honoured_and_auto_is_opt_in(tmp_path):
+    """--parallel is the user's cap, as in the reference (src/associate_kmers.cpp:66): kmers_gwas.py's default 1
+    (src/py/pipeline_parser.py:31) means ONE replay thread (per GPU at least one), with a hint on stderr when the process may
+    use more CPUs; `--parallel 0` and KGWAS_AUTO_PARALLEL=1 take the CPU quota (divided among the GPUs). Results do not
+    depend on it."""
     import re
     names, acc, Y = onp.load_phenotypes(os.path.join(GOLD, "resistence.pheno"))
     S_f, k = 241, 31
@@ -180,27 +181,26 @@ def test_associate_kmers_parallel_1_is_raised_to_the_cpu_quota(tmp_path):
     base = str(tmp_path / "kmers_table")
     onp.write_table(base, acc, k, rows[:, 0], rows[:, 1:])
     outs = []
-    for strict in (False, True):
-        out = tmp_path / ("strict" if strict else "auto")
+    q = _quota()
+    for name, par, auto_env, want in (("one", "1", False, 1), ("zero", "0", False, q), ("env", "1", True, q), ("three", "3", False, 3)):
+        out = tmp_path / name
         out.mkdir()
         cmd = [os.path.join(BIN, "associate_kmers"), "-p", os.path.join(GOLD, "resistence.pheno"), "-b", "pheno", "-o", str(out),
-               "-n", "501", "--parallel", "1", "--kmers_table", base, "--kmer_len", "31", "--maf", "0.050000", "--mac", "5", "--gpus", "2"]
+               "-n", "501", "--parallel", par, "--kmers_table", base, "--kmer_len", "31", "--maf", "0.050000", "--mac", "5", "--gpus", "2"]
         env = dict(os.environ)
-        env.pop("KGWAS_STRICT_PARALLEL", None)
-        if strict:
-            env["KGWAS_STRICT_PARALLEL"] = "1"
+        env.pop("KGWAS_AUTO_PARALLEL", None)
+        if auto_env:
+            env["KGWAS_AUTO_PARALLEL"] = "1"
         r = subprocess.run(cmd, capture_output=True, text=True, env=env)
         assert r.returncode == 0, r.stderr[-2000:]
         m = re.search(r"replay_threads=(\d+) replay_threads_per_gpu=(\d+)", r.stderr)
         assert m, r.stderr[-2000:]
-        q = _quota()
-        if strict or q <= 1:
-            assert (int(m.group(1)), int(m.group(2))) == (1, 1)
-        else:
-            assert int(m.group(1)) == q and int(m.group(2)) == max(1, q // 2)
-            assert "is below the %d CPUs" % q in r.stderr
+        assert (int(m.group(1)), int(m.group(2))) == (want, max(1, want // 2)), r.stderr[-2000:]
+        if name in ("one", "three") and want < q:
+            assert "is below the %d CPUs" % q in r.stderr and "keeps to %s thread(s)" % par in r.stderr
         outs.append(str(out))
-    _compare_dirs(outs[0], outs[1])
+    for o in outs[1:]:
+        _compare_dirs(outs[0], o)
 
 
 @pytest.mark.parametrize("ranks,merge,shape", [(2, "root", "small"), (3, "column", "small"), (2, "root", "north_star"), (2, "column", "north_star")])

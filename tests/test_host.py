@@ -252,6 +252,34 @@ def test_select_mode_decision_equals_the_oracle_heap(N, n_chunks, per, flavour, 
     assert sel.value == expect_selected, (flavour, sel.value)
 
 
+@pytest.mark.parametrize("by_ref,detach", [(1, 0), (1, 2), (0, -1), (1, -1)])
+@pytest.mark.parametrize("empty", [(0,), (0, 1), (2,), (0, 3, 5)])
+def test_select_mode_with_empty_chunks(by_ref, detach, empty):
+    """Chunks that ship no record for a column (a zero-length first chunk with the logs detached behind it was undefined
+    behaviour in LazyCol::detach - advisor, round 5: `segs.back()` of an empty vector): lists equal the oracle heap's."""
+    rng = np.random.default_rng(17 + len(empty))
+    N, n_chunks = 40, 6
+    sizes = np.array([0 if c in empty else 90 for c in range(n_chunks)], np.uint64)
+    n = int(sizes.sum())
+    score = rng.permutation(n).astype(np.float64) + 0.5
+    kmer = np.arange(n, dtype=np.uint64) + 100
+    row_in_chunk = np.concatenate([np.arange(int(k), dtype=np.uint32) for k in sizes]) if n else np.zeros(0, np.uint32)
+    chunk_row0 = np.arange(n_chunks, dtype=np.uint64) * 1000
+    thr = np.zeros(n_chunks)
+    rows = np.concatenate([chunk_row0[c] + np.arange(int(sizes[c]), dtype=np.uint64) for c in range(n_chunks)])
+    o = ob.Heap(N)
+    o.add_many(kmer, score, rows)
+    ek, es, er = o.pop_all()
+    sel, out_n = C.c_int(-1), C.c_uint64(0)
+    ok_ = np.zeros(N, np.uint64); os_ = np.zeros(N, np.float64); or_ = np.zeros(N, np.uint64)
+    rc = capi.lib.kgwas_select_check(N, n_chunks, sizes.ctypes.data, chunk_row0.ctypes.data, thr.ctypes.data, score.ctypes.data, kmer.ctypes.data,
+                                     row_in_chunk.ctypes.data, by_ref, detach, C.byref(sel), ok_.ctypes.data, os_.ctypes.data, or_.ctypes.data, C.byref(out_n))
+    assert rc == 0
+    m = out_n.value
+    assert m == len(ek) == N and sel.value == 1
+    assert ok_[:m].tobytes() == ek.tobytes() and os_[:m].tobytes() == es.tobytes() and or_[:m].tobytes() == er.tobytes()
+
+
 def _python_history(kmer, score, row, N):
     """Effective pushes of a shard-local heap (what kgwas_scan_history returns), via the pure-Python heap."""
     h = onp.BestHeap(N)
@@ -443,6 +471,64 @@ def test_cli_fails_loudly_without_a_gpu(tmp_path, have_gpu):
               "--kmer_len", "31"])
     assert r.returncode == 3 and "no HIP device" in r.stderr
     assert "Effective minor allele count:\t5" in r.stderr
+
+
+def _cpu_quota():
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(q) // int(p)))
+    except Exception:
+        pass
+    return n
+
+
+def test_cli_parallel_is_the_users_cap_and_auto_is_opt_in(tmp_path):
+    """src/associate_kmers.cpp:66 honours --parallel; so does the drop-in (round 5 silently raised the pipeline's 1 to every CPU
+    of the cgroup). `--parallel 0` / KGWAS_AUTO_PARALLEL=1 opt into the CPU quota. The decision is printed before any device
+    work, so this runs with or without a GPU (without one the tool then stops with its no-device error)."""
+    base, names, rows = _write_table(tmp_path)
+    ph = tmp_path / "p.tsv"
+    ph.write_text("accession_id\tphenotype_value\n" + "".join("%s\t%d\n" % (n, i % 3) for i, n in enumerate(names)))
+    q = _cpu_quota()
+    exe = os.path.join(BIN, "associate_kmers")
+    common = ["-p", str(ph), "-b", "out", "-o", str(tmp_path), "--kmers_table", base, "--kmer_len", "31"]
+
+    def requested(extra, env=None):
+        e = dict(os.environ)
+        e.pop("KGWAS_AUTO_PARALLEL", None)
+        e.update(env or {})
+        r = subprocess.run([exe] + common + extra, capture_output=True, text=True, env=e)
+        m = re.search(r"replay threads requested: (\d+)", r.stderr)
+        assert m, r.stderr[-1500:]
+        return int(m.group(1)), r.stderr
+
+    n, err = requested(["--parallel", "1"])
+    assert n == 1
+    assert ("is below the %d CPUs" % q in err) == (q > 1)
+    n, err = requested([])  # the reference's default: 4
+    assert n == 4
+    n, err = requested(["--parallel", "3"])
+    assert n == 3
+    n, err = requested(["--parallel", "0"])
+    assert n == q and "--parallel 0: %d replay threads" % q in err
+    n, err = requested(["--parallel", "1"], {"KGWAS_AUTO_PARALLEL": "1"})
+    assert n == q and "KGWAS_AUTO_PARALLEL" in err
+
+
+def test_heap_emulation_is_checked_against_this_process_std_priority_queue():
+    """csrc/heap_guard.cpp: once per process the hand emulation of libstdc++'s heap moves is held against a literal
+    std::priority_queue over the reference's tuple and comparator (src/kmer_general.h:113-128) on tie / NaN / negative / inf
+    streams, single pushes and the lockstep form; every entry point that builds heaps refuses to run on a mismatch
+    (KGWAS_ERR_STATE). Flag 1 holds the emulation against a reference with a DIFFERENT tie rule: the check must notice."""
+    assert capi.lib.kgwas_heap_selfcheck(0) == capi.KGWAS_OK
+    assert capi.lib.kgwas_heap_selfcheck(1) == capi.KGWAS_ERR_STATE
+    assert b"differs" in capi.lib.kgwas_last_error()
+    assert capi.lib.kgwas_heap_selfcheck(0) == capi.KGWAS_OK  # (the altered run leaves the process's verdict alone)
+    h = kg.BestAssociationsHeap(5)  # kgwas_heap_new passes through the guard
+    h.add_associations(np.arange(3, dtype=np.uint64), np.array([1.0, 1.0, 2.0]), np.arange(3, dtype=np.uint64))
+    assert len(h) == 3
 
 
 def test_bench_live_traffic_measurement_falls_back_instead_of_failing(monkeypatch):
