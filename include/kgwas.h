@@ -269,6 +269,13 @@ void kgwas_scan_destroy(kgwas_scan* s);
  * every column is replayed as it streams (exact-scorer sessions among them). Merge layers use it to pick their route. */
 int kgwas_scan_lowest(kgwas_scan* s, double* lowest, uint8_t* full);
 int kgwas_scan_select_mode(const kgwas_scan* s, int* on);
+/* Test hook (sessions created under KGWAS_DEBUG_RESIDUALS=1, else KGWAS_ERR_STATE): the quantisation residuals of column
+ * `column` in phenotype-file order - resid_i = y_i - c - (the value the filter form's slices encode for sample i) - for form 0
+ * (one-slice operand set), 1 (two-slice set: block-scaled FP6 + FP4 / FP6 + FP6 or int8, whichever the session built) or 2
+ * (narrow filter, three FP8 slices). A row whose set bits are exactly the samples with resid_i > 0 attains
+ * sum_i g_i resid_i = Rall: the filters' bound |yigi_ref - yc| <= Eg + min(Rall, N1 rmax) is tight there, which is where a test
+ * has to look for lost pushes (tests/test_gpu_parity.py::test_adversarial_rows_at_the_filters_bound). */
+int kgwas_scan_debug_residuals(const kgwas_scan* s, uint32_t form, uint64_t column, double* out);
 int kgwas_scan_absorb(kgwas_scan* s, uint64_t n_shards, const uint64_t* counts, const uint64_t* const* kmer,
                       const double* const* score, const uint64_t* const* row);
 /* The part of the recorded history that can still matter after heaps whose minima are thr[j]: entries with

@@ -30,7 +30,7 @@ SYMBOLS = [
     "kgwas_heap_selfcheck", "kgwas_heap_new", "kgwas_heap_add_many", "kgwas_heap_size", "kgwas_heap_pop_all", "kgwas_heap_output_list", "kgwas_heap_rows_sorted", "kgwas_heap_output_to_file", "kgwas_select_check",
     "kgwas_heap_free",
     "kgwas_scan_create", "kgwas_scan_feed_device", "kgwas_scan_feed_host", "kgwas_scan_feed_table", "kgwas_scan_finish", "kgwas_scan_result",
-    "kgwas_scan_history", "kgwas_scan_get_stats", "kgwas_scan_reset", "kgwas_scan_lowest", "kgwas_scan_select_mode", "kgwas_scan_absorb", "kgwas_scan_history_above", "kgwas_scan_heaps_export", "kgwas_scan_heaps_import", "kgwas_scan_expect_finish", "kgwas_scan_history_above_msgs", "kgwas_scan_heaps_export_msgs", "kgwas_scan_destroy", "kgwas_scan_scores_dense",
+    "kgwas_scan_history", "kgwas_scan_get_stats", "kgwas_scan_reset", "kgwas_scan_lowest", "kgwas_scan_select_mode", "kgwas_scan_debug_residuals", "kgwas_scan_absorb", "kgwas_scan_history_above", "kgwas_scan_heaps_export", "kgwas_scan_heaps_import", "kgwas_scan_expect_finish", "kgwas_scan_history_above_msgs", "kgwas_scan_heaps_export_msgs", "kgwas_scan_destroy", "kgwas_scan_scores_dense",
     "kgwas_merge_shards",
     "kgwas_multiscan_create", "kgwas_multiscan_run_table", "kgwas_multiscan_run_device", "kgwas_multiscan_finish",
     "kgwas_multiscan_result", "kgwas_multiscan_get_stats", "kgwas_multiscan_destroy", "kgwas_kinship_table_multi",
@@ -182,6 +182,8 @@ lib.kgwas_scan_reset.argtypes = [_vp]
 lib.kgwas_scan_lowest.argtypes = [_vp, _vp, _vp]
 lib.kgwas_scan_select_mode.argtypes = [_vp, C.POINTER(C.c_int)]
 lib.kgwas_scan_select_mode.restype = C.c_int
+lib.kgwas_scan_debug_residuals.argtypes = [_vp, C.c_uint32, C.c_uint64, _vp]
+lib.kgwas_scan_debug_residuals.restype = C.c_int
 lib.kgwas_heap_selfcheck.argtypes = [C.c_uint32]
 lib.kgwas_heap_selfcheck.restype = C.c_int
 lib.kgwas_scan_absorb.argtypes = [_vp, _u64, _vp, _pp, _pp, _pp]

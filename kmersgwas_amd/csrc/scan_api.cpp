@@ -530,6 +530,14 @@ int kgwas_scan_heaps_export_msgs(kgwas_scan* s, uint64_t n_msgs, const uint64_t*
     });
 }
 
+int kgwas_scan_debug_residuals(const kgwas_scan* s, uint32_t form, uint64_t column, double* out) {
+    return guarded([&] {
+        if (!s || !out || form > 2 || column >= s->n_pheno) throw Error(KGWAS_ERR_ARG, "kgwas_scan_debug_residuals: bad argument");
+        if (!s->dbg_keep_resid) throw Error(KGWAS_ERR_STATE, "kgwas_scan_debug_residuals: the session was not created under KGWAS_DEBUG_RESIDUALS=1");
+        memcpy(out, s->dbg_resid[form].data() + column * s->S, s->S * sizeof(double));
+    });
+}
+
 int kgwas_scan_select_mode(const kgwas_scan* s, int* on) {
     return guarded([&] {
         if (!s || !on) throw Error(KGWAS_ERR_ARG, "kgwas_scan_select_mode: null argument");

@@ -117,6 +117,12 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         // 256 M 21 / 29.7 - identical heaps, tools/p1_large_chunks.py)
         s->chunk_max = p->chunk_rows ? p->chunk_rows : ((s->narrow && s->direct) ? (128ull << 20) : (8ull << 20));
         s->chunk_max = std::max<uint64_t>(128, (s->chunk_max + 127) / 128 * 128);
+        // test hook (kgwas_scan_debug_residuals): keep every filter form's quantisation residuals, so that a test can build the
+        // rows on which the bound |yigi_ref - yc| <= Eg + min(Rall, N1 * rmax) is TIGHT (tests/test_gpu_parity.py, adversarial bound)
+        if (s->coarse && getenv("KGWAS_DEBUG_RESIDUALS")) {
+            s->dbg_keep_resid = true;
+            for (auto& v : s->dbg_resid) v.assign(s->n_pheno * s->S, 0.0);
+        }
         if (s->coarse) {  // survivor keys are (column << row_bits | row) in 32 bits, the 0xFFFFFFFF fill included
             uint32_t pbits = 1;
             while ((1ull << pbits) < s->n_pheno + 1) pbits++;
@@ -289,6 +295,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                     }
                     q0[i] = v0;
                     q1[i] = v1;
+                    if (s->dbg_keep_resid) s->dbg_resid[ns - 1][j * S + i] = r;
                     if (r > 0) rpos += r; else rneg -= r;
                     rmax = std::max(rmax, std::fabs(r));
                 }
@@ -381,6 +388,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                     }
                     double rpos = 0, rneg = 0, rmax = 0;
                     for (uint64_t i = 0; i < S; i++) {
+                        if (s->dbg_keep_resid) s->dbg_resid[2][j * S + i] = t[i];
                         if (t[i] > 0) rpos += t[i]; else rneg -= t[i];
                         rmax = std::max(rmax, std::fabs(t[i]));
                     }
@@ -564,6 +572,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                         a0[i] = b0;
                         a1[i] = b1;
                         const double r = y - w * ((double)(1 << sh) * b0 + b1);
+                        if (s->dbg_keep_resid) s->dbg_resid[ns - 1][j * S + i] = r;
                         if (r > 0) rpos += r; else rneg -= r;
                         rmax = std::max(rmax, std::fabs(r));
                     }

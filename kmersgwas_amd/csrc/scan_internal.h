@@ -549,6 +549,10 @@ struct kgwas_scan {
     std::vector<BestHeap> heaps;
     // columns whose top-N is selected, not replayed (scan_lazy.cpp): lazy[j].on; lazy_any: some column may be
     bool lazy_enabled = false;
+    // KGWAS_DEBUG_RESIDUALS (test hook): y_i - c - (what the slices of a form encode), per form: [0] one-slice set, [1] two-slice
+    // set (block-scaled or int8, whichever was built), [2] narrow filter; [column * S + sample]
+    bool dbg_keep_resid = false;
+    std::vector<double> dbg_resid[3];
     // record_history = 2 sessions (the later shards of a cross-shard merge): their columns stay in select mode whatever their
     // ties - such a session is asked for its final minima and for its records above a threshold (kgwas_scan_lowest,
     // kgwas_scan_history_above: both served from the logs), not for result lists

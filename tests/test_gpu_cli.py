@@ -385,3 +385,33 @@ def test_associate_snps(tmp_path, n_file, n_use, n_snps):
     assert "All accessions should be in fam file: nobody" in str(e.value)
     r = subprocess.run([os.path.join(BIN, "associate_snps"), str(ph)], capture_output=True, text=True)
     assert r.returncode == 1 and "usage:" in r.stderr
+
+
+def test_associate_kmers_without_n_uses_the_reference_default_of_a_million(tmp_path):
+    """No `-n`: the reference's default heap size 1 000 000 (src/associate_kmers.cpp:44) - on a table with more MAC-passing rows
+    than that, so the heaps fill and the default is visible in the outputs: 1 000 000 winners per column, files identical to
+    the oracle's."""
+    S_f, k, P = 64, 31, 2
+    rows = kg.synth_rows_host(0, 1_300_000, S_f, 99)
+    names = ["a%d" % i for i in range(S_f)]
+    base = str(tmp_path / "kmers_table")
+    onp.write_table(base, names, k, rows[:, 0], rows[:, 1:])
+    Y = phenotypes(S_f, P - 1, seed=5)
+    pnames = ["phenotype_value", "P1"]
+    ph = tmp_path / "ph.tsv"
+    with open(ph, "w") as f:
+        f.write("accession_id\t" + "\t".join(pnames) + "\n")
+        for i, a in enumerate(names):
+            f.write(a + "\t" + "\t".join(repr(float(Y[j, i])) for j in range(P)) + "\n")
+    pn, acc, Yl = onp.load_phenotypes(str(ph))
+    out_p, out_o = tmp_path / "prod", tmp_path / "orc"
+    out_p.mkdir(); out_o.mkdir()
+    cmd = [os.path.join(BIN, "associate_kmers"), "-p", str(ph), "-b", "pheno", "-o", str(out_p), "--parallel", "4",
+           "--kmers_table", base, "--kmer_len", "31", "--maf", "0.050000", "--mac", "5"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    mac = onp.min_count(S_f, 0.05, 5)
+    res = _oracle_outputs(str(out_o), "pheno", rows, S_f, names, acc, pn, Yl, 1_000_000, mac, k)
+    assert res["tested"] > 1_000_000 and len(res["per_pheno"][0]["kmer"]) == 1_000_000
+    files = _compare_dirs(str(out_p), str(out_o))
+    assert len(files) == 3 * P + 1

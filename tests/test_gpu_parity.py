@@ -1383,3 +1383,194 @@ def test_random_scans_equal_the_oracle():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "30", "20240601"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "random scans equal the oracle's" in r.stdout
+
+
+# ---- round 6: the reference's DEFAULT heap size with heaps that fill, many columns, the column limit ------------------------
+
+_DEFAULT_TOPN_CASE = {}
+
+
+def _default_topn_case():
+    """8.4 M synthetic rows x 1024 samples x 5 columns, N = 1 000 000 (src/associate_kmers.cpp:44's default): made once."""
+    if not _DEFAULT_TOPN_CASE:
+        S, n, P, N = 1024, 8_400_000, 5, 1_000_000
+        rows = kg.synth_rows_host(0, n, S, 20240601)
+        Y = phenotypes(S, P - 1, seed=61)
+        col = np.arange(S, dtype=np.uint64)
+        mac = onp.min_count(S, 0.05, 5)
+        exp = ob.associate(rows, S, col, Y, N, mac, threads=16)
+        _DEFAULT_TOPN_CASE.update(S=S, n=n, P=P, N=N, rows=rows, Y=Y, col=col, mac=mac, exp=exp)
+    return _DEFAULT_TOPN_CASE
+
+
+@pytest.mark.parametrize("kernel,full_replay,feeds", [(kg.KERNEL_AUTO, False, 1), (kg.KERNEL_AUTO, True, 1), (kg.KERNEL_AUTO, False, 3),
+                                                       (kg.KERNEL_COARSE, False, 1), (kg.KERNEL_MFMA, False, 1), (kg.KERNEL_VALU, False, 2)])
+def test_reference_default_heap_size_with_heaps_that_fill(kernel, full_replay, feeds, monkeypatch):
+    """`-n` defaults to 1 000 000 in the reference (src/associate_kmers.cpp:44). Until round 6 the only test at that size had
+    300 rows (the heaps never filled); here 8.4 M rows fill them eight times over: ~65 dense chunks until the heaps are full,
+    the dense -> sparse hand-over, the device-side threshold selection at N = 10^6, pools of 2 N entries in select mode, the
+    exact replay (KGWAS_FULL_REPLAY=1), all scorers - heaps equal to the oracle's literal std::priority_queue."""
+    c = _default_topn_case()
+    if full_replay:
+        monkeypatch.setenv("KGWAS_FULL_REPLAY", "1")
+    scan = kg.AssociationScan(c["S"], c["col"], c["Y"], c["N"], c["mac"], kernel=kernel)
+    cuts = np.linspace(0, c["n"], feeds + 1).astype(np.int64)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        scan.feed_host(c["rows"][a:b], int(a))
+    scan.finish()
+    st = scan.stats()
+    assert st["rows_tested"] == c["exp"]["tested"]
+    if full_replay:
+        assert st["columns_selected"] == 0
+    elif kernel in (kg.KERNEL_AUTO, kg.KERNEL_COARSE):
+        assert st["columns_selected"] + st["columns_replayed_at_finish"] > 0 or st["heap_pushes"] == c["exp"]["pushes"]
+    _check_topn(scan, c["exp"], c["P"])
+    for j in range(c["P"]):
+        assert len(scan.result(j)[0]) == c["N"]  # the heaps did fill
+    scan.close()
+
+
+@pytest.mark.parametrize("S,P,topn", [(241, 401, 501), (1024, 401, 2001)])
+def test_four_hundred_phenotype_columns(S, P, topn):
+    """kmers_gwas.py takes --permutations from the user (src/py/pipeline_parser.py:43); tests and fuzz stopped at 201 / 130
+    columns. 1 + 400 permutations: several operand groups / launches of the filter per chunk, 401 heaps."""
+    rows = kg.synth_rows_host(0, 300_000, S, 7)
+    Y = phenotypes(S, P - 1, seed=401)
+    col = np.arange(S, dtype=np.uint64)
+    mac = onp.min_count(S, 0.05, 5)
+    exp = ob.associate(rows, S, col, Y, topn, mac, threads=16)
+    scan = kg.AssociationScan(S, col, Y, topn, mac)
+    scan.feed_host(rows)
+    scan.finish()
+    assert scan.stats()["kernel_used"] == kg.KERNEL_COARSE and scan.stats()["rows_tested"] == exp["tested"]
+    _check_topn(scan, exp, P)
+    scan.close()
+
+
+def test_too_many_phenotype_columns_is_a_clean_argument_error():
+    """Survivor keys are `column << row_bits | row` in 32 bits (scan_create.cpp): 2^22 columns and more cannot get a filter
+    session - KGWAS_ERR_ARG with a message before anything is allocated on the device, no crash; the library stays usable."""
+    from kmersgwas_amd import capi
+    S, P = 16, 1 << 22
+    Y = np.zeros((P, S), np.float32)
+    Y[:, 0] = 1.0
+    Y[:, 1] = np.arange(P, dtype=np.float32) % 7.0
+    col = np.arange(S, dtype=np.uint64)
+    with pytest.raises(kg.KgwasError) as e:
+        kg.AssociationScan(S, col, Y, 1, 1, kernel=kg.KERNEL_COARSE)
+    assert e.value.code == capi.KGWAS_ERR_ARG and "too many phenotype columns for 32-bit survivor keys" in e.value.msg
+    with pytest.raises(kg.KgwasError) as e:
+        kg.AssociationScan(S, col, Y, 1, 1)  # AUTO takes the filter too: the same refusal, not a silent other path
+    assert e.value.code == capi.KGWAS_ERR_ARG
+    rows = kg.synth_rows_host(0, 2000, S, 3)
+    scan = kg.AssociationScan(S, col, Y[:3], 10, 1)
+    scan.feed_host(rows)
+    scan.finish()
+    exp = ob.associate(rows, S, col, Y[:3], 10, 1)
+    _check_topn(scan, exp, 3)
+    scan.close()
+
+
+# ---- round 6: rows on which the filters' error bound is TIGHT ----------------------------------------------------------------
+
+def _two_slice_lattice():
+    """The integers t = 8 a6 + a4 the block-scaled filter's FP6 + FP4 slices can encode (scan_create.cpp: A6, A4), ascending."""
+    a6 = list(range(0, 16)) + list(range(16, 31, 2)) + list(range(32, 61, 4))
+    a4 = [0, 1, 2, 3, 4, 6, 8, 12]
+    s6 = sorted(set(a6) | set(-x for x in a6))
+    s4 = sorted(set(a4) | set(-x for x in a4))
+    return np.array(sorted({8 * p + q for p in s6 for q in s4}), dtype=np.float64)
+
+
+def _midpoint_phenotype(S, lattice, t_max, seed, eps):
+    """A column whose values sit just BELOW the midpoints between neighbouring representable values (so each rounds down and
+    leaves a residual of almost half a grid step - the largest the quantiser can leave), in +/- pairs so that its mean is 0 and
+    max |y| = t_max units: y = x / t_max, x = (T[k] + T[k+1]) / 2 - eps * gap and its mirror image."""
+    rng = np.random.default_rng(seed)
+    half = S // 2
+    k = rng.integers(0, len(lattice) - 1, size=half)
+    gap = lattice[k + 1] - lattice[k]
+    x = 0.5 * (lattice[k] + lattice[k + 1]) - eps * gap
+    x[0] = t_max  # the extremes fix the unit
+    y = np.concatenate([x, -x, np.zeros(S - 2 * half)]) / t_max
+    return rng.permutation(y).astype(np.float32)
+
+
+@pytest.mark.parametrize("name,env,P,form", [
+    ("mx", {"KGWAS_COARSE_MX": "1", "KGWAS_MXS": "0"}, 5, 1),
+    ("mx_fp6_fp6", {"KGWAS_COARSE_MX": "1", "KGWAS_MXS": "0", "KGWAS_MX_S1": "6"}, 5, 1),
+    ("mxs", {"KGWAS_COARSE_MX": "1", "KGWAS_MXS": "3"}, 5, 1),
+    ("int8_two", {"KGWAS_COARSE_MX": "0", "KGWAS_COARSE_SLICES": "2"}, 5, 1),
+    ("int8_one", {"KGWAS_COARSE_MX": "0", "KGWAS_COARSE_SLICES": "1"}, 5, 0),
+    ("narrow_1", {}, 1, 2), ("narrow_2", {}, 2, 2), ("narrow_4", {}, 4, 2)])
+@pytest.mark.parametrize("S", [1024, 1135])
+def test_adversarial_rows_at_the_filters_bound(name, env, P, form, S, monkeypatch):
+    """The filters keep a pair iff it cannot be PROVEN to lose: |yigi_ref - yc| <= Eg + min(Rall, N1 rmax), Rall the larger one-sign
+    sum of the quantisation residuals (scan_create.cpp). Random tables never come near that bound - a row's residuals cancel.
+    Here they do not: phenotype values on the midpoints of the slices' grids (residuals of almost half a step, the maximum),
+    and rows whose set bits are EXACTLY the samples with a positive (or exactly those with a negative) residual - read from the
+    session itself (kgwas_scan_debug_residuals) -, so that sum g_i resid_i = Rall: the bound is attained, and only the
+    constants' safety margins (kalpha rounded down, error terms rounded up, the float32 evaluation on the device) stand
+    between the filter and a lost push. Around each such row a cloud of rows that differ from it in a few bits, exact
+    duplicates included, and a heap small enough that its boundary runs through the cloud: scores at, one step above and one
+    step below every threshold the device ever holds. Every column is replayed (KGWAS_FULL_REPLAY=1), so a lost or invented
+    push shows in the count as well as in the heaps."""
+    import ctypes as C
+    from kmersgwas_amd import capi
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("KGWAS_DEBUG_RESIDUALS", "1")
+    monkeypatch.setenv("KGWAS_FULL_REPLAY", "1")
+    lat = _two_slice_lattice()
+    Y = np.stack([_midpoint_phenotype(S, lat, 492.0, 100 + j, 1e-3 if j % 2 == 0 else 0.02) for j in range(P)])
+    if P >= 3:  # one column on the uniform int8 grid's midpoints (two slices: +-(127 * 254 + 127) units), one plain N(0,1)
+        u = np.arange(-32385, 32386, dtype=np.float64)
+        Y[1] = _midpoint_phenotype(S, u, 32385.0, 7, 1e-3)
+        Y[2] = phenotypes(S, 0, seed=3)[0]
+    col = np.arange(S, dtype=np.uint64)
+    mac = onp.min_count(S, 0.05, 5)
+    topn = 300
+    probe = kg.AssociationScan(S, col, Y, topn, mac, chunk_rows=2048)
+    assert probe.stats()["kernel_used"] == (kg.KERNEL_NARROW if form == 2 else kg.KERNEL_COARSE)
+    resid = np.zeros((P, S))
+    for j in range(P):
+        rc = capi.lib.kgwas_scan_debug_residuals(probe._h, form, j, resid[j].ctypes.data)
+        assert rc == 0, capi.lib.kgwas_last_error()
+    probe.close()
+    assert np.abs(resid).max() > 0
+    rng = np.random.default_rng(S + P)
+    W = (S + 63) // 64
+    pats = []
+    for j in range(P):
+        for sign in (1, -1):
+            base = (sign * resid[j]) > 0
+            for _ in range(700):
+                g = base.copy()
+                nf = rng.integers(0, 7)
+                if nf:
+                    g[rng.integers(0, S, size=nf)] ^= True
+                pats.append(g)
+            pats.extend([base] * 40)  # exact duplicates: ties at every threshold the cloud produces
+    filler = rng.random((6000, S)) < rng.uniform(0.05, 0.95, size=(6000, 1))
+    bits = np.concatenate([np.array(pats), filler])
+    bits = bits[rng.permutation(len(bits))]
+    pad = np.zeros((len(bits), W * 64), dtype=bool)
+    pad[:, :S] = bits
+    rows = np.empty((len(bits), 1 + W), np.uint64)
+    rows[:, 0] = np.arange(1, len(bits) + 1, dtype=np.uint64) * 3
+    rows[:, 1:] = np.packbits(pad.reshape(len(bits), W, 64), axis=2, bitorder="little").view(np.uint64).reshape(len(bits), W)
+    exp = ob.associate(rows, S, col, Y, topn, mac, threads=8)
+    scan = kg.AssociationScan(S, col, Y, topn, mac, chunk_rows=2048)
+    for a in range(0, len(rows), 5000):
+        scan.feed_host(rows[a:a + 5000], a)
+    scan.finish()
+    st = scan.stats()
+    assert st["rows_tested"] == exp["tested"] and st["columns_selected"] == 0
+    if name == "mxs":
+        assert st["coarse_mx_stream"] >= 1
+    elif name.startswith("mx"):
+        assert st["coarse_mx"] == 1 and st["coarse_mx_s1_fp6"] == (1 if name == "mx_fp6_fp6" else 0)
+    elif name.startswith("int8"):
+        assert st["coarse_mx"] == 0
+    _check_topn(scan, exp, P)  # (with every column replayed: the effective-push count as well)
+    scan.close()
