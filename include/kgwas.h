@@ -203,7 +203,8 @@ typedef struct kgwas_scan_stats {
                                    columns once other workers had nothing left to do */
     uint64_t columns_popped_ahead; /* columns whose result lists were made by idle replay workers at the end of the last feed
                                       (kgwas_scan_expect_finish) instead of by kgwas_scan_finish */
-    uint32_t coarse_mx32;       /* block-scaled filter in its v_mfma_scale_f32_32x32x64_f8f6f4 form (score_mx32.hip) */
+    uint32_t coarse_mx32;       /* always 0 since round 6: the 32 x 32 x 64 form of the block-scaled filter (built, verified and measured
+                                   slower in round 4: docs/HISTORY.md) was removed; the field keeps the struct's layout */
     uint32_t coarse_mx_stream;  /* block-scaled filter in its operand-streaming form (score_mxs.hip: all column tiles of an operand
                                    group per wave, operands through an LDS ring; every row loaded and expanded once per group):
                                    1 = the default shapes (one column group of up to 7 tiles, or two of them side by side in a

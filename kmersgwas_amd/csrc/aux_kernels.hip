@@ -264,7 +264,7 @@ hipError_t launch_dense_select(const double* dense, const uint32_t* n1, uint32_t
                                const uint64_t* topn, double* thr_a, double* thr_b, double* thr_host_copy, uint32_t* info, hipStream_t st) {
     hipError_t e = hipMemsetAsync(info, 0, 2 * sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
-    static const bool reg_ok = !(getenv("KGWAS_DSEL_REG") && atoi(getenv("KGWAS_DSEL_REG")) == 0);  // experiments: 0 = the first version
+    static const bool reg_ok = !(exp_int("KGWAS_DSEL_REG", 1) == 0);  // experiments: 0 = the first version
     if (reg_ok && n_rows <= (uint32_t)DSEL_KPT * 1024u)
         hipLaunchKernelGGL(dense_select_reg_kernel, dim3(n_pheno), dim3(1024), 0, st, dense, n1, n_rows, S, min_count, topn, thr_a, thr_b,
                            thr_host_copy, info);
@@ -309,7 +309,7 @@ hipError_t launch_chunk_tail(const uint32_t* meta, uint32_t n_meta, uint32_t* h_
 hipError_t launch_records_to_host(const double* sc, const uint64_t* km, const uint32_t* rw, uint32_t n, double* h_sc, uint64_t* h_km, uint32_t* h_rw,
                                   hipStream_t st) {
     if (!n) return hipSuccess;
-    static const uint32_t max_blocks = getenv("KGWAS_RECORD_BLOCKS") ? (uint32_t)atoi(getenv("KGWAS_RECORD_BLOCKS")) : 64u;  // experiments (8 to 512 blocks: the same rates; few blocks leave the CUs to the filter)
+    static const uint32_t max_blocks = (uint64_t)exp_int("KGWAS_RECORD_BLOCKS", 64u);  // experiments (8 to 512 blocks: the same rates; few blocks leave the CUs to the filter)
     const uint32_t blocks = std::min<uint32_t>((n + 255u) / 256u, std::max(1u, max_blocks));
     hipLaunchKernelGGL(records_to_host_kernel, dim3(blocks), dim3(256), 0, st, reinterpret_cast<const unsigned long long*>(sc),
                        reinterpret_cast<const unsigned long long*>(km), rw, n, reinterpret_cast<unsigned long long*>(h_sc),

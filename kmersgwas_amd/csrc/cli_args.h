@@ -2,6 +2,9 @@
 // cxxopts, an empty submodule in its tree). Accepts "--name value", "--name=value", "-x value"
 // and boolean flags, like the invocations kmers_gwas.py builds (kmers_gwas.py:133-148).
 #pragma once
+#include "env.h"
+using kgwas::opt_str;
+using kgwas::opt_int;
 #include <unistd.h>
 
 #include <cstdio>
@@ -123,5 +126,5 @@ inline void cli_finish() {
         fputs("error: writing the output failed\n", stderr);
         _exit(1);
     }
-    if (!getenv("KGWAS_CLI_FULL_TEARDOWN")) _exit(0);
+    if (!opt_str("KGWAS_CLI_FULL_TEARDOWN")) _exit(0);
 }

@@ -136,7 +136,7 @@ int main(int argc, char* argv[]) {
         uint64_t replay_threads = threads;
         {
             const uint64_t quota = kgwas_host_cpu_quota();
-            const char* autop = getenv("KGWAS_AUTO_PARALLEL");
+            const char* autop = opt_str("KGWAS_AUTO_PARALLEL");
             if (threads == 0 || (autop && atoi(autop) != 0)) {
                 replay_threads = std::max<uint64_t>(quota, 1);
                 cerr << "[kgwas] --parallel " << (threads ? "overridden by KGWAS_AUTO_PARALLEL" : "0") << ": " << replay_threads

@@ -50,7 +50,7 @@ int main(int argc, char* argv[]) {
     double mac = atof(argv[6]);
     if (mac < ceil(maf * n_samples)) mac = ceil(maf * n_samples);  // minor allele count
     cerr << "Minor allele count  = " << mac << endl;
-    const int device = getenv("KGWAS_DEVICE") ? atoi(getenv("KGWAS_DEVICE")) : 0;
+    const int device = (int)opt_int("KGWAS_DEVICE", 0);
     cerr << "Associating phenotypes:";
     cerr.flush();
     const auto t0 = chrono::steady_clock::now();

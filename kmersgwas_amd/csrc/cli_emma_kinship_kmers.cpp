@@ -110,7 +110,7 @@ int main(int argc, char* argv[]) {
                 cerr.flush();
             }
             ck(kgwas_kinship_partials(kin, H.data(), &n_snps));
-            if (getenv("KGWAS_CLI_FULL_TEARDOWN")) kgwas_kinship_destroy(kin);  // (otherwise left to the process exit, cli_finish)
+            if (opt_str("KGWAS_CLI_FULL_TEARDOWN")) kgwas_kinship_destroy(kin);  // (otherwise left to the process exit, cli_finish)
         }
         const double t_fed = now_s();
         ck(kgwas_kinship_from_partials(n_acc, H.data(), n_snps, K.data()));

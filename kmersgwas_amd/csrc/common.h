@@ -6,6 +6,7 @@
 #include <string>
 
 #include "../../include/kgwas.h"
+#include "env.h"
 
 namespace kgwas {
 

@@ -66,7 +66,7 @@ struct PinRegion {
     void alloc(size_t bytes) {
         release();
         if (!bytes) return;
-        static const bool plain = getenv("KGWAS_PIN_PLAIN") != nullptr;
+        static const bool plain = opt_set("KGWAS_PIN_PLAIN");
         if (!plain && bytes >= (8u << 20)) {
             const size_t len = (bytes + HUGE - 1) / HUGE * HUGE;
             void* m = mmap(nullptr, len + HUGE, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
@@ -155,12 +155,12 @@ public:
         if (n_rows == 0) return;
         if (!piece_rows_) {
             uint64_t pr = (128ull << 20) / (8 * stride);  // 128 MiB pieces (64 MiB: 30 % slower, 256 MiB: no faster)
-            if (const char* e = getenv("KGWAS_INGEST_PIECE_ROWS"))
+            if (const char* e = opt_str("KGWAS_INGEST_PIECE_ROWS"))
                 if (atoll(e) > 0) pr = (uint64_t)atoll(e);
             pr = std::max<uint64_t>(128, std::min<uint64_t>(pr, max_piece_rows) / 128 * 128);
-            if (const char* e = getenv("KGWAS_INGEST_PINNED"))
+            if (const char* e = opt_str("KGWAS_INGEST_PINNED"))
                 if (atoi(e) >= 2 && atoi(e) <= 16) pinned_pieces_ = (unsigned)atoi(e);
-            if (const char* e = getenv("KGWAS_INGEST_DEVICE"))
+            if (const char* e = opt_str("KGWAS_INGEST_DEVICE"))
                 if (atoi(e) >= 2 && atoi(e) <= 64) device_pieces_ = (unsigned)atoi(e);
             try {
                 h_.resize(pinned_pieces_);
@@ -196,7 +196,7 @@ public:
         // 15 GB/s reading the page cache and 28 GB/s copying memory; one thread per 128 MiB piece, the first version, kept
         // at most three of them busy and delivered 27 / 42 GB/s). Items are handed out in order; a piece may be started
         // once the copy of the piece whose pinned buffer it takes has been queued (its producers then wait for that copy).
-        static const uint64_t sub_mib = getenv("KGWAS_INGEST_SUB_MIB") && atoi(getenv("KGWAS_INGEST_SUB_MIB")) > 0 ? (uint64_t)atoi(getenv("KGWAS_INGEST_SUB_MIB")) : 4u;
+        static const uint64_t sub_mib = exp_str("KGWAS_INGEST_SUB_MIB") && atoi(exp_str("KGWAS_INGEST_SUB_MIB")) > 0 ? (uint64_t)atoi(exp_str("KGWAS_INGEST_SUB_MIB")) : 4u;
         const uint64_t sub_rows = std::max<uint64_t>(128, std::min<uint64_t>(piece, ((sub_mib << 20) / (8 * stride)) / 128 * 128));
         const uint64_t NH = pinned_pieces_;
         auto subs_of = [&](uint64_t k) { return (count_of(k) + sub_rows - 1) / sub_rows; };
@@ -267,7 +267,7 @@ public:
             // get in each other's and the replay's way. (Round 3 measured 8 threads best for files: the bound then was the
             // record copies' late completion, see scan_gpu.cpp fetch_records, not the producers.)
             uint64_t nt = std::max(3u, std::min(6u, producer_cpus_ / 3));
-            if (const char* e = getenv("KGWAS_INGEST_THREADS"))
+            if (const char* e = exp_str("KGWAS_INGEST_THREADS"))
                 if (atoi(e) > 0) nt = (uint64_t)atoi(e);
             uint64_t items = 0;
             for (uint64_t k = 0; k < n_pieces && items < nt; k++) items += subs_of(k);
@@ -308,7 +308,7 @@ public:
         };
         producers.emplace_back(copier_main);  // (joined with the producers, whatever happens)
 
-        static const bool trace = getenv("KGWAS_INGEST_TRACE") != nullptr;  // where the caller's thread spends a run
+        static const bool trace = exp_set("KGWAS_INGEST_TRACE");  // where the caller's thread spends a run
         double t_wait = 0, t_copy = 0, t_consume = 0;
         auto now = [] { return std::chrono::steady_clock::now(); };
         auto ms_since = [&](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(now() - t0).count(); };

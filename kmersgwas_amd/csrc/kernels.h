@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "env.h"
+
 namespace kgwas {
 
 // One candidate record shipped device -> host (sparse mode).
@@ -155,12 +157,6 @@ hipError_t launch_mx(const MxArgs& a, uint32_t CT, uint32_t rows_per_block, hipS
 bool mxs_supported(uint32_t CT, uint32_t NG, uint32_t n_slices, uint32_t s1_fp6);
 size_t mxs_lds_bytes(uint32_t CT, uint32_t NG);
 hipError_t launch_mxs(const MxArgs& a, uint32_t CT, uint32_t NG, uint32_t form, uint32_t rows_per_block, hipStream_t st);
-// The same filter on v_mfma_scale_f32_32x32x64_f8f6f4 (score_mx32.hip): ct32 column tiles of 32 (two slices each) + comb (0 / 1)
-// "combined" tile of up to 16 columns (both slices in one FP6 operand, per-lane block scales). a.n_full = whole 256-sample
-// groups (four K = 64 steps each), a.n_quarter <= 4 steps of 64 samples behind them; a.Bq / a.cols in that file's layout
-// ((ct32 + comb) * 32 slots per LDS group). The bitmap's words come out in row order (no nibble transposition).
-size_t mx32_lds_bytes(uint32_t n_steps, uint32_t ct32, uint32_t comb);
-hipError_t launch_mx32(const MxArgs& a, uint32_t ct32, uint32_t comb, uint32_t rows_per_block, hipStream_t st);
 // Survivors (sorted keys, per-column ranges) -> exact candidates compacted in (column, row) order into a.so_score /
 // a.so_kmer / a.so_row (HBM); meta[0..P) = candidates per column, meta[P..2P) = their offsets, meta[2P] = total,
 // meta[2P + 1] = survivor keys emitted. tile_pref [P + 1], tile_cnt / tile_off [key_cap / 256 + P + 1], tmp_score [key_cap].

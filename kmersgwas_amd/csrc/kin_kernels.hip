@@ -378,11 +378,11 @@ __global__ void __launch_bounds__(256) kin_reduce_kernel(const kin_f32x4* part, 
 size_t kin_transpose_lds_bytes(uint64_t file_stride_w, uint32_t S_pad, uint32_t rpb) {
     return ((size_t)rpb * 2u * file_stride_w + (size_t)S_pad * (rpb / 32u) + 4u * rpb) * 4u;
 }
-static size_t kin_transpose_lds_bytes_direct(uint32_t S_pad, uint32_t rpb) { return ((size_t)S_pad * (rpb / 32u) + 4u * rpb) * 4u; }
+[[maybe_unused]] static size_t kin_transpose_lds_bytes_direct(uint32_t S_pad, uint32_t rpb) { return ((size_t)S_pad * (rpb / 32u) + 4u * rpb) * 4u; }
 
 // Rows per transpose block: the most (256, 128, 64) whose verbatim rows + planes fit the 160 KB of LDS; 0 = none does.
 uint32_t kin_transpose_rows_per_block(uint64_t file_stride_w, uint32_t S_pad) {
-    static const uint32_t rpb_env = getenv("KGWAS_KIN_RPB") ? (uint32_t)atoi(getenv("KGWAS_KIN_RPB")) : 0u;  // experiments
+    static const uint32_t rpb_env = (uint64_t)exp_int("KGWAS_KIN_RPB", 0u);  // experiments
     if (rpb_env && kin_transpose_lds_bytes(file_stride_w, S_pad, rpb_env) <= 160u * 1024u) return rpb_env;
     for (uint32_t rpb : {256u, 128u, 64u})
         if (kin_transpose_lds_bytes(file_stride_w, S_pad, rpb) <= 160u * 1024u) return rpb;
@@ -395,32 +395,39 @@ hipError_t launch_kin_transpose(const uint64_t* file_rows, uint64_t file_stride_
     if (n_rows == 0) return hipSuccess;
     const uint32_t rpb = kin_transpose_rows_per_block(file_stride_w, S_pad);
     if (!rpb) return hipErrorInvalidValue;  // kgwas_kinship_create rejects such sessions with a message
-    static const uint32_t tpr_env = getenv("KGWAS_KIN_TPR") ? (uint32_t)atoi(getenv("KGWAS_KIN_TPR")) : 0u;  // experiments
+    static const uint32_t tpr_env = (uint64_t)exp_int("KGWAS_KIN_TPR", 0u);  // experiments
     const uint32_t tpr = tpr_env ? tpr_env : 4u;  // threads per row (1: 3.55 ms per 8 M rows x 1135, 2: 3.16, 4: 3.11)
     // KGWAS_KIN_DIRECT=1 (experiments): rows straight into registers where a thread's part of a row is at most KIN_DIRECT_DW
     // dwords (up to 1536 accessions at four threads per row) instead of through the verbatim copy in LDS - four blocks per CU
     // instead of two, one barrier fewer: measured SLOWER, 3.30 against 3.13 ms per 8 M rows x 1135 (both kernels; the strided
     // row loads cost more than the LDS passes they replace)
-    static const bool direct_ok = getenv("KGWAS_KIN_DIRECT") && atoi(getenv("KGWAS_KIN_DIRECT")) != 0;
+#ifdef KGWAS_EXPERIMENTS
+    static const bool direct_ok = exp_int("KGWAS_KIN_DIRECT", 0) != 0;
     const bool direct = direct_ok && (S_pad / 32u + tpr - 1u) / tpr <= KIN_DIRECT_DW;
     const size_t lds = direct ? kin_transpose_lds_bytes_direct(S_pad, rpb) : kin_transpose_lds_bytes(file_stride_w, S_pad, rpb);
     const void* fn = direct ? (const void*)kin_transpose_kernel<true> : (const void*)kin_transpose_kernel<false>;
+#else  // (the shipped library holds the LDS-staged form only)
+    const size_t lds = kin_transpose_lds_bytes(file_stride_w, S_pad, rpb);
+    const void* fn = (const void*)kin_transpose_kernel<false>;
+#endif
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     // every word of T up to n_rw is written (blocks beyond the rows write zeros): n_rw / 8 tiles x 256 / rpb blocks
     const dim3 grid((uint32_t)(n_rw / 8u * (256u / rpb))), block(tpr * rpb);
+#ifdef KGWAS_EXPERIMENTS
     if (direct)
         hipLaunchKernelGGL(kin_transpose_kernel<true>, grid, block, lds, st, file_rows, file_stride_w, n_rows, S_f, S_pad, min_count, T, n_rw, n_used, rpb);
     else
+#endif
         hipLaunchKernelGGL(kin_transpose_kernel<false>, grid, block, lds, st, file_rows, file_stride_w, n_rows, S_f, S_pad, min_count, T, n_rw, n_used, rpb);
     return hipGetLastError();
 }
 
 // Row slices per 128 x 128 tile and plane words per slice for a chunk of n_rw plane words.
 static void kin_gram_split(uint64_t n_rw, uint32_t tiles, uint64_t* per_out, uint32_t* splits_out) {
-    static const uint64_t blocks_env = getenv("KGWAS_KIN_BLOCKS") ? (uint64_t)atoll(getenv("KGWAS_KIN_BLOCKS")) : 0;  // experiments
+    static const uint64_t blocks_env = (uint64_t)exp_int("KGWAS_KIN_BLOCKS", 0);  // experiments
     // Row slices per tile: a CU holds four of these 2-wave blocks (two waves per SIMD), the chip 1024, and a launch
     // that is not close to a whole number of such rounds leaves CUs idle at its end (3105 blocks measured 5.5 ms per
     // 8 M rows x 1135 samples, 2025 blocks 5.0): as many slices as make about two full rounds.

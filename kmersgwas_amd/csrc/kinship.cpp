@@ -65,7 +65,7 @@ static void kin_feed(kgwas_kinship* k, const uint64_t* d_rows, uint64_t n_rows) 
         const uint64_t n_rw = (c + 511) / 512 * 16;  // u32 words per sample, whole 512-row blocks
         const int b = (int)(i & 1);
         if (k->gram_pending[b]) KGWAS_HIP(hipStreamWaitEvent(k->stream_tr, k->ev_gram[b], 0));  // buffer b is free again
-        static const bool no_tr = getenv("KGWAS_KIN_NO_TR") != nullptr;  // experiments: the Gram kernel alone (wrong results)
+        static const bool no_tr = exp_set("KGWAS_KIN_NO_TR");  // experiments: the Gram kernel alone (wrong results)
         if (!no_tr || i < 2)
         KGWAS_HIP(launch_kin_transpose(d_rows + pos * stride, stride, c, (uint32_t)k->S_f, k->S_pad,
                                        (uint32_t)std::min<uint64_t>(k->min_count, 0xFFFFFFFFull), k->d_T2[b], n_rw, k->d_n,

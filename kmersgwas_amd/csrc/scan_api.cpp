@@ -628,7 +628,6 @@ int kgwas_scan_reset(kgwas_scan* s) {
         s->st.coarse_mx = old.coarse_mx;
         s->st.coarse_mx_s1_fp6 = old.coarse_mx_s1_fp6;
         s->st.coarse_mx_steps = old.coarse_mx_steps;
-        s->st.coarse_mx32 = old.coarse_mx32;
         s->st.coarse_mx_stream = old.coarse_mx_stream;
         s->st.replay_threads = old.replay_threads;
         for (int mi = 0; mi < 2; mi++) {

@@ -32,7 +32,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         s->record_history = p->record_history == 1;
         if (p->record_history == 2) {
             s->history_ring = 1;  // per heap: 16 standard deviations of the rank distance between two shards' N-th scores
-            if (const char* e = getenv("KGWAS_HISTORY_RING"))
+            if (const char* e = opt_str("KGWAS_HISTORY_RING"))
                 if (atoll(e) > 0) s->history_ring = (size_t)atoll(e);
         }
         s->count_patterns = p->count_patterns != 0;
@@ -81,9 +81,9 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         // needs more than one LDS group - measured level with it, not ahead: 2048 x 201 40.4-41.0 against 39.2-40.3 ms per
         // 100 M rows, 1135 x 101 13.3 against 13.4 -; 3 wherever the form exists. The int8 filter
         // (KGWAS_COARSE_MX=0) stops at 5120 accessions.
-        const int mxs_want = getenv("KGWAS_MXS") ? atoi(getenv("KGWAS_MXS")) : 1;
-        const bool mxs_can = mxs_want != 0 && !(getenv("KGWAS_COARSE_MX") && atoi(getenv("KGWAS_COARSE_MX")) == 0) && getenv("KGWAS_COARSE_SLICES") == nullptr &&
-                             !(getenv("KGWAS_MX_S1") && atoi(getenv("KGWAS_MX_S1")) == 6);
+        const int mxs_want = (int)opt_int("KGWAS_MXS", 1);
+        const bool mxs_can = mxs_want != 0 && !(opt_int("KGWAS_COARSE_MX", 1) == 0) && !opt_set("KGWAS_COARSE_SLICES") &&
+                             !(opt_int("KGWAS_MX_S1", -1) == 6);
         const bool filter_fits = coarse_T != 0 || mxs_can;
         bool want_coarse = false;
         if (kern == KGWAS_KERNEL_COARSE) {
@@ -109,7 +109,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         // One to four columns under AUTO: the narrow filter (FP4 x FP8 block-scaled MFMA, three slices per column)
         // instead of the int8 one, whose 16-column tiles would be mostly padding (KGWAS_NARROW=0: keep the int8 filter).
         s->narrow = want_coarse && p->kernel == KGWAS_KERNEL_AUTO && s->n_pheno <= NARROW_MAX_COLS &&
-                    narrow_lds_bytes(n_kgroups) <= 64u * 1024u && !(getenv("KGWAS_NARROW") && atoi(getenv("KGWAS_NARROW")) == 0);
+                    narrow_lds_bytes(n_kgroups) <= 64u * 1024u && !(opt_int("KGWAS_NARROW", 1) == 0);
 
         // (narrow filter on rows read in place: chunks of up to 128 M rows - with one column a chunk's fixed costs, five
         // launches and a copy with the gaps between them, ~40 us, weigh more than the candidates a staler threshold lets
@@ -119,7 +119,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         s->chunk_max = std::max<uint64_t>(128, (s->chunk_max + 127) / 128 * 128);
         // test hook (kgwas_scan_debug_residuals): keep every filter form's quantisation residuals, so that a test can build the
         // rows on which the bound |yigi_ref - yc| <= Eg + min(Rall, N1 * rmax) is TIGHT (tests/test_gpu_parity.py, adversarial bound)
-        if (s->coarse && getenv("KGWAS_DEBUG_RESIDUALS")) {
+        if (s->coarse && opt_str("KGWAS_DEBUG_RESIDUALS")) {
             s->dbg_keep_resid = true;
             for (auto& v : s->dbg_resid) v.assign(s->n_pheno * s->S, 0.0);
         }
@@ -138,15 +138,15 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         // Dense chunks of a feed: enough rows to fill the largest heap with a margin for the MAC filter (more
         // dense chunks follow while a heap is still short); everything after goes through the sparse path.
         s->dense_chunk = std::min<uint64_t>(s->dense_rows, std::max<uint64_t>(1024, (s->max_topn + s->max_topn / 8 + 512 + 127) / 128 * 128));
-        if (getenv("KGWAS_MODE_K")) s->mode_k = atof(getenv("KGWAS_MODE_K"));  // experiments
-        const uint64_t budget = getenv("KGWAS_CAP_BUDGET") ? strtoull(getenv("KGWAS_CAP_BUDGET"), nullptr, 10) : (4ull << 20);  // candidate records per slot
+        if (exp_str("KGWAS_MODE_K")) s->mode_k = atof(exp_str("KGWAS_MODE_K"));  // experiments
+        const uint64_t budget = (uint64_t)exp_int("KGWAS_CAP_BUDGET", (long long)((4ull << 20)));  // candidate records per slot
         // (few columns: longer lists, so that the ramp takes ~6 chunks instead of ~13 - a chunk's fixed costs, not its
         // rows, are what a one-column scan pays for)
-        const uint64_t cap_mult = getenv("KGWAS_CAP_MULT") ? strtoull(getenv("KGWAS_CAP_MULT"), nullptr, 10) : (s->narrow ? 16 : 2);  // experiments
+        const uint64_t cap_mult = (uint64_t)exp_int("KGWAS_CAP_MULT", (long long)((s->narrow ? 16 : 2)));  // experiments
         uint64_t cap = std::min<uint64_t>(cap_mult * s->max_topn + 4096, std::max<uint64_t>(budget / s->n_pheno, 1024));
         s->cap = (uint32_t)std::min<uint64_t>(cap, 0x7FFFFFFFull);
 
-        const bool trace_create = getenv("KGWAS_TRACE") != nullptr;
+        const bool trace_create = opt_set("KGWAS_TRACE");
         const auto tc0 = std::chrono::steady_clock::now();
         auto tcreate = [&](const char* what) {
             if (trace_create)
@@ -328,7 +328,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                 if (!(e_half <= 0.15 * 2.0 * sigma * std::sqrt((double)S))) one_ok = false;
             }
             bool want[2] = {one_ok, true};
-            if (const char* e = getenv("KGWAS_COARSE_SLICES")) {
+            if (const char* e = opt_str("KGWAS_COARSE_SLICES")) {
                 if (atoi(e) == 1) want[0] = true, want[1] = false;
                 if (atoi(e) == 2) want[0] = false, want[1] = true;
             }
@@ -345,7 +345,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                     return (uint8_t)(sg | ((e + 7) << 3) | ((av * 8) / (1 << e) - 8));
                 };
                 const uint64_t n_steps = 4ull * n_kgroups;
-                s->narrow_pack1 = P == 1 && !(getenv("KGWAS_NARROW_PACK") && atoi(getenv("KGWAS_NARROW_PACK")) == 0);  // (experiments: 0)
+                s->narrow_pack1 = P == 1 && !(exp_int("KGWAS_NARROW_PACK", 1) == 0);  // (experiments: 0)
                 std::vector<uint8_t> Bn(n_steps * 64 * 32, 0);
                 std::vector<NarrowCol> ncols(P);
                 std::vector<int> q(S);
@@ -430,7 +430,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
             // (five equal groups of three column tiles in one launch against four groups of four int8 tiles + the two-slice
             // ramp) 50.1 against 52.2 (51.5 with the int8 one-slice set + a block-scaled ramp, the arrangement beyond).
             bool use_mx;
-            if (const char* e = getenv("KGWAS_COARSE_MX")) {
+            if (const char* e = opt_str("KGWAS_COARSE_MX")) {
                 use_mx = atoi(e) != 0;
             } else {
                 auto groups_for = [&](uint32_t tmax) {
@@ -452,9 +452,9 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
             // K = 128 steps against 28 int8 tile-slices x 32 K = 64 steps - about half the matrix work per row for the same
             // ~1 survivor per candidate - and the chunks stay on it longer before the one-slice int8 set takes over
             // (pick_coarse_mode prices both sets in int8 tile-slice equivalents).
-            const bool mixed = !use_mx && !s->narrow && getenv("KGWAS_COARSE_MX") == nullptr && getenv("KGWAS_COARSE_SLICES") == nullptr &&
-                               want[0] && want[1] && !(getenv("KGWAS_COARSE_MIXED") && atoi(getenv("KGWAS_COARSE_MIXED")) == 0);
-            if (use_mx && !s->narrow && getenv("KGWAS_COARSE_SLICES") == nullptr) want[0] = false;  // one FP6 slice alone: only on request
+            const bool mixed = !use_mx && !s->narrow && !opt_set("KGWAS_COARSE_MX") && !opt_set("KGWAS_COARSE_SLICES") &&
+                               want[0] && want[1] && !(exp_int("KGWAS_COARSE_MIXED", 1) == 0);
+            if (use_mx && !s->narrow && !opt_set("KGWAS_COARSE_SLICES")) want[0] = false;  // one FP6 slice alone: only on request
             auto build_mx = [&](int mi) {
                 const int ns = mi + 1;
                 kgwas_scan::CoarseMode& M = s->cmode[mi];
@@ -504,7 +504,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                 // filter 14.4 against 13.6 ms per 100 M rows and all kernels 18.3 against 17.8. KGWAS_MX_S1=6 selects it
                 // (tests keep that kernel form covered).
                 uint32_t s1_fp6 = 0;
-                if (const char* e = getenv("KGWAS_MX_S1")) s1_fp6 = ns == 2 && atoi(e) == 6 && ct_max(1) ? 1u : 0u;
+                if (const char* e = opt_str("KGWAS_MX_S1")) s1_fp6 = ns == 2 && atoi(e) == 6 && ct_max(1) ? 1u : 0u;
                 const uint32_t CTmax = ct_max(s1_fp6);
                 // Operand-streaming form (score_mxs.hip): every row is loaded and expanded ONCE per operand group of up to 14 column
                 // tiles, whatever the number of accessions; taken where the resident plan would pass every row through several LDS
@@ -515,7 +515,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                 uint64_t stream_groups = 0, stream_ct = 0, stream_ng = 1;
                 uint32_t stream_form = 0;
                 if (mxs_can && ns == 2 && !s1_fp6 && !s->narrow) {
-                    const int form_env = getenv("KGWAS_MXS_FORM") ? atoi(getenv("KGWAS_MXS_FORM")) : 0;
+                    const int form_env = (int)opt_int("KGWAS_MXS_FORM", 0);
                     uint64_t g = 1, ng = 1, ct = 0;
                     if (P + 1 <= 7 * 16) {
                         ct = std::max<uint64_t>(3, (P + 1 + 15) / 16);
@@ -588,125 +588,6 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                     eb.rallD = up((double)eb.rall * iu);
                     eb.rmaxD = up((double)eb.rmax * iu);
                 };
-                // ---- the 32 x 32 x 64 form (score_mx32.hip): tiles of 32 columns + one combined tile for a remainder of up to 16.
-                // Taken when it multiplies no more 16-column tile equivalents, in no more LDS groups, than the 16 x 16 x 128
-                // plan below would (KGWAS_MX32 unset or 0: never - the form is opt-in, it measured slower; =1: where it
-                // multiplies no more tile equivalents in no more LDS groups than the 16 x 16 x 128 plan; =2: wherever its operands fit).
-                {
-                    const char* e32 = getenv("KGWAS_MX32");
-                    const int want32 = e32 ? atoi(e32) : 0;
-                    const uint32_t nf32 = (uint32_t)(S / 256), nq32 = (uint32_t)((S % 256 + 63) / 64), steps32 = 4 * nf32 + nq32;
-                    auto tiles_for = [](uint64_t cols, uint32_t& ct32, uint32_t& comb) {
-                        ct32 = (uint32_t)(cols / 32);
-                        comb = 0;
-                        const uint64_t rem = cols % 32;
-                        if (rem && rem <= 16)
-                            comb = 1;
-                        else if (rem)
-                            ct32++;
-                    };
-                    uint64_t g32 = 0;
-                    uint32_t ct32 = 0, comb = 0;
-                    for (uint64_t g = 1; g <= P && !g32 && want32 && ns == 2 && !s1_fp6 && !s->narrow; g++) {
-                        tiles_for((P + g - 1) / g + 1, ct32, comb);
-                        if (ct32 <= 3 && mx32_lds_bytes(steps32, ct32, comb) <= 160u * 1024u) g32 = g;
-                    }
-                    if (g32) {
-                        const uint64_t g16 = groups_for(CTmax), ct16 = ((P + g16 - 1) / g16 + 1 + 15) / 16;
-                        if (want32 < 2 && (g32 > g16 || g32 * (2 * ct32 + comb) > g16 * ct16)) g32 = 0;  // (KGWAS_MX32=2: wherever it fits)
-                    }
-                    if (g32) {
-                        const uint64_t cper = (P + g32 - 1) / g32;
-                        const uint32_t NT = ct32 + comb, slots = NT * 32;
-                        const uint32_t SB32 = ct32 * 2560u + comb * 1536u;
-                        const size_t group_bytes = (size_t)steps32 * SB32;
-                        std::vector<uint8_t> Bq(g32 * group_bytes, 0);
-                        std::vector<CoarseCol> cols(g32 * slots);
-                        for (auto& cc : cols) {
-                            memset(&cc, 0, sizeof(cc));
-                            cc.pheno = -1;
-                        }
-                        // k = 32 kblk + e of step st <-> sample (score_mx32.hip)
-                        auto sample_of = [&](uint64_t st, uint64_t kblk, uint64_t e) -> uint64_t {
-                            return st < 4ull * nf32 ? 256 * (st / 4) + 128 * kblk + 32 * (e / 8) + 4 * (e % 8) + st % 4
-                                                    : 256ull * nf32 + 64 * (st - 4ull * nf32) + 32 * kblk + 4 * (e % 8) + e / 8;
-                        };
-                        auto put6 = [&](uint8_t* part, uint64_t lane, uint64_t e, int q) {  // 6-bit field e of the lane's 6 dwords: dwords 0-3 | 4-5
-                            const uint32_t code = e2m3(q);
-                            for (int b = 0; b < 6; b++)
-                                if (code & (1u << b)) {
-                                    const uint64_t bit = 6 * e + b, dw = bit / 32;
-                                    uint8_t* d = dw < 4 ? part + lane * 16 + dw * 4 : part + 1024 + lane * 8 + (dw - 4) * 4;
-                                    d[(bit % 32) / 8] |= (uint8_t)(1u << (bit % 8));
-                                }
-                        };
-                        // column `c` of LDS group lg (c < ct32 * 32: a full tile's slot; beyond: slot c - ct32 * 32 < 16 of the combined tile)
-                        auto put32 = [&](uint64_t lg, uint64_t c, const std::vector<int>& v0, const std::vector<int>& v1) {
-                            const uint64_t t = c / 32, n = c % 32;
-                            for (uint64_t st = 0; st < steps32; st++) {
-                                uint8_t* blk = &Bq[lg * group_bytes + st * SB32 + t * 2560u];
-                                for (uint64_t kblk = 0; kblk < 2; kblk++)
-                                    for (uint64_t e = 0; e < 32; e++) {
-                                        const uint64_t smp = sample_of(st, kblk, e);
-                                        if (smp >= S) continue;
-                                        if (t < ct32) {
-                                            const uint64_t lane = kblk * 32 + n;
-                                            put6(blk, lane, e, v0[smp]);
-                                            blk[1536 + lane * 16 + e / 2] |= (uint8_t)(e2m1(v1[smp]) << (4 * (e % 2)));
-                                        } else {  // both slices as FP6 codes: slice 0 in lane n, slice 1 (a1 / 2 = 4 a1 / 8) in lane n + 16
-                                            put6(blk, kblk * 32 + n, e, v0[smp]);
-                                            put6(blk, kblk * 32 + n + 16, e, 4 * v1[smp]);
-                                        }
-                                    }
-                            }
-                        };
-                        for (uint64_t j = 0; j < P; j++) {
-                            const uint64_t lg = j / cper, c = j % cper;
-                            CoarseCol& cc = cols[lg * slots + c];
-                            ErrBound eb;
-                            quantise_mx(j, cc, eb, a0, a1);
-                            M.eg_max = std::max(M.eg_max, eb.egD);
-                            M.rall_max = std::max(M.rall_max, eb.rallD);
-                            M.rmax_max = std::max(M.rmax_max, eb.rmaxD);
-                            cc.pheno = (int32_t)j;
-                            put32(lg, c, a0, a1);
-                        }
-                        {  // ones column: accumulator = N1; the last column slot of the last tile (slot 31 / slot 15 of the combined tile)
-                            std::vector<int> ones(S, t_ones), zeros(S, 0);
-                            const uint64_t c_ones = comb ? (uint64_t)ct32 * 32 + 15 : (uint64_t)ct32 * 32 - 1;
-                            if (cper > c_ones) throw Error(KGWAS_ERR_ARG, "mx32 plan: no slot left for the ones column");
-                            for (uint64_t lg = 0; lg < g32; lg++) put32(lg, c_ones, zeros, ones);
-                        }
-                        kgwas_scan::CoarsePart& Pt = M.part[0];
-                        Pt.T = 2 * ct32 + comb;
-                        Pt.ct32 = ct32;
-                        Pt.comb = comb;
-                        Pt.n_lgroups = (uint32_t)g32;
-                        Pt.d_Bq.alloc(Bq.size());
-                        Pt.d_cols.alloc(cols.size());
-                        KGWAS_HIP(hipMemcpy(Pt.d_Bq.p, Bq.data(), Bq.size(), hipMemcpyHostToDevice));
-                        KGWAS_HIP(hipMemcpy(Pt.d_cols.p, cols.data(), cols.size() * sizeof(CoarseCol), hipMemcpyHostToDevice));
-                        M.mx = true;
-                        M.mx32 = true;
-                        M.mx_full = nf32;
-                        M.mx_quarter = nq32;
-                        M.mx_s1_fp6 = 0;
-                        M.mx_scale0 = 0x01010101u * (uint32_t)(0x7F + 5);
-                        M.slices = 2;
-                        M.n_parts = 1;
-                        M.tile_slices = Pt.T * 2 * (uint32_t)g32;
-                        s->st.coarse_mode_tiles[mi] = Pt.T;
-                        s->st.coarse_mode_lgroups[mi] = (uint32_t)g32;
-                        s->st.coarse_mode_tile_slices[mi] = M.tile_slices;
-                        if (use_mx) s->st.coarse_mx = 1;
-                        s->st.coarse_mx_s1_fp6 = 0;
-                        s->st.coarse_mx_steps = n_steps;  // (in K = 128 steps' worth, as for the 16 x 16 x 128 form)
-                        s->st.coarse_mx32 = 1;
-                        M.tile_slices_eq = (double)M.tile_slices * (double)steps32 / (16.0 * (double)n_kgroups) * (Pt.T <= 3 ? 1.30 : 1.0);
-                        M.ready = true;
-                        return;
-                    }
-                }
                 // LDS groups: as few as hold all columns (+ a ones column each); or groups filled to the last slot and one
                 // smaller launch for the rest when that multiplies fewer tiles
                 uint64_t n_lgroups = stream_groups ? stream_groups : groups_for(CTmax);
@@ -723,7 +604,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                     // (a second launch for the rest is worth two and a half tiles of its own: its few column tiles multiply at
                     // a fraction of the full groups' efficiency. 1135 x 101: 2 x 4 tiles in one launch 13.6 ms per 100 M rows,
                     // 6 + 1 tiles in two 16.3; 2048 x 201: 5 x 3 tiles in one launch 39.2, 4 x 3 + 1 in two 40.2)
-                    const bool no_split = getenv("KGWAS_COARSE_NOSPLIT") != nullptr;  // experiments
+                    const bool no_split = exp_set("KGWAS_COARSE_NOSPLIT");  // experiments
                     if (full >= 1 && full + (rem ? 1 : 0) <= n_lgroups && 2 * (full * CTmax + CTr) + 5 < 2 * n_lgroups * plan[0].CT && !no_split) {
                         plan.clear();
                         plan.push_back(Plan{0, full * cpf, CTmax, full, cpf});
@@ -875,7 +756,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                     const uint64_t cpf = (uint64_t)(Tmax / (uint32_t)ns) * 16 - 1;  // columns of a full group
                     const uint64_t full = P / cpf, rem = P - full * cpf;
                     const uint64_t Tr = rem ? (uint64_t)ns * ((rem + 1 + 15) / 16) : 0;
-                    static const bool no_split = getenv("KGWAS_COARSE_NOSPLIT") != nullptr;  // experiments
+                    static const bool no_split = exp_set("KGWAS_COARSE_NOSPLIT");  // experiments
                     if (full >= 1 && full + (rem ? 1 : 0) <= n_lgroups && full * Tmax + Tr < n_lgroups * T && !no_split) {
                         plan.clear();
                         plan.push_back(Plan{0, full * cpf, Tmax, full, cpf});
@@ -965,7 +846,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
             {
                 int least = 0, greatest = 0;
                 KGWAS_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-                const bool hi = !(getenv("KGWAS_COPY_PRIO") && atoi(getenv("KGWAS_COPY_PRIO")) == 0);
+                const bool hi = !(exp_int("KGWAS_COPY_PRIO", 1) == 0);
                 KGWAS_HIP(hipStreamCreateWithPriority(&s->copy_stream, hipStreamNonBlocking, hi ? greatest : least));
             }
             s->row_key_bits = 1;
@@ -987,8 +868,8 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
                 s->ring_size = (size_t)std::max<uint64_t>(std::min<uint64_t>(1ull << 30, std::min<uint64_t>((uint64_t)s->n_slots * slot_bytes, std::max<uint64_t>(64ull << 20, 8 * slot_bytes))),
                                                           2 * slot_bytes + 4096);
                 // (tests: a ring barely larger than one chunk's worst case, so that it wraps and fills up)
-                if (getenv("KGWAS_RING_BYTES"))
-                    s->ring_size = (size_t)std::max<uint64_t>(strtoull(getenv("KGWAS_RING_BYTES"), nullptr, 10), slot_bytes + 4096);
+                if (opt_str("KGWAS_RING_BYTES"))
+                    s->ring_size = (size_t)std::max<uint64_t>(strtoull(opt_str("KGWAS_RING_BYTES"), nullptr, 10), slot_bytes + 4096);
                 tcreate("device buffers and slots allocated");
                 s->ring.alloc(s->ring_size);
                 s->ring_dev = s->ring.dev();
@@ -1042,7 +923,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
 
         make_heaps(s.get());
         {
-            const char* fr = getenv("KGWAS_FULL_REPLAY");
+            const char* fr = opt_str("KGWAS_FULL_REPLAY");
             s->lazy_enabled = s->coarse && !s->record_history && !(fr && atoi(fr) != 0);
             s->lazy_log_mode = s->lazy_enabled && s->history_ring != 0;
             lazy_reset(s.get());
@@ -1051,9 +932,9 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         s->keys.resize(P);
         s->col_ms.assign(P, 0.0);
         tcreate("buffers done");
-        s->trace = getenv("KGWAS_TRACE") != nullptr;
+        s->trace = opt_set("KGWAS_TRACE");
         unsigned nt = p->host_threads ? p->host_threads : usable_cpus();
-        if (const char* e = getenv("KGWAS_HOST_THREADS"))
+        if (const char* e = opt_str("KGWAS_HOST_THREADS"))
             if (atoi(e) > 0) nt = (unsigned)atoi(e);
         nt = (unsigned)std::min<uint64_t>(nt, P);
         s->pool.reset(new Pool(nt, pick_replay_cpus(nt, s->device)));
@@ -1068,7 +949,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
             const uint64_t T = nt, base = P / T;
             const uint64_t MKc = (uint64_t)BestHeap::MAX_LOCKSTEP;
             uint64_t per = base ? (base + ((base + MKc - 1) / MKc) - 1) / ((base + MKc - 1) / MKc) : 0;  // balanced split
-            if (const char* e = getenv("KGWAS_REPLAY_GROUP"))
+            if (const char* e = exp_str("KGWAS_REPLAY_GROUP"))
                 if (atoi(e) > 0 && per) per = std::min<uint64_t>((uint64_t)atoi(e), MKc);
             for (uint64_t w = 0; w < T && base; w++) {
                 std::vector<uint32_t> cur;
@@ -1098,9 +979,9 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
             s->res_row.resize(P);
             s->res_score.resize(P);
             for (size_t g = 0; g < cap; g++) s->grp_owner[g].store(g < s->n_groups0 ? s->grp_home[g] : -1);
-            if (const char* e = getenv("KGWAS_SPLIT_LAGGING")) s->split_lagging = atoi(e) != 0;
-            if (const char* e = getenv("KGWAS_FLOAT_LEAD")) s->float_lead = (uint64_t)std::max(0, atoi(e));
-            if (const char* e = getenv("KGWAS_DEBUG_SLOW_WORKER")) {
+            if (const char* e = opt_str("KGWAS_SPLIT_LAGGING")) s->split_lagging = atoi(e) != 0;
+            if (const char* e = opt_str("KGWAS_FLOAT_LEAD")) s->float_lead = (uint64_t)std::max(0, atoi(e));
+            if (const char* e = opt_str("KGWAS_DEBUG_SLOW_WORKER")) {
                 int w = -1, pct = 100, min_us = 0;
                 if (sscanf(e, "%d:%d:%d", &w, &pct, &min_us) >= 1) {
                     s->dbg_slow_worker = w;

@@ -349,7 +349,7 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
         c.rmax_max = M.rmax_max;
         c.thr = a.thr;
         c.tested = a.tested;
-        static const uint32_t rpb_env = getenv("KGWAS_COARSE_RPB") ? (uint32_t)atoi(getenv("KGWAS_COARSE_RPB")) : 0u;  // experiments
+        static const uint32_t rpb_env = (uint64_t)exp_int("KGWAS_COARSE_RPB", 0u);  // experiments
         const uint64_t n_words = (n_rows + 63) / 64;
         if (s->narrow) {
             NarrowArgs na;
@@ -413,8 +413,6 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
                     x.rmax_max = c.rmax_max;
                     if (Pt.stream)
                         KGWAS_HIP(launch_mxs(x, Pt.T, Pt.ng, Pt.stream - 1u, rpb_env ? rpb_env : (n_rows >= (1u << 22) ? 4096u : n_rows >= (1u << 20) ? 2048u : 512u), s->stream));
-                    else if (M.mx32)
-                        KGWAS_HIP(launch_mx32(x, Pt.ct32, Pt.comb, rpb_env ? rpb_env : (n_rows >= (1u << 22) ? 4096u : n_rows >= (1u << 20) ? 2048u : 512u), s->stream));
                     else
                     KGWAS_HIP(launch_mx(x, Pt.T, rpb_env ? rpb_env : (n_rows >= (1u << 22) ? 4096u : n_rows >= (1u << 20) ? 2048u : 512u), s->stream));
                 } else
@@ -434,7 +432,7 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
             KGWAS_HIP(launch_rescore_direct(a, s->d_surv_sorted.p, s->d_surv_off.p, s->d_surv_cnt.p, s->row_key_bits, s->d_tile_pref.p, s->stream));
         } else {
         KGWAS_HIP(launch_bitmap_keys(s->d_bitmap.p, n_words, n_rows, (uint32_t)s->n_pheno, s->d_bm_blocks.p, s->d_surv_sorted.p, s->key_slots,
-                                     s->row_key_bits, s->d_surv_off.p, s->d_surv_cnt.p, s->d_key_count.p, s->d_tile_pref.p, /*nibble_transposed=*/!s->narrow && !s->cmode[sl.coarse_mode].mx32, s->stream));
+                                     s->row_key_bits, s->d_surv_off.p, s->d_surv_cnt.p, s->d_key_count.p, s->d_tile_pref.p, /*nibble_transposed=*/!s->narrow, s->stream));
         a.so_score = sl.d_so_score.p;
         a.so_kmer = sl.d_so_kmer.p;
         a.so_row = sl.d_so_row.p;
@@ -450,7 +448,7 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
     if (s->hist_ready && !fused_tail)  // raise the thresholds for whatever is queued next; no host round trip
         KGWAS_HIP(launch_thr_update(s->d_hist.p, s->d_hist_base.p, HIST_BINS, s->d_topn.p, s->d_thr_host.p, s->d_thr.p,
                                     (uint32_t)s->n_pheno, s->stream));
-    static const bool tail_kernel = !(getenv("KGWAS_TAIL_KERNEL") && atoi(getenv("KGWAS_TAIL_KERNEL")) == 0);  // experiments: 0 = hipMemcpyAsync calls
+    static const bool tail_kernel = !(exp_int("KGWAS_TAIL_KERNEL", 1) == 0);  // experiments: 0 = hipMemcpyAsync calls
     const bool one_launch = use_coarse && tail_kernel && sl.h_meta_dev;
     if (!fused_tail && !one_launch)
         KGWAS_HIP(hipMemcpyAsync(sl.h_tested.p, sl.d_tested.p, TESTED_SHARDS * sizeof(unsigned long long), hipMemcpyDeviceToHost,
@@ -540,7 +538,7 @@ uint64_t next_sparse_chunk(const kgwas_scan* s) {
     // of the table, but the thresholds a chunk is filtered against are those of its start, and the single heap's replay
     // is the scan's critical path: 16 chunks instead of 7 halve the records the host has to look at and reject - 298 k
     // -> 147 k at 100 M rows x 1 column, replay 4.8 -> 4.4 ms.)
-    static const double fill_env = getenv("KGWAS_FILL") ? atof(getenv("KGWAS_FILL")) : 0.0;  // experiments
+    static const double fill_env = exp_num("KGWAS_FILL", 0.0);  // experiments
     // (... as long as the column IS replayed: in select mode - scan_lazy.cpp - a record costs the host a copy and a compare, and
     // nine chunks instead of sixteen take the one-column pass over 100 M rows from 3.94 to 3.66 ms)
     const double fill = fill_env > 0.0 ? fill_env : (s->narrow ? (s->lazy_any.load(std::memory_order_relaxed) ? 0.15 : 0.05) : 0.4);
@@ -645,7 +643,7 @@ bool fetch_records(kgwas_scan* s, Slot& sl, uint64_t seq) {
     // mapped ring itself, one launch. Over a table resident in HBM the transfers are punctual and cost the compute units
     // nothing, while the copying kernel's waves - parked on PCIe stores - slow the filter beside them (10.2 -> 12.7 ms per
     // 100 M rows x 101 columns): there the three transfers stay. KGWAS_RECORD_COPY=kernel|memcpy forces one (experiments).
-    static const char* rc_env = getenv("KGWAS_RECORD_COPY");
+    static const char* rc_env = opt_str("KGWAS_RECORD_COPY");
     const bool by_memcpy = rc_env ? strcmp(rc_env, "memcpy") == 0 : !s->streamed_feed;
     if (copy && !by_memcpy) {
         uint8_t* dev_at = s->ring_dev + (reinterpret_cast<uint8_t*>(sl.so_score) - s->ring.p);

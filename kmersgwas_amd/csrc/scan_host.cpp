@@ -31,7 +31,7 @@ std::vector<int> parse_cpulist(const char* path) {
 std::vector<std::vector<int>> pick_replay_cpus(unsigned n, int device) {
     std::vector<std::vector<int>> none;
     int mode = 1;  // 0 off, 1 one core each, 2 the GPU's share of its NUMA node for all, 3 the core's L3 domain
-    if (const char* e = getenv("KGWAS_PIN_THREADS")) mode = atoi(e);
+    if (const char* e = opt_str("KGWAS_PIN_THREADS")) mode = atoi(e);
     if (mode == 0) return none;
     cpu_set_t allowed;
     CPU_ZERO(&allowed);
@@ -130,7 +130,7 @@ std::vector<std::vector<int>> pick_replay_cpus(unsigned n, int device) {
         }
         out.push_back(set);
     }
-    if (getenv("KGWAS_TRACE")) {
+    if (opt_str("KGWAS_TRACE")) {
         fprintf(stderr, "[kgwas] replay workers placed (mode %d, numa node %d, gpu %zu of %zu on it):", mode, node, ordinal,
                 n_gpus);
         for (auto& v : out) fprintf(stderr, " %d%s", v[0], v.size() > 1 ? "+" : "");
@@ -203,7 +203,7 @@ void make_heaps(kgwas_scan* s) {
     uint64_t need = 4096;
     for (uint64_t j = 0; j < s->n_pheno; j++) need += (uint64_t)s->topn[j] * 32 + 512;
     std::pmr::memory_resource* mr = nullptr;
-    static const bool no_huge = getenv("KGWAS_NO_HUGE_HEAPS") != nullptr;  // experiments
+    static const bool no_huge = exp_set("KGWAS_NO_HUGE_HEAPS");  // experiments
     if (need <= (2ull << 30) && !no_huge) {
         const size_t bytes = (size_t)((need + (2u << 20) - 1) / (2u << 20) * (2u << 20));
         if (!s->heap_arena.p) {

@@ -453,7 +453,6 @@ struct kgwas_scan {
     // candidate), mode[1] = two slices (~1). Both may be resident; each chunk picks one (pick_coarse_mode).
     struct CoarsePart {  // one launch of the filter: n_lgroups LDS groups of T operand tiles over a range of columns
         uint32_t T = 0, n_lgroups = 0;
-        uint32_t ct32 = 0, comb = 0;  // 32 x 32 x 64 form of the block-scaled filter (score_mx32.hip): tiles of 32 columns + combined tile
         uint32_t stream = 0;          // operand-streaming form (score_mxs.hip): 1 + launch_mxs's `form`; T = column tiles per column group
         uint32_t ng = 1;              // ... column groups per block (n_lgroups then counts operand groups of ng column groups)
         DevBuf<int8_t> d_Bq;
@@ -463,7 +462,6 @@ struct kgwas_scan {
         bool ready = false;
         // block-scaled filter (score_mx.hip): FP6 (+ FP4 / FP6) slices instead of int8 ones; part[].T = column tiles
         bool mx = false;
-        bool mx32 = false;  // ... in its 32 x 32 x 64 form (mx_full = 256-sample groups, mx_quarter = 64-sample steps)
         uint32_t mx_full = 0, mx_quarter = 0, mx_s1_fp6 = 0, mx_scale0 = 0;
         uint32_t slices = 0, n_parts = 0;
         uint32_t tile_slices = 0;  // operand tiles a row is multiplied with, all parts and groups

@@ -338,7 +338,7 @@ void lazy_reset(kgwas_scan* s) {
     s->tie_check_rows = 4ull << 20;
     // nothing refers to the record ring any more; a session in select mode fills it linearly (scan_internal.h, ring_keep)
     s->ring_head = s->ring_tail = 0;
-    s->ring_keep.store(s->lazy_enabled && s->coarse && !(getenv("KGWAS_LOG_BY_REF") && atoi(getenv("KGWAS_LOG_BY_REF")) == 0), std::memory_order_release);
+    s->ring_keep.store(s->lazy_enabled && s->coarse && !(opt_int("KGWAS_LOG_BY_REF", 1) == 0), std::memory_order_release);
 }
 
 // BestHeap::lowest() / full() of a column in select mode without giving it a heap: a full heap's minimum is the N-th largest
@@ -387,7 +387,7 @@ void lazy_materialize_all(kgwas_scan* s) {
 void lazy_finish_column(kgwas_scan* s, size_t j, bool known_tie) {
     LazyCol& L = s->lazy[j];
     if (L.on) {
-        static const bool trace = getenv("KGWAS_FINISH_TRACE") != nullptr;
+        static const bool trace = exp_set("KGWAS_FINISH_TRACE");
         const double t0 = trace ? s->t_ms() : 0;
         if (!known_tie && L.select(s->res_kmer[j], s->res_score[j], s->res_row[j])) {
             s->n_selected.fetch_add(1, std::memory_order_relaxed);

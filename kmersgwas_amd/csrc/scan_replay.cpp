@@ -15,7 +15,7 @@ void process_range_sync(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_
 // KGWAS_TIE_CHECKS (experiments): 0 = the pools are never looked at for ties during a large feed, 1 = behind every flagged
 // chunk; default: where the host keeps up with the GPU.
 static int tie_checks_mode() {
-    static const int m = getenv("KGWAS_TIE_CHECKS") ? atoi(getenv("KGWAS_TIE_CHECKS")) : -1;
+    static const int m = (int)exp_int("KGWAS_TIE_CHECKS", -1);
     return m;
 }
 
@@ -72,7 +72,7 @@ void replay_group(kgwas_scan* s, Slot& sl, size_t g, ReplayAcc& acc) {
         // streams at once, more than the hardware prefetchers track: pull them in up front, a line at a time.
         // (Prefetching ALL of a unit's records up front - up to a megabyte - pushed the heaps out of the L2 and the
         // records' own first lines out again before their turn: 10 % of the replay's CPU time.)
-        static const uint32_t PF_AHEAD = getenv("KGWAS_REPLAY_PF") ? (uint32_t)atoi(getenv("KGWAS_REPLAY_PF")) : 64u;  // records
+        static const uint32_t PF_AHEAD = (uint64_t)exp_int("KGWAS_REPLAY_PF", 64u);  // records
         auto pf = [&](const void* p) { __builtin_prefetch(p, 0, 3); };
         for (size_t c = 0; c < n_cols; c++) {
             const Cur& cu = cols[c];
@@ -508,7 +508,7 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
             std::lock_guard<std::mutex> lk(s->rp_mu);
             // (every chunk of a final feed is replayed: what is left of the columns' result lists is made before the workers go)
             s->rp_drain.store(s->final_feed.load(std::memory_order_relaxed) && s->rp_all_published.load(std::memory_order_acquire) &&
-                                  replayed() >= sub && !s->rp_failed.load(std::memory_order_acquire) && !getenv("KGWAS_NO_DRAIN"),
+                                  replayed() >= sub && !s->rp_failed.load(std::memory_order_acquire) && !exp_str("KGWAS_NO_DRAIN"),
                               std::memory_order_release);
             s->rp_quit.store(true, std::memory_order_release);
         }
@@ -570,7 +570,7 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
                 // pushed - and takes it as its threshold, so the first sparse chunks are submitted before the host
                 // pushes the 1.2 M (2.4 M at 201 columns) dense scores: the GPU filters while the heaps fill (2 ms of
                 // a 28 ms step at 101 columns, 8 of 126 at 250 M rows x 201).
-                static const bool no_overlap = getenv("KGWAS_NO_DENSE_OVERLAP") != nullptr;  // experiments
+                static const bool no_overlap = exp_set("KGWAS_NO_DENSE_OVERLAP");  // experiments
                 bool empty = s->coarse && !no_overlap && n_rows - pos > c && sub == 0;
                 for (uint64_t j = 0; j < s->n_pheno && empty; j++) empty = s->heaps[j].size() == 0 && s->lazy[j].n_logged == 0;
                 if (empty) {

@@ -772,7 +772,7 @@ static hipError_t launch_coarse_t(const CoarseArgs& a, uint32_t rows_per_block, 
                                            (int)lds);
         if (e != hipSuccess) return e;
     }
-    static const int grid_env = getenv("KGWAS_COARSE_GRIDLG") ? atoi(getenv("KGWAS_COARSE_GRIDLG")) : -1;  // experiments
+    static const int grid_env = (int)exp_int("KGWAS_COARSE_GRIDLG", -1);  // experiments
     const uint32_t grid_lg = (grid_env >= 0 ? grid_env != 0 : true) && a.n_lgroups > 1 ? 1u : 0u;
     const uint32_t grid = grid_lg ? (n_rowblocks + 7u) / 8u * 8u * a.n_lgroups : n_rowblocks;
     hipLaunchKernelGGL((coarse_kernel<T, NS, TH>), dim3(grid), dim3(TH), lds, st, a, rows_per_block, n_rowblocks, grid_lg);
@@ -784,7 +784,7 @@ hipError_t launch_coarse(const CoarseArgs& a, uint32_t T, uint32_t rows_per_bloc
     const size_t lds = coarse_lds_bytes(a.n_kgroups, T);
     if (lds > 160u * 1024u) return hipErrorInvalidValue;
     // Few tiles per LDS group leave registers for a third wave per SIMD (T <= 4: <= 168 VGPRs at 768 threads)
-    static const int th_env = getenv("KGWAS_COARSE_TH") ? atoi(getenv("KGWAS_COARSE_TH")) : 768;  // experiments (512: eight waves as for T > 4)
+    static const int th_env = (int)exp_int("KGWAS_COARSE_TH", 768);  // experiments (512: eight waves as for T > 4)
     const bool wide_block = th_env == 768 && a.n_slices == 1 && T <= 4 && lds + 4u * 768u <= 160u * 1024u;
     const uint32_t threads = wide_block ? 768 : 512;
     if ((a.n_rows * a.src.stride_dw + a.src.off_dw + a.src.avail_dw) * 4ull >= (1ull << 32)) return hipErrorInvalidValue;  // 32-bit byte offsets
@@ -842,20 +842,23 @@ hipError_t launch_rescore(const ScoreArgs& a, const uint32_t* keys, const uint32
     // fixed grid, tiles handed out round-robin: 8 blocks of 256 per CU (the tile count is only known on the device)
     // the tile's column goes through LDS while it fits beside eight blocks per CU (16 KB: 4096 samples); beyond, scalar loads
     const size_t ybytes = 64u * (size_t)a.W_m * sizeof(float);
-    static const bool ylds_ok = getenv("KGWAS_RESCORE_YLDS") ? atoi(getenv("KGWAS_RESCORE_YLDS")) != 0 : true;  // experiments
+    static const bool ylds_ok = exp_str("KGWAS_RESCORE_YLDS") ? atoi(exp_str("KGWAS_RESCORE_YLDS")) != 0 : true;  // experiments
     // (KGWAS_RESCORE_NS=2, experiments: two survivors per lane, the column's values read from LDS once for both - half the LDS
     // reads, but 146 registers instead of 84, three waves per SIMD instead of five: all scoring kernels 14.0 ms per 100 M rows x
     // 1024 x 101 against 13.5; what this kernel waits for is its row gathers, and fewer waves hide them worse)
-    static const int ns_env = getenv("KGWAS_RESCORE_NS") ? atoi(getenv("KGWAS_RESCORE_NS")) : 1;
+    [[maybe_unused]] static const int ns_env = (int)exp_int("KGWAS_RESCORE_NS", 1);
     // (KGWAS_RESCORE_DYN=1, experiments: tiles handed out by an atomic ticket instead of round-robin - a launch is 800-3700 tiles on
     // 1280 block slots - measured slower: re-score + small kernels 4.10-4.12 ms per 100 M rows x 1024 x 101 against 3.65-3.71)
-    static const bool dyn = getenv("KGWAS_RESCORE_DYN") && atoi(getenv("KGWAS_RESCORE_DYN")) != 0;
-    static const uint32_t grid = getenv("KGWAS_RESCORE_GRID") ? (uint32_t)atoi(getenv("KGWAS_RESCORE_GRID")) : 2048u;
+    static const bool dyn = exp_int("KGWAS_RESCORE_DYN", 0) != 0;
+    static const uint32_t grid = (uint64_t)exp_int("KGWAS_RESCORE_GRID", 2048u);
     uint32_t* ticket = dyn ? const_cast<uint32_t*>(key_count) + 1 : nullptr;  // (d_key_count has two words; chunk_prep_kernel zeroes both)
+#ifdef KGWAS_EXPERIMENTS
     if (ylds_ok && ybytes <= 16384u && ns_env == 2)
         hipLaunchKernelGGL((rescore_kernel<true, false, 2>), dim3(grid), dim3(256), ybytes, st, a, keys, surv_off, surv_cnt, tile_pref, row_mask,
                            tmp_score, tile_cnt, ticket);
-    else if (ylds_ok && ybytes <= 16384u)
+    else
+#endif
+    if (ylds_ok && ybytes <= 16384u)
         hipLaunchKernelGGL(rescore_kernel<true>, dim3(grid), dim3(256), ybytes, st, a, keys, surv_off, surv_cnt, tile_pref, row_mask,
                            tmp_score, tile_cnt, ticket);
     else

@@ -738,7 +738,7 @@ hipError_t launch_narrow(const NarrowArgs& a, uint32_t rows_per_block, hipStream
     const int np = (int)((64u * stride_b + 1023u) / 1024u);
     const uint32_t stage_bytes = (uint32_t)np * 1024u;  // whole lane-linear pieces
     const size_t lds_staged = narrow_lds_bytes(a.n_kgroups) + 4u * (size_t)stage_bytes;
-    static const bool no_stage = getenv("KGWAS_NARROW_STAGED") && atoi(getenv("KGWAS_NARROW_STAGED")) == 0;  // experiments
+    static const bool no_stage = exp_int("KGWAS_NARROW_STAGED", 1) == 0;  // experiments
     // The staged kernel reads a pass (64 rows) as np whole KB, i.e. up to 1 KB - 16 past the 64 rows: it takes the
     // rows whose passes can be read that way without leaving the launch's rows; the last few rows (fewer than 128 + a
     // KB's worth) go through the direct kernel in a second, tiny launch.

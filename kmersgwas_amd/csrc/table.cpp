@@ -313,7 +313,7 @@ int kgwas_write_plink_many(uint64_t n_cols, const char* const* out_bases, kgwas_
         if (!t || !col || !acc_names || (n_cols && (!out_bases || !Y || !n_win || !kmer_pop || !row_pop)))
             throw Error(KGWAS_ERR_ARG, "kgwas_write_plink_many: null argument");
         const unsigned T = threads ? threads : usable_cpus();
-        const bool trace = getenv("KGWAS_TRACE") != nullptr;
+        const bool trace = opt_set("KGWAS_TRACE");
         double ph[6] = {0, 0, 0, 0, 0, 0};  // sort + union, read-ahead, read + expand, append, fam, output files created
         auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         double tp = tnow();
@@ -400,8 +400,8 @@ int kgwas_write_plink_many(uint64_t n_cols, const char* const* out_bases, kgwas_
         // 32 KB of other rows is cheaper than a second call; from a device every 4 KB page read for nothing is bandwidth
         // lost. The first pieces run at 8 KB and time their small reads; the rest of the call uses 32 KB (page cache) or
         // 4 KB + read-ahead hints (cold file). KGWAS_PLINK_COALESCE=bytes: fixed.
-        const bool coalesce_fixed = getenv("KGWAS_PLINK_COALESCE") != nullptr;
-        std::atomic<uint64_t> coalesce(coalesce_fixed ? strtoull(getenv("KGWAS_PLINK_COALESCE"), nullptr, 10) : 8192);
+        const bool coalesce_fixed = exp_set("KGWAS_PLINK_COALESCE");
+        std::atomic<uint64_t> coalesce(coalesce_fixed ? strtoull(exp_str("KGWAS_PLINK_COALESCE"), nullptr, 10) : 8192);
         std::atomic<uint64_t> probe_ns(0), probe_n(0);
         const size_t BLOCK = 1u << 16;  // distinct rows per block
         const uint64_t exp_bytes = (bed_bytes + 15) / 16 * 16 + 16;  // room for the word-wise expansion's overshoot

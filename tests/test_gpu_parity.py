@@ -228,51 +228,6 @@ def test_coarse_filter_shapes(monkeypatch, mx, slices, S, P, shift):
     scan.close()
 
 
-@pytest.mark.parametrize("S_f,S,P,kind,reorder", [
-    (241, 241, 5, "normal", False),      # quarter steps only (4 x 64 samples); 6 operand columns: the combined tile alone
-    (64, 64, 15, "binary", False),       # one quarter step; 16 columns: the combined tile filled to its ones column
-    (300, 300, 16, "normal", False),     # 1 group of 256 + 1 quarter step; 17 columns: one tile of 32
-    (511, 511, 40, "heavy", False),      # 1 group + 4 quarter steps; 41 columns: 1 tile + combined
-    (1024, 1024, 63, "normal", False),   # 4 groups; 64 columns: 2 tiles, none combined
-    (1024, 1024, 101, "normal", False),  # BASELINE configs[1]: 3 tiles + combined
-    (1135, 1135, 101, "heavy", False),   # BASELINE configs[2]: two LDS groups of 2 tiles
-    (700, 650, 40, "normal", True),      # squeezed rows (subset, shuffled)
-    (2048, 2048, 201, "normal", False),  # BASELINE configs[3] per GPU: five LDS groups of 1 tile + combined
-    (1500, 1500, 130, "constant", False)])
-def test_block_scaled_filter_32x32x64_form(monkeypatch, S_f, S, P, kind, reorder):
-    """score_mx32.hip (KGWAS_MX32=2: wherever its operands fit): the block-scaled filter on the 32 x 32 x 64 instruction in
-    every tile arrangement (1-3 tiles of 32 columns, with and without the combined tile that carries both slices of up to 16
-    columns in one FP6 operand with per-lane block scales, one and several LDS groups), whole 256-sample groups and quarter
-    steps of 64, direct and squeezed rows, duplicated row patterns: survivors, pop order, score bytes, push and tested
-    counts equal the oracle's."""
-    monkeypatch.setenv("KGWAS_COARSE_MX", "1")
-    monkeypatch.setenv("KGWAS_MX32", "2")
-    rows = random_table(40_000, S_f, seed=S_f * 11 + P, dup_frac=0.25)
-    rng = np.random.default_rng(S + P)
-    col = rng.permutation(S_f)[:S].astype(np.uint64) if reorder else np.arange(S, dtype=np.uint64)
-    Y = phenotypes(S, P - 1, seed=P + 13, binary=(kind == "binary"))
-    if kind == "heavy":
-        Y = Y.copy()
-        Y[:, 0] += np.float32(50.0)
-        Y[1] = (rng.standard_cauchy(S) * 3).astype(np.float32)
-    if kind == "constant":
-        Y = Y.copy()
-        Y[2] = np.float32(1.25)
-        Y[5] = np.float32(0.0)
-    mac = onp.min_count(S, 0.05, 5) if S >= 100 else 1
-    topn = 211
-    exp = ob.associate(rows, S_f, col, Y, topn, mac, batch_size=9000, threads=4)
-    scan = kg.AssociationScan(S_f, col, Y, topn, mac, kernel=kg.KERNEL_COARSE, chunk_rows=4096)
-    scan.feed_host(rows[:23_000], 0)
-    scan.feed_host(rows[23_000:], 23_000)
-    scan.finish()
-    st = scan.stats()
-    assert st["kernel_used"] == kg.KERNEL_COARSE and st["coarse_mx"] == 1 and st["coarse_mx32"] == 1 and st["coarse_launches"] > 0
-    _check_topn(scan, exp, P)
-    assert st["rows_tested"] == exp["tested"]
-    scan.close()
-
-
 def _late_dup_table(n, S, seed, first_dup_row, dup_frac):
     """A table whose rows repeat earlier rows' presence/absence patterns (tied scores) only from `first_dup_row` on."""
     rows = random_table(n, S, seed=seed, dup_frac=0.0)
@@ -1167,8 +1122,7 @@ def _exact_case(name):
     ("s241_p24", "mx"), ("s241_p24", "int8"), ("s241_p24", "mfma"), ("s241_p24", "valu"),
     ("s1024_p101", "mx"), ("s1024_p101", "int8"), ("s1135_p40", "mx"), ("s1135_p40", "mx6"), ("s1135_p40", "int8"),
     ("s2048_p64", "mx"), ("s2048_p64", "int8"),
-    ("s1024_p1", "narrow"), ("s1135_p2", "narrow"), ("s2048_p4", "narrow"), ("s2048_p4", "mx"),
-    ("s241_p24", "mx32"), ("s1024_p101", "mx32"), ("s1135_p40", "mx32"), ("s2048_p64", "mx32")])
+    ("s1024_p1", "narrow"), ("s1135_p2", "narrow"), ("s2048_p4", "narrow"), ("s2048_p4", "mx")])
 def test_exact_rational_topn_through_the_production_kernels(monkeypatch, name, mode):
     """Top-N of 200 k-row scans against exact rational arithmetic (tests/exact_topn.py, tests/golden/exact_topn.json: integer
     phenotypes make every float32 add of calculate_kmer_score exact, so the expected score is r^2 / d rounded once and the
@@ -1176,7 +1130,6 @@ def test_exact_rational_topn_through_the_production_kernels(monkeypatch, name, m
     mode reaches is asserted from the session's statistics:
       mx     mx_kernel (FP4 x FP6 + FP4 block-scaled filter) -> bitmap keys -> rescore_kernel          [KGWAS_COARSE_MX=1]
       mx6    the same with an FP6 second slice                                                          [KGWAS_MX_S1=6]
-      mx32   mx32_kernel (the same filter on v_mfma_scale_f32_32x32x64_f8f6f4: tiles of 32 columns + combined tile) [KGWAS_MX32=2]
       int8   coarse_kernel (int8 MFMA filter, chunk-wise one or two slices) -> rescore_kernel           [KGWAS_COARSE_MX=0]
       narrow narrow_staged_kernel / narrow_kernel (FP4 x FP8, 1-4 columns) -> rescore_kernel            [AUTO]
       mfma / valu  the exact scorers alone (score_mfma_kernel / score_valu_kernel), dense and sparse phase
@@ -1185,11 +1138,10 @@ def test_exact_rational_topn_through_the_production_kernels(monkeypatch, name, m
     import exact_topn as ex
     rows, Y, mac, topn, exp, tested, fx = _exact_case(name)
     S, P = Y.shape[1], Y.shape[0]
-    kernel = {"mx": kg.KERNEL_COARSE, "mx6": kg.KERNEL_COARSE, "mx32": kg.KERNEL_COARSE, "int8": kg.KERNEL_COARSE, "narrow": kg.KERNEL_AUTO,
+    kernel = {"mx": kg.KERNEL_COARSE, "mx6": kg.KERNEL_COARSE, "int8": kg.KERNEL_COARSE, "narrow": kg.KERNEL_AUTO,
               "mfma": kg.KERNEL_MFMA, "valu": kg.KERNEL_VALU}[mode]
-    if mode in ("mx", "mx6", "mx32"):
+    if mode in ("mx", "mx6"):
         monkeypatch.setenv("KGWAS_COARSE_MX", "1")
-    monkeypatch.setenv("KGWAS_MX32", "2" if mode == "mx32" else "0")
     if mode == "mx6":
         monkeypatch.setenv("KGWAS_MX_S1", "6")
     if mode == "int8":
@@ -1204,9 +1156,8 @@ def test_exact_rational_topn_through_the_production_kernels(monkeypatch, name, m
     scan.feed_host(rows[cut:], cut)
     scan.finish()
     st = scan.stats()
-    if mode in ("mx", "mx6", "mx32", "int8"):
+    if mode in ("mx", "mx6", "int8"):
         assert st["kernel_used"] == kg.KERNEL_COARSE and st["coarse_launches"] > 0 and st["coarse_mx"] == (0 if mode == "int8" else 1)
-        assert st["coarse_mx32"] == (1 if mode == "mx32" else 0)
         if mode != "int8":
             assert st["coarse_mx_s1_fp6"] == (1 if mode == "mx6" else 0)
     elif mode == "narrow":

@@ -54,7 +54,7 @@ while time.time() < t_end:
     dup = float(rng.choice([0.0, 0.0, 0.2, 0.6]))
     kind = str(rng.choice(["normal", "binary", "shifted", "heavy", "tiny", "ints", "subnormal", "near_overflow", "onehot"]))
     kernel = int(rng.choice([kg.KERNEL_AUTO, kg.KERNEL_AUTO, kg.KERNEL_COARSE, kg.KERNEL_MFMA, kg.KERNEL_VALU]))
-    env = {"KGWAS_COARSE_MX": str(rng.choice(["", "0", "1"])), "KGWAS_MX32": str(rng.choice(["0", "0", "2"])),
+    env = {"KGWAS_COARSE_MX": str(rng.choice(["", "0", "1"])),
            "KGWAS_COARSE_SLICES": str(rng.choice(["", "", "1", "2"])),
            "KGWAS_MXS": str(rng.choice(["", "", "0", "2", "3", "3"])), "KGWAS_MXS_FORM": str(rng.choice(["", "", "1", "2"])),
            "KGWAS_FULL_REPLAY": str(rng.choice(["", "", "", "1"])), "KGWAS_LOG_BY_REF": str(rng.choice(["", "", "0"])),
