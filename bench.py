@@ -29,6 +29,8 @@ import os
 import sys
 import time
 
+T_START = time.perf_counter()
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -1239,6 +1241,14 @@ def main():
             out["single_gpu_same_shard"] = single
         if merge_check is not None:
             out["merge_check"] = bool(merge_check)
+        secs = {"setup_and_timed_steps": round(time.perf_counter() - T_START, 1)}
+        out["seconds"] = secs  # wall clock of this script's parts
+        _t_mark = [time.perf_counter()]
+
+        def lap(name):
+            now = time.perf_counter()
+            secs[name] = round(now - _t_mark[0], 1)
+            _t_mark[0] = now
         if not dist_on and not args.no_cpu_baseline:
             rec, ores = cpu_baseline(S, Y, mac, args.topn, seed_table, min(args.cpu_sample_rows, M),
                                      threads=min(usable_cpus(), P))
@@ -1249,15 +1259,18 @@ def main():
             except Exception as e:  # a failed comparison must show up in the line, not kill it
                 out["parity_check"] = False
                 out["parity_check_error"] = repr(e)
+        lap("cpu_baseline_and_parity_check")
         if not dist_on and not args.no_subrecords and config_name == "BASELINE.json configs[1]":
             try:
                 out["p1_scan"] = p1_scan_record(kg, torch, table, stream, M, S, Y, args.topn, mac, dev, host_threads)
             except Exception as e:
                 out["p1_scan"] = {"error": repr(e)}
+            lap("p1_scan")
             try:
                 out["starved_host"] = starved_host_record(kg, torch, table, stream, M, S, Y, args.topn, mac, dev)
             except Exception as e:
                 out["starved_host"] = {"error": repr(e)}
+            lap("starved_host")
             last.close()
             last = None
             session.close()
@@ -1265,21 +1278,25 @@ def main():
                 out["default_topn"] = default_topn_record(kg, torch, table, stream, M, S, Y, mac, dev, host_threads)
             except Exception as e:
                 out["default_topn"] = {"error": repr(e)}
+            lap("default_topn")
             try:  # (modifies the table in place: last of its users)
                 out["tie_heavy"] = tie_heavy_record(kg, torch, table, stream, M, S, Y, args.topn, mac, dev, host_threads)
             except Exception as e:
                 out["tie_heavy"] = {"error": repr(e)}
+            lap("tie_heavy")
             del table
             torch.cuda.empty_cache()
             try:
                 out["p1_scan_large"] = p1_scan_large_record(kg, torch, stream, S, Y, args.topn, mac, dev, host_threads, seed_table)
             except Exception as e:
                 out["p1_scan_large"] = {"error": repr(e)}
+            lap("p1_scan_large")
             torch.cuda.empty_cache()
             try:
                 out["kinship"] = kinship_record(kg, torch, stream, dev)
             except Exception as e:
                 out["kinship"] = {"error": repr(e)}
+            lap("kinship")
             torch.cuda.empty_cache()
             if not args.no_scale_records:
                 try:
@@ -1287,17 +1304,20 @@ def main():
                 except Exception as e:
                     out["configs_2_and_4_at_scale"] = {"error": repr(e)}
                 torch.cuda.empty_cache()
+            lap("configs_2_and_4_at_scale")
             if not args.no_north_star_shard:
                 try:
                     out["north_star_shard"] = north_star_shard_record(kg, torch, stream, dev, host_threads)
                 except Exception as e:
                     out["north_star_shard"] = {"error": repr(e)}
                 torch.cuda.empty_cache()
+            lap("north_star_shard")
             if not args.no_ingest:
                 try:
                     out["ingest"] = ingest_record(kg, torch, stream, dev, host_threads, rows=args.ingest_rows)
                 except Exception as e:
                     out["ingest"] = {"error": repr(e)}
+            lap("ingest")
             # `roofline.traffic` measured in THIS run (the GPU is free now: table and sessions are gone): PMC passes around two
             # short child runs. KGWAS_BENCH_LIVE_PMC=0 (and every failure) leaves the quotation of the committed profile.
             if kernel_name == "mx_kernel" and os.environ.get("KGWAS_BENCH_LIVE_PMC", "1") != "0":
@@ -1309,6 +1329,8 @@ def main():
                     rl["traffic_quoted_from_profile"] = rl["traffic"]
                     rl["traffic"] = live["bytes_per_row"] * (rl["algorithmic_GB_per_launch"] * 1e9 / (8.0 * W)) / 1e9
                     rl["traffic_from_profile"] = False
+                lap("live_pmc_traffic")
+                if "bytes_per_row" in live:
                     rl["traffic_source"] = ("live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) around two child runs "
                                             "of this script, bytes per row of the steady launches x rows per average launch of the timed steps")
         print(json.dumps(out if args.full else compact_line(out)))

@@ -590,7 +590,10 @@ __global__ void __launch_bounds__(256) KGWAS_RESCORE_OCC rescore_kernel(ScoreArg
             for (uint32_t k = threadIdx.x; k < L / 4u; k += 256u) ytile[k] = ysrc[k];
             __syncthreads();
         }
-        // the rows' words for block b + 1 are asked for before block b's lane-ops start
+        // the rows' words for block b + 1 are asked for before block b's lane-ops start (round 6: ALL of a row's words - eight
+        // blocks at 1024 samples - requested at once, before the first block: re-score + small kernels 5.6 ms per 100 M rows x
+        // 1024 x 101 against 3.67, four blocks at a time 4.45: the wave-loads, 64 cache lines each, then queue up in the
+        // texture-address path instead of being spread between the lane-ops)
         uint2 nx[NS][2];
         auto fetch = [&](uint32_t b) {
 #pragma unroll

@@ -54,11 +54,21 @@
 #define KGWAS_MX_NT 0
 #endif
 
-// KGWAS_MX_WARM=1: every wave asks for the cache lines of its NEXT pass's rows at the top of a pass - one
-// `global_load_lds_dword` per 8 KB, a lane per 128-byte line, landing in a junk LDS word - so that the pass's real row loads
-// (one step ahead of their use: all the registers allow) find the rows in the L2 instead of waiting out HBM's latency.
+// KGWAS_MX_WARM=1 (experiments, measured SLOWER: 10.2 against 9.55 ms per 100 M rows x 1024 x 101): every wave asks for the cache
+// lines of its NEXT pass's rows at the top of a pass - one `global_load_lds_dword` per 8 KB, a lane per 128-byte line, landing in
+// a junk LDS word - so that the pass's real row loads (one step ahead of their use: all the registers allow) find the rows in
+// the L2. The row loads' 1.5 ms in the ablations is not HBM latency waited out: under the board's power limit
+// every extra request costs clock.
 #ifndef KGWAS_MX_WARM
 #define KGWAS_MX_WARM 0
+#endif
+// KGWAS_MX_PERSIST=1 (shapes with ONE LDS group; the default since round 6): as many blocks as the chip holds at once (one per
+// CU: the operands fill the LDS), each taking the 512-row passes b, b + grid, b + 2 grid, ... of the chunk - the operands are
+// copied into the LDS once per block and LAUNCH instead of once per 4096 rows, every CU gets the same number of passes, and no
+// CU waits for a last long block while others are done: 9.0 against 9.5 ms per 100 M rows x 1024 x 101 in alternating runs
+// (tools/mx_ab.sh). 0: one block per 512 .. 4096 rows, as in rounds 3-5.
+#ifndef KGWAS_MX_PERSIST
+#define KGWAS_MX_PERSIST 1
 #endif
 
 namespace kgwas {
@@ -96,7 +106,8 @@ __global__ void __launch_bounds__(TH) mx_kernel(MxArgs a, uint32_t rows_per_bloc
         lg0 = idx % a.n_lgroups;
         lg1 = lg0 + 1u;
     }
-    if (rb >= n_rowblocks) return;
+    const bool persist = KGWAS_MX_PERSIST && !grid_lg;
+    if (!persist && rb >= n_rowblocks) return;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t kb = lane >> 4, m = lane & 15u;
     const uint32_t n_steps = 4u * a.n_full + a.n_quarter;
@@ -218,19 +229,23 @@ __global__ void __launch_bounds__(TH) mx_kernel(MxArgs a, uint32_t rows_per_bloc
             }
         };
         uint32_t piece[RT][4];
-        set_rows(ro, wave_row0);
-        if (a.n_full && wave_row0 < a.n_rows) load_group(piece, ro, 0);
+        // the rows of this wave's pass ps: consecutive passes of a block, or - persistent blocks - every gridDim.x-th pass of the chunk
+        const uint64_t pass_stride = persist ? (uint64_t)gridDim.x * rows_per_pass : rows_per_pass;
+        const uint64_t wave_row00 = persist ? (uint64_t)blockIdx.x * rows_per_pass + wave * (RT * 16u) : wave_row0;
+        const uint64_t n_pass_blk = persist ? ~0ull : (rows_per_block + rows_per_pass - 1) / rows_per_pass;
+        set_rows(ro, wave_row00);
+        if (a.n_full && wave_row00 < a.n_rows) load_group(piece, ro, 0);
         StepAddr sadr = step_addr(lds);
         read_unit(0, sadr);  // step 0 of the first pass; every pass's last step fetches it for the next
-        for (uint32_t ps = 0; ps * rows_per_pass < rows_per_block; ps++) {
-            const uint64_t rbase = wave_row0 + (uint64_t)ps * rows_per_pass;
+        for (uint64_t ps = 0; ps < n_pass_blk; ps++) {
+            const uint64_t rbase = wave_row00 + ps * pass_stride;
             if (rbase >= a.n_rows) break;  // wave-uniform
             uint32_t ro_next[RT];
-            set_rows(ro_next, rbase + rows_per_pass);
+            set_rows(ro_next, rbase + pass_stride);
 #if KGWAS_MX_WARM
             {
                 // rows [rbase + rows_per_pass, + RT*16) of this wave: a contiguous span of the table (whatever the stride)
-                const uint64_t r0 = rbase + rows_per_pass;
+                const uint64_t r0 = rbase + pass_stride;
                 if (r0 < a.n_rows) {  // wave-uniform
                     const uint64_t r1 = r0 + RT * 16u < a.n_rows ? r0 + RT * 16u : a.n_rows;
                     const uint32_t b0 = ((uint32_t)r0 * (uint32_t)a.src.stride_dw + a.src.off_dw) * 4u & ~127u;
@@ -534,7 +549,17 @@ static hipError_t launch_mx_t(const MxArgs& a, uint32_t rows_per_block, size_t l
         if (e != hipSuccess) return e;
     }
     const uint32_t grid_lg = a.n_lgroups > 1 ? 1u : 0u;
-    const uint32_t grid = grid_lg ? (n_rowblocks + 7u) / 8u * 8u * a.n_lgroups : n_rowblocks;
+    uint32_t grid = grid_lg ? (n_rowblocks + 7u) / 8u * 8u * a.n_lgroups : n_rowblocks;
+    if (KGWAS_MX_PERSIST && !grid_lg) {
+        static int n_cu = 0;
+        if (!n_cu) {
+            int dev = 0;
+            hipDeviceProp_t pr;
+            n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+        }
+        const uint64_t n_pass = (a.n_rows + rpp - 1) / rpp;
+        grid = (uint32_t)std::min<uint64_t>(n_pass, (uint64_t)n_cu);
+    }
     hipLaunchKernelGGL((mx_kernel<CT, RT, NS, S1F, TH>), dim3(grid), dim3(TH), lds, st, a, rows_per_block, n_rowblocks, grid_lg);
     return hipGetLastError();
 }
