@@ -91,7 +91,13 @@ __device__ __forceinline__ void narrow_group(const uint32_t (&piece)[NRT][4], co
 // A lane's per-column constants (column p = lane >> 4), read once per block.
 struct NarrowLane {
     float wf0, wf1, wf2, slackf, thrf;
-    bool live;  // p < n_pheno
+    double thrd;  // the column's threshold as the launch found it (read once per block: the exact test must not wait for a load)
+    bool live;    // p < n_pheno
+    // survivors per (column, 65 536-row segment) are added up per BLOCK in LDS (a block's rows touch at most two segments) and
+    // reach the chunk's counters with one atomic per block, column and segment: in the first chunks of a scan - thresholds still
+    // low, a survivor in nearly every wave pass - every pass's own atomic landed on the few words of a one-column chunk
+    uint32_t* lcnt;  // [NARROW_MAX_COLS][2] in LDS
+    uint32_t seg0;   // the block's first segment
 };
 
 // Lane (r = lane & 15, p = lane >> 4) holds D_0, D_1, D_2 (units of 0.5) and N1 / 2 of pair (table row rt * 16 + r,
@@ -124,7 +130,7 @@ __device__ __forceinline__ void narrow_test(const NarrowArgs& a, const NarrowCol
             bool hit = false;
             if (maybe1) {
                 const NarrowCol& cc = cols[0];
-                const double Nd = (double)a.S, thr = a.thr[0];
+                const double Nd = (double)a.S, thr = L.thrd;
                 const double N1 = (double)(2.0f * on);
                 const double yc = cc.w[0] * (double)d0 + cc.w[1] * (double)d1 + cc.w[2] * (double)d2;
                 const double rc = Nd * yc + N1 * cc.t1;
@@ -136,7 +142,7 @@ __device__ __forceinline__ void narrow_test(const NarrowArgs& a, const NarrowCol
             if (w && lane == 0u) {
                 const uint64_t word = (a.row_off + rbase) >> 6;
                 a.bitmap[word] = w;
-                if (a.seg_cnt) atomicAdd(&a.seg_cnt[(uint32_t)(word >> 10)], (uint32_t)__popcll(w));
+                if (a.seg_cnt) atomicAdd(&L.lcnt[(uint32_t)(word >> 10) - L.seg0], (uint32_t)__popcll(w));
             }
         }
         return;
@@ -157,7 +163,7 @@ __device__ __forceinline__ void narrow_test(const NarrowArgs& a, const NarrowCol
         uint32_t hit = 0;
         if (maybe) {
             const NarrowCol& cc = cols[p];
-            const double Nd = (double)a.S, thr = a.thr[p];
+            const double Nd = (double)a.S, thr = L.thrd;
 #pragma unroll
             for (int rt = 0; rt < NRT; rt++)
                 if (maybe & (1u << rt)) {
@@ -189,15 +195,25 @@ __device__ __forceinline__ void narrow_test(const NarrowArgs& a, const NarrowCol
                 if (w) {
                     a.bitmap[(uint64_t)q * a.words_per_col + word] = w;
                     // survivors per (column, 65 536-row segment): what launch_narrow_keys' blocks add up instead of a count kernel
-                    if (a.seg_cnt) atomicAdd(&a.seg_cnt[q * a.n_segs + (uint32_t)(word >> 10)], (uint32_t)__popcll(w));
+                    if (a.seg_cnt) atomicAdd(&L.lcnt[q * 2u + (uint32_t)(word >> 10) - L.seg0], (uint32_t)__popcll(w));
                 }
             }
         }
     }
 }
 
-__device__ __forceinline__ NarrowLane narrow_lane_constants(const NarrowArgs& a, const NarrowCol* cols, uint32_t lane) {
+// the block's segment counters leave for the chunk's (the caller has a barrier between the block's last pass and this)
+__device__ __forceinline__ void narrow_flush_counts(const NarrowArgs& a, const NarrowLane& L) {
+    if (a.seg_cnt && threadIdx.x < 2u * NARROW_MAX_COLS) {
+        const uint32_t c = L.lcnt[threadIdx.x], q = threadIdx.x >> 1, sg = L.seg0 + (threadIdx.x & 1u);
+        if (c && q < a.n_pheno && sg < a.n_segs) atomicAdd(&a.seg_cnt[q * a.n_segs + sg], c);
+    }
+}
+
+__device__ __forceinline__ NarrowLane narrow_lane_constants(const NarrowArgs& a, const NarrowCol* cols, uint32_t lane, uint32_t* lcnt, uint64_t blk_row0) {
     NarrowLane L;
+    L.lcnt = lcnt;
+    L.seg0 = (uint32_t)((a.row_off + blk_row0) >> 16);
     const uint32_t p = a.pack1 ? 0u : lane >> 4;  // (pack1: every lane group tests column 0, narrow_test)
     L.live = p < a.n_pheno;
     const NarrowCol& cc = cols[L.live ? p : 0u];
@@ -205,7 +221,8 @@ __device__ __forceinline__ NarrowLane narrow_lane_constants(const NarrowArgs& a,
     L.wf1 = cc.wf[1];
     L.wf2 = cc.wf[2];
     L.slackf = cc.slackf;
-    L.thrf = (float)a.thr[L.live ? p : 0u];
+    L.thrd = a.thr[L.live ? p : 0u];
+    L.thrf = (float)L.thrd;
     return L;
 }
 
@@ -225,11 +242,13 @@ __global__ void __launch_bounds__(256) narrow_kernel(NarrowArgs a, uint32_t rows
     NarrowCol* lcols = reinterpret_cast<NarrowCol*>(nlds + n_steps * 128u);
     if (threadIdx.x < a.n_pheno * (sizeof(NarrowCol) / 8u))
         reinterpret_cast<double*>(lcols)[threadIdx.x] = reinterpret_cast<const double*>(a.cols)[threadIdx.x];
+    __shared__ uint32_t lcnt_s[2 * NARROW_MAX_COLS];
+    if (threadIdx.x < 2u * NARROW_MAX_COLS) lcnt_s[threadIdx.x] = 0u;
     __syncthreads();
-    const NarrowLane L = narrow_lane_constants(a, lcols, lane);
+    const uint64_t blk_row0 = (uint64_t)blockIdx.x * rows_per_block;
+    const NarrowLane L = narrow_lane_constants(a, lcols, lane, lcnt_s, blk_row0);
     const char* rows_base = reinterpret_cast<const char*>(a.src.base);
     const uint32_t avail_b = a.src.avail_dw * 4u;
-    const uint64_t blk_row0 = (uint64_t)blockIdx.x * rows_per_block;
     uint32_t tested_local = 0;
     const bool mac_any = a.S >= 2u * a.min_count;
     const uint32_t span = a.S - 2u * a.min_count;
@@ -267,6 +286,8 @@ __global__ void __launch_bounds__(256) narrow_kernel(NarrowArgs a, uint32_t rows
         }
         narrow_test(a, lcols, L, acc, lane, rbase, mac_any, span, tested_local);
     }
+    __syncthreads();
+    narrow_flush_counts(a, L);
     if (a.tested) {
         uint32_t v = tested_local;
 #pragma unroll
@@ -321,13 +342,15 @@ __global__ void __launch_bounds__(256) narrow_staged_kernel(NarrowArgs a, uint32
     if (threadIdx.x < a.n_pheno * (sizeof(NarrowCol) / 8u))
         reinterpret_cast<double*>(lcols)[threadIdx.x] = reinterpret_cast<const double*>(a.cols)[threadIdx.x];
     char* stage = reinterpret_cast<char*>(lcols) + 4u * sizeof(NarrowCol) + (size_t)wave * stage_bytes;
+    __shared__ uint32_t lcnt_s[2 * NARROW_MAX_COLS];
+    if (threadIdx.x < 2u * NARROW_MAX_COLS) lcnt_s[threadIdx.x] = 0u;
     __syncthreads();
-    const NarrowLane L = narrow_lane_constants(a, lcols, lane);
+    const uint64_t blk_row0 = (uint64_t)blockIdx.x * rows_per_block;
+    const NarrowLane L = narrow_lane_constants(a, lcols, lane, lcnt_s, blk_row0);
     const char* rows_base = reinterpret_cast<const char*>(a.src.base);
     const uint32_t stride_b = (uint32_t)a.src.stride_dw * 4u, off_b = a.src.off_dw * 4u;
     const uint32_t avail_b = a.src.avail_dw * 4u;
     const uint64_t total_b = a.n_rows * (uint64_t)stride_b;  // bytes of this launch's rows
-    const uint64_t blk_row0 = (uint64_t)blockIdx.x * rows_per_block;
     uint32_t tested_local = 0;
     const bool mac_any = a.S >= 2u * a.min_count;
     const uint32_t span = a.S - 2u * a.min_count;
@@ -423,6 +446,8 @@ __global__ void __launch_bounds__(256) narrow_staged_kernel(NarrowArgs a, uint32
 #undef NARROW_EACH
 #undef NARROW_LOAD
 #undef NARROW_PUT
+    __syncthreads();
+    narrow_flush_counts(a, L);
     if (a.tested) {
         uint32_t v = tested_local;
 #pragma unroll

@@ -13,7 +13,7 @@ for r in csv.DictReader(open(f)):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short))
 rows.sort()
 # the LAST step: from the last dense scorer launch on
-idx = [i for i, r in enumerate(rows) if r[2] == "score_mfma_kernel"]
+idx = [i for i, r in enumerate(rows) if r[2] in ("score_mfma_kernel", "score_valu_kernel")]
 start = idx[-1] if idx else 0
 rows = rows[start:]
 t0 = rows[0][0]
