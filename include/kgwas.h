@@ -221,8 +221,11 @@ typedef struct kgwas_scan_stats {
 } kgwas_scan_stats;
 
 /* Version of this header's struct layouts and entry points. A caller built against an older header must not pass its (smaller)
- * kgwas_scan_stats to a newer library: compare KGWAS_ABI_VERSION with kgwas_abi_version() at start-up. */
-#define KGWAS_ABI_VERSION 5
+ * kgwas_scan_stats to a newer library: compare KGWAS_ABI_VERSION with kgwas_abi_version() at start-up.
+ * Version 6 (round 6): no struct changed; new entry points kgwas_heap_selfcheck, kgwas_scan_select_mode and the test hook
+ * kgwas_scan_debug_residuals; kgwas_scan_lowest takes a non-const session (it always mutated it); kgwas_scan_stats.coarse_mx32 is
+ * always 0 (the 32 x 32 x 64 filter form was removed). */
+#define KGWAS_ABI_VERSION 6
 uint32_t kgwas_abi_version(void);
 
 int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out);

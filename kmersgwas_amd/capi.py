@@ -138,7 +138,7 @@ lib.kgwas_version.restype = C.c_int
 lib.kgwas_device_count.argtypes = [C.POINTER(C.c_int)]
 lib.kgwas_abi_version.argtypes = []
 lib.kgwas_abi_version.restype = C.c_uint32
-ABI_VERSION = 5  # KGWAS_ABI_VERSION of include/kgwas.h this mirror was written against
+ABI_VERSION = 6  # KGWAS_ABI_VERSION of include/kgwas.h this mirror was written against
 if lib.kgwas_abi_version() != ABI_VERSION:
     raise ImportError("libkgwas.so speaks ABI version %d, kmersgwas_amd/capi.py %d: rebuild (make -C kmersgwas_amd/csrc)" % (lib.kgwas_abi_version(), ABI_VERSION))
 lib.kgwas_host_cpu_quota.argtypes = []

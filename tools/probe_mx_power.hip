@@ -7,6 +7,7 @@
 //   sparseA   A = table-like nibbles (one of bits 0..2 set at density 1/2), B = random FP6 / FP4 codes: the filter's data
 //   denseA    A and B random bit patterns
 //   sparseA+V the same with 8 / 16 / 24 independent v_and_b32 per 16 MFMAs (the filter's main loop has ~8, with its epilogue ~24)
+//   ... + L   and six ds_read_b128 per 16 MFMAs (the operand pieces the filter reads from LDS), waited for one unit later
 // For each: MFMAs per second and SIMD, the implied pipe-busy fraction at the MEASURED mean clock, mean / max socket power, cap.
 #include <hip/hip_runtime.h>
 
@@ -32,6 +33,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #define MFMA4(c, a, b, sa, sb) \
     asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0] cbsz:4 blgp:4" : "+v"(c) : "v"(a), "v"(b), "v"(sa), "v"(sb))
 #define VALU(x, y) asm volatile("v_and_b32 %0, %1, %2" : "=v"(x) : "v"(y), "v"(msk))
+#define LDSR(b, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b) : "v"(addr), "n"(off))
 
 __device__ inline uint32_t mixu(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
@@ -39,9 +41,19 @@ __device__ inline uint32_t mixu(uint32_t x) {
 }
 
 // DATA: 0 zeros, 1 sparse A + random B, 2 dense A + random B.   V: independent VALU per unit of 16 MFMAs
-template <int DATA, int V>
+// L: ds_read_b128 per unit (the filter reads six operand pieces per unit; waited for one unit later, as there)
+template <int DATA, int V, int L = 0>
 __global__ void __launch_bounds__(512) k(float* out, int passes, uint32_t seed) {
+    __shared__ v4i lds[L ? 4096 : 1];
     const uint32_t lane = threadIdx.x & 63u, gid = blockIdx.x * 512u + threadIdx.x;
+    if (L) {
+        for (uint32_t i = threadIdx.x; i < 4096u; i += blockDim.x) lds[i] = (v4i){(int)mixu(i + seed), (int)mixu(i * 3u), (int)mixu(i * 5u), (int)mixu(i * 7u)};
+        __syncthreads();
+    }
+    const uint32_t laddr = (uint32_t)(size_t)lds + lane * 16u;
+    v4i ld[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) ld[i] = (v4i){0, 0, 0, 0};
     v4f acc[28];
 #pragma unroll
     for (int i = 0; i < 28; i++) acc[i] = (v4f){0, 0, 0, 0};
@@ -72,6 +84,11 @@ __global__ void __launch_bounds__(512) k(float* out, int passes, uint32_t seed) 
     for (int p = 0; p < passes; p++) {
 #pragma unroll
         for (int u = 0; u < 28; u++) {  // a unit: two column tiles x four row tiles x two slices
+            if (L > 0) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int l = 0; l < L; l++) LDSR(ld[l & 7], laddr, ((u * 8 + l) & 63) * 1024);
+            }
 #pragma unroll
             for (int t = 0; t < 2; t++) {
 #pragma unroll
@@ -87,7 +104,7 @@ __global__ void __launch_bounds__(512) k(float* out, int passes, uint32_t seed) 
 #pragma unroll
     for (int i = 0; i < 28; i++) r += acc[i][0] + acc[i][3];
 #pragma unroll
-    for (int i = 0; i < 8; i++) r += (float)x[i];
+    for (int i = 0; i < 8; i++) r += (float)x[i] + (float)(ld[i][0] & 1);
     if (r == 12345.678f) out[gid] = r;
 }
 
@@ -129,13 +146,13 @@ static Sensors find_sensors(const char* pci) {  // the hwmon directory of the ca
     return s;
 }
 
-template <int DATA, int V>
+template <int DATA, int V, int L = 0>
 static void run(const char* name, float* d, const Sensors& sn, double seconds) {
     const int passes = 4000;  // 448 MFMAs per pass and wave: ~30 ms per launch
     std::atomic<bool> stop{false};
     double p_sum = 0, p_max = 0, f_sum = 0, f_min = 1e30, f_max = 0;
     long n = 0;
-    hipLaunchKernelGGL((k<DATA, V>), dim3(256), dim3(512), 0, 0, d, 100, 1u);
+    hipLaunchKernelGGL((k<DATA, V, L>), dim3(256), dim3(512), 0, 0, d, 100, 1u);
     hipDeviceSynchronize();
     std::thread th([&] {
         std::this_thread::sleep_for(std::chrono::milliseconds(500));  // let the clock settle under the load
@@ -157,7 +174,7 @@ static void run(const char* name, float* d, const Sensors& sn, double seconds) {
     long launches = 0;
     while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
         hipEventRecord(e0);
-        for (int i = 0; i < 4; i++) hipLaunchKernelGGL((k<DATA, V>), dim3(256), dim3(512), 0, 0, d, passes, (uint32_t)launches);
+        for (int i = 0; i < 4; i++) hipLaunchKernelGGL((k<DATA, V, L>), dim3(256), dim3(512), 0, 0, d, passes, (uint32_t)launches);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms;
@@ -191,5 +208,7 @@ int main(int argc, char** argv) {
     run<1, 8>("sparse A + 8 VALU per 16 MFMAs", d, sn, secs);
     run<1, 16>("sparse A + 16 VALU per 16 MFMAs", d, sn, secs);
     run<1, 24>("sparse A + 24 VALU per 16 MFMAs", d, sn, secs);
+    run<1, 8, 6>("sparse A + 8 VALU + 6 ds_read_b128 per 16 MFMAs", d, sn, secs);
+    run<1, 24, 6>("sparse A + 24 VALU + 6 ds_read_b128 per 16", d, sn, secs);
     return 0;
 }
