@@ -964,6 +964,10 @@ def main():
     by_column = os.environ.get("KGWAS_BENCH_MERGE", "") == "column"  # (else kdist.merge_shards: to the root while the sessions are in select mode)
     if world > 1 and rank == 0 and by_column and "KGWAS_FULL_REPLAY" not in os.environ:
         os.environ["KGWAS_FULL_REPLAY"] = "1"
+    if world > 1 and rank == 0:
+        # rank 0 finishes the merged columns while the other ranks wait: the columns that need the exact replay go side by side on
+        # the CPUs the waiting ranks are not using, not one after the other on this rank's share of them (kgwas_scan_finish)
+        os.environ.setdefault("KGWAS_FINISH_THREADS", str(usable_cpus()))
     session = kg.AssociationScan(S, col, Y, args.topn, mac, device=dev, kernel=args.kernel,
                                  chunk_rows=args.chunk_rows, record_history=(2 if (world > 1 and rank > 0) else 0), host_threads=host_threads)
 

@@ -12,6 +12,7 @@
 //   KGWAS_MXS_FORM=1|2         its block shapes with one column group of up to 13 tiles
 //   KGWAS_NARROW=0             1-4 columns through the wide filter instead of the narrow one
 //   KGWAS_HOST_THREADS=n       replay threads of a session (overrides kgwas_scan_params.host_threads)
+//   KGWAS_FINISH_THREADS=n     kgwas_scan_finish makes the select-mode columns' lists on n threads if that is more than the pool
 //   KGWAS_PIN_THREADS=0|1|2    replay threads: unpinned / one CPU each (default) / one core (SMT pair) each
 //   KGWAS_SPLIT_LAGGING=0      a column group that falls behind is not cut into single columns
 //   KGWAS_FLOAT_LEAD=n         chunks a group may lag before it floats to the workers that are ahead (default 2, 0: never)

@@ -133,6 +133,9 @@ __device__ __forceinline__ uint32_t transpose32(uint32_t x, uint32_t lane) {
 // transposes: the block's LDS is the planes alone (37 KB instead of 76 at 1135 samples), one barrier and two passes over LDS
 // fewer; but a wave's loads touch 64 rows x 36 bytes at a 152-byte stride - 64 addresses per instruction.
 constexpr uint32_t KIN_DIRECT_DW = 12u;
+#ifndef KGWAS_KIN_FLIP
+#define KGWAS_KIN_FLIP 1  // rows with more than half of their bits set enter the planes complemented (kin_transpose_kernel)
+#endif
 template <bool DIRECT_IN>
 __global__ void __launch_bounds__(1024) kin_transpose_kernel(const uint64_t* file_rows, uint64_t file_stride_w, uint64_t n_rows,
                                                             uint32_t S_f, uint32_t S_pad, uint32_t min_count, uint32_t* T,
@@ -192,6 +195,16 @@ __global__ void __launch_bounds__(1024) kin_transpose_kernel(const uint64_t* fil
     // src/emma_kinship_kmers.cpp:83,89 -> load_kmers' predicate with all S_f columns
     const bool pass = (r < n_rows) && (S_f >= min_count) && (n1 >= min_count) && (n1 <= S_f - min_count);
     const unsigned long long kept = half == 0u ? __popcll(__ballot(pass)) : 0ull;  // (half is wave-uniform: rpb >= 64)
+#if KGWAS_KIN_FLIP
+    // Hamming(i, j) = sum_rows g_i ^ g_j = c_ii + c_jj - 2 c_ij does not change when a ROW is complemented (both of its bits
+    // flip), and that is all the Gram matrix is used for (kgwas_kinship_partials): a row with more than half of its S_f bits set
+    // goes into the planes complemented (its padding bits stay zero). The planes' density falls from the rows' mean frequency to
+    // the mean of min(f, 1 - f) - 0.5 -> 0.26 on the synthetic tables -, and with it the operands' toggle rate under the Gram
+    // kernel's MFMAs: the board is power-limited on this instruction, so sparser operands are clock.
+    const uint32_t flipm = (n1 * 2u > S_f) ? 0xFFFFFFFFu : 0u;
+#else
+    const uint32_t flipm = 0u;
+#endif
     auto plane_store = [&](uint32_t d, uint32_t x) {
         x = transpose32(x, lane);
         // lane s of 32-lane group g now holds sample 32d + s over the group's 32 rows
@@ -202,9 +215,9 @@ __global__ void __launch_bounds__(1024) kin_transpose_kernel(const uint64_t* fil
     if (DIRECT_IN) {
 #pragma unroll
         for (uint32_t i = 0; i < KIN_DIRECT_DW; i++)
-            if (d0 + i < d1) plane_store(d0 + i, pass ? own[i] : 0u);  // (d0, d1 are wave-uniform: transpose32 runs with all lanes)
+            if (d0 + i < d1) plane_store(d0 + i, pass ? mask_of(d0 + i, own[i] ^ flipm) : 0u);  // (d0, d1 are wave-uniform: transpose32 runs with all lanes)
     } else {
-        for (uint32_t d = d0; d < d1; d++) plane_store(d, (pass && d < in_dw) ? masked(d) : 0u);
+        for (uint32_t d = d0; d < d1; d++) plane_store(d, (pass && d < in_dw) ? mask_of(d, my[d] ^ flipm) : 0u);
     }
     if (lane == 0 && kept) atomicAdd(&n_used[blockIdx.x % TESTED_SHARDS], kept);  // each wave adds the rows it counted
     __syncthreads();

@@ -154,10 +154,25 @@ int kgwas_scan_finish(kgwas_scan* s) {
             // 0.1 ms per selection. Looking at every pool first - keys only - so that those replays start at once was measured:
             // 6.5 ms against 6.1, the selections in front of a replay are too short to matter. KGWAS_FINISH_TRACE=1 prints each
             // column's parts.)
-            s->pool->parallel_for(lz.size(), [&](size_t i) {
-                lazy_finish_column(s, lz[i]);
-                s->col_popped[lz[i]].store(2, std::memory_order_release);
-            });
+            // KGWAS_FINISH_THREADS=n: a wider team for this step than the session's replay pool. A rank of a multi-GPU job scans with
+            // its share of the node's CPUs (two of sixteen at eight ranks), but when rank 0 finishes the MERGED columns the other
+            // ranks wait: the columns that need the exact replay (~10 ms each at the north-star shard) then go side by side on the
+            // CPUs nobody is using instead of queueing on two threads (bench.py sets it for rank 0).
+            const unsigned ft = (unsigned)std::max<long long>(0, opt_int("KGWAS_FINISH_THREADS", 0));
+            if (ft > s->pool->size() && lz.size() > s->pool->size()) {
+                std::atomic<size_t> next(0);
+                kgwas_run_on_threads((unsigned)std::min<size_t>(ft, lz.size()), "kgwas-finish", [&] {
+                    for (size_t i; (i = next.fetch_add(1, std::memory_order_relaxed)) < lz.size();) {
+                        lazy_finish_column(s, lz[i]);
+                        s->col_popped[lz[i]].store(2, std::memory_order_release);
+                    }
+                });
+            } else {
+                s->pool->parallel_for(lz.size(), [&](size_t i) {
+                    lazy_finish_column(s, lz[i]);
+                    s->col_popped[lz[i]].store(2, std::memory_order_release);
+                });
+            }
         }
         s->st.heap_pushes += s->lazy_pushes.exchange(0);
         s->st.columns_selected = (uint32_t)s->n_selected.exchange(0);  // (as of this finish)

@@ -1525,3 +1525,25 @@ def test_adversarial_rows_at_the_filters_bound(name, env, P, form, S, monkeypatc
         assert st["coarse_mx"] == 0
     _check_topn(scan, exp, P)  # (with every column replayed: the effective-push count as well)
     scan.close()
+
+
+def test_finish_on_a_wider_team_than_the_replay_pool(monkeypatch):
+    """KGWAS_FINISH_THREADS: rank 0 of a multi-GPU job scans with two replay threads and finishes the merged columns on the CPUs the
+    waiting ranks leave idle. Tie-heavy table (every column needs the exact replay at finish or before), two replay threads, eight
+    finish threads: the same lists as the oracle's, with and without the switch."""
+    S, P, topn = 241, 24, 300
+    rows = random_table(120_000, S, seed=77, dup_frac=0.4)
+    col = np.arange(S, dtype=np.uint64)
+    Y = phenotypes(S, P - 1, seed=9)
+    Y[3] = phenotypes(S, 0, seed=5, binary=True)[0]
+    mac = onp.min_count(S, 0.05, 5)
+    exp = ob.associate(rows, S, col, Y, topn, mac, threads=8)
+    for ft in ("8", "0"):
+        monkeypatch.setenv("KGWAS_FINISH_THREADS", ft)
+        scan = kg.AssociationScan(S, col, Y, topn, mac, host_threads=2)
+        scan.feed_host(rows[:70_000], 0)
+        scan.feed_host(rows[70_000:], 70_000)
+        scan.finish()
+        _check_topn(scan, exp, P)
+        assert scan.stats()["replay_threads"] == 2
+        scan.close()
