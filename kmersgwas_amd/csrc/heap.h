@@ -154,6 +154,22 @@ class alignas(128) BestHeap {
     // order, with the comparator Greater. Only the child choice is made branch-free (it is a coin flip for
     // the branch predictor, 13 levels deep at N = 10001). tests/test_host.py drives this against a literal
     // std::priority_queue on tie-heavy streams.
+    // Heaps that do not fit the cache (the reference's default -n 1 000 000: 16 MB of entries): the hole walk is a chain of
+    // dependent misses, 20 levels deep. Which way it turns is not known in advance, but WHERE it can be three levels down is:
+    // the 16 descendants of node c at depth + 4 are contiguous (16 c + 15 .. 16 c + 30, five cache lines); asking for them while
+    // the compares of the levels in between are made turns every miss but the first into a hit in flight
+    // (tools/heap_one_bench.cpp, N = 10^6). No effect on what is moved where.
+    static constexpr ptrdiff_t BIG_HEAP = 1 << 16;
+    static inline void prefetch_below(const Ent* a, ptrdiff_t c, ptrdiff_t n) {
+        const ptrdiff_t d = 16 * c + 15;
+        if (d + 15 < n) {
+            __builtin_prefetch(a + d);
+            __builtin_prefetch(a + d + 4);
+            __builtin_prefetch(a + d + 8);
+            __builtin_prefetch(a + d + 12);
+            __builtin_prefetch(a + d + 15);
+        }
+    }
     template <bool INT>
     static inline void replace_top(Ent* a, ptrdiff_t n, Ent x) {
         const Ent value = a[n - 1];
@@ -165,7 +181,9 @@ class alignas(128) BestHeap {
             // stops there instead (same final array; one heap at a time this saves the last level or two and the climb:
             // 40 -> 34 ns per push, tools/heap_soa_bench.cpp; in lockstep the extra compare per level costs more).
             bool open = true;
+            const bool big = n > BIG_HEAP;
             while (child < (len - 1) / 2) {
+                if (big) prefetch_below(a, child, n);
                 ptrdiff_t cc = 2 * (child + 1);
                 cc -= gt<true>(a[cc], a[cc - 1]) ? 1 : 0;
                 if (gt<true>(a[cc], value)) {
@@ -193,7 +211,9 @@ class alignas(128) BestHeap {
             a[hole] = x;
             return;
         }
+        const bool big = n > BIG_HEAP;
         while (child < (len - 1) / 2) {
+            if (big) prefetch_below(a, child, n);
             child = 2 * (child + 1);
             child -= gt<INT>(a[child], a[child - 1]) ? 1 : 0;
             a[hole] = a[child];
@@ -259,11 +279,13 @@ class alignas(128) BestHeap {
             hp[0]->lowest_ = a[0][0].score;
             return;
         }
+        const bool big = n > BIG_HEAP;
         for (;;) {  // hole walks: all reach the leaf level within one step of each other
             bool any = false;
 #pragma unroll
             for (int k = 0; k < K; k++) {
                 if (c[k] < lim) {
+                    if (big) prefetch_below(a[k], c[k], n);
                     ptrdiff_t cc = 2 * (c[k] + 1);
                     cc -= gt<INT>(a[k][cc], a[k][cc - 1]) ? 1 : 0;
                     a[k][h[k]] = a[k][cc];

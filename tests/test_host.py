@@ -131,7 +131,8 @@ def test_min_count_matches_the_reference_rule():
 
 
 @pytest.mark.parametrize("N,n,levels", [(1, 60, 3), (2, 100, 3), (3, 200, 2), (10, 500, 4), (64, 4000, 9), (200, 150, 5), (33, 3000, 2),
-                                        (1000, 30000, 40), (1001, 30000, 2000)])
+                                        (1000, 30000, 40), (1001, 30000, 2000),
+                                        (70001, 400000, 3000)])  # (> 65 536 entries: the hole walks prefetch the descendants three levels down)
 @pytest.mark.parametrize("flavour", ["nan", "plain", "negative", "distinct", "one_tie"])
 def test_heap_mirror_equals_oracle_heap_under_ties(N, n, levels, flavour):
     """(plain: scores in +0 .. +inf, the heap compares their bit patterns as integers; nan / negative: it must notice
