@@ -536,6 +536,17 @@ __device__ __forceinline__ void rescore_finish(const ScoreArgs& a, uint32_t p, b
 
 // Rows are read in place by their own lane, 8 bytes x 2 per 128-sample block. (Staging a wave's 64 rows through LDS with
 // coalesced copies - every line fetched once - measured 30-50 % SLOWER: the gathers are not what this kernel waits for.)
+// Round 6 went through the remaining suspects with counters and build variants (tools/pmc_rescore_mem.sh, tools/coarse_variants.sh;
+// re-score + small kernels per 100 M rows x 1024 x 101, alternating runs, 3.64-3.74 ms as it is): the counters of its large
+// launches say 65 % of the wave cycles are spent in s_waitcnt and two thirds of the L1's accesses go on to the L2 (a row's line
+// is asked for 16 times, a 128-sample block apart, and the L1 sees 1300 other rows in between) - and yet: ONE 16-byte request per
+// block instead of two 8-byte ones 3.62-3.64; the wave fetching its 64 rows together, eight lanes per row, through a
+// conflict-free LDS area (every line requested once) 3.77; all of a row's requests at once 5.6; a wave's candidates added to the
+// column's histogram with one atomic per distinct bin instead of one each 4.44 (the loop over ~30 distinct bins costs more than
+// the atomics did); a block taking a RUN of consecutive tiles, the column copied into LDS once per column instead of once per
+// tile, 3.64. tools/probe_gather.hip: a bare gather of 2^20 rows in this access pattern takes 45 us while the rows sit in the L2
+// and 135 us once they are spread over more than 256 MB - the kernel's launches over the chunks of 1-8 M rows are where its time
+// goes (0.4 ms each for ~10^6 survivors against 0.09 ms for the same number in a chunk of 50 k rows). Left as it is.
 // DIRECT (scans of a few columns, launch_rescore_direct): the survivor's record is written at its place in the key order -
 // score or -inf, k-mer, row - and nothing is counted or compacted afterwards.
 // NS = 2 (experiments): a block takes two consecutive tiles at a time and, where both belong to the same column - all but

@@ -59,7 +59,8 @@ while time.time() < t_end:
            "KGWAS_MXS": str(rng.choice(["", "", "0", "2", "3", "3"])), "KGWAS_MXS_FORM": str(rng.choice(["", "", "1", "2"])),
            "KGWAS_FULL_REPLAY": str(rng.choice(["", "", "", "1"])), "KGWAS_LOG_BY_REF": str(rng.choice(["", "", "0"])),
            "KGWAS_RING_BYTES": str(rng.choice(["", "", "1", "3000000"])), "KGWAS_DSEL_REG": str(rng.choice(["", "", "0"])),
-           "KGWAS_TAIL_KERNEL": str(rng.choice(["", "", "0"])), "KGWAS_TIE_CHECKS": str(rng.choice(["", "", "0", "1"]))}
+           "KGWAS_TAIL_KERNEL": str(rng.choice(["", "", "0"])), "KGWAS_TIE_CHECKS": str(rng.choice(["", "", "0", "1"])),
+           "KGWAS_FINISH_THREADS": str(rng.choice(["", "", "7"]))}
     for k, v in env.items():
         if v: os.environ[k] = v
         else: os.environ.pop(k, None)
