@@ -306,6 +306,30 @@ hipError_t launch_chunk_tail(const uint32_t* meta, uint32_t n_meta, uint32_t* h_
     return hipGetLastError();
 }
 
+// The wide path's chunk end in ONE launch: block p raises thr[p] (thr_update_kernel's body) and writes it to the mapped buffer,
+// block 0 also copies the counts and the tested-row shards (chunk_tail_kernel's work): the launch after the compaction is the
+// chunk's last. The thresholds and what the host reads are what the two launches produced.
+__global__ void __launch_bounds__(256) thr_tail_kernel(const uint32_t* hist, const uint32_t* hist_base, uint32_t bins, const uint64_t* topn,
+                                                       const double* thr_host, double* thr, const uint32_t* __restrict__ meta, uint32_t n_meta,
+                                                       uint32_t* __restrict__ h_meta, const unsigned long long* __restrict__ tested, uint32_t n_tested,
+                                                       unsigned long long* __restrict__ h_tested, double* __restrict__ h_thr) {
+    thr_update_block(hist, hist_base, bins, topn, thr_host, thr, blockIdx.x);  // (ends with a block barrier)
+    if (h_thr && threadIdx.x == 0) h_thr[blockIdx.x] = thr[blockIdx.x];
+    if (blockIdx.x == 0) {
+        for (uint32_t i = threadIdx.x; i < n_meta; i += 256u) h_meta[i] = meta[i];
+        for (uint32_t i = threadIdx.x; i < n_tested; i += 256u) h_tested[i] = tested[i];
+    }
+}
+
+hipError_t launch_thr_tail(const uint32_t* hist, const uint32_t* hist_base, uint32_t bins, const uint64_t* topn, const double* thr_host, double* thr,
+                           uint32_t n_pheno, const uint32_t* meta, uint32_t n_meta, uint32_t* h_meta, const unsigned long long* tested,
+                           uint32_t n_tested, unsigned long long* h_tested, double* h_thr, hipStream_t st) {
+    if (n_pheno == 0 || bins % 256u) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(thr_tail_kernel, dim3(n_pheno), dim3(256), 0, st, hist, hist_base, bins, topn, thr_host, thr, meta, n_meta, h_meta, tested,
+                       n_tested, h_tested, h_thr);
+    return hipGetLastError();
+}
+
 hipError_t launch_records_to_host(const double* sc, const uint64_t* km, const uint32_t* rw, uint32_t n, double* h_sc, uint64_t* h_km, uint32_t* h_rw,
                                   hipStream_t st) {
     if (!n) return hipSuccess;

@@ -75,6 +75,11 @@ hipError_t launch_copy_to_host(const void* src, void* dst_dev, size_t bytes, hip
 // a chunk's counts, tested-row shards and current thresholds into mapped host buffers, one launch (n_* = 0: skip that part)
 hipError_t launch_chunk_tail(const uint32_t* meta, uint32_t n_meta, uint32_t* h_meta, const unsigned long long* tested, uint32_t n_tested,
                              unsigned long long* h_tested, const double* thr, uint32_t n_thr, double* h_thr, hipStream_t st);
+// launch_thr_update and launch_chunk_tail in one launch (block p: column p's threshold, also into h_thr[p] unless h_thr is null;
+// block 0: the counts and the tested-row shards)
+hipError_t launch_thr_tail(const uint32_t* hist, const uint32_t* hist_base, uint32_t bins, const uint64_t* topn, const double* thr_host, double* thr,
+                           uint32_t n_pheno, const uint32_t* meta, uint32_t n_meta, uint32_t* h_meta, const unsigned long long* tested,
+                           uint32_t n_tested, unsigned long long* h_tested, double* h_thr, hipStream_t st);
 hipError_t launch_records_to_host(const double* sc, const uint64_t* km, const uint32_t* rw, uint32_t n, double* h_sc, uint64_t* h_km, uint32_t* h_rw,
                                   hipStream_t st);
 hipError_t launch_thr_update(const uint32_t* hist, const uint32_t* hist_base, uint32_t bins, const uint64_t* topn,
@@ -159,9 +164,9 @@ size_t mxs_lds_bytes(uint32_t CT, uint32_t NG);
 hipError_t launch_mxs(const MxArgs& a, uint32_t CT, uint32_t NG, uint32_t form, uint32_t rows_per_block, hipStream_t st);
 // Survivors (sorted keys, per-column ranges) -> exact candidates compacted in (column, row) order into a.so_score /
 // a.so_kmer / a.so_row (HBM); meta[0..P) = candidates per column, meta[P..2P) = their offsets, meta[2P] = total,
-// meta[2P + 1] = survivor keys emitted. tile_pref [P + 1], tile_cnt / tile_off [key_cap / 256 + P + 1], tmp_score [key_cap].
+// meta[2P + 1] = survivor keys emitted. tile_pref [P + 1], tile_cnt [key_cap / 256 + P + 1], tmp_score [key_cap].
 hipError_t launch_rescore(const ScoreArgs& a, const uint32_t* keys, const uint32_t* surv_off, const uint32_t* surv_cnt,
-                          uint32_t row_bits, uint32_t* tile_pref, uint32_t* tile_cnt, uint32_t* tile_off, double* tmp_score,
+                          uint32_t row_bits, uint32_t* tile_pref, uint32_t* tile_cnt, double* tmp_score,
                           const uint32_t* key_count, uint32_t* meta, hipStream_t st);
 // Scans of a few columns: every survivor's record goes straight to its place in the key order (a.so_score = exact score or
 // -inf for a survivor that is no candidate - the host's replay skips those), no tile scan, no compaction; meta was written
@@ -218,10 +223,12 @@ struct NarrowArgs {
 // The bitmap's set bits as row-ordered keys (column << row_bits | row), column after column, with each column's range
 // (surv_off, surv_cnt) and the total (key_count; above key_cap = overflow, the ranges are then emptied). No sort: counts
 // per 65 536-row block, a scan, a scatter. nibble_transposed: the words come from the int8 filters (quarter word kg,
-// nibble rt = rows 16 rt + 4 kg ..+3). tile_pref[n_pheno + 1]: launch_rescore's tile table (first tile of each column). blk_scratch: n_pheno * (ceil(n_rows / 65536) + 1) words.
-hipError_t launch_bitmap_keys(const unsigned long long* bitmap, uint64_t words_per_col, uint64_t n_rows, uint32_t n_pheno, uint32_t* blk_scratch,
-                              uint32_t* keys_sorted, uint32_t key_cap, uint32_t row_bits, uint32_t* surv_off, uint32_t* surv_cnt,
-                              uint32_t* key_count, uint32_t* tile_pref, bool nibble_transposed, hipStream_t st);
+// nibble rt = rows 16 rt + 4 kg ..+3). tile_pref[n_pheno + 1]: launch_rescore's tile table (first tile of each column). blk_scratch: n_pheno * (ceil(n_rows / 65536) + 1) words;
+// blk_mask: 4 x 64 bits per (column, block) - the count kernel marks the threads whose words hold a survivor, the scatter kernel
+// loads only those and CLEARS them: the bitmap is all zero again behind this call (the caller zeroes it once, not per chunk).
+hipError_t launch_bitmap_keys(unsigned long long* bitmap, uint64_t words_per_col, uint64_t n_rows, uint32_t n_pheno, uint32_t* blk_scratch,
+                              unsigned long long* blk_mask, uint32_t* keys_sorted, uint32_t key_cap, uint32_t row_bits, uint32_t* surv_off,
+                              uint32_t* surv_cnt, uint32_t* key_count, uint32_t* tile_pref, bool nibble_transposed, hipStream_t st);
 // The same for the narrow filter (one to four columns), whose kernels have already counted the survivors per segment
 // (NarrowArgs::seg_cnt): ONE launch instead of four - every (segment, column) block adds up the counts before it and
 // writes its keys; block (0, 0) writes the ranges, the tile table and meta (records = survivors: see launch_rescore_direct).

@@ -832,12 +832,13 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
             s->bitmap_words = (s->chunk_max + 63) / 64;
             s->d_bitmap.alloc(P * s->bitmap_words);
             s->d_bm_blocks.alloc(P * ((s->bitmap_words + 1023) / 1024 + 1) + 4);
+            if (!s->narrow) s->d_bm_mask.alloc(P * ((s->bitmap_words + 1023) / 1024) * 4 + 4);
+            s->bitmap_clean = false;
             s->d_surv_cnt.alloc(P);
             s->d_surv_off.alloc(P);
             s->d_key_count.alloc(2);  // the survivor count; the narrow re-score kernel's block counter
             s->d_tile_pref.alloc(P + 1);
             s->d_tile_cnt.alloc((size_t)s->key_slots / 256 + P + 2);
-            s->d_tile_off.alloc((size_t)s->key_slots / 256 + P + 2);
             s->d_tmp_score.alloc(s->key_slots);
             // The record copies run as blit kernels (rocprofv3 shows __amd_rocclr_copyBuffer, not SDMA transfers), and at
             // normal priority they are only dispatched in the gaps of the compute stream: behind a 0.75 ms filter launch

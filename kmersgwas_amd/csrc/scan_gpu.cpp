@@ -324,8 +324,12 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
             tu.thr_host = s->d_thr_host.p;
             tu.thr = s->d_thr.p;
         }
+        // (wide path: the key launches clear the words they list, so the bitmap is zeroed here only before a session's first
+        // chunk or after a chunk whose key launches were never queued - in full, the chunks' geometries differ)
+        const bool zero_bitmap = use_coarse && (s->narrow || !s->bitmap_clean);
+        const uint64_t zero_words = !zero_bitmap ? 0 : (s->narrow ? s->n_pheno * n_words : s->d_bitmap.n);
         KGWAS_HIP(launch_chunk_prep(sl.d_cnt.p, (uint32_t)s->n_pheno, sl.d_tested.p, use_coarse ? s->d_key_count.p : nullptr,
-                                    use_coarse ? s->d_bitmap.p : nullptr, use_coarse ? s->n_pheno * n_words : 0,
+                                    zero_bitmap ? s->d_bitmap.p : nullptr, zero_words,
                                     (use_coarse && s->narrow) ? s->d_bm_blocks.p : nullptr, (use_coarse && s->narrow) ? (uint32_t)s->n_pheno * n_segs : 0u,
                                     tu, s->stream));
     }
@@ -378,6 +382,7 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
             // 1280: 26.3 ms per 1.2 G rows against 27.1 with 768, 26.5 with 1024 or 1536)
             KGWAS_HIP(launch_narrow(na, rpb_env ? rpb_env : (n_rows >= (1u << 24) ? 1280u : n_rows >= (1u << 18) ? 768u : 256u), s->stream));
         } else {
+            s->bitmap_clean = false;  // (until the key launches are queued behind the filter)
             c.bitmap = s->d_bitmap.p;
             c.words_per_col = n_words;
             // rows per block: the operand tiles (up to 128 KB) are loaded into LDS once per block, so blocks are long
@@ -431,13 +436,14 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
                                          s->row_key_bits, s->d_surv_off.p, s->d_surv_cnt.p, s->d_key_count.p, s->d_tile_pref.p, sl.d_meta.p, sl.d_tested.p, s->stream));
             KGWAS_HIP(launch_rescore_direct(a, s->d_surv_sorted.p, s->d_surv_off.p, s->d_surv_cnt.p, s->row_key_bits, s->d_tile_pref.p, s->stream));
         } else {
-        KGWAS_HIP(launch_bitmap_keys(s->d_bitmap.p, n_words, n_rows, (uint32_t)s->n_pheno, s->d_bm_blocks.p, s->d_surv_sorted.p, s->key_slots,
+        KGWAS_HIP(launch_bitmap_keys(s->d_bitmap.p, n_words, n_rows, (uint32_t)s->n_pheno, s->d_bm_blocks.p, s->d_bm_mask.p, s->d_surv_sorted.p, s->key_slots,
                                      s->row_key_bits, s->d_surv_off.p, s->d_surv_cnt.p, s->d_key_count.p, s->d_tile_pref.p, /*nibble_transposed=*/!s->narrow, s->stream));
+        s->bitmap_clean = true;
         a.so_score = sl.d_so_score.p;
         a.so_kmer = sl.d_so_kmer.p;
         a.so_row = sl.d_so_row.p;
         KGWAS_HIP(launch_rescore(a, s->d_surv_sorted.p, s->d_surv_off.p, s->d_surv_cnt.p, s->row_key_bits, s->d_tile_pref.p,
-                                 s->d_tile_cnt.p, s->d_tile_off.p, s->d_tmp_score.p, s->d_key_count.p, sl.d_meta.p, s->stream));
+                                 s->d_tile_cnt.p, s->d_tmp_score.p, s->d_key_count.p, sl.d_meta.p, s->stream));
         }
         s->st.score_launches++;
     } else {
@@ -445,16 +451,24 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
     }
     KGWAS_HIP(hipEventRecord(sl.ev_k1, s->stream));
     const bool fused_tail = use_coarse && s->narrow;  // thresholds: raised by the next chunk's prep launch; the tested count: in meta (launch_narrow_keys)
-    if (s->hist_ready && !fused_tail)  // raise the thresholds for whatever is queued next; no host round trip
-        KGWAS_HIP(launch_thr_update(s->d_hist.p, s->d_hist_base.p, HIST_BINS, s->d_topn.p, s->d_thr_host.p, s->d_thr.p,
-                                    (uint32_t)s->n_pheno, s->stream));
     static const bool tail_kernel = !(exp_int("KGWAS_TAIL_KERNEL", 1) == 0);  // experiments: 0 = hipMemcpyAsync calls
     const bool one_launch = use_coarse && tail_kernel && sl.h_meta_dev;
+    // wide path: the threshold update and the chunk's tail (counts, tested-row shards, thresholds into the mapped buffers) are one launch
+    const bool thr_and_tail = one_launch && s->hist_ready && !fused_tail;
+    if (s->hist_ready && !fused_tail && !thr_and_tail)  // raise the thresholds for whatever is queued next; no host round trip
+        KGWAS_HIP(launch_thr_update(s->d_hist.p, s->d_hist_base.p, HIST_BINS, s->d_topn.p, s->d_thr_host.p, s->d_thr.p,
+                                    (uint32_t)s->n_pheno, s->stream));
     if (!fused_tail && !one_launch)
         KGWAS_HIP(hipMemcpyAsync(sl.h_tested.p, sl.d_tested.p, TESTED_SHARDS * sizeof(unsigned long long), hipMemcpyDeviceToHost,
                                  s->stream));
     sl.tested_in_meta = fused_tail;
-    if (one_launch) {
+    if (thr_and_tail) {
+        const bool thr_too = s->lazy_any.load(std::memory_order_relaxed);
+        KGWAS_HIP(launch_thr_tail(s->d_hist.p, s->d_hist_base.p, HIST_BINS, s->d_topn.p, s->d_thr_host.p, s->d_thr.p, (uint32_t)s->n_pheno, sl.d_meta.p,
+                                  (uint32_t)(2 * s->n_pheno + 4), sl.h_meta_dev, sl.d_tested.p, (uint32_t)TESTED_SHARDS, sl.h_tested_dev,
+                                  thr_too ? sl.h_thr_dev : nullptr, s->stream));
+        KGWAS_HIP(hipEventRecord(sl.ev_counts, s->stream));
+    } else if (one_launch) {
         // counts, tested-row shards and - for the columns in select mode, which bound their pools with them - the device's
         // thresholds as they stand behind this chunk: one launch into the mapped buffers; the record copies follow on the copy
         // stream once the control thread has read the counts (fetch_records)

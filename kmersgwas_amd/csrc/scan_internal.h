@@ -490,11 +490,13 @@ struct kgwas_scan {
     DevBuf<unsigned long long> d_bitmap;  // survivors of the chunk being filtered: [n_pheno][bitmap_words]
     uint64_t bitmap_words = 0;
     DevBuf<uint32_t> d_bm_blocks;                  // block counts of launch_bitmap_keys / the narrow filter's per-segment counts
+    DevBuf<unsigned long long> d_bm_mask;          // launch_bitmap_keys: per (column, block) the threads whose words hold a survivor
+    bool bitmap_clean = false;                     // wide path: the key launches leave the bitmap all zero, so a chunk's prep launch has nothing to zero
     uint64_t slack_rows = 0;                       // rows of the feed's device buffer behind the chunk being submitted
     // survivors of the chunk being filtered: bitmap [column][64-row word], then row-ordered keys per column with each
     // column's range; shared by all chunks (consumed by the re-score kernel in stream order)
     DevBuf<uint32_t> d_surv_sorted, d_surv_cnt, d_surv_off, d_key_count;  // row-ordered keys per column, the columns' ranges, the total
-    DevBuf<uint32_t> d_tile_pref, d_tile_cnt, d_tile_off;  // tiles of 256 survivors (launch_rescore)
+    DevBuf<uint32_t> d_tile_pref, d_tile_cnt;  // tiles of 256 survivors (launch_rescore)
     DevBuf<double> d_tmp_score;                            // exact score of every survivor (-inf: not a candidate)
     uint32_t key_slots = 0;  // capacity of the key list = n_pheno * cap
     uint32_t row_key_bits = 32;

@@ -371,13 +371,13 @@ __global__ void __launch_bounds__(TH) coarse_kernel(CoarseArgs a, uint32_t rows_
 }
 
 // ---- survivors -> exact candidates, compacted in (column, row) order --------------------------------------------
-// The sorted key list is cut into tiles of 256 survivors that never straddle a column (launch_bitmap_keys fills tile_pref); the three
+// The sorted key list is cut into tiles of 256 survivors that never straddle a column (launch_bitmap_keys fills tile_pref); the two
 // kernels below walk the tiles with a fixed grid:
 //   rescore_kernel      exact re-scoring of a tile's survivors (one lane each, the column wave-uniform), exact test
 //                       against thr, threshold histogram; score (or -inf: not a candidate) to HBM, candidates per tile
-//   tile_scan_kernel    exclusive scan of the tiles' candidate counts: where each tile's candidates go, each column's
-//                       range in the compacted list, their total
-//   compact_kernel      candidates to their final place: score f64 | kmer u64 | chunk-local row u32, three arrays
+//   compact_kernel      candidates to their final place: score f64 | kmer u64 | chunk-local row u32, three arrays (a tile's
+//                       place = the candidates of the tiles before it, summed by the block itself; the grid's last block
+//                       writes each column's range in the compacted list and their total: meta)
 // The compacted arrays live in HBM; the host copies exactly `total` records per array over PCIe on a copy stream
 // (the first version wrote every survivor, candidate or not, from the kernel into mapped host memory: 20 B per
 // survivor over PCIe inside the compute stream, 7 ms of a 22 ms pass).
@@ -673,50 +673,74 @@ __global__ void __launch_bounds__(256) KGWAS_RESCORE_OCC rescore_kernel(ScoreArg
     }
 }
 
-// meta: [0 .. P) candidates per column, [P .. 2P) each column's offset in the compacted arrays, [2P] their total,
-// [2P + 1] the survivor keys the coarse kernel emitted (> key_cap: the list overflowed).
-__global__ void __launch_bounds__(1024) tile_scan_kernel(const uint32_t* tile_cnt, const uint32_t* tile_pref, uint32_t n_pheno,
-                                                         const uint32_t* key_count, uint32_t* tile_off, uint32_t* meta) {
-    __shared__ uint32_t part[1024];
-    const uint32_t n_tiles = tile_pref[n_pheno];
-    const uint32_t per = (n_tiles + 1023u) / 1024u;
-    const uint32_t lo = threadIdx.x * per, hi = lo + per < n_tiles ? lo + per : n_tiles;
-    uint32_t s = 0;
-    for (uint32_t i = lo; i < hi; i++) s += tile_cnt[i];
-    part[threadIdx.x] = s;
+// Candidates to their final place. A tile's place in the compacted arrays is the number of candidates in the tiles before
+// it: every block adds those up for itself - its first tile's prefix over tile_cnt[0 .. t), then gridDim.x - 1 more counts
+// per further tile - instead of waiting for a one-block scan launch between the re-score and this kernel (16 us per chunk,
+// 0.4 ms of a 100 M-row pass). The grid's extra last block writes meta: [0 .. P) candidates per column, [P .. 2P) each
+// column's offset in the compacted arrays, [2P] their total, [2P + 1] the survivor keys the filter emitted (> key_cap: the
+// list overflowed).
+__device__ __forceinline__ uint32_t block_sum_256(uint32_t v, uint32_t* red) {  // sum over the block's 256 threads; two barriers
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d);
+    __syncthreads();  // (the previous call's readers are done with red)
+    if (lane == 0u) red[wave] = v;
     __syncthreads();
-    for (uint32_t d = 1; d < 1024u; d <<= 1) {
-        const uint32_t x = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
-        __syncthreads();
-        part[threadIdx.x] += x;
-        __syncthreads();
-    }
-    uint32_t run = part[threadIdx.x] - s;
-    for (uint32_t i = lo; i < hi; i++) {
-        tile_off[i] = run;
-        run += tile_cnt[i];
-    }
-    if (threadIdx.x == 1023u) tile_off[n_tiles] = part[1023];
-    __syncthreads();
-    for (uint32_t p = threadIdx.x; p < n_pheno; p += 1024u) {
-        const uint32_t a = tile_off[tile_pref[p]], b = tile_off[tile_pref[p + 1]];
-        meta[p] = b - a;
-        meta[n_pheno + p] = a;
-    }
-    if (threadIdx.x == 0) {
-        meta[2u * n_pheno] = part[1023];
-        meta[2u * n_pheno + 1u] = *key_count;
-    }
+    return red[0] + red[1] + red[2] + red[3];
 }
 
 __global__ void __launch_bounds__(256) compact_kernel(ScoreArgs a, const uint32_t* keys, const uint32_t* surv_off,
                                                       const uint32_t* surv_cnt, const uint32_t* tile_pref, uint32_t row_mask,
-                                                      const double* tmp_score, const uint32_t* tile_off) {
+                                                      const double* tmp_score, const uint32_t* tile_cnt, const uint32_t* key_count,
+                                                      uint32_t* meta) {
     __shared__ uint32_t wcnt[4];
+    __shared__ uint32_t red[4];
+    __shared__ uint32_t cpre[257];
     const uint32_t n_tiles = tile_pref[a.n_pheno];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        if (tile_off[t + 1] == tile_off[t]) continue;  // block-uniform: no candidate in this tile
+    const uint32_t n_workers = gridDim.x - 1u;
+    if (blockIdx.x == n_workers) {
+        // meta. Thread i sums the counts of tiles [i * per, (i + 1) * per); an exclusive scan over the 256 sums; a column's
+        // offset is the prefix at its first tile.
+        const uint32_t per = (n_tiles + 255u) / 256u;
+        const uint32_t lo = threadIdx.x * per < n_tiles ? threadIdx.x * per : n_tiles;
+        const uint32_t hi = lo + per < n_tiles ? lo + per : n_tiles;
+        uint32_t sm = 0;
+        for (uint32_t i = lo; i < hi; i++) sm += tile_cnt[i];
+        cpre[threadIdx.x + 1u] = sm;
+        if (threadIdx.x == 0u) cpre[0] = 0u;
+        __syncthreads();
+        for (uint32_t d = 1; d < 256u; d <<= 1) {
+            const uint32_t x = threadIdx.x + 1u > d ? cpre[threadIdx.x + 1u - d] : 0u;  // (cpre[0] = 0 joins nothing)
+            __syncthreads();
+            cpre[threadIdx.x + 1u] += x;
+            __syncthreads();
+        }
+        auto prefix_at = [&](uint32_t x) {  // candidates in tiles [0, x)
+            if (x >= n_tiles) return cpre[256];
+            const uint32_t seg = per ? x / per : 0u;
+            uint32_t v = cpre[seg];
+            for (uint32_t i = seg * per; i < x; i++) v += tile_cnt[i];
+            return v;
+        };
+        for (uint32_t p = threadIdx.x; p < a.n_pheno; p += 256u) {
+            const uint32_t o0 = prefix_at(tile_pref[p]), o1 = prefix_at(tile_pref[p + 1u]);
+            meta[p] = o1 - o0;
+            meta[a.n_pheno + p] = o0;
+        }
+        if (threadIdx.x == 0u) {
+            meta[2u * a.n_pheno] = cpre[256];
+            meta[2u * a.n_pheno + 1u] = *key_count;
+        }
+        return;
+    }
+    uint32_t base = 0, done = 0;  // candidates in tiles [0, done)
+    for (uint32_t t = blockIdx.x; t < n_tiles; t += n_workers) {
+        uint32_t part = 0;
+        for (uint32_t i = done + threadIdx.x; i < t; i += 256u) part += tile_cnt[i];
+        base += block_sum_256(part, red);
+        done = t;
+        if (tile_cnt[t] == 0u) continue;  // block-uniform: no candidate in this tile
         const uint32_t p = __builtin_amdgcn_readfirstlane(tile_column(tile_pref, a.n_pheno, t));  // the column's values come by scalar loads
         const uint32_t i = (t - tile_pref[p]) * 256u + threadIdx.x;
         const bool valid = i < surv_cnt[p];
@@ -730,7 +754,7 @@ __global__ void __launch_bounds__(256) compact_kernel(ScoreArgs a, const uint32_
         for (uint32_t w = 0; w < wave; w++) before += wcnt[w];
         if (is_cand) {
             const uint32_t r = keys[gi] & row_mask;
-            const uint32_t o = tile_off[t] + before;
+            const uint32_t o = base + before;
             a.so_score[o] = sc;
             a.so_kmer[o] = a.file_rows[(uint64_t)r * a.file_stride_w];
             a.so_row[o] = r;
@@ -849,7 +873,7 @@ extern "C" int kgwas_debug_coarse_timeline(unsigned long long* out, unsigned lon
 #endif
 
 hipError_t launch_rescore(const ScoreArgs& a, const uint32_t* keys, const uint32_t* surv_off, const uint32_t* surv_cnt,
-                          uint32_t row_bits, uint32_t* tile_pref, uint32_t* tile_cnt, uint32_t* tile_off, double* tmp_score,
+                          uint32_t row_bits, uint32_t* tile_pref, uint32_t* tile_cnt, double* tmp_score,
                           const uint32_t* key_count, uint32_t* meta, hipStream_t st) {
     if (a.n_pheno == 0) return hipSuccess;
     const uint32_t row_mask = row_bits >= 32 ? 0xFFFFFFFFu : ((1u << row_bits) - 1u);
@@ -878,9 +902,8 @@ hipError_t launch_rescore(const ScoreArgs& a, const uint32_t* keys, const uint32
     else
         hipLaunchKernelGGL(rescore_kernel<false>, dim3(grid), dim3(256), 0, st, a, keys, surv_off, surv_cnt, tile_pref, row_mask,
                            tmp_score, tile_cnt, ticket);
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, tile_cnt, tile_pref, a.n_pheno, key_count, tile_off, meta);
-    hipLaunchKernelGGL(compact_kernel, dim3(2048), dim3(256), 0, st, a, keys, surv_off, surv_cnt, tile_pref, row_mask, tmp_score,
-                       tile_off);
+    hipLaunchKernelGGL(compact_kernel, dim3(2048 + 1), dim3(256), 0, st, a, keys, surv_off, surv_cnt, tile_pref, row_mask, tmp_score,
+                       tile_cnt, key_count, meta);
     return hipGetLastError();
 }
 

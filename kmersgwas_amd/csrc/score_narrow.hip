@@ -462,7 +462,7 @@ __global__ void __launch_bounds__(256) narrow_staged_kernel(NarrowArgs a, uint32
 constexpr uint32_t BM_WORDS = 1024;
 
 __global__ void __launch_bounds__(256) bitmap_count_kernel(const unsigned long long* bm, uint64_t words_per_col, uint32_t n_words,
-                                                           uint32_t n_blocks, uint32_t* blk_cnt) {
+                                                           uint32_t n_blocks, uint32_t* blk_cnt, unsigned long long* blk_mask) {
     __shared__ uint32_t part[4];
     const uint32_t p = blockIdx.y, b = blockIdx.x;
     const unsigned long long* w = bm + (uint64_t)p * words_per_col;
@@ -472,6 +472,11 @@ __global__ void __launch_bounds__(256) bitmap_count_kernel(const unsigned long l
         const uint32_t x = b * BM_WORDS + threadIdx.x * 4u + i;
         if (x < n_words) c += __popcll(w[x]);
     }
+    // which threads' words hold anything: the scatter kernel reads (and clears) only those - a steady chunk has a survivor
+    // in one word of thirty, so its pass over the bitmap touches an eighth of the lines and the chunk's prep launch has
+    // nothing to zero
+    const unsigned long long m = __ballot(c != 0u);
+    if ((threadIdx.x & 63u) == 0u) blk_mask[((uint64_t)p * n_blocks + b) * 4u + (threadIdx.x >> 6)] = m;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) c += __shfl_xor(c, d);
     if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = c;
@@ -558,34 +563,46 @@ __global__ void __launch_bounds__(256) bitmap_bases_kernel(const uint32_t* col_t
     if (threadIdx.x == 0) tile_pref[n_pheno] = carry;
 }
 
-__global__ void __launch_bounds__(256) bitmap_scatter_kernel(const unsigned long long* bm, uint64_t words_per_col, uint32_t n_words,
-                                                             uint32_t n_blocks, const uint32_t* blk_off, const uint32_t* surv_off, uint32_t* keys,
+// blk_off: the scanned block counts (bitmap_scan_kernel), col_total: the columns' totals - a block's own count is the
+// difference to the next offset. Only the threads the count kernel marked load their words, and they store zeros back: the
+// bitmap is all zero again when the launch ends (scan_gpu.cpp: bitmap_clean), whatever the key list could hold.
+__global__ void __launch_bounds__(256) bitmap_scatter_kernel(unsigned long long* bm, uint64_t words_per_col, uint32_t n_words,
+                                                             uint32_t n_blocks, const uint32_t* blk_off, const uint32_t* col_total,
+                                                             const unsigned long long* blk_mask, const uint32_t* surv_off, uint32_t* keys,
                                                              uint32_t key_cap, uint32_t row_bits, bool nibble_transposed) {
     __shared__ uint32_t part[4];
     const uint32_t p = blockIdx.y, b = blockIdx.x;
-    const unsigned long long* w = bm + (uint64_t)p * words_per_col;
-    unsigned long long x[4];
+    const uint32_t my_off = blk_off[p * n_blocks + b];
+    const uint32_t next_off = b + 1u < n_blocks ? blk_off[p * n_blocks + b + 1u] : col_total[p];
+    if (next_off == my_off) return;  // nothing in this block (block-uniform)
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const bool mine = (blk_mask[((uint64_t)p * n_blocks + b) * 4u + wave] >> lane) & 1ull;
+    unsigned long long* w = bm + (uint64_t)p * words_per_col;
+    unsigned long long x[4] = {0ull, 0ull, 0ull, 0ull};
     uint32_t c = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const uint32_t idx = b * BM_WORDS + threadIdx.x * 4u + i;
-        x[i] = idx < n_words ? w[idx] : 0ull;
-        c += __popcll(x[i]);
-    }
-    if (!__syncthreads_or(c != 0u)) return;  // nothing in this block (the common case)
-    if (nibble_transposed) {  // the int8 filters write nibble 4 kg + rt for rows 16 rt + 4 kg ..+3: back to row order
+    if (mine) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            if (!x[i]) continue;
-            unsigned long long y = 0;
+            const uint32_t idx = b * BM_WORDS + threadIdx.x * 4u + i;
+            if (idx < n_words) {
+                x[i] = w[idx];
+                if (x[i]) w[idx] = 0ull;
+            }
+            c += __popcll(x[i]);
+        }
+        if (nibble_transposed) {  // the int8 filters write nibble 4 kg + rt for rows 16 rt + 4 kg ..+3: back to row order
 #pragma unroll
-            for (int kg = 0; kg < 4; kg++)
+            for (int i = 0; i < 4; i++) {
+                if (!x[i]) continue;
+                unsigned long long y = 0;
 #pragma unroll
-                for (int rt = 0; rt < 4; rt++) y |= ((x[i] >> (4 * (4 * kg + rt))) & 0xFull) << (4 * (4 * rt + kg));
-            x[i] = y;
+                for (int kg = 0; kg < 4; kg++)
+#pragma unroll
+                    for (int rt = 0; rt < 4; rt++) y |= ((x[i] >> (4 * (4 * kg + rt))) & 0xFull) << (4 * (4 * rt + kg));
+                x[i] = y;
+            }
         }
     }
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t incl = c;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -594,7 +611,7 @@ __global__ void __launch_bounds__(256) bitmap_scatter_kernel(const unsigned long
     }
     if (lane == 63u) part[wave] = incl;
     __syncthreads();
-    uint32_t o = surv_off[p] + blk_off[p * n_blocks + b] + incl - c;
+    uint32_t o = surv_off[p] + my_off + incl - c;
     for (uint32_t k = 0; k < wave; k++) o += part[k];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -609,17 +626,17 @@ __global__ void __launch_bounds__(256) bitmap_scatter_kernel(const unsigned long
     }
 }
 
-hipError_t launch_bitmap_keys(const unsigned long long* bitmap, uint64_t words_per_col, uint64_t n_rows, uint32_t n_pheno, uint32_t* blk_scratch,
-                              uint32_t* keys_sorted, uint32_t key_cap, uint32_t row_bits, uint32_t* surv_off, uint32_t* surv_cnt,
-                              uint32_t* key_count, uint32_t* tile_pref, bool nibble_transposed, hipStream_t st) {
+hipError_t launch_bitmap_keys(unsigned long long* bitmap, uint64_t words_per_col, uint64_t n_rows, uint32_t n_pheno, uint32_t* blk_scratch,
+                              unsigned long long* blk_mask, uint32_t* keys_sorted, uint32_t key_cap, uint32_t row_bits, uint32_t* surv_off,
+                              uint32_t* surv_cnt, uint32_t* key_count, uint32_t* tile_pref, bool nibble_transposed, hipStream_t st) {
     const uint32_t n_words = (uint32_t)((n_rows + 63) / 64);
     const uint32_t n_blocks = (n_words + BM_WORDS - 1) / BM_WORDS;
-    hipLaunchKernelGGL(bitmap_count_kernel, dim3(n_blocks, n_pheno), dim3(256), 0, st, bitmap, words_per_col, n_words, n_blocks, blk_scratch);
+    hipLaunchKernelGGL(bitmap_count_kernel, dim3(n_blocks, n_pheno), dim3(256), 0, st, bitmap, words_per_col, n_words, n_blocks, blk_scratch, blk_mask);
     uint32_t* col_total = blk_scratch + (size_t)n_pheno * n_blocks;
     hipLaunchKernelGGL(bitmap_scan_kernel, dim3(n_pheno), dim3(256), 0, st, blk_scratch, n_blocks, col_total);
     hipLaunchKernelGGL(bitmap_bases_kernel, dim3(1), dim3(256), 0, st, col_total, n_pheno, key_cap, surv_off, surv_cnt, key_count, tile_pref);
     hipLaunchKernelGGL(bitmap_scatter_kernel, dim3(n_blocks, n_pheno), dim3(256), 0, st, bitmap, words_per_col, n_words, n_blocks, blk_scratch,
-                       surv_off, keys_sorted, key_cap, row_bits, nibble_transposed);
+                       col_total, blk_mask, surv_off, keys_sorted, key_cap, row_bits, nibble_transposed);
     return hipGetLastError();
 }
 
