@@ -302,7 +302,7 @@ __global__ void __launch_bounds__(256) chunk_tail_kernel(const uint32_t* __restr
 
 hipError_t launch_chunk_tail(const uint32_t* meta, uint32_t n_meta, uint32_t* h_meta, const unsigned long long* tested, uint32_t n_tested,
                              unsigned long long* h_tested, const double* thr, uint32_t n_thr, double* h_thr, hipStream_t st) {
-    hipLaunchKernelGGL(chunk_tail_kernel, dim3(1), dim3(256), 0, st, meta, n_meta, h_meta, tested, n_tested, h_tested, thr, n_thr, h_thr);
+    launch_last(chunk_tail_kernel, dim3(1), dim3(256), 0, st, meta, n_meta, h_meta, tested, n_tested, h_tested, thr, n_thr, h_thr);
     return hipGetLastError();
 }
 
@@ -325,8 +325,8 @@ hipError_t launch_thr_tail(const uint32_t* hist, const uint32_t* hist_base, uint
                            uint32_t n_pheno, const uint32_t* meta, uint32_t n_meta, uint32_t* h_meta, const unsigned long long* tested,
                            uint32_t n_tested, unsigned long long* h_tested, double* h_thr, hipStream_t st) {
     if (n_pheno == 0 || bins % 256u) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(thr_tail_kernel, dim3(n_pheno), dim3(256), 0, st, hist, hist_base, bins, topn, thr_host, thr, meta, n_meta, h_meta, tested,
-                       n_tested, h_tested, h_thr);
+    launch_last(thr_tail_kernel, dim3(n_pheno), dim3(256), 0, st, hist, hist_base, bins, topn, thr_host, thr, meta, n_meta, h_meta, tested,
+                n_tested, h_tested, h_thr);
     return hipGetLastError();
 }
 

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "env.h"
+#include "launch.h"
 
 namespace kgwas {
 

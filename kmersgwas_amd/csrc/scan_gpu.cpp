@@ -303,9 +303,14 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
         a.thr = s->d_thr_redo.p;
     }
     const bool use_coarse = s->coarse && count_hist;
-    if (!s->direct) KGWAS_HIP(hipEventRecord(sl.ev_sq0, s->stream));  // (only read when rows are squeezed: an event costs the stream ~5 us)
-    maybe_squeeze(s, d_rows, n_rows);
-    KGWAS_HIP(hipEventRecord(sl.ev_k0, s->stream));
+    // The chunk's four events - start (ev_k0), filter done (ev_mid), kernels done (ev_k1), counts on the host (ev_counts) - are bound
+    // to the prep launch, the last filter launch, the compaction and the tail launch (launch.h: a recorded event costs the stream
+    // 2.9 us, a bound one nothing); ev_k0 is the END of the prep launch, i.e. the kernel statistics no longer count its 2-3 us.
+    if (!s->direct) {
+        KGWAS_HIP(hipEventRecord(sl.ev_sq0, s->stream));  // (only read when rows are squeezed)
+        maybe_squeeze(s, d_rows, n_rows);
+        KGWAS_HIP(hipEventRecord(sl.ev_k0, s->stream));
+    }
     {
         // One launch for the chunk's counters, its survivors' bitmap ([column][64-row word], which a popcount scan turns
         // into row-ordered keys per column: no key list, no sort) and the narrow filter's per-segment counts - inside the
@@ -328,10 +333,14 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
         // chunk or after a chunk whose key launches were never queued - in full, the chunks' geometries differ)
         const bool zero_bitmap = use_coarse && (s->narrow || !s->bitmap_clean);
         const uint64_t zero_words = !zero_bitmap ? 0 : (s->narrow ? s->n_pheno * n_words : s->d_bitmap.n);
-        KGWAS_HIP(launch_chunk_prep(sl.d_cnt.p, (uint32_t)s->n_pheno, sl.d_tested.p, use_coarse ? s->d_key_count.p : nullptr,
-                                    zero_bitmap ? s->d_bitmap.p : nullptr, zero_words,
-                                    (use_coarse && s->narrow) ? s->d_bm_blocks.p : nullptr, (use_coarse && s->narrow) ? (uint32_t)s->n_pheno * n_segs : 0u,
-                                    tu, s->stream));
+        const auto prep = [&] {
+            return launch_chunk_prep(sl.d_cnt.p, (uint32_t)s->n_pheno, sl.d_tested.p, use_coarse ? s->d_key_count.p : nullptr,
+                                     zero_bitmap ? s->d_bitmap.p : nullptr, zero_words,
+                                     (use_coarse && s->narrow) ? s->d_bm_blocks.p : nullptr, (use_coarse && s->narrow) ? (uint32_t)s->n_pheno * n_segs : 0u,
+                                     tu, s->stream);
+        };
+        if (s->direct) KGWAS_HIP(bind_stop(sl.ev_k0, s->stream, prep));
+        else KGWAS_HIP(prep());
     }
     sl.used_coarse = use_coarse;
     if (use_coarse) {
@@ -380,7 +389,7 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
             // 768 block slots, so long blocks leave CUs idle at the end of every launch: 4096 rows per block measured
             // 3.4 ms per 100 M rows, 768 rows 3.0; the large chunks of a table that fills the HBM - 48-128 M rows - take
             // 1280: 26.3 ms per 1.2 G rows against 27.1 with 768, 26.5 with 1024 or 1536)
-            KGWAS_HIP(launch_narrow(na, rpb_env ? rpb_env : (n_rows >= (1u << 24) ? 1280u : n_rows >= (1u << 18) ? 768u : 256u), s->stream));
+            KGWAS_HIP(bind_stop(sl.ev_mid, s->stream, [&] { return launch_narrow(na, rpb_env ? rpb_env : (n_rows >= (1u << 24) ? 1280u : n_rows >= (1u << 18) ? 768u : 256u), s->stream); }));
         } else {
             s->bitmap_clean = false;  // (until the key launches are queued behind the filter)
             c.bitmap = s->d_bitmap.p;
@@ -393,6 +402,8 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
                 c.Bq = Pt.d_Bq.p;
                 c.cols = Pt.d_cols.p;
                 c.tested = pi == 0 ? a.tested : nullptr;  // every launch sees every row: one of them counts
+                const bool last_part = pi + 1u == M.n_parts;
+                const uint32_t rpb = rpb_env ? rpb_env : (n_rows >= (1u << 22) ? 4096u : n_rows >= (1u << 20) ? 2048u : 512u);
                 if (M.mx) {
                     MxArgs x;
                     memset(&x, 0, sizeof(x));
@@ -416,15 +427,19 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
                     x.eg_max = c.eg_max;
                     x.rall_max = c.rall_max;
                     x.rmax_max = c.rmax_max;
-                    if (Pt.stream)
-                        KGWAS_HIP(launch_mxs(x, Pt.T, Pt.ng, Pt.stream - 1u, rpb_env ? rpb_env : (n_rows >= (1u << 22) ? 4096u : n_rows >= (1u << 20) ? 2048u : 512u), s->stream));
-                    else
-                    KGWAS_HIP(launch_mx(x, Pt.T, rpb_env ? rpb_env : (n_rows >= (1u << 22) ? 4096u : n_rows >= (1u << 20) ? 2048u : 512u), s->stream));
-                } else
-                    KGWAS_HIP(launch_coarse(c, Pt.T, rpb_env ? rpb_env : (n_rows >= (1u << 22) ? 4096u : n_rows >= (1u << 20) ? 2048u : 512u), s->stream));
+                    const auto filt = [&] {
+                        return Pt.stream ? launch_mxs(x, Pt.T, Pt.ng, Pt.stream - 1u, rpb, s->stream) : launch_mx(x, Pt.T, rpb, s->stream);
+                    };
+                    if (last_part) KGWAS_HIP(bind_stop(sl.ev_mid, s->stream, filt));
+                    else KGWAS_HIP(filt());
+                } else {
+                    const auto filt = [&] { return launch_coarse(c, Pt.T, rpb, s->stream); };
+                    if (last_part) KGWAS_HIP(bind_stop(sl.ev_mid, s->stream, filt));
+                    else KGWAS_HIP(filt());
+                }
             }
+            if (!M.n_parts) KGWAS_HIP(hipEventRecord(sl.ev_mid, s->stream));
         }
-        KGWAS_HIP(hipEventRecord(sl.ev_mid, s->stream));
         a.tested = nullptr;  // counted by the filter
         a.so_score = sl.d_so_score.p;
         a.so_kmer = sl.d_so_kmer.p;
@@ -434,7 +449,7 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
             // record written in place by the re-score kernel - a chunk is five launches, not thirteen
             KGWAS_HIP(launch_narrow_keys(s->d_bitmap.p, n_words, n_rows, (uint32_t)s->n_pheno, s->d_bm_blocks.p, s->d_surv_sorted.p, s->key_slots,
                                          s->row_key_bits, s->d_surv_off.p, s->d_surv_cnt.p, s->d_key_count.p, s->d_tile_pref.p, sl.d_meta.p, sl.d_tested.p, s->stream));
-            KGWAS_HIP(launch_rescore_direct(a, s->d_surv_sorted.p, s->d_surv_off.p, s->d_surv_cnt.p, s->row_key_bits, s->d_tile_pref.p, s->stream));
+            KGWAS_HIP(bind_stop(sl.ev_k1, s->stream, [&] { return launch_rescore_direct(a, s->d_surv_sorted.p, s->d_surv_off.p, s->d_surv_cnt.p, s->row_key_bits, s->d_tile_pref.p, s->stream); }));
         } else {
         KGWAS_HIP(launch_bitmap_keys(s->d_bitmap.p, n_words, n_rows, (uint32_t)s->n_pheno, s->d_bm_blocks.p, s->d_bm_mask.p, s->d_surv_sorted.p, s->key_slots,
                                      s->row_key_bits, s->d_surv_off.p, s->d_surv_cnt.p, s->d_key_count.p, s->d_tile_pref.p, /*nibble_transposed=*/!s->narrow, s->stream));
@@ -442,14 +457,17 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
         a.so_score = sl.d_so_score.p;
         a.so_kmer = sl.d_so_kmer.p;
         a.so_row = sl.d_so_row.p;
-        KGWAS_HIP(launch_rescore(a, s->d_surv_sorted.p, s->d_surv_off.p, s->d_surv_cnt.p, s->row_key_bits, s->d_tile_pref.p,
-                                 s->d_tile_cnt.p, s->d_tmp_score.p, s->d_key_count.p, sl.d_meta.p, s->stream));
+        KGWAS_HIP(bind_stop(sl.ev_k1, s->stream, [&] {
+            return launch_rescore(a, s->d_surv_sorted.p, s->d_surv_off.p, s->d_surv_cnt.p, s->row_key_bits, s->d_tile_pref.p,
+                                  s->d_tile_cnt.p, s->d_tmp_score.p, s->d_key_count.p, sl.d_meta.p, s->stream);
+        }));
         }
         s->st.score_launches++;
     } else {
+        if (s->direct) KGWAS_HIP(hipEventRecord(sl.ev_k0, s->stream));  // (bound to nothing above: the prep launch of an exact-scorer chunk is not timed)
         launch_score(s, a);
+        KGWAS_HIP(hipEventRecord(sl.ev_k1, s->stream));
     }
-    KGWAS_HIP(hipEventRecord(sl.ev_k1, s->stream));
     const bool fused_tail = use_coarse && s->narrow;  // thresholds: raised by the next chunk's prep launch; the tested count: in meta (launch_narrow_keys)
     static const bool tail_kernel = !(exp_int("KGWAS_TAIL_KERNEL", 1) == 0);  // experiments: 0 = hipMemcpyAsync calls
     const bool one_launch = use_coarse && tail_kernel && sl.h_meta_dev;
@@ -464,18 +482,20 @@ void submit_sparse(kgwas_scan* s, Slot& sl, const uint64_t* d_rows, uint64_t n_r
     sl.tested_in_meta = fused_tail;
     if (thr_and_tail) {
         const bool thr_too = s->lazy_any.load(std::memory_order_relaxed);
-        KGWAS_HIP(launch_thr_tail(s->d_hist.p, s->d_hist_base.p, HIST_BINS, s->d_topn.p, s->d_thr_host.p, s->d_thr.p, (uint32_t)s->n_pheno, sl.d_meta.p,
-                                  (uint32_t)(2 * s->n_pheno + 4), sl.h_meta_dev, sl.d_tested.p, (uint32_t)TESTED_SHARDS, sl.h_tested_dev,
-                                  thr_too ? sl.h_thr_dev : nullptr, s->stream));
-        KGWAS_HIP(hipEventRecord(sl.ev_counts, s->stream));
+        KGWAS_HIP(bind_stop(sl.ev_counts, s->stream, [&] {
+            return launch_thr_tail(s->d_hist.p, s->d_hist_base.p, HIST_BINS, s->d_topn.p, s->d_thr_host.p, s->d_thr.p, (uint32_t)s->n_pheno, sl.d_meta.p,
+                                   (uint32_t)(2 * s->n_pheno + 4), sl.h_meta_dev, sl.d_tested.p, (uint32_t)TESTED_SHARDS, sl.h_tested_dev,
+                                   thr_too ? sl.h_thr_dev : nullptr, s->stream);
+        }));
     } else if (one_launch) {
         // counts, tested-row shards and - for the columns in select mode, which bound their pools with them - the device's
         // thresholds as they stand behind this chunk: one launch into the mapped buffers; the record copies follow on the copy
         // stream once the control thread has read the counts (fetch_records)
         const bool thr_too = s->lazy_any.load(std::memory_order_relaxed);
-        KGWAS_HIP(launch_chunk_tail(sl.d_meta.p, (uint32_t)(2 * s->n_pheno + 4), sl.h_meta_dev, sl.d_tested.p, fused_tail ? 0u : (uint32_t)TESTED_SHARDS,
-                                    sl.h_tested_dev, s->d_thr.p, thr_too ? (uint32_t)s->n_pheno : 0u, sl.h_thr_dev, s->stream));
-        KGWAS_HIP(hipEventRecord(sl.ev_counts, s->stream));
+        KGWAS_HIP(bind_stop(sl.ev_counts, s->stream, [&] {
+            return launch_chunk_tail(sl.d_meta.p, (uint32_t)(2 * s->n_pheno + 4), sl.h_meta_dev, sl.d_tested.p, fused_tail ? 0u : (uint32_t)TESTED_SHARDS,
+                                     sl.h_tested_dev, s->d_thr.p, thr_too ? (uint32_t)s->n_pheno : 0u, sl.h_thr_dev, s->stream);
+        }));
     } else if (use_coarse) {
         // the record copies follow on the copy stream once the control thread has read the counts (fetch_records)
         KGWAS_HIP(hipMemcpyAsync(sl.h_meta.p, sl.d_meta.p, (2 * s->n_pheno + 4) * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));

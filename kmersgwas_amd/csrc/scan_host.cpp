@@ -5,6 +5,9 @@
 
 namespace kgwas {
 
+thread_local hipEvent_t g_bound_stop = nullptr;  // launch.h
+
+
 std::vector<int> parse_cpulist(const char* path) {
     std::vector<int> out;
     FILE* f = fopen(path, "r");

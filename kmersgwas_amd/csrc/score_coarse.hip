@@ -792,7 +792,7 @@ hipError_t launch_chunk_prep(uint32_t* cand_cnt, uint32_t n_pheno, unsigned long
     const uint64_t blocks = std::min<uint64_t>((n + 255u) / 256u, 8192u);
     if (blocks * 256u < std::max<uint64_t>(std::max<uint64_t>(n_pheno, TESTED_SHARDS), n_seg_words)) return hipErrorInvalidValue;
     if (tu.hist && (tu.bins % 1024u || tu.bins / 256u > 64u)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(chunk_prep_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, cand_cnt, n_pheno, tested, key_count, bitmap, bitmap_words,
+    launch_last(chunk_prep_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, cand_cnt, n_pheno, tested, key_count, bitmap, bitmap_words,
                        seg_cnt, n_seg_words, tu);
     return hipGetLastError();
 }
@@ -813,7 +813,7 @@ static hipError_t launch_coarse_t(const CoarseArgs& a, uint32_t rows_per_block, 
     static const int grid_env = (int)exp_int("KGWAS_COARSE_GRIDLG", -1);  // experiments
     const uint32_t grid_lg = (grid_env >= 0 ? grid_env != 0 : true) && a.n_lgroups > 1 ? 1u : 0u;
     const uint32_t grid = grid_lg ? (n_rowblocks + 7u) / 8u * 8u * a.n_lgroups : n_rowblocks;
-    hipLaunchKernelGGL((coarse_kernel<T, NS, TH>), dim3(grid), dim3(TH), lds, st, a, rows_per_block, n_rowblocks, grid_lg);
+    launch_last(coarse_kernel<T, NS, TH>, dim3(grid), dim3(TH), lds, st, a, rows_per_block, n_rowblocks, grid_lg);
     return hipGetLastError();
 }
 
@@ -902,7 +902,7 @@ hipError_t launch_rescore(const ScoreArgs& a, const uint32_t* keys, const uint32
     else
         hipLaunchKernelGGL(rescore_kernel<false>, dim3(grid), dim3(256), 0, st, a, keys, surv_off, surv_cnt, tile_pref, row_mask,
                            tmp_score, tile_cnt, ticket);
-    hipLaunchKernelGGL(compact_kernel, dim3(2048 + 1), dim3(256), 0, st, a, keys, surv_off, surv_cnt, tile_pref, row_mask, tmp_score,
+    launch_last(compact_kernel, dim3(2048 + 1), dim3(256), 0, st, a, keys, surv_off, surv_cnt, tile_pref, row_mask, tmp_score,
                        tile_cnt, key_count, meta);
     return hipGetLastError();
 }
@@ -915,10 +915,10 @@ hipError_t launch_rescore_direct(const ScoreArgs& a, const uint32_t* keys, const
     // (a few tiles per launch: a small grid - an empty block costs its launch slot, and a scan of a few columns is made of
     // these launches)
     if (ybytes <= 16384u)
-        hipLaunchKernelGGL((rescore_kernel<true, true>), dim3(512), dim3(256), ybytes, st, a, keys, surv_off, surv_cnt, tile_pref, row_mask,
+        launch_last(rescore_kernel<true, true>, dim3(512), dim3(256), ybytes, st, a, keys, surv_off, surv_cnt, tile_pref, row_mask,
                            (double*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
     else
-        hipLaunchKernelGGL((rescore_kernel<false, true>), dim3(512), dim3(256), 0, st, a, keys, surv_off, surv_cnt, tile_pref, row_mask,
+        launch_last(rescore_kernel<false, true>, dim3(512), dim3(256), 0, st, a, keys, surv_off, surv_cnt, tile_pref, row_mask,
                            (double*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
     return hipGetLastError();
 }

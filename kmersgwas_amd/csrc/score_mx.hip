@@ -560,7 +560,7 @@ static hipError_t launch_mx_t(const MxArgs& a, uint32_t rows_per_block, size_t l
         const uint64_t n_pass = (a.n_rows + rpp - 1) / rpp;
         grid = (uint32_t)std::min<uint64_t>(n_pass, (uint64_t)n_cu);
     }
-    hipLaunchKernelGGL((mx_kernel<CT, RT, NS, S1F, TH>), dim3(grid), dim3(TH), lds, st, a, rows_per_block, n_rowblocks, grid_lg);
+    launch_last(mx_kernel<CT, RT, NS, S1F, TH>, dim3(grid), dim3(TH), lds, st, a, rows_per_block, n_rowblocks, grid_lg);
     return hipGetLastError();
 }
 

@@ -606,9 +606,9 @@ static hipError_t launch_mxs_t(const MxArgs& a, uint32_t rows_per_block, hipStre
     }
     const uint32_t grid = a.n_lgroups > 1 ? (n_rowblocks + 7u) / 8u * 8u * a.n_lgroups : n_rowblocks;
     if (ring4)
-        hipLaunchKernelGGL((mxs_kernel<CT, RT, NG, TH, 4>), dim3(grid), dim3(TH), lds, st, a, rows_per_block, n_rowblocks);
+        launch_last(mxs_kernel<CT, RT, NG, TH, 4>, dim3(grid), dim3(TH), lds, st, a, rows_per_block, n_rowblocks);
     else
-        hipLaunchKernelGGL((mxs_kernel<CT, RT, NG, TH, 3>), dim3(grid), dim3(TH), lds, st, a, rows_per_block, n_rowblocks);
+        launch_last(mxs_kernel<CT, RT, NG, TH, 3>, dim3(grid), dim3(TH), lds, st, a, rows_per_block, n_rowblocks);
     return hipGetLastError();
 }
 

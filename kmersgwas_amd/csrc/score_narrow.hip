@@ -761,12 +761,15 @@ size_t narrow_lds_bytes(uint32_t n_kgroups) { return (size_t)n_kgroups * 4u * 20
 
 template <int NP>
 static hipError_t launch_staged_t(const NarrowArgs& a, uint32_t rows_per_block, uint32_t n_blocks, uint32_t stage_bytes, size_t lds,
-                                  hipStream_t st) {
+                                  hipStream_t st, bool last) {
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)narrow_staged_kernel<NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((narrow_staged_kernel<NP>), dim3(n_blocks), dim3(256), lds, st, a, rows_per_block, stage_bytes);
+    if (last)  // (no second launch for a tail behind it: a caller's event is bound to this one, launch.h)
+        launch_last(narrow_staged_kernel<NP>, dim3(n_blocks), dim3(256), lds, st, a, rows_per_block, stage_bytes);
+    else
+        hipLaunchKernelGGL((narrow_staged_kernel<NP>), dim3(n_blocks), dim3(256), lds, st, a, rows_per_block, stage_bytes);
     return hipGetLastError();
 }
 
@@ -802,18 +805,18 @@ hipError_t launch_narrow(const NarrowArgs& a, uint32_t rows_per_block, hipStream
         const uint32_t nb = (uint32_t)((n_staged + rows_per_block - 1) / rows_per_block);
         hipError_t e = hipSuccess;
         switch (np) {
-            case 1: e = launch_staged_t<1>(s1, rows_per_block, nb, stage_bytes, lds_staged, st); break;
-            case 2: e = launch_staged_t<2>(s1, rows_per_block, nb, stage_bytes, lds_staged, st); break;
-            case 3: e = launch_staged_t<3>(s1, rows_per_block, nb, stage_bytes, lds_staged, st); break;
-            case 4: e = launch_staged_t<4>(s1, rows_per_block, nb, stage_bytes, lds_staged, st); break;
-            case 5: e = launch_staged_t<5>(s1, rows_per_block, nb, stage_bytes, lds_staged, st); break;
-            case 6: e = launch_staged_t<6>(s1, rows_per_block, nb, stage_bytes, lds_staged, st); break;
-            case 7: e = launch_staged_t<7>(s1, rows_per_block, nb, stage_bytes, lds_staged, st); break;
-            case 8: e = launch_staged_t<8>(s1, rows_per_block, nb, stage_bytes, lds_staged, st); break;
-            case 9: e = launch_staged_t<9>(s1, rows_per_block, nb, stage_bytes, lds_staged, st); break;
-            case 10: e = launch_staged_t<10>(s1, rows_per_block, nb, stage_bytes, lds_staged, st); break;
-            case 11: e = launch_staged_t<11>(s1, rows_per_block, nb, stage_bytes, lds_staged, st); break;
-            default: e = launch_staged_t<12>(s1, rows_per_block, nb, stage_bytes, lds_staged, st); break;
+            case 1: e = launch_staged_t<1>(s1, rows_per_block, nb, stage_bytes, lds_staged, st, n_staged == a.n_rows); break;
+            case 2: e = launch_staged_t<2>(s1, rows_per_block, nb, stage_bytes, lds_staged, st, n_staged == a.n_rows); break;
+            case 3: e = launch_staged_t<3>(s1, rows_per_block, nb, stage_bytes, lds_staged, st, n_staged == a.n_rows); break;
+            case 4: e = launch_staged_t<4>(s1, rows_per_block, nb, stage_bytes, lds_staged, st, n_staged == a.n_rows); break;
+            case 5: e = launch_staged_t<5>(s1, rows_per_block, nb, stage_bytes, lds_staged, st, n_staged == a.n_rows); break;
+            case 6: e = launch_staged_t<6>(s1, rows_per_block, nb, stage_bytes, lds_staged, st, n_staged == a.n_rows); break;
+            case 7: e = launch_staged_t<7>(s1, rows_per_block, nb, stage_bytes, lds_staged, st, n_staged == a.n_rows); break;
+            case 8: e = launch_staged_t<8>(s1, rows_per_block, nb, stage_bytes, lds_staged, st, n_staged == a.n_rows); break;
+            case 9: e = launch_staged_t<9>(s1, rows_per_block, nb, stage_bytes, lds_staged, st, n_staged == a.n_rows); break;
+            case 10: e = launch_staged_t<10>(s1, rows_per_block, nb, stage_bytes, lds_staged, st, n_staged == a.n_rows); break;
+            case 11: e = launch_staged_t<11>(s1, rows_per_block, nb, stage_bytes, lds_staged, st, n_staged == a.n_rows); break;
+            default: e = launch_staged_t<12>(s1, rows_per_block, nb, stage_bytes, lds_staged, st, n_staged == a.n_rows); break;
         }
         if (e != hipSuccess || n_staged == a.n_rows) return e;
     }
@@ -828,7 +831,7 @@ hipError_t launch_narrow(const NarrowArgs& a, uint32_t rows_per_block, hipStream
         hipError_t e = hipFuncSetAttribute((const void*)narrow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(narrow_kernel, dim3(n_blocks2), dim3(256), lds, st, a2, rows_per_block);
+    launch_last(narrow_kernel, dim3(n_blocks2), dim3(256), lds, st, a2, rows_per_block);
     return hipGetLastError();
 }
 
