@@ -86,6 +86,46 @@ __global__ void __launch_bounds__(256) thr_update_kernel(const uint32_t* hist, c
     thr_update_block(hist, hist_base, bins, topn, thr_host, thr, blockIdx.x);
 }
 
+// One digit of the radix select, by wave 0: the highest bin b with (counts of the bins above b) < need <= (those + hist[b]);
+// need becomes what is still wanted inside b, the prefix takes b as its next byte. (One thread walking the 256 bins from the top
+// was a chain of dependent LDS reads - 9 us per digit, 72 of the 107 us the selection took at the head of every scan.) Lane l holds
+// bins 4 l .. 4 l + 3; a suffix sum over the lanes finds the lane, the lane finds the bin. The walk of the first version ended at
+// bin 0 whatever was left: so does this one.
+__device__ __forceinline__ void pick_bin_from_top(const uint32_t* hist, unsigned long long prefix, unsigned long long* need_s,
+                                                  unsigned long long* prefix_s) {
+    const uint32_t l = threadIdx.x & 63u;
+    const uint4 c = reinterpret_cast<const uint4*>(hist)[l];
+    const unsigned long long mine = (unsigned long long)c.x + c.y + c.z + c.w;
+    unsigned long long suf = mine;  // lanes l .. 63
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long x = __shfl_down(suf, d);
+        if (l + (uint32_t)d < 64u) suf += x;
+    }
+    const unsigned long long need = *need_s;
+    const unsigned long long above = suf - mine;
+    const bool here = above < need && need <= suf;
+    const unsigned long long m = __ballot(here);
+    if (m ? here : l == 0u) {
+        unsigned long long left = need - above;  // (m == 0: fewer than `need` keys in all - cannot happen; bin 0, as the walk did)
+        uint32_t j = 3;  // (no array indexed by j: that would live in scratch memory, 0.2 ms per launch)
+        if (c.w < left) {
+            left -= c.w;
+            j = 2;
+            if (c.z < left) {
+                left -= c.z;
+                j = 1;
+                if (c.y < left) {
+                    left -= c.y;
+                    j = 0;
+                }
+            }
+        }
+        *need_s = left;
+        *prefix_s = (prefix << 8) | (unsigned long long)(4u * l + j);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Launchers
 // ------------------------------------------------------------------------------------------
@@ -98,7 +138,7 @@ __global__ void __launch_bounds__(256) thr_update_kernel(const uint32_t* hist, c
 __global__ void __launch_bounds__(256) dense_select_kernel(const double* dense, const uint32_t* n1, uint32_t n_rows, uint32_t S,
                                                            uint32_t min_count, const uint64_t* topn, double* thr_a, double* thr_b,
                                                            double* thr_host_copy, uint32_t* info) {
-    __shared__ uint32_t hist[256];
+    __shared__ __attribute__((aligned(16))) uint32_t hist[256];
     __shared__ unsigned long long prefix_s, need_s;
     __shared__ uint32_t kept_s, nan_s;
     const uint32_t p = blockIdx.x, t = threadIdx.x;
@@ -137,6 +177,7 @@ __global__ void __launch_bounds__(256) dense_select_kernel(const double* dense, 
         prefix_s = 0;
         need_s = N;
     }
+#pragma unroll 1
     for (int byte = 7; byte >= 0; byte--) {
         hist[t] = 0;
         __syncthreads();
@@ -147,16 +188,7 @@ __global__ void __launch_bounds__(256) dense_select_kernel(const double* dense, 
                 if (byte == 7 || (k >> (8 * (byte + 1))) == prefix) atomicAdd(&hist[(uint32_t)(k >> (8 * byte)) & 255u], 1u);
             }
         __syncthreads();
-        if (t == 0) {
-            unsigned long long need = need_s;
-            int b = 255;
-            for (; b > 0; b--) {
-                if (hist[b] >= need) break;
-                need -= hist[b];
-            }
-            need_s = need;
-            prefix_s = (prefix << 8) | (unsigned long long)b;
-        }
+        if (t < 64u) pick_bin_from_top(hist, prefix, &need_s, &prefix_s);
         __syncthreads();
     }
     if (t == 0) {
@@ -178,7 +210,7 @@ constexpr int DSEL_KPT = 16;
 __global__ void __launch_bounds__(1024) dense_select_reg_kernel(const double* dense, const uint32_t* n1, uint32_t n_rows, uint32_t S,
                                                                 uint32_t min_count, const uint64_t* topn, double* thr_a, double* thr_b,
                                                                 double* thr_host_copy, uint32_t* info) {
-    __shared__ uint32_t hist[256];
+    __shared__ __attribute__((aligned(16))) uint32_t hist[256];
     __shared__ unsigned long long prefix_s, need_s;
     __shared__ uint32_t kept_s, nan_s;
     const uint32_t p = blockIdx.x, t = threadIdx.x, lane = t & 63u;
@@ -219,6 +251,7 @@ __global__ void __launch_bounds__(1024) dense_select_reg_kernel(const double* de
         prefix_s = 0;
         need_s = N;
     }
+#pragma unroll 1
     for (int byte = 7; byte >= 0; byte--) {
         if (t < 256u) hist[t] = 0;
         __syncthreads();
@@ -238,16 +271,7 @@ __global__ void __launch_bounds__(1024) dense_select_reg_kernel(const double* de
             }
         }
         __syncthreads();
-        if (t == 0) {
-            unsigned long long need = need_s;
-            int b = 255;
-            for (; b > 0; b--) {
-                if (hist[b] >= need) break;
-                need -= hist[b];
-            }
-            need_s = need;
-            prefix_s = (prefix << 8) | (unsigned long long)b;
-        }
+        if (t < 64u) pick_bin_from_top(hist, prefix, &need_s, &prefix_s);
         __syncthreads();
     }
     if (t == 0) {

@@ -161,6 +161,7 @@ int kgwas_scan_create(const kgwas_scan_params* p, kgwas_scan** out) {
         // not worth 20 ms. The first uses are paid where they occur.)
         KGWAS_HIP(hipEventCreate(&s->ev_user));
         KGWAS_HIP(hipEventCreate(&s->ev_ds));
+        KGWAS_HIP(hipEventCreateWithFlags(&s->ev_dcopy, hipEventDisableTiming));
         KGWAS_HIP(hipEventCreate(&s->ev_d0));
         KGWAS_HIP(hipEventCreate(&s->ev_d1));
 

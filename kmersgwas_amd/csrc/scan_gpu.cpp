@@ -162,7 +162,17 @@ void run_dense(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, uint64_t 
     }
     lap();  // 3: select + its copies
     // (by kernels into the mapped buffers: no SDMA device -> host transfer anywhere in a scan, kernels.h launch_copy_to_host)
-    KGWAS_HIP(launch_copy_to_host(s->d_dense.p, s->h_dense_dev, s->n_pheno * n_rows * sizeof(double), s->stream));
+    // A dense START's scores (9.5 MB at 101 columns: 0.17 ms of PCIe) travel on the copy stream, behind the scorer and beside the
+    // selection and the first sparse chunk, which the caller submits before it waits for them (wait_dense_copy): the stream's
+    // first sparse launch does not queue up behind a kernel that is parked on PCIe stores.
+    static const bool dcopy_side = !exp_set("KGWAS_DENSE_COPY_INLINE");  // experiments: the copy on the scan's stream, as before
+    if (select && dcopy_side && s->copy_stream) {
+        KGWAS_HIP(hipStreamWaitEvent(s->copy_stream, e1, 0));
+        KGWAS_HIP(launch_copy_to_host(s->d_dense.p, s->h_dense_dev, s->n_pheno * n_rows * sizeof(double), s->copy_stream));
+        KGWAS_HIP(hipEventRecord(s->ev_dcopy, s->copy_stream));
+        s->dense_copy_pending = true;
+    } else
+        KGWAS_HIP(launch_copy_to_host(s->d_dense.p, s->h_dense_dev, s->n_pheno * n_rows * sizeof(double), s->stream));
     lap();  // 4: scores' copy
     KGWAS_HIP(launch_copy_to_host(s->d_n1.p, s->h_n1_dev, n_rows * sizeof(uint32_t), s->stream));
     KGWAS_HIP(launch_copy_to_host(s->d_kmer.p, s->h_kmer_dev, n_rows * sizeof(uint64_t), s->stream));
@@ -184,16 +194,25 @@ void run_dense(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, uint64_t 
         s->st.squeeze_kernel_ms += ms;
     }
     s->st.chunks++;
+    if (out_scores || !select) wait_dense_copy(s);
     if (out_scores) memcpy(out_scores, s->h_dense.p, s->n_pheno * n_rows * sizeof(double));
     if (out_n1) memcpy(out_n1, s->h_n1.p, n_rows * sizeof(uint32_t));
     if (!replay || select) return;  // select: the caller pushes the rows (dense_fill) after submitting sparse chunks
     dense_fill(s, n_rows, first_row, td0);
 }
 
+// The dense start's scores, copied on the copy stream (run_dense), are in host memory when this returns.
+void wait_dense_copy(kgwas_scan* s) {
+    if (!s->dense_copy_pending) return;
+    s->dense_copy_pending = false;
+    KGWAS_HIP(hipEventSynchronize(s->ev_dcopy));
+}
+
 // The host half of a dense chunk: every MAC-passing row into every heap. meanwhile: run by the calling thread while the
 // pool's workers push (the control thread submits the first sparse chunks there).
 void dense_fill(kgwas_scan* s, uint64_t n_rows, uint64_t first_row, std::chrono::steady_clock::time_point td0,
                 const std::function<void()>* meanwhile) {
+    wait_dense_copy(s);  // (a caller that had something to submit meanwhile has waited already)
     auto t0 = std::chrono::steady_clock::now();
     const uint64_t S = s->S, mc = s->min_count;
     uint64_t kept = 0;

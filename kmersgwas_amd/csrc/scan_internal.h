@@ -433,6 +433,8 @@ struct kgwas_scan {
 
     hipStream_t stream = nullptr, copy_stream = nullptr;  // copy_stream: candidate records HBM -> host
     hipEvent_t ev_user = nullptr, ev_ds = nullptr, ev_d0 = nullptr, ev_d1 = nullptr;  // caller sync + dense-chunk timing
+    hipEvent_t ev_dcopy = nullptr;     // the dense start's scores are in host memory (their copy runs on copy_stream, run_dense)
+    bool dense_copy_pending = false;   // ... and nobody has waited for it yet (wait_dense_copy)
     DevBuf<uint32_t> d_dmask, d_colmap, d_sq;
     DevBuf<float> d_Yperm, d_Ymfma, d_sums;
     DevBuf<double> d_thr;
@@ -629,6 +631,7 @@ struct kgwas_scan {
         drop_events(redo);
         if (ev_user) (void)hipEventDestroy(ev_user);
         if (ev_ds) (void)hipEventDestroy(ev_ds);
+        if (ev_dcopy) (void)hipEventDestroy(ev_dcopy);
         if (ev_d0) (void)hipEventDestroy(ev_d0);
         if (ev_d1) (void)hipEventDestroy(ev_d1);
         if (stream) (void)hipStreamDestroy(stream);
@@ -647,6 +650,7 @@ void upload_thresholds(kgwas_scan* s);
 void refresh_full(kgwas_scan* s);
 void run_dense(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, uint64_t first_row, double* scores_out, uint32_t* popcnt_out,
                bool replay, bool select = false);
+void wait_dense_copy(kgwas_scan* s);
 void dense_fill(kgwas_scan* s, uint64_t n_rows, uint64_t first_row, std::chrono::steady_clock::time_point td0,
                 const std::function<void()>* meanwhile = nullptr);
 int pick_coarse_mode(const kgwas_scan* s);

@@ -581,12 +581,7 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
                     // every heap will be full after these rows, and no score is a NaN (the heap's order with NaNs in it is
                     // not a total one: plain path)
                     const bool early = s->h_sel_info.p[0] >= s->max_topn && s->h_sel_info.p[1] == 0;
-                    const std::function<void()> presubmit = [&]() {  // (the replay workers start after the fill)
-                        s->sel_valid = true;
-                        s->rows_submitted = std::max(s->rows_submitted, s->rows_done + c);
-                        // GPU work for the duration of the fill: at least two chunks, more only while the workers are
-                        // still pushing (a submission costs this thread 0.1-0.2 ms; the replay starts when both are done)
-                        while (pos < n_rows && sub < std::min<uint64_t>(depth, 12) && (sub < 2 || !s->pool->finished())) {
+                    const auto submit_one = [&]() {
                             const uint64_t cs = std::min<uint64_t>(next_sparse_chunk(s), n_rows - pos);
                             const size_t si = (size_t)(sub % (uint64_t)s->n_slots);
                             s->slot_left[si].store((uint32_t)s->n_pheno, std::memory_order_release);  // (columns: groups may be split)
@@ -599,7 +594,21 @@ void feed_device_impl(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, ui
                             s->seq_submitted.store(sub, std::memory_order_release);
                             pos += cs;
                             if (s->trace) fprintf(stderr, "[kgwas t=%.3f] presubmitted chunk %llu (%llu rows), fill %s\n", s->t_ms(), (unsigned long long)(sub - 1), (unsigned long long)cs, s->pool->finished() ? "done" : "running");
-                        }
+                    };
+                    if (early && pos < n_rows) {
+                        // the first sparse chunk goes out before the dense scores are in host memory (their copy runs beside it)
+                        s->sel_valid = true;
+                        s->rows_submitted = std::max(s->rows_submitted, s->rows_done + c);
+                        submit_one();
+                        s->sel_valid = false;
+                    }
+                    wait_dense_copy(s);
+                    const std::function<void()> presubmit = [&]() {  // (the replay workers start after the fill)
+                        s->sel_valid = true;
+                        s->rows_submitted = std::max(s->rows_submitted, s->rows_done + c);
+                        // GPU work for the duration of the fill: at least two chunks, more only while the workers are
+                        // still pushing (a submission costs this thread 0.1-0.2 ms; the replay starts when both are done)
+                        while (pos < n_rows && sub < std::min<uint64_t>(depth, 12) && (sub < 2 || !s->pool->finished())) submit_one();
                         s->sel_valid = false;
                         // While the workers go on pushing: order the record copies of the chunks whose counts have come in,
                         // so the first chunks' records are in host memory when the fill ends (the copy of chunk 0 - 28 MB
