@@ -27,5 +27,11 @@ KIN_CPU_ROWS=500 rocprofv3 --kernel-trace --stats -f csv -d $O/kin_stats -- pyth
 rocprofv3 --kernel-trace --stats -f csv -d $O/c3_stats -- python bench.py --samples 2048 --perms 200 --rows 100000000 --steps 2 --warmup 1 $B > $O/c3_stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $O/pmc_c3r_fetch -- python bench.py --samples 2048 --perms 200 --rows 40000000 --steps 1 --warmup 0 $B > $O/pmc_c3r_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $O/pmc_c3r_write -- python bench.py --samples 2048 --perms 200 --rows 40000000 --steps 1 --warmup 0 $B > $O/pmc_c3r_write.log 2>&1
+# 5. what the round's second half measured: event packets, the record copies' path, the chunk timeline, steps and one-column passes of the final library
+timeout 60 tools/bin/probe_events > $O/probe_events.txt 2>&1
+timeout 120 tools/probe_d2h.sh 2>&1 | cut -c1-260 | grep -v "amdgpu.ids" > $O/probe_d2h.txt
+rocprofv3 --kernel-trace -f csv -d $O/ktrace -- python bench.py --steps 1 --warmup 1 $B > /dev/null 2>&1
+python tools/chunk_timeline.py $O/ktrace > $O/chunk_timeline.txt 2>&1
+(python tools/steps_stat.py 200 final; python tools/one_column_passes.py 100) 2>&1 | grep -E "step median|one column" > $O/steps_final.txt
 find $O -name "*.csv" | xargs ls -la | awk '{print $5, $9}' | tail -30
 python tools/publish_profiles_r06.py

@@ -69,7 +69,7 @@ strip_stats(one("kin_stats/*/*_kernel_stats.csv"), "profiles/r06_kinship_kernel_
 strip_stats(one("c3_stats/*/*_kernel_stats.csv"), "profiles/r06_config4_kernel_stats.csv")
 line = [l for l in open(os.path.join(src, "bench_line.json")) if l.startswith("{")][-1]
 open("profiles/r06_bench_line.json", "w").write(line)
-for name in ("probe_mx_power.txt", "power_trace_mx.json"):
+for name in ("probe_mx_power.txt", "power_trace_mx.json", "probe_events.txt", "probe_d2h.txt", "chunk_timeline.txt", "steps_final.txt"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), "profiles/r06_" + name)
 
