@@ -847,10 +847,19 @@ def live_pmc_traffic(kname, grid, rows_per_launch, rows=40_000_000, timeout_s=90
             if not seq:
                 return {"error": "%s pass: no %s launch in the counter file" % (counter, kname)}
             # The steady launches (`rows_per_launch` rows each). Persistent blocks (round 6) give every launch of 131 072 rows and
-            # more the same grid, so the grid no longer tells them apart: they are the launches that READ the most - within 10 % of
-            # the largest FETCH_SIZE -, and the WRITE pass (same plan, same launch sequence) averages the launches at the same
-            # positions.
-            if counter == "FETCH_SIZE":
+            # more the same grid, so the grid no longer tells them apart: they are the pass's LONGEST launches (within 10 % of the
+            # longest, from the pass's own kernel trace) - found in each pass by itself: how many chunks a pass takes depends on
+            # how fast the host's dense fill was (the two passes of one run had 32 and 30 launches). Without a kernel trace: the
+            # launches that read the most, and the same positions in the WRITE pass if it has as many launches.
+            dur = {}
+            for f in glob.glob(os.path.join(d, "**", "*_kernel_trace.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if kname in r["Kernel_Name"]:
+                        dur[int(r["Dispatch_Id"])] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            if dur and all(i in dur for i, _ in seq):
+                top = max(dur[i] for i, _ in seq)
+                steady_pos = [k for k, (i, _) in enumerate(seq) if dur[i] >= 0.9 * top]
+            elif counter == "FETCH_SIZE":
                 top = max(v for _, v in seq)
                 steady_pos = [i for i, (_, v) in enumerate(seq) if v >= 0.9 * top]
                 n_seq = len(seq)

@@ -167,8 +167,11 @@ void run_dense(kgwas_scan* s, const uint64_t* d_rows, uint64_t n_rows, uint64_t 
     // first sparse launch does not queue up behind a kernel that is parked on PCIe stores.
     static const bool dcopy_side = !exp_set("KGWAS_DENSE_COPY_INLINE");  // experiments: the copy on the scan's stream, as before
     if (select && dcopy_side && s->copy_stream) {
+        // (an SDMA transfer, not the copying kernel: its waves, parked on PCIe stores, doubled the selection's time beside them -
+        // 199 against 101 us under the profiler, profiles/r06_chunk_timeline.txt of the first version; tools/probe_d2h.hip: a
+        // transfer costs the kernels beside it nothing)
         KGWAS_HIP(hipStreamWaitEvent(s->copy_stream, e1, 0));
-        KGWAS_HIP(launch_copy_to_host(s->d_dense.p, s->h_dense_dev, s->n_pheno * n_rows * sizeof(double), s->copy_stream));
+        KGWAS_HIP(hipMemcpyAsync(s->h_dense.p, s->d_dense.p, s->n_pheno * n_rows * sizeof(double), hipMemcpyDeviceToHost, s->copy_stream));
         KGWAS_HIP(hipEventRecord(s->ev_dcopy, s->copy_stream));
         s->dense_copy_pending = true;
     } else
