@@ -13,7 +13,7 @@
 //   KGWAS_NARROW=0             1-4 columns through the wide filter instead of the narrow one
 //   KGWAS_HOST_THREADS=n       replay threads of a session (overrides kgwas_scan_params.host_threads)
 //   KGWAS_FINISH_THREADS=n     kgwas_scan_finish makes the select-mode columns' lists on n threads if that is more than the pool
-//   KGWAS_PIN_THREADS=0|1|2    replay threads: unpinned / one CPU each (default) / one core (SMT pair) each
+//   KGWAS_PIN_THREADS=0|1|2    replay threads: unpinned / one CPU each / one core (SMT pair) each (default: 1 where the CPU quota covers the CPU set, else 0)
 //   KGWAS_SPLIT_LAGGING=0      a column group that falls behind is not cut into single columns
 //   KGWAS_FLOAT_LEAD=n         chunks a group may lag before it floats to the workers that are ahead (default 2, 0: never)
 //   KGWAS_HISTORY_RING=n       record_history = 2: evictions kept per heap (default 16 sqrt(2 N))

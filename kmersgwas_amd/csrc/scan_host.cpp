@@ -34,11 +34,23 @@ std::vector<int> parse_cpulist(const char* path) {
 std::vector<std::vector<int>> pick_replay_cpus(unsigned n, int device) {
     std::vector<std::vector<int>> none;
     int mode = 1;  // 0 off, 1 one core each, 2 the GPU's share of its NUMA node for all, 3 the core's L3 domain
-    if (const char* e = opt_str("KGWAS_PIN_THREADS")) mode = atoi(e);
+    const char* e = opt_str("KGWAS_PIN_THREADS");
+    if (e) mode = atoi(e);
     if (mode == 0) return none;
     cpu_set_t allowed;
     CPU_ZERO(&allowed);
     if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return none;
+    // A process under a CPU-time quota smaller than its CPU set (a container on a shared host: 16 CPUs' worth of time on any of
+    // 256) owns no core: the ones it would pin its workers to run other tenants' threads too, and a pinned worker that loses its
+    // CPU for a few ms holds up its columns - or the whole dense fill - where an unpinned one is moved. Measured on test boxes
+    // with a load average of 35-50 (round 6): headline step mean 18.7-19.5 ms pinned against 18.3-18.5 unpinned (medians 18.4
+    // and 18.3: the pinned runs' outliers), the 16 MB heaps of -n 1000000 0.80 s against 0.50-0.71 per 100 M rows. The default
+    // is therefore: one core each where the quota covers the CPU set (a node of one's own), none otherwise; KGWAS_PIN_THREADS=1..3
+    // pins regardless, =0 never.
+    if (!e && usable_cpus() < (unsigned)CPU_COUNT(&allowed)) {
+        if (opt_str("KGWAS_TRACE")) fprintf(stderr, "[kgwas] replay workers not pinned: a quota of %u CPUs on a set of %d\n", usable_cpus(), CPU_COUNT(&allowed));
+        return none;
+    }
     int node = -1;
     char bus[64] = {0};
     if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) == hipSuccess) {
