@@ -57,7 +57,7 @@ class Pool {
    public:
     // cpus: optional CPU to pin worker i to (empty = leave placement to the scheduler).
     explicit Pool(unsigned n, const std::vector<std::vector<int>>& cpus = {})
-        : stop_(false), gen_(0), pending_(0), n_items_(0) {
+        : stop_(false), gen_(0), n_items_(0) {
         if (n < 1) n = 1;
         for (unsigned i = 0; i < n; i++) {
             const std::vector<int> mine = i < cpus.size() ? cpus[i] : std::vector<int>();
@@ -109,18 +109,28 @@ class Pool {
         }
         if (e) std::rethrow_exception(e);
     }
-    // The two halves of parallel_for: start() hands the items out and returns, wait() blocks until every worker is
-    // done. Between the two the workers run on their own (the streaming replay: items are worker loops that end when
-    // told to). fn must stay alive until wait() returns; one start at a time.
+    // The two halves of parallel_for: start() hands the items out and returns, wait() blocks until every ITEM is done - not
+    // until every worker has looked in: on a shared host a worker that was asleep may get its CPU milliseconds late, and its
+    // items are long done by the others (they are claimed, not assigned) - the dense fill of a headline step, 1.4 ms of work,
+    // took 6-9 ms in one step of twenty on such boxes while wait() counted workers. Between the two the workers run on their own
+    // (the streaming replay: items are worker loops that end when told to). fn must stay alive until wait() returns; one start
+    // at a time.
     void start(size_t n, const std::function<void(size_t)>& fn) {
         std::unique_lock<std::mutex> lk(mu_);
+        // (a worker of the previous start that woke late may still be walking the claim flags - it finds nothing - before they
+        // are reset: workers enter run() under mu_, so none slips in behind this check)
+        while (in_run_.load(std::memory_order_acquire) != 0) {
+            lk.unlock();
+            __builtin_ia32_pause();
+            lk.lock();
+        }
         fn_ = &fn;
         n_items_ = n;
         if (claimed_.size() < n) claimed_ = std::vector<std::atomic<uint8_t>>(n);
         for (size_t i = 0; i < n; i++) claimed_[i].store(0, std::memory_order_relaxed);
-        pending_ = th_.size();
+        left_.store(n, std::memory_order_relaxed);
         err_ = nullptr;
-        done_.store(0, std::memory_order_relaxed);
+        done_.store(n == 0 ? 1 : 0, std::memory_order_relaxed);
         gen_.fetch_add(1, std::memory_order_release);
         lk.unlock();
         cv_.notify_all();
@@ -131,22 +141,35 @@ class Pool {
             __builtin_ia32_pause();
         }
         std::unique_lock<std::mutex> lk(mu_);
-        done_cv_.wait(lk, [this] { return pending_ == 0; });
-        fn_ = nullptr;
+        done_cv_.wait(lk, [this] { return done_.load(std::memory_order_acquire) != 0; });
     }
     size_t size() const { return th_.size(); }
-    bool finished() const { return done_.load(std::memory_order_acquire) != 0; }  // every worker is through the started items
+    bool finished() const { return done_.load(std::memory_order_acquire) != 0; }  // every started item has run
 
    private:
     // Own items first, in increasing order; then take whatever nobody has started yet, from the far end
     // (with 101 columns on 16 workers the five workers that own a seventh column give it away to a worker
-    // that is done with its six). An item runs exactly once, on one thread.
+    // that is done with its six). An item runs exactly once, on one thread; one that throws (an allocation that fails) is
+    // done all the same, and the first such exception is kept for rethrow().
+    void item(size_t i) {
+        try {
+            (*fn_)(i);
+        } catch (...) {
+            std::unique_lock<std::mutex> lk(mu_);
+            if (!err_) err_ = std::current_exception();
+        }
+        if (left_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+            std::unique_lock<std::mutex> lk(mu_);
+            done_.store(1, std::memory_order_release);
+            done_cv_.notify_all();
+        }
+    }
     void run(size_t me) {
         const size_t T = th_.size();
         for (size_t i = me; i < n_items_; i += T)
-            if (!claimed_[i].exchange(1, std::memory_order_acq_rel)) (*fn_)(i);
+            if (!claimed_[i].exchange(1, std::memory_order_acq_rel)) item(i);
         for (size_t i = n_items_; i-- > 0;)
-            if (!claimed_[i].load(std::memory_order_relaxed) && !claimed_[i].exchange(1, std::memory_order_acq_rel)) (*fn_)(i);
+            if (!claimed_[i].load(std::memory_order_relaxed) && !claimed_[i].exchange(1, std::memory_order_acq_rel)) item(i);
     }
     void loop(size_t me) {
         uint64_t seen = 0;
@@ -166,21 +189,10 @@ class Pool {
                 if (!got) cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen; });
                 seen = gen_.load(std::memory_order_acquire);
                 if (stop_) return;
+                in_run_.fetch_add(1, std::memory_order_acq_rel);  // (under mu_: start() looks at it there)
             }
-            std::exception_ptr err;
-            try {
-                run(me);
-            } catch (...) {
-                err = std::current_exception();
-            }
-            {
-                std::unique_lock<std::mutex> lk(mu_);
-                if (err && !err_) err_ = err;
-                if (--pending_ == 0) {
-                    done_.store(1, std::memory_order_release);
-                    done_cv_.notify_all();
-                }
-            }
+            run(me);
+            in_run_.fetch_sub(1, std::memory_order_acq_rel);
         }
     }
     std::vector<std::thread> th_;
@@ -189,8 +201,9 @@ class Pool {
     bool stop_;
     std::atomic<uint64_t> gen_;
     std::atomic<int> done_{0};
+    std::atomic<int> in_run_{0};      // workers between the claim of their first item and their last look at the flags
+    std::atomic<size_t> left_{0};     // items of the current start that have not finished
     std::vector<std::atomic<uint8_t>> claimed_;
-    size_t pending_;
     const std::function<void(size_t)>* fn_ = nullptr;
     size_t n_items_;
     std::exception_ptr err_;  // the first exception an item of the current start() threw (guarded by mu_)
