@@ -1021,6 +1021,11 @@ def main():
             n = int(tn.item())
         args.steps = n
     n_merge_warm = len(merge_ms)
+    # (the interpreter's cyclic garbage collector stays out of the timed region, as timeit keeps it: a full collection of this
+    # process's heap - torch is imported - is a ~10 ms pause that has nothing to do with the scan)
+    import gc
+    gc.collect()
+    gc.disable()
     sync()
     thr0 = cgroup_throttle()
     t0 = time.perf_counter()
@@ -1034,6 +1039,7 @@ def main():
         step_ms.append((time.perf_counter() - ts) * 1e3)
     sync()
     dt = time.perf_counter() - t0
+    gc.enable()
     thr1 = cgroup_throttle()
     if dist_on:
         tmax = torch.tensor([dt], dtype=torch.float64, device=kdist._dev())
