@@ -24,6 +24,7 @@ in HBM when the timed region starts.
          --master-port P bench.py --gpus N --steps K --warmup W
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -1022,8 +1023,7 @@ def main():
         args.steps = n
     n_merge_warm = len(merge_ms)
     # (the interpreter's cyclic garbage collector stays out of the timed region, as timeit keeps it: a full collection of this
-    # process's heap - torch is imported - is a ~10 ms pause that has nothing to do with the scan)
-    import gc
+    # process's heap - torch is imported - is a pause of 10-40 ms that has nothing to do with the scan)
     gc.collect()
     gc.disable()
     sync()
@@ -1280,7 +1280,10 @@ def main():
         def lap(name):
             now = time.perf_counter()
             secs[name] = round(now - _t_mark[0], 1)
-            _t_mark[0] = now
+            gc.collect()  # (between the parts, not inside their timed loops: the collector is off from here on)
+            _t_mark[0] = time.perf_counter()
+        gc.collect()
+        gc.disable()
         if not dist_on and not args.no_cpu_baseline:
             rec, ores = cpu_baseline(S, Y, mac, args.topn, seed_table, min(args.cpu_sample_rows, M),
                                      threads=min(usable_cpus(), P))
