@@ -510,9 +510,10 @@ __global__ void __launch_bounds__(256) bitmap_scan_kernel(uint32_t* blk_cnt, uin
     if (threadIdx.x == 0) col_total[p] = carry;
 }
 
-// each column's range in the key list and the total
-__global__ void __launch_bounds__(256) bitmap_bases_kernel(const uint32_t* col_total, uint32_t n_pheno, uint32_t key_cap, uint32_t* surv_off,
-                                                           uint32_t* surv_cnt, uint32_t* key_count, uint32_t* tile_pref) {
+// each column's range in the key list and the total: the work of one 256-thread block (block (0, 0) of the scatter launch - a
+// launch of its own for these few microseconds cost the stream as much again)
+__device__ __forceinline__ void bitmap_bases_block(const uint32_t* col_total, uint32_t n_pheno, uint32_t key_cap, uint32_t* surv_off,
+                                                   uint32_t* surv_cnt, uint32_t* key_count, uint32_t* tile_pref) {
     __shared__ uint32_t part[256];
     __shared__ uint32_t carry;
     if (threadIdx.x == 0) carry = 0;
@@ -561,6 +562,7 @@ __global__ void __launch_bounds__(256) bitmap_bases_kernel(const uint32_t* col_t
         __syncthreads();
     }
     if (threadIdx.x == 0) tile_pref[n_pheno] = carry;
+    __syncthreads();
 }
 
 // blk_off: the scanned block counts (bitmap_scan_kernel), col_total: the columns' totals - a block's own count is the
@@ -568,14 +570,30 @@ __global__ void __launch_bounds__(256) bitmap_bases_kernel(const uint32_t* col_t
 // bitmap is all zero again when the launch ends (scan_gpu.cpp: bitmap_clean), whatever the key list could hold.
 __global__ void __launch_bounds__(256) bitmap_scatter_kernel(unsigned long long* bm, uint64_t words_per_col, uint32_t n_words,
                                                              uint32_t n_blocks, const uint32_t* blk_off, const uint32_t* col_total,
-                                                             const unsigned long long* blk_mask, const uint32_t* surv_off, uint32_t* keys,
+                                                             const unsigned long long* blk_mask, uint32_t n_pheno, uint32_t* surv_off,
+                                                             uint32_t* surv_cnt, uint32_t* key_count, uint32_t* tile_pref, uint32_t* keys,
                                                              uint32_t key_cap, uint32_t row_bits, bool nibble_transposed) {
     __shared__ uint32_t part[4];
+    __shared__ uint32_t basep[4];
     const uint32_t p = blockIdx.y, b = blockIdx.x;
+    // block (0, 0) writes what the kernels behind this one read: the columns' ranges, the total, the re-score tiles' table
+    if (p == 0u && b == 0u) bitmap_bases_block(col_total, n_pheno, key_cap, surv_off, surv_cnt, key_count, tile_pref);
     const uint32_t my_off = blk_off[p * n_blocks + b];
     const uint32_t next_off = b + 1u < n_blocks ? blk_off[p * n_blocks + b + 1u] : col_total[p];
     if (next_off == my_off) return;  // nothing in this block (block-uniform)
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // where column p's keys begin: the totals of the columns before it, added up by the block itself (surv_off[p] is block
+    // (0, 0)'s to write, in this same launch)
+    uint32_t col_base;
+    {
+        uint32_t v = 0;
+        for (uint32_t q = threadIdx.x; q < p; q += 256u) v += col_total[q];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d);
+        if (lane == 0u) basep[wave] = v;
+        __syncthreads();
+        col_base = basep[0] + basep[1] + basep[2] + basep[3];
+    }
     const bool mine = (blk_mask[((uint64_t)p * n_blocks + b) * 4u + wave] >> lane) & 1ull;
     unsigned long long* w = bm + (uint64_t)p * words_per_col;
     unsigned long long x[4] = {0ull, 0ull, 0ull, 0ull};
@@ -611,7 +629,7 @@ __global__ void __launch_bounds__(256) bitmap_scatter_kernel(unsigned long long*
     }
     if (lane == 63u) part[wave] = incl;
     __syncthreads();
-    uint32_t o = surv_off[p] + my_off + incl - c;
+    uint32_t o = col_base + my_off + incl - c;
     for (uint32_t k = 0; k < wave; k++) o += part[k];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -634,9 +652,8 @@ hipError_t launch_bitmap_keys(unsigned long long* bitmap, uint64_t words_per_col
     hipLaunchKernelGGL(bitmap_count_kernel, dim3(n_blocks, n_pheno), dim3(256), 0, st, bitmap, words_per_col, n_words, n_blocks, blk_scratch, blk_mask);
     uint32_t* col_total = blk_scratch + (size_t)n_pheno * n_blocks;
     hipLaunchKernelGGL(bitmap_scan_kernel, dim3(n_pheno), dim3(256), 0, st, blk_scratch, n_blocks, col_total);
-    hipLaunchKernelGGL(bitmap_bases_kernel, dim3(1), dim3(256), 0, st, col_total, n_pheno, key_cap, surv_off, surv_cnt, key_count, tile_pref);
     hipLaunchKernelGGL(bitmap_scatter_kernel, dim3(n_blocks, n_pheno), dim3(256), 0, st, bitmap, words_per_col, n_words, n_blocks, blk_scratch,
-                       col_total, blk_mask, surv_off, keys_sorted, key_cap, row_bits, nibble_transposed);
+                       col_total, blk_mask, n_pheno, surv_off, surv_cnt, key_count, tile_pref, keys_sorted, key_cap, row_bits, nibble_transposed);
     return hipGetLastError();
 }
 
