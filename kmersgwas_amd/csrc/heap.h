@@ -389,7 +389,9 @@ class alignas(128) BestHeap {
     // digits in which all keys agree skipped: the top-N of a scan share sign, exponent and often the leading mantissa
     // bits) and neighbours compared; on the first equal pair the function gives up (false, outputs untouched) and the
     // caller pops for real. 10 001 entries: ~0.1 ms against 0.5 ms of pops alone, 0.27 in 8-way lockstep.
-    bool pop_all_sorted(std::vector<uint64_t>& kmer, std::vector<double>& score, std::vector<uint64_t>& row) const {
+    // last_tie (optional): where a tie stops the function, the index - in ascending order - of the LAST entry that equals its
+    // predecessor: everything behind it is distinct, and pop_all pops only up to it for real.
+    bool pop_all_sorted(std::vector<uint64_t>& kmer, std::vector<double>& score, std::vector<uint64_t>& row, size_t* last_tie = nullptr) const {
         if (!ints_ok_) return false;
         const size_t n = v_.size();
         struct Key {
@@ -423,22 +425,50 @@ class alignas(128) BestHeap {
             for (size_t i = 0; i < n; i++) dst[cnt[(src[i].bits >> shift) & 0x7FFu]++] = src[i];
             std::swap(src, dst);
         }
-        for (size_t i = 1; i < n; i++)
-            if (src[i].bits == src[i - 1].bits) return false;  // a tie: its pop order is the layout's business
+        size_t tie_at = 0;  // the last i with src[i] == src[i - 1]
+        for (size_t i = n; i-- > 1;)
+            if (src[i].bits == src[i - 1].bits) {
+                tie_at = i;
+                break;
+            }
+        const size_t first = tie_at ? tie_at + 1 : 0;  // entries [first, n) are distinct and above every tied score
+        if (tie_at && (!last_tie || first > n - n / 8)) return false;  // a tie: its pop order is the layout's business
         kmer.resize(n);
         score.resize(n);
         row.resize(n);
-        for (size_t i = 0; i < n; i++) {
+        for (size_t i = first; i < n; i++) {
             memcpy(&score[i], &src[i].bits, 8);
             kmer[i] = pay_[src[i].slot].kmer;
             row[i] = pay_[src[i].slot].row;
         }
+        if (tie_at) {
+            *last_tie = tie_at;
+            return false;  // (outputs [first, n) are filled; the caller pops the first `first` entries for real)
+        }
         return true;
     }
 
+    // Pops are ascending in score whatever the layout; only the order of EQUAL scores is the layout's. So a heap with ties is
+    // popped for real just until its last tied score has come out - the entries above it are distinct, and their pop order is
+    // their sorted order (a column whose tie turned up late in a scan is replayed and popped at the scan's very end: the pair that
+    // ties sits anywhere among its 10 001 entries, half the pops go on average).
     void pop_all(std::vector<uint64_t>& kmer, std::vector<double>& score, std::vector<uint64_t>& row) const {
-        if (pop_all_sorted(kmer, score, row)) return;
-        pop_all_classic(kmer, score, row);
+        size_t last_tie = 0;
+        if (pop_all_sorted(kmer, score, row, &last_tie)) return;
+        if (!last_tie) {
+            pop_all_classic(kmer, score, row);
+            return;
+        }
+        // outputs [last_tie + 1, n) are in place; the first last_tie + 1 pops on a copy of the array
+        std::vector<Ent> tmp(v_.begin(), v_.end());
+        const size_t n = tmp.size();
+        Ent* a = tmp.data();
+        for (size_t i = 0; i <= last_tie; i++) {
+            kmer[i] = pay_[a[0].slot].kmer;
+            score[i] = a[0].score;
+            row[i] = pay_[a[0].slot].row;
+            pop_top<true>(a, (ptrdiff_t)(n - i));
+        }
     }
     // get_rows_sorted_indices (src/best_associations_heap.cpp:135-147): the entries' rows, ascending
     std::vector<uint64_t> rows_sorted() const {

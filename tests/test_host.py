@@ -133,25 +133,34 @@ def test_min_count_matches_the_reference_rule():
 @pytest.mark.parametrize("N,n,levels", [(1, 60, 3), (2, 100, 3), (3, 200, 2), (10, 500, 4), (64, 4000, 9), (200, 150, 5), (33, 3000, 2),
                                         (1000, 30000, 40), (1001, 30000, 2000),
                                         (70001, 400000, 3000)])  # (> 65 536 entries: the hole walks prefetch the descendants three levels down)
-@pytest.mark.parametrize("flavour", ["nan", "plain", "negative", "distinct", "one_tie"])
+@pytest.mark.parametrize("flavour", ["nan", "plain", "negative", "distinct", "one_tie", "low_tie", "mid_ties"])
 def test_heap_mirror_equals_oracle_heap_under_ties(N, n, levels, flavour):
     """(plain: scores in +0 .. +inf, the heap compares their bit patterns as integers; nan / negative: it must notice
     and compare as doubles; distinct: no two scores equal - the pop sequence is then produced by sorting, not popping;
-    one_tie: distinct but for ONE pair of equal scores among the largest - sorting must give up and pop for real)"""
+    one_tie: distinct but for ONE pair of equal scores among the largest - sorting must give up and pop for real;
+    low_tie / mid_ties: distinct but for a pair of equal scores in the lowest tenth of the entries that stay / three pairs
+    spread over their lower half - the heap is popped for real up to its last tied score and sorted from there)"""
     rng = np.random.default_rng(N * 31 + n)
     k = np.arange(n, dtype=np.uint64) + 7
     s = rng.integers(0, levels, size=n).astype(np.float64) / 8.0
-    if flavour in ("distinct", "one_tie"):
+    if flavour in ("distinct", "one_tie", "low_tie", "mid_ties"):
         s = rng.permutation(n).astype(np.float64) * 0.37 + rng.random(n) * 0.1  # all different
+        top = np.argsort(s)[-min(N, n):]  # the entries that stay, ascending
         if flavour == "one_tie" and n >= 4:
-            top = np.argsort(s)[-min(N, n):]
             s[top[0]] = s[top[-1]]  # the weakest entry that stays gets the best one's score
+        if flavour == "low_tie" and len(top) >= 4:
+            a = len(top) // 10
+            s[top[a]] = s[top[a + 1]]
+        if flavour == "mid_ties" and len(top) >= 16:
+            for f in (0.05, 0.3, 0.5):
+                a = int(f * len(top))
+                s[top[a]] = s[top[a + 1]]
     if flavour == "nan":
         s[rng.random(n) < 0.01] = np.nan
     elif flavour == "negative":
         s -= 0.25
         s[rng.random(n) < 0.05] = -0.0
-    else:
+    elif flavour not in ("low_tie", "mid_ties"):  # (several +inf are ties at the very top: everything would be popped for real)
         s[rng.random(n) < 0.01] = np.inf
     r = np.arange(n, dtype=np.uint64) * 3
     h = kg.BestAssociationsHeap(N)
