@@ -618,7 +618,8 @@ uint64_t next_sparse_chunk(const kgwas_scan* s) {
 void wait_event(kgwas_scan* s, hipEvent_t ev) {
     auto w0 = std::chrono::steady_clock::now();
     bool done = false;
-    for (int i = 0; i < 400 && !done; i++) {
+    static const int polls = (int)exp_int("KGWAS_WAIT_POLLS", 400);  // experiments
+    for (int i = 0; i < polls && !done; i++) {
         const hipError_t q = hipEventQuery(ev);
         if (q == hipSuccess) done = true;
         else if (q != hipErrorNotReady) KGWAS_HIP(q);
